@@ -1,0 +1,126 @@
+/*
+ * tedspad_hip.h -- C ABI of libtedspad_hip.so, the MI355X (gfx950) kernels behind the
+ * TeD-SPAD video-encoder hot path (I3D clip feature extraction, UNet anonymizer, losses).
+ *
+ * The reference has NO native layer: every op below is reached there through a stock
+ * torch.nn module (cuDNN).  Each entry point cites the reference call it replaces.
+ * Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     the name says host; `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success, a negative TEDSPAD_E* code otherwise and
+ *     never throws; tedspad_last_error() gives the message (thread-local).
+ *   - no hidden allocation, no synchronisation: launches are asynchronous on `stream`
+ *     and are hipGraph-capturable.
+ *   - activations are channels-last (N,T,H,W,C) 16-bit (f16 or bf16, see `dtype`),
+ *     accumulation and the BN/residual/ReLU epilogue are fp32.
+ */
+#ifndef TEDSPAD_HIP_H
+#define TEDSPAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEDSPAD_ABI_VERSION 1
+
+enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1 };
+enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
+
+/* Geometry of one convolution in channels-last form.  2-D convs (UNet) use t = kt = 1. */
+typedef struct tedspad_conv_desc {
+    int32_t n, t, h, w;          /* input pixels                                              */
+    int32_t cin;                 /* channels read per pixel, multiple of 8                    */
+    int32_t ldx;                 /* elements between consecutive input pixels (>= cin)        */
+    int32_t cout;                /* output channels written, multiple of 8                    */
+    int32_t ldy;                 /* elements between consecutive output pixels (concat slices) */
+    int32_t ldres;               /* same for the residual tensor; ignored if residual == NULL */
+    int32_t kt, kh, kw;          /* kernel                                                    */
+    int32_t st, sh, sw;          /* stride                                                    */
+    int32_t pt, ph, pw;          /* FRONT zero padding (TF-SAME is asymmetric: i3d.py:82-106) */
+    int32_t to, ho, wo;          /* output pixels                                             */
+    int32_t relu;                /* 1: ReLU after scale/shift(+residual)                      */
+    int32_t dtype;               /* TEDSPAD_F16 | TEDSPAD_BF16                                */
+} tedspad_conv_desc;
+
+typedef struct tedspad_pool_desc {
+    int32_t n, t, h, w, c;       /* input, c multiple of 8                                    */
+    int32_t ldx, ldy;            /* pixel strides (elements)                                  */
+    int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+    int32_t to, ho, wo;
+    int32_t pad_zero;            /* 1: padded taps contribute 0 (MaxPool3dSamePadding, i3d.py:41-45) */
+    int32_t dtype;
+} tedspad_pool_desc;
+
+int32_t     tedspad_abi_version(void);
+const char *tedspad_last_error(void);
+
+/* ---- packing helpers (HOST side, pure CPU) ------------------------------------------------ */
+
+/* K = kt*kh*kw*cin rounded up to the kernel's K tile; rows of the packed weight matrix. */
+int32_t tedspad_conv_kpad(const tedspad_conv_desc *d);
+int32_t tedspad_conv_cout_pad(const tedspad_conv_desc *d);
+/* Number of int32 pairs in the K-chunk table (= kpad / 8). */
+int32_t tedspad_conv_ktab_entries(const tedspad_conv_desc *d);
+/* Fills host_out[2*entries]: {element offset of the tap+channel chunk, packed (dt,dh,dw,valid)}. */
+int32_t tedspad_conv_build_ktab(const tedspad_conv_desc *d, int32_t *host_out);
+
+/* ---- device launchers --------------------------------------------------------------------- */
+
+/*
+ * y[n,to,ho,wo,co] = act( scale[co] * sum_{dt,dh,dw,ci} x[n, to*st-pt+dt, ..., ci] * w[co][(dt,dh,dw,ci)]
+ *                         + shift[co] (+ residual[n,to,ho,wo,co]) )
+ * Replaces nn.Conv3d/Conv2d + BatchNorm(eval) + ReLU (+ residual add):
+ *   Unit3D.forward            aux_code/models/i3d.py:89-120
+ *   Bottleneck.forward        aux_code/models/large_i3d.py:61-84
+ *   I3Res50 stem              aux_code/models/large_i3d.py:229-231
+ *   DoubleConv / OutConv      aux_code/models/unet_parts.py:8-25,71-77
+ * w_packed: [cout_pad][kpad] 16-bit, K ordered (dt,dh,dw,ci), zero padded.
+ * ktab: device copy of tedspad_conv_build_ktab.  scale/shift: fp32 [cout_pad].
+ * act: relu if d->relu; `sigmoid` != 0 applies a logistic instead (UNet output, unet_model.py:37).
+ */
+int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed,
+                         const int32_t *ktab, const float *scale, const float *shift,
+                         const void *residual, void *y, int32_t sigmoid, void *stream);
+
+/* nn.MaxPool3d / MaxPool3dSamePadding / nn.MaxPool2d: large_i3d.py:138-139, i3d.py:13-45, unet_parts.py:34 */
+int32_t tedspad_maxpool_fwd(const tedspad_pool_desc *d, const void *x, void *y, void *stream);
+
+/* AdaptiveAvgPool3d(1) / AvgPool3d([2,7,7]) over `spatial` pixels: large_i3d.py:146,262; i3d.py:293,340.
+ * x: (n, spatial, c) 16-bit with pixel stride ldx -> y fp32 (n, c). */
+int32_t tedspad_global_avgpool_fwd(const void *x, float *y, int32_t n, int32_t spatial, int32_t c,
+                                   int32_t ldx, int32_t dtype, void *stream);
+
+/* fp32 NCTHW clip (as ft.extract_features takes it: large_i3d.py:249) -> 16-bit NTHWC with the
+ * channel dim zero-padded to cpad (4: stem pixel-pair form; 8: UNet).  x strides in elements. */
+int32_t tedspad_clip_to_channels_last(const float *x, void *y, int32_t n, int32_t c, int32_t t,
+                                      int32_t h, int32_t w, int64_t sn, int64_t sc, int64_t st_,
+                                      int64_t sh, int64_t sw, int32_t cpad, int32_t dtype, void *stream);
+
+/* 16-bit NTHWC (pixel stride ldx, first c channels) -> fp32 NCTHW contiguous (module boundary out). */
+int32_t tedspad_channels_last_to_nchw(const void *x, float *y, int32_t n, int32_t c, int32_t t,
+                                      int32_t h, int32_t w, int32_t ldx, int32_t dtype, void *stream);
+
+/* y[b,n] = act( scale[n] * sum_k x[b,k] * w[n,k] + shift[n] ), all fp32 (scale/shift may be NULL).
+ * Replaces nn.Linear (+ BatchNorm1d eval + ReLU): I3Res50.fc large_i3d.py:147,245; mlp.fc1/bn1/fc2/bn2
+ * aux_code/model_loaders.py:242-253. */
+int32_t tedspad_linear_fwd(const float *x, const float *w, const float *scale, const float *shift, float *y,
+                           int32_t B, int32_t K, int32_t N, int32_t relu, void *stream);
+
+/* y[b,:] = x[b,:] / max(||x[b,:]||_2, eps): nn.functional.normalize(p=2, dim=1), model_loaders.py:253. */
+int32_t tedspad_l2_normalize_rows(const float *x, float *y, int32_t B, int32_t N, float eps, void *stream);
+
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) + F.pad to the skip size
+ * (unet_parts.py:50,56-62), written straight into its channel slice of the concat buffer (:67).
+ * x: (n,h,w,c) pixel stride ldx -> y: (n,ho,wo,c) pixel stride ldy; rows/cols outside
+ * [pad_top, pad_top+2h) x [pad_left, pad_left+2w) are zero-filled. */
+int32_t tedspad_upsample_bilinear2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c,
+                                        int32_t ldx, int32_t ldy, int32_t ho, int32_t wo, int32_t pad_top,
+                                        int32_t pad_left, int32_t dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEDSPAD_HIP_H */

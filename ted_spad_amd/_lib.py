@@ -1,0 +1,77 @@
+"""ctypes binding of libtedspad_hip.so (C ABI: include/tedspad_hip.h).
+
+The HIP library is the ONLY compute path of this package: if it is missing, loading fails
+loudly -- there is no eager/PyTorch/CPU fallback (a fallback would void every parity claim).
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtedspad_hip.so")
+
+F16, BF16 = 0, 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "t", "h", "w", "cin", "ldx", "cout", "ldy", "ldres",
+        "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
+        "to", "ho", "wo", "relu", "dtype")]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "t", "h", "w", "c", "ldx", "ldy",
+        "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
+        "to", "ho", "wo", "pad_zero", "dtype")]
+
+
+# name -> (restype, argtypes); must list every symbol include/tedspad_hip.h declares
+_P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
+SYMBOLS = {
+    "tedspad_abi_version": (_I32, []),
+    "tedspad_last_error": (C.c_char_p, []),
+    "tedspad_conv_kpad": (_I32, [C.POINTER(ConvDesc)]),
+    "tedspad_conv_cout_pad": (_I32, [C.POINTER(ConvDesc)]),
+    "tedspad_conv_ktab_entries": (_I32, [C.POINTER(ConvDesc)]),
+    "tedspad_conv_build_ktab": (_I32, [C.POINTER(ConvDesc), _P]),
+    "tedspad_conv_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "tedspad_maxpool_fwd": (_I32, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "tedspad_global_avgpool_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_clip_to_channels_last": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _P]),
+    "tedspad_channels_last_to_nchw": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_upsample_bilinear2x_fwd": (_I32, [_P, _P] + [_I32] * 11 + [_P]),
+    "tedspad_linear_fwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_l2_normalize_rows": (_I32, [_P, _P, _I32, _I32, C.c_float, _P]),
+}
+
+_lib = None
+
+
+class TedSpadHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -m ted_spad_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TedSpadHipError(
+                "libtedspad_hip.so not found at %s -- the HIP extension is the only compute path "
+                "(no CPU/PyTorch fallback). Build it: python -c 'import __graft_entry__ as g; g.build()'" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        if l.tedspad_abi_version() != 1:
+            raise TedSpadHipError("libtedspad_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tedspad_last_error()
+        raise TedSpadHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,76 @@
+// Shared helpers for the gfx950 kernels of libtedspad_hip.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "tedspad_hip.h"
+
+namespace tedspad {
+
+void set_error(const char *fmt, ...);
+
+#define TS_REQUIRE(cond, ...)                     \
+    do {                                          \
+        if (!(cond)) {                            \
+            tedspad::set_error(__VA_ARGS__);      \
+            return TEDSPAD_EINVAL;                \
+        }                                         \
+    } while (0)
+
+inline int32_t check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return TEDSPAD_ELAUNCH;
+    }
+    return TEDSPAD_OK;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-bit storage types. Both run the same MFMA rate on CDNA4; f16 carries 3 more mantissa
+// bits, which is what the 1e-3 feature-parity gate needs (DESIGN.md "precision").
+struct F16 {
+    static constexpr int kDtype = TEDSPAD_F16;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) {
+        f = __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);  // saturate instead of inf
+        return __builtin_bit_cast(uint16_t, (_Float16)f);
+    }
+};
+
+struct BF16 {
+    static constexpr int kDtype = TEDSPAD_BF16;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = T::to_f32((uint16_t)(w[i] & 0xffffu));
+        f[2 * i + 1] = T::to_f32((uint16_t)(w[i] >> 16));
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f32(f[2 * i]) | ((uint32_t)T::from_f32(f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+}  // namespace tedspad

@@ -1,0 +1,257 @@
+// HBM-bound helpers of the I3D / UNet forward path for gfx950: max-pool, global average
+// pool and the layout conversions at the module boundary.  All of them move 16 bytes per
+// lane (8 channels of one channels-last pixel) so every wave instruction is a run of
+// full 128-byte lines; grids are sized >> 256 workgroups.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace tedspad {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+struct PoolKP {
+    const uint16_t *x;
+    uint16_t *y;
+    int Ti, Hi, Wi, C8, ldx, ldy;
+    int To, Ho, Wo;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw;
+    int pad_zero;
+    long total;  // n*to*ho*wo*C8
+};
+
+// max over the window, 8 channels per thread. Padded taps contribute 0 when pad_zero
+// (MaxPool3dSamePadding pads with zeros BEFORE pooling, i3d.py:41-45), else are skipped
+// (nn.MaxPool3d semantics, large_i3d.py:138-139).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % p.C8);
+        long r = idx / p.C8;
+        const int wo = (int)(r % p.Wo); r /= p.Wo;
+        const int ho = (int)(r % p.Ho); r /= p.Ho;
+        const int to = (int)(r % p.To);
+        const int n = (int)(r / p.To);
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = -3.0e38f;
+        bool padded = false;
+        for (int dt = 0; dt < p.kt; ++dt) {
+            const int it = to * p.st - p.pt + dt;
+            for (int dh = 0; dh < p.kh; ++dh) {
+                const int ih = ho * p.sh - p.ph + dh;
+                for (int dw = 0; dw < p.kw; ++dw) {
+                    const int iw = wo * p.sw - p.pw + dw;
+                    if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+                        const size_t off = ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.ldx + c8 * 8;
+                        float v[8];
+                        unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + off), v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) m[i] = __builtin_fmaxf(m[i], v[i]);
+                    } else {
+                        padded = true;
+                    }
+                }
+            }
+        }
+        if (padded && p.pad_zero) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = __builtin_fmaxf(m[i], 0.f);
+        }
+        const size_t yo = ((((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo) * p.ldy + c8 * 8;
+        *reinterpret_cast<uint4 *>(p.y + yo) = pack8<T>(m);
+    }
+}
+
+// mean over `spatial` pixels; one thread per (n, 8-channel chunk), fp32 accumulate + output.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const uint16_t *x, float *y, int n, int spatial, int c8n, int ldx) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * c8n) return;
+    const int c8 = idx % c8n, b = idx / c8n;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t *px = x + (size_t)b * spatial * ldx + c8 * 8;
+    for (int i = 0; i < spatial; ++i) {
+        float v[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(px + (size_t)i * ldx), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+    const float inv = 1.f / (float)spatial;
+    float *py = y + (size_t)b * c8n * 8 + c8 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) py[j] = s[j] * inv;
+}
+
+// fp32 (n,c,t,h,w) with arbitrary element strides -> 16-bit (n,t,h,w,cpad).
+// One thread per 8 output channels-last elements: cpad=4 -> two pixels, cpad=8 -> one.
+template <typename T>
+__global__ __launch_bounds__(256) void to_channels_last_kernel(const float *x, uint16_t *y, int c, int t, int h, int w, long sn,
+                                                                long sc, long st, long sh, long sw, int cpad, long total8) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
+        const int ppt = 8 / cpad;  // pixels per thread
+        long pix = idx * ppt;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        for (int j = 0; j < ppt; ++j) {
+            long r = pix + j;
+            const int iw = (int)(r % w); r /= w;
+            const int ih = (int)(r % h); r /= h;
+            const int it = (int)(r % t);
+            const long n = r / t;
+            const float *px = x + n * sn + it * st + ih * sh + iw * sw;
+            for (int ch = 0; ch < c; ++ch) v[j * cpad + ch] = px[ch * sc];
+        }
+        *reinterpret_cast<uint4 *>(y + idx * 8) = pack8<T>(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_nchw_kernel(const uint16_t *x, float *y, int c, long thw, int ldx, long total) {
+    // idx over (n, c, thw): writes coalesced along thw, reads strided (tiny tensors only)
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx % thw;
+        const long r = idx / thw;
+        const int ch = (int)(r % c);
+        const long n = r / c;
+        y[idx] = T::to_f32(x[(n * thw + p) * ldx + ch]);
+    }
+}
+
+// Bilinear x2 upsample, align_corners=True (nn.Upsample in unet_parts.py:50), written into a
+// channel slice of the (larger, zero-padded) skip-concat buffer: unet_parts.py:56-67.
+// fp32 index/lambda arithmetic follows torch's area_pixel_compute_source_index.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t *x, uint16_t *y, int h, int w, int C8, int ldx, int ldy,
+                                                          int Ho, int Wo, int py, int px, long total) {
+    const int oh_sz = 2 * h, ow_sz = 2 * w;
+    const float rh = oh_sz > 1 ? (float)(h - 1) / (float)(oh_sz - 1) : 0.f;
+    const float rw = ow_sz > 1 ? (float)(w - 1) / (float)(ow_sz - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long r = idx / C8;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const long n = r / Ho;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        const int uh = oh - py, uw = ow - px;
+        if ((unsigned)uh < (unsigned)oh_sz && (unsigned)uw < (unsigned)ow_sz) {
+            const float h1r = rh * uh, w1r = rw * uw;
+            const int h1 = (int)h1r, w1 = (int)w1r;
+            const int h1p = h1 < h - 1 ? 1 : 0, w1p = w1 < w - 1 ? 1 : 0;
+            const float hl1 = h1r - h1, hl0 = 1.f - hl1, wl1 = w1r - w1, wl0 = 1.f - wl1;
+            const uint16_t *p00 = x + ((n * h + h1) * w + w1) * (long)ldx + c8 * 8;
+            float v00[8], v01[8], v10[8], v11[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00), v00);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00 + (long)w1p * ldx), v01);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00 + (long)h1p * w * ldx), v10);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00 + ((long)h1p * w + w1p) * ldx), v11);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = hl0 * (wl0 * v00[i] + wl1 * v01[i]) + hl1 * (wl0 * v10[i] + wl1 * v11[i]);
+        }
+        *reinterpret_cast<uint4 *>(y + ((n * Ho + oh) * Wo + ow) * (long)ldy + c8 * 8) = pack8<T>(o);
+    }
+}
+
+inline int grid_for(long work_items) {
+    long g = (work_items + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;  // grid-stride the rest
+    return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace
+}  // namespace tedspad
+
+using namespace tedspad;
+
+extern "C" int32_t tedspad_abi_version(void) { return TEDSPAD_ABI_VERSION; }
+extern "C" const char *tedspad_last_error(void) { return g_err; }
+
+extern "C" int32_t tedspad_maxpool_fwd(const tedspad_pool_desc *d, const void *x, void *y, void *stream) {
+    TS_REQUIRE(d && x && y, "tedspad_maxpool_fwd: null pointer");
+    TS_REQUIRE(d->c > 0 && d->c % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->c && d->ldy >= d->c,
+               "tedspad_maxpool_fwd: c/ldx/ldy must be multiples of 8");
+    TS_REQUIRE(d->n > 0 && d->to > 0 && d->ho > 0 && d->wo > 0 && d->kt > 0 && d->kh > 0 && d->kw > 0 && d->st > 0 && d->sh > 0 && d->sw > 0,
+               "tedspad_maxpool_fwd: bad geometry");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_maxpool_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(d->dtype == TEDSPAD_F16 || d->dtype == TEDSPAD_BF16, "tedspad_maxpool_fwd: bad dtype");
+    TS_REQUIRE(d->pt >= 0 && d->ph >= 0 && d->pw >= 0 && d->pt < d->kt && d->ph < d->kh && d->pw < d->kw,
+               "tedspad_maxpool_fwd: front padding must be smaller than the window");
+    PoolKP p;
+    p.x = (const uint16_t *)x; p.y = (uint16_t *)y;
+    p.Ti = d->t; p.Hi = d->h; p.Wi = d->w; p.C8 = d->c / 8; p.ldx = d->ldx; p.ldy = d->ldy;
+    p.To = d->to; p.Ho = d->ho; p.Wo = d->wo;
+    p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.st = d->st; p.sh = d->sh; p.sw = d->sw; p.pt = d->pt; p.ph = d->ph; p.pw = d->pw;
+    p.pad_zero = d->pad_zero;
+    p.total = (long)d->n * d->to * d->ho * d->wo * p.C8;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_kernel<F16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(maxpool_kernel<BF16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+    return check_launch("tedspad_maxpool_fwd");
+}
+
+extern "C" int32_t tedspad_global_avgpool_fwd(const void *x, float *y, int32_t n, int32_t spatial, int32_t c, int32_t ldx,
+                                              int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && spatial > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldx >= c, "tedspad_global_avgpool_fwd: bad arguments");
+    TS_REQUIRE(((uintptr_t)x) % 16 == 0, "tedspad_global_avgpool_fwd: x must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_global_avgpool_fwd: bad dtype");
+    const int items = n * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(avgpool_kernel<F16>, dim3((items + 255) / 256), dim3(256), 0, s, (const uint16_t *)x, y, n, spatial, c / 8, ldx);
+    else hipLaunchKernelGGL(avgpool_kernel<BF16>, dim3((items + 255) / 256), dim3(256), 0, s, (const uint16_t *)x, y, n, spatial, c / 8, ldx);
+    return check_launch("tedspad_global_avgpool_fwd");
+}
+
+extern "C" int32_t tedspad_clip_to_channels_last(const float *x, void *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w,
+                                                 int64_t sn, int64_t sc, int64_t st_, int64_t sh, int64_t sw, int32_t cpad,
+                                                 int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && t > 0 && h > 0 && w > 0, "tedspad_clip_to_channels_last: bad arguments");
+    TS_REQUIRE((cpad == 4 || cpad == 8) && c <= cpad, "tedspad_clip_to_channels_last: cpad must be 4 or 8 and >= c");
+    TS_REQUIRE(cpad == 8 || w % 2 == 0, "tedspad_clip_to_channels_last: cpad=4 packs pixel pairs, w must be even");
+    TS_REQUIRE(((uintptr_t)y) % 16 == 0, "tedspad_clip_to_channels_last: y must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_clip_to_channels_last: bad dtype");
+    const long total8 = (long)n * t * h * w * cpad / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(to_channels_last_kernel<F16>, dim3(grid_for(total8)), dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, cpad, total8);
+    else hipLaunchKernelGGL(to_channels_last_kernel<BF16>, dim3(grid_for(total8)), dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, cpad, total8);
+    return check_launch("tedspad_clip_to_channels_last");
+}
+
+extern "C" int32_t tedspad_channels_last_to_nchw(const void *x, float *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w,
+                                                 int32_t ldx, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && t > 0 && h > 0 && w > 0 && ldx >= c, "tedspad_channels_last_to_nchw: bad arguments");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_channels_last_to_nchw: bad dtype");
+    const long thw = (long)t * h * w, total = (long)n * c * thw;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(to_nchw_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, c, thw, ldx, total);
+    else hipLaunchKernelGGL(to_nchw_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, c, thw, ldx, total);
+    return check_launch("tedspad_channels_last_to_nchw");
+}
+
+extern "C" int32_t tedspad_upsample_bilinear2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx,
+                                                   int32_t ldy, int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left,
+                                                   int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c,
+               "tedspad_upsample_bilinear2x_fwd: bad arguments");
+    TS_REQUIRE(pad_top >= 0 && pad_left >= 0 && ho >= 2 * h + pad_top && wo >= 2 * w + pad_left,
+               "tedspad_upsample_bilinear2x_fwd: output smaller than the upsampled map");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_upsample_bilinear2x_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_upsample_bilinear2x_fwd: bad dtype");
+    const long total = (long)n * ho * wo * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, (uint16_t *)y, h, w, c / 8, ldx, ldy, ho, wo, pad_top, pad_left, total);
+    else hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, (uint16_t *)y, h, w, c / 8, ldx, ldy, ho, wo, pad_top, pad_left, total);
+    return check_launch("tedspad_upsample_bilinear2x_fwd");
+}

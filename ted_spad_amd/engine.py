@@ -1,0 +1,230 @@
+"""Host-side plumbing between torch tensors (device memory, streams) and the C-ABI HIP
+library: channels-last activation views, weight packing / BatchNorm folding, launchers.
+
+torch is used here for device memory and the current HIP stream only; every arithmetic
+op of the hot path is a kernel of libtedspad_hip.so. Nothing in this file computes on the
+CPU and nothing falls back to torch ops: CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, PoolDesc, check
+
+DTYPES = {"f16": (torch.float16, _lib.F16), "bf16": (torch.bfloat16, _lib.BF16)}
+DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e-3 feature gate
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.TedSpadHipError(
+            "%s: got a %s tensor. ted_spad_amd runs only on MI355X through libtedspad_hip.so; "
+            "there is no CPU path (use oracle/ for a CPU reference in tests)." % (what, t.device))
+
+
+@dataclass
+class Act:
+    """A channels-last activation: `buf` is (n, t, h, w, ld) 16-bit; this view covers
+    channels [coff, coff + c) of every pixel (concat slices share one buffer)."""
+    buf: torch.Tensor
+    c: int
+    coff: int = 0
+
+    @property
+    def dims(self) -> Tuple[int, int, int, int]:
+        return tuple(self.buf.shape[:4])
+
+    @property
+    def ld(self) -> int:
+        return self.buf.shape[4]
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + self.coff * 2
+
+    def slice(self, coff: int, c: int) -> "Act":
+        assert coff % 8 == 0 and c % 8 == 0 and coff + c <= self.c
+        return Act(self.buf, c, self.coff + coff)
+
+    @staticmethod
+    def empty(n, t, h, w, c, dtype, device) -> "Act":
+        return Act(torch.empty((n, t, h, w, c), dtype=dtype, device=device), c)
+
+
+def conv_out(size, k, s, pf, pb):
+    return (size + pf + pb - k) // s + 1
+
+
+def same_pads(size, k, s):
+    """TF-SAME front/back zero padding of one dim (reference rule: i3d.py:82-86,101-106)."""
+    total = max(k - s, 0) if size % s == 0 else max(k - (size % s), 0)
+    return total // 2, total - total // 2
+
+
+def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
+    """y = gamma*(x + b - mean)/sqrt(var+eps) + beta  ==  x*scale + shift   (fp64 -> fp32)."""
+    inv = gamma.double() / torch.sqrt(var.double() + eps)
+    shift = beta.double() - mean.double() * inv
+    if conv_bias is not None:
+        shift = shift + conv_bias.double() * inv
+    return inv.float(), shift.float()
+
+
+class PackedConv:
+    """One convolution resident on the device in the kernel's layout:
+    weights [cout_pad][kpad] 16-bit with K ordered (dt, dh, dw, ci); fp32 scale/shift;
+    per-input-geometry K-chunk gather tables."""
+
+    def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(1, 1, 1),
+                 dtype: str = DEFAULT_DTYPE, device="cuda", pair_w: Optional[int] = None):
+        """weight: (cout, cin, kt, kh, kw) fp32 (2-D convs: kt = 1).
+        pair_w: if not None, the conv has cin <= 4 and stride 2 along W with FRONT pad `pair_w`:
+        it is rewritten over pixel PAIRS (cin' = 8 = 2 pixels x 4 channels, kw' = ceil((kw+shift)/2),
+        stride_w' = 1), so the Cin=3 stems run on the generic 8-channel-chunk gather."""
+        w = weight.detach().to(torch.float32).cpu()
+        cout, cin, kt, kh, kw = w.shape
+        st, sh, sw = stride
+        self.pair = pair_w is not None
+        if self.pair:
+            assert cin <= 4 and sw == 2
+            pw2 = (pair_w + 1) // 2
+            shift_k = 2 * pw2 - pair_w
+            kw2 = (kw + shift_k + 1) // 2
+            w2 = torch.zeros(cout, 8, kt, kh, kw2)
+            for d in range(kw2):
+                for j in range(2):
+                    k = 2 * d + j - shift_k
+                    if 0 <= k < kw:
+                        w2[:, j * 4:j * 4 + cin, :, :, d] = w[:, :, :, :, k]
+            w, cin, kw, sw = w2, 8, kw2, 1
+            self.pair_pw = pw2
+        elif cin % 8:
+            cpad = (cin + 7) // 8 * 8
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cpad - cin))
+            cin = cpad
+        self.cout_real = cout
+        self.cout = (cout + 7) // 8 * 8
+        self.cin, self.k, self.stride = cin, (kt, kh, kw), (st, sh, sw)
+        self.torch_dtype, self.dtype_code = DTYPES[dtype]
+        d = self._desc(1, 1, 1, 1, cin, (0, 0, 0), (1, 1, 1), self.cout, 0, True)
+        kpad = _lib.lib().tedspad_conv_kpad(d)
+        cpad = _lib.lib().tedspad_conv_cout_pad(d)
+        K = kt * kh * kw * cin
+        wp = torch.zeros(cpad, kpad, dtype=torch.float32)
+        wp[:cout, :K] = w.permute(0, 2, 3, 4, 1).reshape(cout, K)
+        self.w = wp.to(self.torch_dtype).to(device)
+        sc = torch.zeros(cpad, dtype=torch.float32)
+        sf = torch.zeros(cpad, dtype=torch.float32)
+        sc[:cout] = scale.detach().float().cpu()
+        sf[:cout] = shift.detach().float().cpu()
+        self.scale, self.shift = sc.to(device), sf.to(device)
+        self.device = device
+        self._ktabs = {}
+
+    def _desc(self, n, t, h, w, ldx, pads, out, ldy, ldres, relu):
+        kt, kh, kw = self.k
+        st, sh, sw = self.stride
+        return ConvDesc(n=n, t=t, h=h, w=w, cin=self.cin, ldx=ldx, cout=self.cout, ldy=ldy, ldres=ldres,
+                        kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pads[0], ph=pads[1], pw=pads[2],
+                        to=out[0], ho=out[1], wo=out[2], relu=int(relu), dtype=self.dtype_code)
+
+    def _ktab(self, d: ConvDesc):
+        key = (d.t, d.h, d.w, d.ldx)
+        tab = self._ktabs.get(key)
+        if tab is None:
+            n = _lib.lib().tedspad_conv_ktab_entries(d)
+            host = (C.c_int32 * (2 * n))()
+            check(_lib.lib().tedspad_conv_build_ktab(d, host), "tedspad_conv_build_ktab")
+            tab = torch.frombuffer(host, dtype=torch.int32).clone().to(self.device)
+            self._ktabs[key] = tab
+        return tab
+
+    def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
+                 residual: Optional[Act] = None, relu=True, sigmoid=False) -> Act:
+        """pads: FRONT zero padding (t,h,w); pads_back defaults to pads (symmetric, as nn.Conv3d)."""
+        n, t, h, w = x.dims
+        assert x.c == self.cin, "conv expects %d input channels, got %d" % (self.cin, x.c)
+        pb = pads if pads_back is None else pads_back
+        kt, kh, kw = self.k
+        st, sh, sw = self.stride
+        o = (conv_out(t, kt, st, pads[0], pb[0]), conv_out(h, kh, sh, pads[1], pb[1]), conv_out(w, kw, sw, pads[2], pb[2]))
+        if out is None:
+            out = Act.empty(n, o[0], o[1], o[2], self.cout, self.torch_dtype, x.buf.device)
+        assert out.dims == (n,) + o and out.c == self.cout, (out.dims, (n,) + o, out.c, self.cout)
+        if residual is not None:
+            assert residual.dims == out.dims and residual.c == self.cout
+        d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
+        check(_lib.lib().tedspad_conv_fwd(C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(),
+                                          self.scale.data_ptr(), self.shift.data_ptr(),
+                                          residual.ptr if residual is not None else None, out.ptr,
+                                          int(sigmoid), _stream_ptr()), "tedspad_conv_fwd")
+        return out
+
+
+def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: Optional[Act] = None) -> Act:
+    n, t, h, w = x.dims
+    pb = pads if pads_back is None else pads_back
+    o = tuple(conv_out(sz, kk, ss, pf, pbk) for sz, kk, ss, pf, pbk in zip((t, h, w), k, s, pads, pb))
+    if out is None:
+        out = Act.empty(n, o[0], o[1], o[2], x.c, x.buf.dtype, x.buf.device)
+    code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
+    d = PoolDesc(n=n, t=t, h=h, w=w, c=x.c, ldx=x.ld, ldy=out.ld, kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2],
+                 pt=pads[0], ph=pads[1], pw=pads[2], to=o[0], ho=o[1], wo=o[2], pad_zero=int(pad_zero), dtype=code)
+    check(_lib.lib().tedspad_maxpool_fwd(C.byref(d), x.ptr, out.ptr, _stream_ptr()), "tedspad_maxpool_fwd")
+    return out
+
+
+def global_avgpool(x: Act) -> torch.Tensor:
+    """(n,t,h,w,c) -> fp32 (n, c): mean over all pixels."""
+    n, t, h, w = x.dims
+    y = torch.empty((n, x.c), dtype=torch.float32, device=x.buf.device)
+    code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
+    check(_lib.lib().tedspad_global_avgpool_fwd(x.ptr, y.data_ptr(), n, t * h * w, x.c, x.ld, code, _stream_ptr()),
+          "tedspad_global_avgpool_fwd")
+    return y
+
+
+def clip_to_act(x: torch.Tensor, cpad: int, dtype: str = DEFAULT_DTYPE) -> Act:
+    """fp32 (n,c,t,h,w) (any strides) -> channels-last 16-bit Act. cpad=4 returns the
+    pixel-pair view (n,t,h,w/2,8) the stems consume; cpad=8 returns (n,t,h,w,8)."""
+    require_cuda(x, "clip_to_act")
+    if x.dtype != torch.float32:
+        x = x.float()
+    n, c, t, h, w = x.shape
+    tdt, code = DTYPES[dtype]
+    wv = w // 2 if cpad == 4 else w
+    buf = torch.empty((n, t, h, wv, 8), dtype=tdt, device=x.device)
+    sn, sc, st, sh, sw = x.stride()
+    check(_lib.lib().tedspad_clip_to_channels_last(x.data_ptr(), buf.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw,
+                                                   cpad, code, _stream_ptr()), "tedspad_clip_to_channels_last")
+    return Act(buf, 8)
+
+
+def act_to_nchw(x: Act, c: Optional[int] = None) -> torch.Tensor:
+    n, t, h, w = x.dims
+    c = x.c if c is None else c
+    y = torch.empty((n, c, t, h, w), dtype=torch.float32, device=x.buf.device)
+    code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
+    check(_lib.lib().tedspad_channels_last_to_nchw(x.ptr, y.data_ptr(), n, c, t, h, w, x.ld, code, _stream_ptr()),
+          "tedspad_channels_last_to_nchw")
+    return y
+
+
+def upsample2x_into(x: Act, out: Act, pad_top=0, pad_left=0):
+    """Bilinear x2 (align_corners=True) of `x` (t == 1) into the channel slice `out`, zero-padded to out's size."""
+    n, t, h, w = x.dims
+    no, to, ho, wo = out.dims
+    assert t == 1 and to == 1 and no == n and out.c == x.c
+    code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
+    check(_lib.lib().tedspad_upsample_bilinear2x_fwd(x.ptr, out.ptr, n, h, w, x.c, x.ld, out.ld, ho, wo, pad_top, pad_left,
+                                                     code, _stream_ptr()), "tedspad_upsample_bilinear2x_fwd")
+    return out

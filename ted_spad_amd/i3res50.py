@@ -1,0 +1,132 @@
+"""ResNet-50 I3D ("largei3d", 2048-d clip feature) on MI355X.
+
+Mirrors the reference module `I3Res50` (aux_code/models/large_i3d.py:130-263): same
+constructor arguments, same `state_dict` key names, `forward(x) -> (logits, feat)` and
+`extract_features(x) -> (B, 2048, 1, 1, 1)`. The arithmetic is the HIP implicit-GEMM conv
+kernel with the BatchNorm / residual / ReLU epilogue fused (include/tedspad_hip.h); the
+network is just the launch sequence below.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .params import BNParams, ConvParams, LinearParams, params_signature
+
+# (planes, blocks, spatial stride, temp_conv) -- large_i3d.py:142-145
+LAYER_PLAN = ((64, 3, 1, (1, 1, 1)), (128, 4, 2, (1, 0, 1, 0)), (256, 6, 2, (1, 0, 1, 0, 1, 0)), (512, 3, 2, (0, 1, 0)))
+
+
+class Bottleneck(nn.Module):
+    """Parameter layout of large_i3d.py:42-84 (conv1 3x1x1|1x1x1, conv2 1x3x3, conv3 1x1x1)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, has_down, temp_conv):
+        super().__init__()
+        self.conv1 = ConvParams(inplanes, planes, (1 + 2 * temp_conv, 1, 1), init="kaiming_fan_out")
+        self.bn1 = BNParams(planes)
+        self.conv2 = ConvParams(planes, planes, (1, 3, 3), init="kaiming_fan_out")
+        self.bn2 = BNParams(planes)
+        self.conv3 = ConvParams(planes, planes * 4, (1, 1, 1), init="kaiming_fan_out")
+        self.bn3 = BNParams(planes * 4)
+        self.downsample = None
+        if has_down:
+            self.downsample = nn.Sequential(ConvParams(inplanes, planes * 4, (1, 1, 1), init="kaiming_fan_out"),
+                                            BNParams(planes * 4))
+        self.stride, self.temp_conv = stride, temp_conv
+
+
+class I3Res50(nn.Module):
+    def __init__(self, num_classes=400, use_nl=False, dtype=E.DEFAULT_DTYPE):
+        super().__init__()
+        if use_nl:
+            raise NotImplementedError("NonLocalBlock is never enabled by the reference (model_loaders.py:262)")
+        self.conv1 = ConvParams(3, 64, (5, 7, 7), init="kaiming_fan_out")
+        self.bn1 = BNParams(64)
+        inplanes = 64
+        for li, (planes, blocks, stride, tc) in enumerate(LAYER_PLAN, 1):
+            blks = []
+            for i in range(blocks):
+                blks.append(Bottleneck(inplanes, planes, stride if i == 0 else 1, i == 0, tc[i]))
+                inplanes = planes * 4
+            setattr(self, "layer%d" % li, nn.Sequential(*blks))
+        self.fc = LinearParams(2048, num_classes)
+        self.drop_p = 0.5
+        self.compute_dtype = dtype
+        self._packed = None
+        self._packed_sig = None
+
+    # ---- weight packing (BN folded to fp32 scale/shift; 16-bit K-major weights) --------
+    def _bn_fold(self, bn: BNParams):
+        return E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+    def packed(self):
+        sig = (params_signature(self), self.compute_dtype)
+        if self._packed is None or self._packed_sig != sig:
+            dev = self.conv1.weight.device
+            E.require_cuda(self.conv1.weight, "I3Res50")
+            P = {}
+            s, b = self._bn_fold(self.bn1)
+            P["stem"] = E.PackedConv(self.conv1.weight, s, b, stride=(2, 2, 2), dtype=self.compute_dtype, device=dev, pair_w=3)
+            for li in range(1, 5):
+                for i, blk in enumerate(getattr(self, "layer%d" % li)):
+                    p = "layer%d.%d." % (li, i)
+                    s, b = self._bn_fold(blk.bn1)
+                    P[p + "conv1"] = E.PackedConv(blk.conv1.weight, s, b, dtype=self.compute_dtype, device=dev)
+                    s, b = self._bn_fold(blk.bn2)
+                    P[p + "conv2"] = E.PackedConv(blk.conv2.weight, s, b, stride=(1, blk.stride, blk.stride),
+                                                  dtype=self.compute_dtype, device=dev)
+                    s, b = self._bn_fold(blk.bn3)
+                    P[p + "conv3"] = E.PackedConv(blk.conv3.weight, s, b, dtype=self.compute_dtype, device=dev)
+                    if blk.downsample is not None:
+                        s, b = self._bn_fold(blk.downsample[1])
+                        P[p + "down"] = E.PackedConv(blk.downsample[0].weight, s, b, stride=(1, blk.stride, blk.stride),
+                                                     dtype=self.compute_dtype, device=dev)
+            self._packed, self._packed_sig = P, sig
+        return self._packed
+
+    # ---- the launch sequence ---------------------------------------------------------------
+    def _trunk(self, x: torch.Tensor, taps=None) -> E.Act:
+        """conv1 .. layer4 (large_i3d.py:229-238 == :251-260) on a (B,3,T,H,W) fp32 clip batch."""
+        if self.training:
+            raise NotImplementedError("train-mode (batch-statistics BN + backward) is not built yet; call .eval()")
+        E.require_cuda(x, "I3Res50")
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise ValueError("expected (B,3,T,H,W), got %s" % (tuple(x.shape),))
+        if x.shape[4] % 2:
+            raise ValueError("W must be even")
+        P = self.packed()
+        a = E.clip_to_act(x, cpad=4, dtype=self.compute_dtype)           # (B,T,H,W/2, 2px x 4ch)
+        a = P["stem"](a, pads=(2, 3, P["stem"].pair_pw), pads_back=(2, 3, 1))   # 5x7x7 s2 p(2,3,3) + BN + ReLU
+        if taps is not None:
+            taps["stem"] = a
+        a = E.maxpool(a, (2, 3, 3), (2, 2, 2))                           # large_i3d.py:138
+        if taps is not None:
+            taps["maxpool1"] = a
+        for li in range(1, 5):
+            if li == 2:
+                a = E.maxpool(a, (2, 1, 1), (2, 1, 1))                   # large_i3d.py:139
+            for i, blk in enumerate(getattr(self, "layer%d" % li)):
+                p = "layer%d.%d." % (li, i)
+                h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
+                h = P[p + "conv2"](h, pads=(0, 1, 1))
+                res = P[p + "down"](a, relu=False) if blk.downsample is not None else a
+                a = P[p + "conv3"](h, residual=res, relu=True)           # bn3 + (+= residual) + ReLU fused
+            if taps is not None:
+                taps["layer%d" % li] = a
+        return a
+
+    def extract_features(self, x: torch.Tensor) -> torch.Tensor:
+        """large_i3d.py:249-263 -> (B, 2048, 1, 1, 1) fp32."""
+        a = self._trunk(x)
+        return E.global_avgpool(a).view(x.shape[0], -1, 1, 1, 1)
+
+    def forward(self, x: torch.Tensor):
+        """large_i3d.py:228-246 -> (logits (B,nc), feat). `feat = x.squeeze()` drops the batch
+        dim at B=1 exactly like the reference. Dropout is identity in eval."""
+        from . import head
+        f = E.global_avgpool(self._trunk(x))
+        feat = f.view(x.shape[0], -1, 1, 1, 1).squeeze()
+        logits = head.linear(f, self.fc.weight, self.fc.bias)
+        return logits, feat

@@ -1,0 +1,157 @@
+"""Drop-in for the reference's model factory `aux_code/model_loaders.py`: same function
+names, arguments, return conventions, print messages and checkpoint-key fallbacks, with
+the networks running on MI355X HIP kernels (libtedspad_hip.so).
+
+    load_fa_model(saved_model_file=None, arch='unet++')                       model_loaders.py:17-52
+    load_ft_model(arch='r3d', saved_model_file=None, num_classes=400,
+                  kin_pretrained=False)                                       model_loaders.py:56-90
+    mlp, wrapper_i3d                                                          model_loaders.py:235-268
+
+In scope: arch 'largei3d' and 'i3d' for ft, 'unet' for fa (the architectures whose source
+is part of the reference). 'unet++', 'r3d_18', 'mvitv2' and fb 'r50' are third-party models
+(segmentation_models_pytorch / torchvision) that are out of scope: they
+raise NotImplementedError rather than silently falling back.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from . import head
+from .i3res50 import I3Res50
+from .params import BNParams, LinearParams
+
+
+class mlp(nn.Module):
+    """2048 -> 512 -> 128 projection, BN1d after each Linear, L2-normalised output
+    (model_loaders.py:235-254). State-dict keys: fc1.{weight,bias}, bn1.*, bn2.*, fc2.weight."""
+
+    def __init__(self, final_embedding_size=128, use_normalization=True):
+        super().__init__()
+        self.final_embedding_size = final_embedding_size
+        self.use_normalization = use_normalization
+        self.fc1 = LinearParams(2048, 512, bias=True)
+        self.bn1 = BNParams(512)
+        self.bn2 = BNParams(128)
+        self.fc2 = LinearParams(512, final_embedding_size, bias=False)
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("train-mode mlp (batch-statistics BN1d + backward) is not built yet; call .eval()")
+        if x.dim() != 2:
+            # the reference's BatchNorm1d raises here too when I3Res50.forward squeezed B=1 away
+            raise ValueError("mlp expects (B, 2048) with B >= 2, got %s" % (tuple(x.shape),))
+        h = head.linear(x, self.fc1.weight, self.fc1.bias, bn=self.bn1, relu=True)
+        h = head.linear(h, self.fc2.weight, None, bn=self.bn2, relu=False)
+        return head.l2_normalize(h)
+
+
+class wrapper_i3d(nn.Module):
+    """model_loaders.py:258-268: returns (pred, mlp(feature)); keys `i3d.*`, `mlp.*`."""
+
+    def __init__(self, num_classes=102, dtype=E.DEFAULT_DTYPE):
+        super().__init__()
+        self.i3d = I3Res50(num_classes=num_classes, use_nl=False, dtype=dtype)
+        self.mlp = mlp()
+
+    def forward(self, x):
+        pred, feature = self.i3d(x)
+        feature = self.mlp(feature)
+        return pred, feature
+
+
+def build_i3d_classifier(num_classes=400, pretrained=True):
+    """model_loaders.py:171-182."""
+    from .inception_i3d import InceptionI3d
+    temp_classes = 0
+    if pretrained:
+        temp_classes = num_classes
+        num_classes = 400
+    model = InceptionI3d(num_classes=num_classes, dropout_keep_prob=0.5)
+    if pretrained:
+        saved_weights = torch.load(os.path.join("..", "saved_models", "rgb_imagenet.pt"))
+        model.load_state_dict(saved_weights, strict=True)
+    if pretrained and temp_classes != 400:
+        model.replace_logits(temp_classes)
+    return model
+
+
+def build_largei3d_classifier(num_classes=400, pretrained=True):
+    """model_loaders.py:185-196."""
+    temp_classes = 0
+    if pretrained:
+        temp_classes = num_classes
+        num_classes = 400
+    model = wrapper_i3d(num_classes=num_classes)
+    if pretrained:
+        saved_weights = torch.load(os.path.join("..", "saved_models", "i3d_r50_kinetics.pth"))
+        model.i3d.load_state_dict(saved_weights, strict=True)
+    if pretrained and temp_classes != 400:
+        model.i3d.fc = LinearParams(512 * 4, temp_classes)
+    return model
+
+
+def _strip_module(sd):
+    return OrderedDict((k[7:], v) for k, v in sd.items())  # remove 'module.' (DataParallel checkpoints)
+
+
+def load_fa_model(saved_model_file=None, arch="unet++"):
+    if arch == "unet++":
+        raise NotImplementedError("arch 'unet++' is segmentation_models_pytorch's UnetPlusPlus (third-party, not part of "
+                                  "the reference repo): out of scope. Use arch='unet'.")
+    elif arch == "unet":
+        from .unet import UNet
+        fa_model = UNet(n_channels=3, n_classes=3)
+    else:
+        print(f"Architecture {arch} invalid for fa_model. Try 'unet' or 'unet++'")
+        return None
+    if saved_model_file:
+        saved_dict = torch.load(saved_model_file)
+        try:
+            fa_model.load_state_dict(saved_dict["fa_model_state_dict"], strict=True)
+        except Exception:
+            fa_model.load_state_dict(_strip_module(saved_dict["fa_model_state_dict"]), strict=True)
+        print(f"fa_model loaded from {saved_model_file} successfully!")
+    else:
+        print("fa_model freshly initialized!")
+    return fa_model
+
+
+def load_ft_model(arch="r3d", saved_model_file=None, num_classes=400, kin_pretrained=False):
+    if arch == "i3d":
+        ft_model = build_i3d_classifier(num_classes=num_classes, pretrained=kin_pretrained)
+    elif arch == "largei3d":
+        ft_model = build_largei3d_classifier(num_classes=num_classes, pretrained=kin_pretrained)
+    elif arch in ("mvitv2", "r3d_18"):
+        raise NotImplementedError("arch '%s' is a torchvision model (third-party): out of scope." % arch)
+    else:
+        print(f"Architecture {arch} invalid for ft_model. Try 'i3d', 'largei3d', 'mvitv2', or 'r3d_18'.")
+        return
+    if saved_model_file:
+        saved_dict = torch.load(saved_model_file)
+        try:
+            ft_model.load_state_dict(saved_dict["ft_model_state_dict"], strict=True)
+        except Exception:
+            try:
+                new_state_dict = OrderedDict((k.replace("scale", "weight"), v)  # FrozenBN-style Kinetics ckpts (:80)
+                                             for k, v in saved_dict["ft_model_state_dict"].items())
+                ft_model.load_state_dict(new_state_dict, strict=True)
+            except Exception:
+                ft_model.i3d.load_state_dict(saved_dict["ft_model_state_dict"], strict=True)
+        print(f"ft_model loaded from {saved_model_file} successfully!")
+    else:
+        print(f"ft_model freshly initialized! Pretrained: {kin_pretrained}")
+    return ft_model
+
+
+def load_fb_model(arch="r50", saved_model_file=None, num_pa=7, ssl=False, pretrained=True):
+    """model_loaders.py:94-120. fb is torchvision's ResNet-50 (third-party): not built."""
+    if arch != "r50":
+        print(f"Architecture {arch} invalid for fb_model. Try 'r50'")
+        return
+    raise NotImplementedError("fb 'r50' is torchvision's resnet50 (third-party): out of scope for this path; the "
+                              "training step takes fb embeddings as an input (DESIGN.md).")

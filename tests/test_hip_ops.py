@@ -1,0 +1,152 @@
+"""-m gpu: each HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs (values pre-rounded to the 16-bit storage type, so the only differences are
+fp32 summation order and the final 16-bit rounding)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_tensor
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, (n,t,h,w), cin, cout, k, stride, pads_front, pads_back, residual
+    ("pointwise_64_256_res", (2, 4, 13, 11), 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (0, 0, 0), True),
+    ("t3x1x1", (2, 4, 9, 10), 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 0, 0), False),
+    ("s1x3x3", (1, 4, 15, 14), 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1), False),
+    ("s1x3x3_stride2", (2, 2, 55, 55), 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (0, 1, 1), False),
+    ("down_stride2", (2, 2, 55, 55), 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (0, 0, 0), False),
+    ("k3x3x3_same", (1, 8, 14, 14), 96, 208, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), False),
+    ("k3x3x3_cin16", (1, 4, 14, 14), 16, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), False),
+    ("k3x3x3_cin24_cout24", (2, 4, 7, 7), 24, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), False),
+    ("asym_same_pad", (1, 5, 9, 9), 32, 64, (3, 3, 3), (2, 2, 2), (0, 1, 1), (1, 1, 1), False),
+    ("big_k_small_m", (2, 2, 7, 7), 2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 0, 0), False),
+    ("unet_2d_3x3", (3, 1, 28, 28), 256, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (0, 1, 1), False),
+    ("ragged_m_1px", (1, 1, 1, 1), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (0, 0, 0), False),
+]
+
+
+def _round(t, dt):
+    return t.to(dt).float()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_fused(case, dtype):
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    name, dims, cin, cout, k, stride, pf, pb, use_res = case
+    tdt = E.DTYPES[dtype][0]
+    n, t, h, w = dims
+    x = _round(synth_tensor(1, name + "x", (n, t, h, w, cin), -1, 1), tdt)
+    wgt = _round(synth_tensor(1, name + "w", (cout, cin) + k, -1, 1) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5, tdt)
+    scale = synth_tensor(1, name + "s", (cout,), 0.5, 1.5)
+    shift = synth_tensor(1, name + "b", (cout,), -0.3, 0.3)
+    ref_nores = conv_cl(x, wgt, scale, shift, stride, pf, pb, None, relu=False)
+    res = _round(synth_tensor(1, name + "r", tuple(ref_nores.shape), -1, 1), tdt) if use_res else None
+    ref = conv_cl(x, wgt, scale, shift, stride, pf, pb, res, relu=True)
+    pc = E.PackedConv(wgt, scale, shift, stride=stride, dtype=dtype, device="cuda")
+    xa = E.Act(x.to(tdt).cuda(), cin)
+    ra = E.Act(res.to(tdt).cuda(), cout) if use_res else None
+    out = pc(xa, pads=pf, pads_back=pb, residual=ra, relu=True)
+    torch.cuda.synchronize()
+    got = out.buf.float().cpu()
+    assert got.shape == ref.shape
+    tol = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    err = (got - ref).abs()
+    bound = tol * ref.abs() + 1e-3
+    assert bool((err <= bound).all()), "max err %g at ref %g" % (float(err.max()), float(ref.abs().max()))
+    assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
+
+
+def test_conv_into_concat_slice_and_from_slice():
+    """Inception-style: write into a channel slice of a wider tensor, read from a slice."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = torch.float16
+    x = _round(synth_tensor(2, "cx", (2, 4, 7, 7, 96), -1, 1), tdt)
+    wgt = _round(synth_tensor(2, "cw", (32, 64, 1, 1, 1), -0.2, 0.2), tdt)
+    scale, shift = torch.ones(32), torch.zeros(32)
+    ref = conv_cl(x[..., 32:96], wgt, scale, shift, relu=False)
+    pc = E.PackedConv(wgt, scale, shift, dtype="f16", device="cuda")
+    big = E.Act(torch.full((2, 4, 7, 7, 80), 7.0, dtype=tdt, device="cuda"), 80)
+    pc(E.Act(x.to(tdt).cuda(), 96).slice(32, 64), out=big.slice(40, 32), relu=False)
+    torch.cuda.synchronize()
+    got = big.buf.float().cpu()
+    assert bool((got[..., :40] == 7).all()) and bool((got[..., 72:] == 7).all())  # neighbours untouched
+    assert rel_l2(got[..., 40:72], ref) < 4e-4
+
+
+@pytest.mark.parametrize("arch,k,pw", [("largei3d", (5, 7, 7), 3), ("i3d", (7, 7, 7), 2)])
+def test_stem_pixel_pair_rewrite(arch, k, pw):
+    """Cin=3 stride-2 stems run as an 8-channel conv over pixel pairs (engine.PackedConv pair_w)."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = torch.float16
+    clip = _round(synth_tensor(3, "clip" + arch, (2, 3, 8, 32, 32)), tdt)
+    wgt = _round(synth_tensor(3, "stemw" + arch, (64, 3) + k, -0.1, 0.1), tdt)
+    scale = synth_tensor(3, "stems", (64,), 0.5, 1.5)
+    shift = synth_tensor(3, "stemb", (64,), -0.3, 0.3)
+    if arch == "largei3d":
+        pf, pb = (2, 3, 3), (2, 3, 3)
+    else:  # TF-SAME for even sizes, k=7, s=2: (2,3)
+        pf, pb = (2, 2, 2), (3, 3, 3)
+    ref = conv_cl(clip.permute(0, 2, 3, 4, 1), wgt, scale, shift, (2, 2, 2), pf, pb)
+    pc = E.PackedConv(wgt, scale, shift, stride=(2, 2, 2), dtype="f16", device="cuda", pair_w=pw)
+    a = E.clip_to_act(clip.cuda(), cpad=4, dtype="f16")
+    kw2 = pc.k[2]
+    out = pc(a, pads=(pf[0], pf[1], pc.pair_pw), pads_back=(pb[0], pb[1], kw2 - 1 - pc.pair_pw))
+    torch.cuda.synchronize()
+    got = out.buf.float().cpu()
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < 4e-4
+
+
+POOLS = [
+    ("res_maxpool1", (2, 8, 30, 30), 64, (2, 3, 3), (2, 2, 2), (0, 0, 0), (0, 0, 0), False),
+    ("res_maxpool2", (2, 4, 9, 9), 256, (2, 1, 1), (2, 1, 1), (0, 0, 0), (0, 0, 0), False),
+    ("inc_1x3x3_s2_same", (1, 8, 28, 28), 64, (1, 3, 3), (1, 2, 2), (0, 0, 0), (0, 1, 1), True),
+    ("inc_3x3x3_s1_same", (1, 4, 14, 14), 480, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),
+    ("inc_3x3x3_s2_same", (1, 8, 28, 28), 32, (3, 3, 3), (2, 2, 2), (0, 0, 0), (1, 1, 1), True),
+    ("inc_2x2x2_s2_odd", (1, 4, 7, 7), 64, (2, 2, 2), (2, 2, 2), (0, 0, 0), (0, 1, 1), True),
+    ("unet_2x2", (3, 1, 14, 14), 128, (1, 2, 2), (1, 2, 2), (0, 0, 0), (0, 0, 0), False),
+]
+
+
+@pytest.mark.parametrize("case", POOLS, ids=[c[0] for c in POOLS])
+def test_maxpool_bit_exact(case):
+    from oracle.conv_ref import maxpool_cl
+    from ted_spad_amd import engine as E
+    name, dims, c, k, s, pf, pb, pz = case
+    # signed inputs: zero-padding semantics (i3d.py:41-45) differ from -inf padding here
+    x = synth_tensor(4, name, dims + (c,), -1, 1).half()
+    ref = maxpool_cl(x.float(), k, s, pf, pb, pad_zero=pz)
+    out = E.maxpool(E.Act(x.cuda(), c), k, s, pf, pb, pad_zero=pz)
+    torch.cuda.synchronize()
+    assert torch.equal(out.buf.float().cpu(), ref)
+
+
+def test_avgpool_and_layouts():
+    from ted_spad_amd import engine as E
+    x = synth_tensor(5, "avg", (3, 2, 7, 7, 2048), 0, 4).half()
+    got = E.global_avgpool(E.Act(x.cuda(), 2048)).cpu()
+    ref = x.float().mean(dim=(1, 2, 3))
+    assert rel_l2(got, ref) < 1e-6
+    clip = synth_tensor(5, "clip", (2, 3, 4, 6, 8))
+    for cpad in (4, 8):
+        a = E.clip_to_act(clip.cuda().permute(0, 1, 2, 4, 3).contiguous().permute(0, 1, 2, 4, 3), cpad=cpad)  # strided input
+        cl = a.buf.float().cpu().reshape(2, 4, 6, 8, cpad)
+        assert torch.equal(cl[..., :3], clip.permute(0, 2, 3, 4, 1).half().float())
+        assert bool((cl[..., 3:] == 0).all())
+    back = E.act_to_nchw(E.Act(clip.permute(0, 2, 3, 4, 1).half().cuda().contiguous(), 3), 3)
+    assert torch.equal(back.cpu(), clip.half().float())
+
+
+def test_bad_arguments_fail_loudly():
+    from ted_spad_amd import _lib, engine as E
+    with pytest.raises(_lib.TedSpadHipError):
+        E.clip_to_act(torch.zeros(1, 3, 2, 4, 4), cpad=4)  # CPU tensor: no CPU path
+    pc = E.PackedConv(torch.zeros(8, 8, 1, 1, 1), torch.ones(8), torch.zeros(8), device="cuda")
+    with pytest.raises(AssertionError):
+        pc(E.Act(torch.zeros(1, 1, 2, 2, 16, dtype=torch.float16, device="cuda"), 16))
