@@ -1,0 +1,171 @@
+"""Headline benchmark (BASELINE.json): clips/sec of 16x224^2 I3D feature extraction on
+1/2/4/8 MI355X, with the feature relative-L2 against the fp32 CPU path and the CPU
+extractor timed beside it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic UCF-Crime-length video per GPU:
+225 clip times x 10 crops = 2250 clip-forwards of (3,16,224,224) fp32 (cfg2), inputs
+resident in HBM before the timed region, features all-gathered over RCCL when N > 1 (cfg4;
+weak scaling: the video grows with N, each rank keeps 225 clip times) and copied to the host
+(the .npy rows). Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_CLIP = {"largei3d": 32.829145088, "i3d": 55.575138304}  # BASELINE.md §2 (conv MACs x 2)
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--arch", default="largei3d", choices=["largei3d", "i3d"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--batch", type=int, default=50, help="clips per forward")
+    ap.add_argument("--clip-times", type=int, default=225, help="clip times per GPU (7200 frames / 32)")
+    ap.add_argument("--crops", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ted_spad_amd import extraction, sharding
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.synth import synth_clips, synth_state_dict
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ft = load_ft_model(args.arch, num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    ft.load_state_dict(sd, strict=True)
+    for m in ft.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = args.dtype
+    ft = ft.to(dev).eval()
+    fx = ft.extract_features if hasattr(ft, "extract_features") else ft.i3d.extract_features
+    F = 2048 if args.arch == "largei3d" else 1024
+
+    # ---- this rank's shard of the synthetic video, resident in HBM -------------------------------
+    T_total = args.clip_times * world
+    lo, hi = sharding.shard_range(T_total, rank, world)
+    n_local = (hi - lo) * args.crops
+    shape = (3, 16, 224, 224)
+    clips = torch.empty((n_local,) + shape, dtype=torch.float32, device=dev)
+    for i in range(0, n_local, 25):
+        k = min(25, n_local - i)
+        clips[i:i + k] = synth_clips(0, k, shape, device=dev, first=lo * args.crops + i)
+    torch.cuda.synchronize()
+
+    feats = torch.empty((n_local, F), dtype=torch.float32, device=dev)
+    ev = []
+
+    def step(timed):
+        for i in range(0, n_local, args.batch):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            f = fx(clips[i:i + args.batch]).flatten(1)
+            if timed:
+                e1.record()
+                ev.append((e0, e1, f.shape[0]))
+            feats[i:i + f.shape[0]] = f
+        full = sharding.gather_video_features(feats.view(hi - lo, args.crops, F), T_total)
+        return full.cpu() if rank == 0 else full  # the .npy rows reach the host on rank 0
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(False)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    total_clips = T_total * args.crops * args.steps
+    value = total_clips / dt
+
+    # ---- roofline of the conv stack: algorithmic FLOPs of a forward / its device time (HIP events) ---
+    fwd_ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+    fwd_clips = sum(n for _, _, n in ev)
+    achieved = fwd_clips * GFLOP_PER_CLIP[args.arch] / fwd_ms  # GFLOP / ms == TFLOP/s
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "conv_igemm_kernel (all conv launches of one batch forward)",
+                "ms_per_forward": round(fwd_ms / len(ev), 3), "clips_per_forward": args.batch}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    res = {"metric": "clips/sec (16x224^2 I3D features)", "value": round(value, 2), "unit": "clips/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "cfg2 dali_extraction path: %s extract_features, %d clip times x %d crops = %d clip-forwards of "
+                                  "3x16x224x224 per GPU per step, random-init weights" % (args.arch, args.clip_times, args.crops, n_local),
+                      "global_batch": args.batch * world, "clips_per_step": T_total * args.crops,
+                      "parallelism": "clip-sharded x%d + RCCL all-gather of (T,10,F) features" % world},
+           "roofline": roofline}
+
+    # ---- CPU baseline + parity on a bounded sample: the oracle on this box's host cores ------------
+    if not args.no_cpu_baseline:
+        from oracle import i3res50_ref, inception_i3d_ref
+        cores = min(os.cpu_count(), 32)  # measured on the GPU box's host: 8/16/32/64/128 threads -> 6.6/9.2/10.2/7.7/4.0 clips/s
+        torch.set_num_threads(cores)
+        xs = clips[:10].cpu()
+        if args.arch == "largei3d":
+            sdc = {k[4:]: v for k, v in sd.items() if k.startswith("i3d.")}
+            cpu_fx = lambda x: i3res50_ref.extract_features(x, sdc)
+        else:
+            cpu_fx = lambda x: inception_i3d_ref.extract_features(x, sd)
+        with torch.no_grad():
+            ref = cpu_fx(xs)  # warm-up (also the parity reference)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cpu_fx(xs)
+            cdt = time.perf_counter() - t0
+        ref = ref.flatten(1)
+        got = out.reshape(-1, F)[:10]
+        rel = ((got.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1))
+        res["cpu_baseline"] = {"value": round(30.0 / cdt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+                               "sample": "oracle (fp32 torch CPU restatement) on the first 10 clips (one 10-crop group), 1 warm-up + 3 timed passes"}
+        res["feature_rel_l2_max"] = float(rel.max())
+        res["feature_rel_l2_tol"] = 1e-3
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

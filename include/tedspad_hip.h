@@ -43,6 +43,8 @@ typedef struct tedspad_conv_desc {
     int32_t to, ho, wo;          /* output pixels                                             */
     int32_t relu;                /* 1: ReLU after scale/shift(+residual)                      */
     int32_t dtype;               /* TEDSPAD_F16 | TEDSPAD_BF16                                */
+    int32_t tile_cfg;            /* 0: built-in heuristic; 1..tedspad_conv_num_tile_cfgs(): forced
+                                    (the host autotuner's analogue of cudnn.benchmark, train_anonymizer.py:28) */
 } tedspad_conv_desc;
 
 typedef struct tedspad_pool_desc {
@@ -62,6 +64,8 @@ const char *tedspad_last_error(void);
 /* K = kt*kh*kw*cin rounded up to the kernel's K tile; rows of the packed weight matrix. */
 int32_t tedspad_conv_kpad(const tedspad_conv_desc *d);
 int32_t tedspad_conv_cout_pad(const tedspad_conv_desc *d);
+/* Number of tile configurations of the conv kernel (valid tile_cfg values are 1..this). */
+int32_t tedspad_conv_num_tile_cfgs(void);
 /* Number of int32 pairs in the K-chunk table (= kpad / 8). */
 int32_t tedspad_conv_ktab_entries(const tedspad_conv_desc *d);
 /* Fills host_out[2*entries]: {element offset of the tap+channel chunk, packed (dt,dh,dw,valid)}. */

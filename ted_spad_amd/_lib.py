@@ -16,7 +16,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "t", "h", "w", "cin", "ldx", "cout", "ldy", "ldres",
         "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
-        "to", "ho", "wo", "relu", "dtype")]
+        "to", "ho", "wo", "relu", "dtype", "tile_cfg")]
 
 
 class PoolDesc(C.Structure):
@@ -33,6 +33,7 @@ SYMBOLS = {
     "tedspad_last_error": (C.c_char_p, []),
     "tedspad_conv_kpad": (_I32, [C.POINTER(ConvDesc)]),
     "tedspad_conv_cout_pad": (_I32, [C.POINTER(ConvDesc)]),
+    "tedspad_conv_num_tile_cfgs": (_I32, []),
     "tedspad_conv_ktab_entries": (_I32, [C.POINTER(ConvDesc)]),
     "tedspad_conv_build_ktab": (_I32, [C.POINTER(ConvDesc), _P]),
     "tedspad_conv_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I32, _P]),

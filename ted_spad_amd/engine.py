@@ -8,6 +8,7 @@ CPU and nothing falls back to torch ops: CPU tensors are rejected.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -18,6 +19,12 @@ from ._lib import ConvDesc, PoolDesc, check
 
 DTYPES = {"f16": (torch.float16, _lib.F16), "bf16": (torch.bfloat16, _lib.BF16)}
 DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e-3 feature gate
+
+# Tile autotuning (the reference sets cudnn.benchmark = True, train_anonymizer.py:28): on the first
+# call of a conv on a new geometry every tile configuration of the kernel is timed with HIP events
+# and the fastest is kept. Same arithmetic for every configuration (K order per output is fixed), so
+# results do not depend on the choice. Off inside hipGraph capture: warm up first.
+AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 
 
 def _stream_ptr():
@@ -129,13 +136,14 @@ class PackedConv:
         self.scale, self.shift = sc.to(device), sf.to(device)
         self.device = device
         self._ktabs = {}
+        self._cfgs = {}
 
     def _desc(self, n, t, h, w, ldx, pads, out, ldy, ldres, relu):
         kt, kh, kw = self.k
         st, sh, sw = self.stride
         return ConvDesc(n=n, t=t, h=h, w=w, cin=self.cin, ldx=ldx, cout=self.cout, ldy=ldy, ldres=ldres,
                         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pads[0], ph=pads[1], pw=pads[2],
-                        to=out[0], ho=out[1], wo=out[2], relu=int(relu), dtype=self.dtype_code)
+                        to=out[0], ho=out[1], wo=out[2], relu=int(relu), dtype=self.dtype_code, tile_cfg=0)
 
     def _ktab(self, d: ConvDesc):
         key = (d.t, d.h, d.w, d.ldx)
@@ -147,6 +155,25 @@ class PackedConv:
             tab = torch.frombuffer(host, dtype=torch.int32).clone().to(self.device)
             self._ktabs[key] = tab
         return tab
+
+    def _autotune(self, d, args):
+        L = _lib.lib()
+        best, best_ms = 0, float("inf")
+        stream = _stream_ptr()
+        for cfg in range(0, L.tedspad_conv_num_tile_cfgs() + 1):
+            d.tile_cfg = cfg
+            if L.tedspad_conv_fwd(*args, stream) != 0:   # configuration not applicable to this K
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                L.tedspad_conv_fwd(*args, stream)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if ms < best_ms * 0.97:  # prefer the heuristic / earlier entry on ties
+                best, best_ms = cfg, ms
+        return best
 
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
                  residual: Optional[Act] = None, relu=True, sigmoid=False) -> Act:
@@ -163,10 +190,15 @@ class PackedConv:
         if residual is not None:
             assert residual.dims == out.dims and residual.c == self.cout
         d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
-        check(_lib.lib().tedspad_conv_fwd(C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(),
-                                          self.scale.data_ptr(), self.shift.data_ptr(),
-                                          residual.ptr if residual is not None else None, out.ptr,
-                                          int(sigmoid), _stream_ptr()), "tedspad_conv_fwd")
+        args = (C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                residual.ptr if residual is not None else None, out.ptr, int(sigmoid))
+        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None)
+        cfg = self._cfgs.get(key)
+        if cfg is None:
+            cfg = self._autotune(d, args) if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else 0
+            self._cfgs[key] = cfg
+        d.tile_cfg = cfg
+        check(_lib.lib().tedspad_conv_fwd(*args, _stream_ptr()), "tedspad_conv_fwd")
         return out
 
 

@@ -1,0 +1,108 @@
+"""-m gpu: InceptionI3d, UNet, the wrapper head and the extraction driver on MI355X against
+the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_clips, synth_state_dict, synth_tensor
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _load(m):
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0), strict=True)
+    return m.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def inception():
+    from ted_spad_amd.model_loaders import load_ft_model
+    return _load(load_ft_model("i3d", num_classes=102))
+
+
+@pytest.fixture(scope="module")
+def wrapper():
+    from ted_spad_amd.model_loaders import load_ft_model
+    return _load(load_ft_model("largei3d", num_classes=102))
+
+
+@pytest.fixture(scope="module")
+def unet():
+    from ted_spad_amd.model_loaders import load_fa_model
+    return _load(load_fa_model(arch="unet"))
+
+
+def test_inception_features_224(inception, golden, golden_meta):
+    x = synth_clips(0, 2, (3, 16, 224, 224), device="cuda")
+    taps = {}
+    a = inception._trunk(x, taps=taps)
+    f = inception.extract_features(x).cpu().reshape(2, 1024)
+    for i in range(2):
+        assert rel_l2(f[i], golden["inception_feat_224"][i]) < TOL
+    for name, (mean, l2) in golden_meta["inception_taps_224"].items():
+        assert abs(float(taps[name].buf.double().norm()) - l2) < 2e-3 * l2, name
+
+
+def test_inception_forward_112_and_q4(inception, golden):
+    x = synth_clips(0, 2, (3, 16, 112, 112), device="cuda")
+    lg = inception(x)
+    assert lg.shape == (2, 102)
+    assert rel_l2(lg.cpu(), golden["inception_logits_112"]) < TOL
+    with pytest.raises(RuntimeError):
+        inception.extract_features(x)
+
+
+def test_wrapper_forward_eval(wrapper, golden):
+    x = synth_clips(0, 2, (3, 16, 112, 112), device="cuda")
+    pred, feat = wrapper(x)
+    assert pred.shape == (2, 102) and feat.shape == (2, 128)
+    assert rel_l2(pred.cpu(), golden["wrapper_eval_pred"]) < TOL
+    assert rel_l2(feat.cpu(), golden["wrapper_eval_feat"]) < TOL
+    assert torch.allclose(feat.norm(dim=1).cpu(), torch.ones(2), atol=1e-5)
+    # Q3: at B=1 I3Res50.forward's feat is squeezed to (2048,) and the mlp refuses it
+    with pytest.raises(ValueError):
+        wrapper(x[:1])
+
+
+def test_unet_eval(unet, golden, golden_meta):
+    frames = synth_tensor(0, "unet_frames", (4, 3, 112, 112)).cuda()
+    y = unet(frames)
+    assert y.shape == (4, 3, 112, 112) and y.dtype == torch.float32
+    y = y.cpu()
+    assert rel_l2(y[0, :, 40:56, 40:56], golden["unet_out_crop"]) < TOL
+    assert rel_l2(y.mean(3), golden["unet_out_rowmeans"]) < TOL
+    assert float(y.min()) > 0 and float(y.max()) < 1
+
+
+def test_unet_odd_size_vs_oracle(unet):
+    """Up's pad-to-skip path (unet_parts.py:56-62): 100x92 -> 6x5 at the bottom, skips are odd."""
+    from oracle import unet_ref
+    frames = synth_tensor(0, "unet_odd", (2, 3, 100, 92))
+    with torch.no_grad():
+        ref = unet_ref.forward(frames, {k: v.cpu() for k, v in unet.state_dict().items()})
+    assert rel_l2(unet(frames.cuda()).cpu(), ref) < TOL
+
+
+def test_extraction_driver_q1_and_npy(wrapper, unet, tmp_path):
+    """st_feature_extraction.extract_features counterpart: anonymized feed (Q1), float64 (T,F) .npy,
+    consumed by the restated MGFN loader."""
+    from oracle import extract_ref, i3res50_ref, unet_ref
+    from ted_spad_amd import extraction
+    T = 5
+    vid = [synth_tensor(7, "vid%d" % i, (16, 3, 32, 32)) for i in range(T)]
+    feats = np.zeros((T, 2048))
+    p = str(tmp_path / "Shoplifting033_x264.npy")
+    extraction.extract_features(vid, feats, p, unet, wrapper, True, False, batch=2)
+    arr = np.load(p)
+    assert arr.dtype == np.float64 and arr.shape == (T, 2048) and not np.isfortran(arr)
+    sd_u = {k: v.cpu() for k, v in unet.state_dict().items()}
+    sd_i = {k[4:]: v.cpu() for k, v in wrapper.state_dict().items() if k.startswith("i3d.")}
+    with torch.no_grad():
+        ref = extract_ref.extract_video(vid, lambda x: i3res50_ref.extract_features(x, sd_i),
+                                        fa=lambda x: unet_ref.forward(x, sd_u), layout="reference")
+    for t in range(T):
+        assert rel_l2(arr[t], ref[t]) < TOL
+    assert extract_ref.mgfn_getitem(p).shape == (1, 32, 2049)
+    assert extraction.save_video_features(str(tmp_path), "/x/Abuse001_x264.mp4", torch.zeros(3, 1, 8)).endswith("Abuse001_x264.npy")
