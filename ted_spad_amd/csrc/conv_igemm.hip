@@ -251,6 +251,181 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Halo-direct kernel for the two Cin=3 stems in pixel-pair form (cin' = 8 -> one K chunk = one
+// tap = 16 bytes): the im2col matrix of a stem tile is 10-35x larger than the input patch it is
+// built from, and the generic kernel above is bound by exactly that L2->LDS traffic (N = 64 only).
+// Here a workgroup owns a 1 x 8 x 32 output patch (256 pixels x all 64 channels): its input halo
+// (kt x ((8-1)*sh+kh) x (31+kw) positions x 16 B ~ 59 KB for the 5x7x7 stem) is DMA'd into LDS
+// ONCE, and every MFMA B fragment (8 channels of one tap for one pixel) is read straight from the
+// halo at `pixel base + tap delta`: consecutive lanes = consecutive pixels along W = consecutive
+// 16-byte slots, conflict-free. Only the 8 KB weight tile streams per K step (2-slot ring).
+// 4 waves, each 64 pixels (2 output rows) x 64 channels; <= 80 KB LDS so two workgroups share a CU
+// (one loads its halo while the other computes).
+// ------------------------------------------------------------------------------------------
+constexpr int ST_TH = 8, ST_TW = 32;          // output patch (rows x cols); ST_TW = one MFMA pixel group
+constexpr int ST_WSTAGE = 64 * BK * 2;        // 64 channels x 64 k x 2 B
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, const int HH, const int WH, const int tiles_h, const int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h; b /= tiles_h;
+    const int to = b % p.To;
+    const int n = b / p.To;
+    const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
+    const int P = p.kt * HH * WH;                       // halo positions
+    const int NH = (P + 255) / 256;                     // DMA instructions per thread for the halo
+    const int halo_bytes = NH * 256 * 16;
+    unsigned char *wring = dsm + halo_bytes;            // [2][64][64] 16-bit
+    int *tapd = reinterpret_cast<int *>(wring + 2 * ST_WSTAGE);  // byte delta of every K chunk (= tap)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
+
+    for (int i = tid; i < p.nk * 8; i += 256) {
+        const int y = p.ktab[i].y;
+        const int dt = y & 255, dh = ((y >> 8) & 255) - 8, dw = (y >> 16) - 16;
+        tapd[i] = dt < 8 ? ((dt * HH + dh) * WH + dw) * 16 : 0;   // K padding: zero weights, any in-range address
+    }
+    __syncthreads();  // table complete (and its global loads retired) before any DMA is counted
+    // ---- halo: one 16-byte DMA per position, lane-linear in LDS --------------------------------
+    const int t0 = to * p.st - p.pt, h0 = ho0 * p.sh - p.ph, w0 = wo0 * p.sw - p.pw;
+    for (int i = 0; i < NH; ++i) {
+        const int idx = i * 256 + tid;
+        const int ww = idx % WH; const int r = idx / WH;
+        const int hh = r % HH; const int dt = r / HH;
+        const int it = t0 + dt, ih = h0 + hh, iw = w0 + ww;
+        const bool ok = idx < P && (unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        const uint16_t *src = ok ? p.x + ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.ldx : zero;
+        lds_dma16(src, lds0 + (i * 256 + wave * 64) * 16);
+    }
+    // ---- weights: [64][64] tile per K step, swizzled on the source like the generic kernel ------
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w + (size_t)rsub * p.Kpad + kc * 8;
+    auto issue_w = [&](int kt, int slot) {
+        const unsigned dst = lds0 + halo_bytes + slot * ST_WSTAGE + wave * 8 * (BK * 2);
+        lds_dma16(wsrc + kt * BK, dst);
+        lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));
+    };
+    issue_w(0, 0);
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    // wave `wave` owns output rows 2*wave, 2*wave+1 of the patch; B-fragment base of pixel (row, l31)
+    int pixb[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) pixb[g] = ((2 * wave + g) * p.sh * WH + l31 * p.sw) * 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][g][r] = 0.f;
+
+    for (int kt = 0; kt < p.nk; ++kt) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // weight stage kt (+ halo, tap table on kt = 0) visible; other slot free
+        asm volatile("" ::: "memory");
+        if (kt + 1 < p.nk) issue_w(kt + 1, (kt + 1) & 1);
+        const uint16_t *W = reinterpret_cast<const uint16_t *>(wring + (kt & 1) * ST_WSTAGE) + l31 * BK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int d = tapd[kt * 8 + ks * 2 + lh];
+            const int coff = (((ks << 1) | lh) ^ swz) << 3;
+            uint4 fa[2], fw[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) fa[g] = *reinterpret_cast<const uint4 *>(dsm + pixb[g] + d);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(W + a * 32 * BK + coff);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc[a][g] = T::mfma(fw[a], fa[g], acc[a][g]);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: fp32 patch [256 pixels][64 channels] -> LDS -> coalesced rows -----------------
+    constexpr int STG_LD = 64 + 4;
+    float *stg = reinterpret_cast<float *>(dsm);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ml = (2 * wave + g) * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = a * 32 + 8 * q + 4 * lh;
+                f32x4 v = {acc[a][g][4 * q], acc[a][g][4 * q + 1], acc[a][g][4 * q + 2], acc[a][g][4 * q + 3]};
+                *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
+            }
+        }
+    __syncthreads();
+    const int cc = tid & 7, r0 = tid >> 3;     // 8 chunks of 8 channels per pixel, 32 pixels per pass
+    const int nch = cc * 8;
+    if (nch >= p.Cout) return;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
+    for (int r = r0; r < 256; r += 32) {
+        const int ho = ho0 + (r >> 5), wo = wo0 + (r & 31);
+        if (ho >= p.Ho || wo >= p.Wo) continue;
+        const size_t m = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch + 4);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+        if (p.res) {
+            float rr[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + m * p.ldres + nch), rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rr[i];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+    }
+}
+
+template <typename T>
+int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
+    if (p.ldx < 8 || p.Cout > 64 || p.Kpad > 8 * 256 * 8 || p.sw != 1 || p.sigmoid) {
+        set_error("tedspad_conv_fwd: halo-direct config needs cin == 8, cout <= 64, sw == 1");
+        return TEDSPAD_EINVAL;
+    }
+    const int HH = (ST_TH - 1) * p.sh + p.kh, WH = (ST_TW - 1) * p.sw + p.kw;
+    const int P = p.kt * HH * WH, NH = (P + 255) / 256;
+    const int main_bytes = NH * 256 * 16 + 2 * ST_WSTAGE + p.nk * 8 * 4;
+    const int stage_bytes = 256 * (64 + 4) * 4;
+    const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
+    if (lds > 160 * 1024) {
+        set_error("tedspad_conv_fwd: halo-direct config: halo does not fit LDS (%d bytes)", lds);
+        return TEDSPAD_EINVAL;
+    }
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_stem_halo_kernel<T>;
+    if (attr_set[T::kDtype] < lds) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 160 * 1024;
+    }
+    const int tiles_h = (p.Ho + ST_TH - 1) / ST_TH, tiles_w = (p.Wo + ST_TW - 1) / ST_TW;
+    hipLaunchKernelGGL(kfn, dim3(N * p.To * tiles_h * tiles_w), dim3(256), lds, s, p, HH, WH, tiles_h, tiles_w);
+    return check_launch("tedspad_conv_fwd(halo)");
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
 int32_t launch(const ConvKP &p, hipStream_t s) {
     if (p.Kpad > KT) {
@@ -276,11 +451,13 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //   6  128 x 128          2x2    2      68 KB   short K (<= 1024): HBM-bound 1x1 convs, 2 WG/CU
 //   7  128 x  64          2x2    2      50 KB   short K, N <= 64: 3 WG/CU
 //   8   64 x 128          2x2    2      50 KB   short K, small M
-constexpr int NUM_CFGS = 8;
+//   9  1x8x32 patch, halo-direct (cin == 8 stems only): input patch resident in LDS, 2 WG/CU
+constexpr int NUM_CFGS = 9;
 
 template <typename T>
-int32_t launch_cfg(int cfg, const ConvKP &p, hipStream_t s) {
+int32_t launch_cfg(int cfg, const ConvKP &p, int N, hipStream_t s) {
     switch (cfg) {
+        case 9: return launch_stem_halo<T>(p, N, s);
         case 1: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 2: return launch<T, 256, 64, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 3: return launch<T, 128, 128, 2, 2, 3, KTAB_MAX_BYTES>(p, s);
@@ -294,8 +471,9 @@ int32_t launch_cfg(int cfg, const ConvKP &p, hipStream_t s) {
     return TEDSPAD_EINVAL;
 }
 
-inline int heuristic_cfg(const ConvKP &p) {
+inline int heuristic_cfg(const ConvKP &p, int cin) {
     const bool narrow = p.Cout <= 64;
+    if (cin == 8 && narrow && p.sw == 1 && p.kt * p.kh * p.kw >= 32 && !p.sigmoid) return 9;  // the stems
     if (p.Kpad <= 512) {  // short K: little to pipeline, bandwidth-bound -> more resident workgroups
         if (narrow) return 7;
         return ntiles(p, 128, 128) >= 512 ? 6 : 8;
@@ -392,6 +570,7 @@ extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, c
                    d->ph == 0 && d->pw == 0 && d->to == d->t && d->ho == d->h && d->wo == d->w);
     p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    const int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p);
-    return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, s) : launch_cfg<BF16>(cfg, p, s);
+    const int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, d->cin);
+    if (cfg == 9) TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
+    return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, s) : launch_cfg<BF16>(cfg, p, d->n, s);
 }
