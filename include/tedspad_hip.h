@@ -124,6 +124,24 @@ int32_t tedspad_upsample_bilinear2x_fwd(const void *x, void *y, int32_t n, int32
                                         int32_t ldx, int32_t ldy, int32_t ho, int32_t wo, int32_t pad_top,
                                         int32_t pad_left, int32_t dtype, void *stream);
 
+/* ---- losses of the anonymizer training step: value AND input gradients in one launch ---------- */
+
+/* NTXentLoss(device, N, temperature, use_cosine)(zis, zjs)  -- aux_code/nt_xent_original.py:49-70.
+ * zis, zjs: fp32 (N, C); loss: fp32[1]; dzis/dzjs: fp32 (N, C) = dloss/dz (both or neither NULL).
+ * 2N <= 64, even C <= 256 (reference call sites: N = 12, C = 128, T = 0.1, dot similarity). */
+int32_t tedspad_ntxent_fwd_bwd(const float *zis, const float *zjs, float *loss, float *dzis, float *dzjs,
+                               int32_t N, int32_t C, float temperature, int32_t use_cosine, void *stream);
+
+/* nn.TripletMarginLoss(margin, p=2, eps=1e-6), mean reduction -- train_anonymizer.py:349-350,115.
+ * a,p,n: fp32 (B, C); row_ws: fp32[B] workspace; da/dp/dn may all be NULL (value only). */
+int32_t tedspad_triplet_fwd_bwd(const float *a, const float *p, const float *n, float *loss, float *row_ws,
+                                float *da, float *dp, float *dn, int32_t B, int32_t C, float margin, float eps,
+                                void *stream);
+
+/* nn.CrossEntropyLoss() (mean) -- train_anonymizer.py:347,107. logits fp32 (B, C), labels int64 (B). */
+int32_t tedspad_cross_entropy_fwd_bwd(const float *logits, const int64_t *labels, float *loss, float *row_ws,
+                                      float *dlogits, int32_t B, int32_t C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

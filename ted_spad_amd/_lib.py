@@ -42,6 +42,9 @@ SYMBOLS = {
     "tedspad_clip_to_channels_last": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _P]),
     "tedspad_channels_last_to_nchw": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_upsample_bilinear2x_fwd": (_I32, [_P, _P] + [_I32] * 11 + [_P]),
+    "tedspad_ntxent_fwd_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, C.c_float, _I32, _P]),
+    "tedspad_triplet_fwd_bwd": (_I32, [_P] * 8 + [_I32, _I32, C.c_float, C.c_float, _P]),
+    "tedspad_cross_entropy_fwd_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "tedspad_linear_fwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "tedspad_l2_normalize_rows": (_I32, [_P, _P, _I32, _I32, C.c_float, _P]),
 }

@@ -1,0 +1,139 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tedspad_hip.h declares (no
+compute calls), the host-side packing logic, the loader's checkpoint fallbacks, and that the
+product refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+from ted_spad_amd import _lib, engine as E
+from ted_spad_amd.synth import synth_state_dict, synth_tensor
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tedspad_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tedspad_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libtedspad_hip.so lacks %s" % name
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert _lib.lib().tedspad_abi_version() == 1
+
+
+def test_ktab_and_padding_helpers():
+    d = _lib.ConvDesc(n=1, t=4, h=6, w=5, cin=16, ldx=24, cout=40, ldy=40, ldres=0, kt=3, kh=3, kw=3, st=1, sh=1, sw=1,
+                      pt=1, ph=1, pw=1, to=4, ho=6, wo=5, relu=1, dtype=0, tile_cfg=0)
+    L = _lib.lib()
+    assert L.tedspad_conv_kpad(d) == 448 and L.tedspad_conv_cout_pad(d) == 128 and L.tedspad_conv_ktab_entries(d) == 56
+    buf = (ctypes.c_int32 * 112)()
+    assert L.tedspad_conv_build_ktab(d, buf) == 0
+    tab = np.array(buf).reshape(56, 2)
+    for e in range(54):
+        tap, c8 = divmod(e, 2)
+        dt, dh, dw = tap // 9, (tap // 3) % 3, tap % 3
+        assert tab[e, 0] == ((dt * 6 + dh) * 5 + dw) * 24 + c8 * 8
+        assert tab[e, 1] == dt | ((8 + dh) << 8) | ((16 + dw) << 16)
+    assert (tab[54:, 1] == (31 | 31 << 8 | 31 << 16)).all()      # K padding -> zero page
+    bad = _lib.ConvDesc(n=1, t=1, h=1, w=1, cin=12, ldx=12, cout=8, ldy=8, kt=1, kh=1, kw=1, st=1, sh=1, sw=1, to=1, ho=1, wo=1)
+    assert L.tedspad_conv_kpad(bad) < 0                           # cin not a multiple of 8
+    assert L.tedspad_conv_fwd(ctypes.byref(bad), None, None, None, None, None, None, None, 0, None) < 0
+    assert b"descriptor" in L.tedspad_last_error()
+
+
+@pytest.mark.parametrize("k,pw", [((5, 7, 7), 3), ((7, 7, 7), 2)])
+def test_stem_pair_rewrite_is_the_same_convolution(k, pw):
+    """PackedConv(pair_w=...) turns the Cin=3 stride-2 stem into an 8-channel conv over pixel pairs."""
+    from oracle.conv_ref import conv_cl
+    w = synth_tensor(0, "w", (16, 3) + k, -1, 1)
+    x = synth_tensor(0, "x", (1, 3, 6, 12, 12))
+    pc = E.PackedConv(w, torch.ones(16), torch.zeros(16), stride=(2, 2, 2), dtype="f16", device="cpu", pair_w=pw)
+    kt, kh, kw2 = pc.k
+    w2 = pc.w[:16, :kt * kh * kw2 * 8].float().reshape(16, kt, kh, kw2, 8).permute(0, 4, 1, 2, 3)   # back to (co, ci, kt, kh, kw)
+    xp = torch.zeros(1, 6, 12, 6, 8)
+    xp.view(1, 6, 12, 6, 2, 4)[..., :3] = x.permute(0, 2, 3, 4, 1).reshape(1, 6, 12, 6, 2, 3)
+    pf = (k[0] // 2, 3, pw) if pw == 3 else (2, 2, 2)
+    pb = (k[0] // 2, 3, 3) if pw == 3 else (3, 3, 3)
+    ref = conv_cl(x.permute(0, 2, 3, 4, 1), w.half().float(), torch.ones(16), torch.zeros(16), (2, 2, 2), pf, pb, relu=False)
+    got = conv_cl(xp, w2, torch.ones(16), torch.zeros(16), (2, 2, 1), (pf[0], pf[1], pc.pair_pw),
+                  (pb[0], pb[1], kw2 - 1 - pc.pair_pw), relu=False)
+    assert got.shape == ref.shape and rel_l2(got, ref) < 1e-6
+
+
+def test_fold_bn_matches_torch_batchnorm_eval():
+    bn = torch.nn.BatchNorm3d(8, eps=1e-3).eval()
+    sd = synth_state_dict(bn.state_dict(), 3)
+    bn.load_state_dict(sd)
+    x = synth_tensor(3, "x", (2, 8, 2, 3, 3), -2, 2)
+    s, b = E.fold_bn(sd["weight"], sd["bias"], sd["running_mean"], sd["running_var"], 1e-3)
+    assert torch.allclose(bn(x), x * s.view(1, -1, 1, 1, 1) + b.view(1, -1, 1, 1, 1), atol=1e-6)
+
+
+def test_same_pads_rule():
+    assert E.same_pads(224, 7, 2) == (2, 3) and E.same_pads(16, 7, 2) == (2, 3)
+    assert E.same_pads(112, 3, 2) == (0, 1) and E.same_pads(7, 2, 2) == (0, 1) and E.same_pads(28, 3, 1) == (1, 1)
+
+
+def test_loader_signatures_and_checkpoint_fallbacks(tmp_path, capsys):
+    from ted_spad_amd import model_loaders as ml
+    assert ml.load_ft_model() is None                      # default arch 'r3d' matches no branch (model_loaders.py:65-67)
+    assert "invalid for ft_model" in capsys.readouterr().out
+    assert ml.load_fa_model(arch="nope") is None
+    with pytest.raises(NotImplementedError):
+        ml.load_fa_model()                                 # default 'unet++' is third-party
+    ft = ml.load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 5)
+    # (1) plain checkpoint dict, as train_anonymizer.py:519-550 writes it
+    p1 = str(tmp_path / "a.pth")
+    torch.save({"epoch": 3, "ft_model_state_dict": sd, "fa_model_state_dict": ml.load_fa_model(arch="unet").state_dict()}, p1)
+    m1 = ml.load_ft_model("largei3d", saved_model_file=p1, num_classes=102)
+    assert torch.equal(m1.state_dict()["i3d.layer3.2.conv2.weight"], sd["i3d.layer3.2.conv2.weight"])
+    # (2) FrozenBN-style keys: `scale` instead of `weight`, no num_batches_tracked (model_loaders.py:76-82)
+    frozen = OrderedDict()
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        is_bn = k.rsplit(".", 1)[0] + ".running_mean" in sd
+        frozen[k.replace(".weight", ".scale") if (is_bn and k.endswith(".weight")) else k] = v
+    p2 = str(tmp_path / "b.pth")
+    torch.save({"ft_model_state_dict": frozen}, p2)
+    m2 = ml.load_ft_model("largei3d", saved_model_file=p2, num_classes=102)
+    assert torch.equal(m2.state_dict()["i3d.bn1.weight"], sd["i3d.bn1.weight"])
+    # (3) bare I3Res50 dict -> ft_model.i3d.load_state_dict (model_loaders.py:84)
+    p3 = str(tmp_path / "c.pth")
+    torch.save({"ft_model_state_dict": OrderedDict((k[4:], v) for k, v in sd.items() if k.startswith("i3d."))}, p3)
+    m3 = ml.load_ft_model("largei3d", saved_model_file=p3, num_classes=102)
+    assert torch.equal(m3.state_dict()["i3d.fc.weight"], sd["i3d.fc.weight"])
+    # (4) fa: DataParallel 'module.' prefix (model_loaders.py:41-46)
+    fa_sd = synth_state_dict(ml.load_fa_model(arch="unet").state_dict(), 5)
+    p4 = str(tmp_path / "d.pth")
+    torch.save({"fa_model_state_dict": OrderedDict(("module." + k, v) for k, v in fa_sd.items())}, p4)
+    fa = ml.load_fa_model(saved_model_file=p4, arch="unet")
+    assert torch.equal(fa.state_dict()["up1.conv.double_conv.0.weight"], fa_sd["up1.conv.double_conv.0.weight"])
+    # the i3d logits are registered first and can be replaced
+    inc = ml.load_ft_model("i3d", num_classes=400)
+    assert list(inc.state_dict())[0] == "logits.conv3d.weight"
+    inc.replace_logits(102)
+    assert inc.state_dict()["logits.conv3d.weight"].shape == (102, 1024, 1, 1, 1)
+
+
+def test_no_cpu_fallback():
+    from ted_spad_amd import model_loaders as ml
+    ft = ml.load_ft_model("largei3d", num_classes=102).eval()
+    with pytest.raises(_lib.TedSpadHipError):
+        ft.i3d.extract_features(torch.zeros(1, 3, 16, 32, 32))
+    fa = ml.load_fa_model(arch="unet").eval()
+    with pytest.raises(_lib.TedSpadHipError):
+        fa(torch.zeros(1, 3, 32, 32))
+    from ted_spad_amd.losses import NTXentLoss
+    with pytest.raises(_lib.TedSpadHipError):
+        NTXentLoss("cpu", 4, 0.1, False)(torch.zeros(4, 8), torch.zeros(4, 8))
+    for holder in (ft.i3d.conv1, ft.i3d.bn1, ft.mlp.fc1):
+        with pytest.raises(RuntimeError):
+            holder(torch.zeros(1))
