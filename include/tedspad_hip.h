@@ -89,8 +89,40 @@ int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *
                          const int32_t *ktab, const float *scale, const float *shift,
                          const void *residual, void *y, int32_t sigmoid, void *stream);
 
+/* Optional epilogue extras used by the training path (all-zero / NULL = plain tedspad_conv_fwd):
+ *   mask   : 16-bit tensor shaped like the output; out = mask > 0 ? out : 0. Fuses the ReLU backward
+ *            into the data-gradient conv that produces d(input) (the input IS the ReLU output).
+ *   stats  : fp32 [2][stats_ld], pre-zeroed; receives per-channel sum and sum of squares of
+ *            scale*conv+shift over all output pixels (BatchNorm batch statistics, train mode:
+ *            train_anonymizer.py:73,139) via one atomic per channel per workgroup.
+ *   out_strided: output pixel (n,to,ho,wo) is written at (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a
+ *            (tf,hf,wf) tensor: lets the stride-s data gradient run as s^d dense sub-convolutions
+ *            (one per output parity class) that interleave their results in place. */
+typedef struct tedspad_conv_extras {
+    const void *mask;
+    float      *stats;
+    int32_t     ldmask, stats_ld;
+    int32_t     out_strided, ost, osh, osw, oot, ooh, oow, tf, hf, wf;
+} tedspad_conv_extras;
+
+int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed,
+                            const int32_t *ktab, const float *scale, const float *shift,
+                            const void *residual, void *y, int32_t sigmoid,
+                            const tedspad_conv_extras *ex, void *stream);
+
+/* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
+ * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be
+ * zeroed by the caller (hipMemsetAsync on the same stream); accumulation uses float atomics.
+ * `d` is the FORWARD descriptor of the convolution (d->ldy = pixel stride of dy). Replaces the
+ * autograd of nn.Conv3d/Conv2d in loss.backward(): train_anonymizer.py:122,190-191. */
+int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x, const void *dy, const int32_t *ktab,
+                           float *dw, void *stream);
+
 /* nn.MaxPool3d / MaxPool3dSamePadding / nn.MaxPool2d: large_i3d.py:138-139, i3d.py:13-45, unet_parts.py:34 */
 int32_t tedspad_maxpool_fwd(const tedspad_pool_desc *d, const void *x, void *y, void *stream);
+/* Same, also recording the window-local index of the FIRST maximum of every output element
+ * (uint8, laid out (n,to,ho,wo,c) contiguous) for tedspad_maxpool_bwd. */
+int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const void *x, void *y, uint8_t *idx, void *stream);
 
 /* AdaptiveAvgPool3d(1) / AvgPool3d([2,7,7]) over `spatial` pixels: large_i3d.py:146,262; i3d.py:293,340.
  * x: (n, spatial, c) 16-bit with pixel stride ldx -> y fp32 (n, c). */
@@ -141,6 +173,59 @@ int32_t tedspad_triplet_fwd_bwd(const float *a, const float *p, const float *n, 
 /* nn.CrossEntropyLoss() (mean) -- train_anonymizer.py:347,107. logits fp32 (B, C), labels int64 (B). */
 int32_t tedspad_cross_entropy_fwd_bwd(const float *logits, const int64_t *labels, float *loss, float *row_ws,
                                       float *dlogits, int32_t B, int32_t C, void *stream);
+
+/* ---- training path: train-mode BatchNorm around the conv kernels, backward of the pooling / resize ops ----
+ * Reference: autograd of the torch.nn modules of aux_code/models/{large_i3d,unet_parts}.py under
+ * fa_model.train() / ft_model.train() (anonymization_training/train_anonymizer.py:73-75,137-139). */
+
+/* From the per-channel sum / sum-of-squares the conv epilogue accumulated (tedspad_conv_extras.stats) over
+ * `count` pixels: batch mean / biased variance -> scale = gamma*invstd, shift = beta - mean*scale; updates
+ * running_mean / running_var in place (momentum, unbiased variance) when they are not NULL. */
+int32_t tedspad_bn_finalize(const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+                            float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                            float *shift, float *mean, float *invstd, int32_t C, void *stream);
+
+/* y = act(z*scale[c] + shift[c] (+ res)), 16-bit channels-last, `pixels` rows with strides ldz/ldres/ldy. */
+int32_t tedspad_scale_shift_act(const void *z, const float *scale, const float *shift, const void *res, void *y,
+                                int64_t pixels, int32_t C, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
+                                int32_t dtype, void *stream);
+
+/* sums[0][c] += sum_px g, sums[1][c] += sum_px g*xhat  with g = dy*(y>0 if relu), xhat = (z-mean)*invstd
+ * (second row skipped when z == NULL: plain per-channel sum = bias gradient). `sums` pre-zeroed. */
+int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, const float *mean, const float *invstd,
+                              float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
+                              int32_t ldz, int32_t relu, int32_t dtype, void *stream);
+
+/* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input). */
+int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, const float *mean, const float *invstd,
+                             const float *gamma, const float *sums, int32_t sums_ld, void *dz, void *dres,
+                             int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
+                             int32_t lddres, int32_t relu, int32_t dtype, void *stream);
+
+/* dx[i] = (add ? add[i] : 0) + sum over pooling windows o containing i of dy[o]*[argmax(o) == i]; `d` = forward
+ * desc, idx from tedspad_maxpool_fwd_idx (first maximum wins, as torch). relu_mask != 0 additionally zeroes dx
+ * where x <= 0 (x is a ReLU output: folds that ReLU's backward in). */
+int32_t tedspad_maxpool_bwd(const tedspad_pool_desc *d, const void *x, const uint8_t *idx, const void *dy, int32_t lddy,
+                            const void *add, int32_t ldadd, void *dx, int32_t lddx, int32_t relu_mask, void *stream);
+
+/* dx[n,p,c] = dfeat[n,c] / spatial, zeroed where mask <= 0 (mask may be NULL). */
+int32_t tedspad_global_avgpool_bwd(const float *dfeat, const void *mask, int32_t ldmask, void *dx, int32_t n,
+                                   int32_t spatial, int32_t c, int32_t lddx, int32_t dtype, void *stream);
+
+/* Backward of tedspad_upsample_bilinear2x_fwd: dy is the (n,ho,wo,c) slice the forward wrote, dx is (n,h,w,c). */
+int32_t tedspad_upsample_bilinear2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c,
+                                        int32_t lddy, int32_t lddx, int32_t ho, int32_t wo, int32_t pad_top,
+                                        int32_t pad_left, int32_t dtype, void *stream);
+
+/* fp32 (n,c,thw) gradient -> 16-bit (n,thw,8) channels-last; if y_sigmoid != NULL multiplies by y*(1-y)
+ * (backward of the UNet's sigmoid output, unet_model.py:37). */
+int32_t tedspad_nchw_grad_to_channels_last(const float *dy, const float *y_sigmoid, void *out, int32_t n, int32_t c,
+                                           int64_t thw, int32_t dtype, void *stream);
+
+/* 16-bit (n,t,h,w,ldx) first c channels -> fp32 tensor with arbitrary element strides (gradient w.r.t. a clip view). */
+int32_t tedspad_channels_last_to_nchw_strided(const void *x, float *y, int32_t n, int32_t c, int32_t t, int32_t h,
+                                              int32_t w, int32_t ldx, int64_t sn, int64_t sc, int64_t st_, int64_t sh,
+                                              int64_t sw, int32_t dtype, void *stream);
 
 #ifdef __cplusplus
 }

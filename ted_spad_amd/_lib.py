@@ -19,6 +19,11 @@ class ConvDesc(C.Structure):
         "to", "ho", "wo", "relu", "dtype", "tile_cfg")]
 
 
+class ConvExtras(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("stats", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "ldmask", "stats_ld", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf")]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "t", "h", "w", "c", "ldx", "ldy",
@@ -37,7 +42,10 @@ SYMBOLS = {
     "tedspad_conv_ktab_entries": (_I32, [C.POINTER(ConvDesc)]),
     "tedspad_conv_build_ktab": (_I32, [C.POINTER(ConvDesc), _P]),
     "tedspad_conv_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "tedspad_conv_fwd_ex": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I32, C.POINTER(ConvExtras), _P]),
+    "tedspad_conv_wgrad": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "tedspad_maxpool_fwd": (_I32, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "tedspad_maxpool_fwd_idx": (_I32, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "tedspad_global_avgpool_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_clip_to_channels_last": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _P]),
     "tedspad_channels_last_to_nchw": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
@@ -45,6 +53,15 @@ SYMBOLS = {
     "tedspad_ntxent_fwd_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, C.c_float, _I32, _P]),
     "tedspad_triplet_fwd_bwd": (_I32, [_P] * 8 + [_I32, _I32, C.c_float, C.c_float, _P]),
     "tedspad_cross_entropy_fwd_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
+    "tedspad_bn_finalize": (_I32, [_P, _I32, _I64, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "tedspad_scale_shift_act": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_bn_bwd_reduce": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_bn_bwd_apply": (_I32, [_P] * 7 + [_I32, _P, _P, _I64] + [_I32] * 8 + [_P]),
+    "tedspad_maxpool_bwd": (_I32, [C.POINTER(PoolDesc), _P, _P, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
+    "tedspad_global_avgpool_bwd": (_I32, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_upsample_bilinear2x_bwd": (_I32, [_P, _P] + [_I32] * 11 + [_P]),
+    "tedspad_nchw_grad_to_channels_last": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I32, _P]),
+    "tedspad_channels_last_to_nchw_strided": (_I32, [_P, _P] + [_I32] * 6 + [_I64] * 5 + [_I32, _P]),
     "tedspad_linear_fwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "tedspad_l2_normalize_rows": (_I32, [_P, _P, _I32, _I32, C.c_float, _P]),
 }

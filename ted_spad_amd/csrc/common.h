@@ -73,4 +73,25 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_dst + lane*16].
+// Written as inline asm on purpose: hipcc treats the builtin form as an LDS store it must
+// drain (s_waitcnt vmcnt(0)) before ANY later ds_read of the same array, which serialises the
+// ring. In asm form the compiler does not count it; the kernel waits with counted vmcnt itself.
+// M0 (the DMA's LDS base) is compiler-reserved: saved/restored inside the same statement.
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 }  // namespace tedspad

@@ -44,6 +44,12 @@ struct ConvKP {
     int st, sh, sw, pt, ph, pw;
     int relu, sigmoid, pointwise;
     int tiles_n;
+    // optional epilogue extras (training path)
+    const uint16_t *mask;   // out = mask > 0 ? out : 0   (ReLU backward fused into the dgrad that produces d(input))
+    float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)
+    int ldmask, stats_ld;
+    int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
+    int ost, osh, osw, oot, ooh, oow, TF, HF, WF;
 };
 
 constexpr int BK = 64;                  // K elements per LDS tile row (8 chunks of 16 bytes)
@@ -51,27 +57,6 @@ constexpr int KTAB_MAX_BYTES = 10240;   // Kpad <= 10240 (one int2 per 8 K eleme
 constexpr int KTAB_SMALL_BYTES = 1024;  // "short-K" configs: Kpad <= 1024, smaller LDS -> 2-3 workgroups per CU
 
 __device__ uint4 g_zero16;              // zero page for padded taps (zero-initialised by the loader)
-
-typedef const __attribute__((address_space(1))) void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// One LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_dst + lane*16].
-// Written as inline asm on purpose: hipcc treats the builtin form as an LDS store it must
-// drain (s_waitcnt vmcnt(0)) before ANY later ds_read of the same array, which serialises the
-// ring. In asm form the compiler does not count it; the kernel waits with counted vmcnt itself.
-// M0 (the DMA's LDS base) is compiler-reserved: saved/restored inside the same statement.
-__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
 __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p) {
@@ -89,6 +74,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     constexpr int LDS_BYTES = LDS_MAIN > LDS_STAGE ? LDS_MAIN : LDS_STAGE;
     static_assert(BM % RPS == 0 && BN % RPS == 0 && TM >= 1 && TN >= 1, "tile/wave geometry");
     static_assert(S >= 2 && (S - 2) * L <= 63, "vmcnt is a 6-bit counter");
+    static_assert(2 * (NT / (BN / 8)) * BN * 4 <= LDS_BYTES, "batch-statistics reduction buffer must fit the staging area");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];  // ONE array: see cdna guide, glds traps
     int2 *ktab_lds = reinterpret_cast<int2 *>(smem + S * STAGE);
 
@@ -216,41 +202,77 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     constexpr int RPP = NT / CPR;        // rows per pass
     const int cc = tid % CPR, r0 = tid / CPR;
     const int n = n0 + cc * 8;
-    if (n >= p.Cout) return;
-    float sc[8], sf[8];
-    {
-        const f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.scale + n), s1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
+    const bool active = n < p.Cout;
+    float sc[8], sf[8], s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = 0.f; sf[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+    if (active) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
         const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sc[i] = s0[i]; sc[i + 4] = s1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
+        for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
     }
+    if (active) {
 #pragma unroll 4
-    for (int r = r0; r < BM; r += RPP) {
-        const int m = m0 + r;
-        if (m >= p.M) break;
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
-        float v[8];
+        for (int r = r0; r < BM; r += RPP) {
+            const int m = m0 + r;
+            if (m >= p.M) break;
+            size_t op = (size_t)m;
+            if (p.ostrided) {
+                const int wo = m % p.Wo; const int q1 = m / p.Wo;
+                const int ho = q1 % p.Ho; const int q2 = q1 / p.Ho;
+                const int to = q2 % p.To; const int nb = q2 / p.To;
+                op = (((size_t)nb * p.TF + to * p.ost + p.oot) * p.HF + ho * p.osh + p.ooh) * p.WF + wo * p.osw + p.oow;
+            }
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
+            float v[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
-        if (p.res) {
-            float rr[8];
-            unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n), rr);
+            for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+            if (p.stats) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += rr[i];
+                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+            }
+            if (p.res) {
+                float rr[8];
+                unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + op * p.ldres + n), rr);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += rr[i];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+            }
+            if (p.sigmoid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 1.f / (1.f + __expf(-v[i]));
+            }
+            if (p.mask) {
+                float mk[8];
+                unpack8<T>(*reinterpret_cast<const uint4 *>(p.mask + op * p.ldmask + n), mk);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
+            }
+            *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
         }
-        if (p.relu) {
+    }
+    if (p.stats) {   // block-level reduction of the batch statistics, then one atomic per channel
+        __syncthreads();
+        float *red = stg;   // [2][RPP][BN]
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        for (int i = 0; i < 8; ++i) {
+            red[r0 * BN + cc * 8 + i] = s1[i];
+            red[(RPP + r0) * BN + cc * 8 + i] = s2[i];
         }
-        if (p.sigmoid) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = 1.f / (1.f + __expf(-v[i]));
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RPP; ++r) { a += red[r * BN + tid]; b += red[(RPP + r) * BN + tid]; }
+            atomicAdd(p.stats + n0 + tid, a);
+            atomicAdd(p.stats + p.stats_ld + n0 + tid, b);
         }
-        *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + n) = pack8<T>(v);
     }
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Halo-direct kernel for the two Cin=3 stems in pixel-pair form (cin' = 8 -> one K chunk = one
@@ -541,9 +563,9 @@ extern "C" int32_t tedspad_conv_build_ktab(const tedspad_conv_desc *d, int32_t *
     return TEDSPAD_OK;
 }
 
-extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
-                                    const float *scale, const float *shift, const void *residual, void *y,
-                                    int32_t sigmoid, void *stream) {
+extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
+                                       const float *scale, const float *shift, const void *residual, void *y, int32_t sigmoid,
+                                       const tedspad_conv_extras *ex, void *stream) {
     TS_REQUIRE(desc_ok(d), "tedspad_conv_fwd: bad descriptor (cin/cout/ld* multiples of 8, kernel dims <= 7)");
     TS_REQUIRE(x && w_packed && ktab && scale && shift && y, "tedspad_conv_fwd: null pointer");
     TS_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) % 16 == 0,
@@ -569,8 +591,34 @@ extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, c
     p.pointwise = (d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
                    d->ph == 0 && d->pw == 0 && d->to == d->t && d->ho == d->h && d->wo == d->w);
     p.tiles_n = 0;
+    p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0;
+    p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
+    bool extras = false;
+    if (ex) {
+        TS_REQUIRE(!ex->mask || (ex->ldmask % 8 == 0 && ex->ldmask >= d->cout && (uintptr_t)ex->mask % 16 == 0), "tedspad_conv_fwd_ex: bad mask");
+        TS_REQUIRE(!ex->stats || ex->stats_ld >= d->cout, "tedspad_conv_fwd_ex: stats_ld must be >= cout");
+        p.mask = (const uint16_t *)ex->mask; p.ldmask = ex->ldmask; p.stats = ex->stats; p.stats_ld = ex->stats_ld;
+        if (ex->out_strided) {
+            TS_REQUIRE(ex->ost > 0 && ex->osh > 0 && ex->osw > 0 && ex->oot >= 0 && ex->ooh >= 0 && ex->oow >= 0 &&
+                           (d->to - 1) * ex->ost + ex->oot < ex->tf && (d->ho - 1) * ex->osh + ex->ooh < ex->hf &&
+                           (d->wo - 1) * ex->osw + ex->oow < ex->wf,
+                       "tedspad_conv_fwd_ex: strided output does not fit the (tf,hf,wf) tensor");
+            p.ostrided = 1; p.ost = ex->ost; p.osh = ex->osh; p.osw = ex->osw; p.oot = ex->oot; p.ooh = ex->ooh; p.oow = ex->oow;
+            p.TF = ex->tf; p.HF = ex->hf; p.WF = ex->wf;
+        }
+        extras = p.mask || p.stats || p.ostrided;
+    }
     hipStream_t s = (hipStream_t)stream;
-    const int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, d->cin);
-    if (cfg == 9) TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
+    int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
+    if (cfg == 9) {
+        TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
+        TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
+    }
     return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, s) : launch_cfg<BF16>(cfg, p, d->n, s);
+}
+
+extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
+                                    const float *scale, const float *shift, const void *residual, void *y,
+                                    int32_t sigmoid, void *stream) {
+    return tedspad_conv_fwd_ex(d, x, w_packed, ktab, scale, shift, residual, y, sigmoid, nullptr, stream);
 }

@@ -22,6 +22,7 @@ namespace {
 struct PoolKP {
     const uint16_t *x;
     uint16_t *y;
+    unsigned char *idx;   // optional: window-local index of the FIRST maximum per output element (training)
     int Ti, Hi, Wi, C8, ldx, ldy;
     int To, Ho, Wo;
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
@@ -42,8 +43,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
         const int to = (int)(r % p.To);
         const int n = (int)(r / p.To);
         float m[8];
+        int am[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m[i] = -3.0e38f;
+        for (int i = 0; i < 8; ++i) { m[i] = -3.0e38f; am[i] = 0; }
         bool padded = false;
         for (int dt = 0; dt < p.kt; ++dt) {
             const int it = to * p.st - p.pt + dt;
@@ -55,8 +57,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
                         const size_t off = ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.ldx + c8 * 8;
                         float v[8];
                         unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + off), v);
+                        const int li = (dt * p.kh + dh) * p.kw + dw;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) m[i] = __builtin_fmaxf(m[i], v[i]);
+                        for (int i = 0; i < 8; ++i) {
+                            if (v[i] > m[i]) { m[i] = v[i]; am[i] = li; }   // strict: the first maximum wins (torch semantics)
+                        }
                     } else {
                         padded = true;
                     }
@@ -65,10 +70,18 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
         }
         if (padded && p.pad_zero) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) m[i] = __builtin_fmaxf(m[i], 0.f);
+            for (int i = 0; i < 8; ++i) {
+                if (m[i] < 0.f) { m[i] = 0.f; am[i] = 255; }   // the zero padding wins: no input element gets the gradient
+            }
         }
-        const size_t yo = ((((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo) * p.ldy + c8 * 8;
-        *reinterpret_cast<uint4 *>(p.y + yo) = pack8<T>(m);
+        const size_t opix = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+        *reinterpret_cast<uint4 *>(p.y + opix * p.ldy + c8 * 8) = pack8<T>(m);
+        if (p.idx) {
+            uint2 pk;
+            pk.x = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+            pk.y = (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24);
+            *reinterpret_cast<uint2 *>(p.idx + (opix * p.C8 + c8) * 8) = pk;
+        }
     }
 }
 
@@ -179,8 +192,15 @@ using namespace tedspad;
 extern "C" int32_t tedspad_abi_version(void) { return TEDSPAD_ABI_VERSION; }
 extern "C" const char *tedspad_last_error(void) { return g_err; }
 
+extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const void *x, void *y, uint8_t *idx, void *stream);
+
 extern "C" int32_t tedspad_maxpool_fwd(const tedspad_pool_desc *d, const void *x, void *y, void *stream) {
+    return tedspad_maxpool_fwd_idx(d, x, y, nullptr, stream);
+}
+
+extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const void *x, void *y, uint8_t *idx, void *stream) {
     TS_REQUIRE(d && x && y, "tedspad_maxpool_fwd: null pointer");
+    TS_REQUIRE(!idx || (d->kt * d->kh * d->kw <= 255 && (uintptr_t)idx % 8 == 0), "tedspad_maxpool_fwd_idx: window too large for 8-bit indices");
     TS_REQUIRE(d->c > 0 && d->c % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->c && d->ldy >= d->c,
                "tedspad_maxpool_fwd: c/ldx/ldy must be multiples of 8");
     TS_REQUIRE(d->n > 0 && d->to > 0 && d->ho > 0 && d->wo > 0 && d->kt > 0 && d->kh > 0 && d->kw > 0 && d->st > 0 && d->sh > 0 && d->sw > 0,
@@ -190,7 +210,7 @@ extern "C" int32_t tedspad_maxpool_fwd(const tedspad_pool_desc *d, const void *x
     TS_REQUIRE(d->pt >= 0 && d->ph >= 0 && d->pw >= 0 && d->pt < d->kt && d->ph < d->kh && d->pw < d->kw,
                "tedspad_maxpool_fwd: front padding must be smaller than the window");
     PoolKP p;
-    p.x = (const uint16_t *)x; p.y = (uint16_t *)y;
+    p.x = (const uint16_t *)x; p.y = (uint16_t *)y; p.idx = idx;
     p.Ti = d->t; p.Hi = d->h; p.Wi = d->w; p.C8 = d->c / 8; p.ldx = d->ldx; p.ldy = d->ldy;
     p.To = d->to; p.Ho = d->ho; p.Wo = d->wo;
     p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.st = d->st; p.sh = d->sh; p.sw = d->sw; p.pt = d->pt; p.ph = d->ph; p.pw = d->pw;

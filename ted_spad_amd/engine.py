@@ -86,6 +86,33 @@ def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
     return inv.float(), shift.float()
 
 
+def stem_pair_form(w: torch.Tensor, pair_w: int):
+    """(co, ci<=4, kt, kh, kw) stride-2-along-W weights with FRONT pad `pair_w` -> the equivalent
+    (co, 8, kt, kh, kw') weights over pixel PAIRS (2 pixels x 4 channels, stride 1): tap k of the
+    original lands on pair-tap d = (k + shift) // 2, half j = (k + shift) % 2."""
+    co, ci, kt, kh, kw = w.shape
+    assert ci <= 4
+    pw2 = (pair_w + 1) // 2
+    shift_k = 2 * pw2 - pair_w
+    kw2 = (kw + shift_k + 1) // 2
+    w2 = torch.zeros((co, 8, kt, kh, kw2), dtype=w.dtype, device=w.device)
+    for k in range(kw):
+        d, j = divmod(k + shift_k, 2)
+        w2[:, j * 4:j * 4 + ci, :, :, d] = w[:, :, :, :, k]
+    return w2, kw2, pw2
+
+
+def stem_pair_grad(dw2: torch.Tensor, ci: int, kw: int, pair_w: int):
+    """Inverse gather of `stem_pair_form` for gradients: (co, 8, kt, kh, kw') -> (co, ci, kt, kh, kw)."""
+    pw2 = (pair_w + 1) // 2
+    shift_k = 2 * pw2 - pair_w
+    cols = []
+    for k in range(kw):
+        d, j = divmod(k + shift_k, 2)
+        cols.append(dw2[:, j * 4:j * 4 + ci, :, :, d])
+    return torch.stack(cols, dim=4)
+
+
 class PackedConv:
     """One convolution resident on the device in the kernel's layout:
     weights [cout_pad][kpad] 16-bit with K ordered (dt, dh, dw, ci); fp32 scale/shift;
@@ -97,23 +124,14 @@ class PackedConv:
         pair_w: if not None, the conv has cin <= 4 and stride 2 along W with FRONT pad `pair_w`:
         it is rewritten over pixel PAIRS (cin' = 8 = 2 pixels x 4 channels, kw' = ceil((kw+shift)/2),
         stride_w' = 1), so the Cin=3 stems run on the generic 8-channel-chunk gather."""
-        w = weight.detach().to(torch.float32).cpu()
+        device = torch.device(device)
+        w = weight.detach().to(device=device, dtype=torch.float32)
         cout, cin, kt, kh, kw = w.shape
         st, sh, sw = stride
         self.pair = pair_w is not None
         if self.pair:
-            assert cin <= 4 and sw == 2
-            pw2 = (pair_w + 1) // 2
-            shift_k = 2 * pw2 - pair_w
-            kw2 = (kw + shift_k + 1) // 2
-            w2 = torch.zeros(cout, 8, kt, kh, kw2)
-            for d in range(kw2):
-                for j in range(2):
-                    k = 2 * d + j - shift_k
-                    if 0 <= k < kw:
-                        w2[:, j * 4:j * 4 + cin, :, :, d] = w[:, :, :, :, k]
-            w, cin, kw, sw = w2, 8, kw2, 1
-            self.pair_pw = pw2
+            w, kw, self.pair_pw = stem_pair_form(w, pair_w)
+            cin, sw = 8, 1
         elif cin % 8:
             cpad = (cin + 7) // 8 * 8
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cpad - cin))
@@ -123,17 +141,15 @@ class PackedConv:
         self.cin, self.k, self.stride = cin, (kt, kh, kw), (st, sh, sw)
         self.torch_dtype, self.dtype_code = DTYPES[dtype]
         d = self._desc(1, 1, 1, 1, cin, (0, 0, 0), (1, 1, 1), self.cout, 0, True)
-        kpad = _lib.lib().tedspad_conv_kpad(d)
-        cpad = _lib.lib().tedspad_conv_cout_pad(d)
-        K = kt * kh * kw * cin
-        wp = torch.zeros(cpad, kpad, dtype=torch.float32)
-        wp[:cout, :K] = w.permute(0, 2, 3, 4, 1).reshape(cout, K)
-        self.w = wp.to(self.torch_dtype).to(device)
-        sc = torch.zeros(cpad, dtype=torch.float32)
-        sf = torch.zeros(cpad, dtype=torch.float32)
-        sc[:cout] = scale.detach().float().cpu()
-        sf[:cout] = shift.detach().float().cpu()
-        self.scale, self.shift = sc.to(device), sf.to(device)
+        self.kpad = _lib.lib().tedspad_conv_kpad(d)
+        self.cpad = _lib.lib().tedspad_conv_cout_pad(d)
+        self.K = kt * kh * kw * cin
+        self.w = torch.zeros(self.cpad, self.kpad, dtype=self.torch_dtype, device=device)
+        self.w[:cout, :self.K] = w.permute(0, 2, 3, 4, 1).reshape(cout, self.K).to(self.torch_dtype)
+        self.scale = torch.zeros(self.cpad, dtype=torch.float32, device=device)
+        self.shift = torch.zeros(self.cpad, dtype=torch.float32, device=device)
+        self.scale[:cout] = scale.detach().to(device=device, dtype=torch.float32)
+        self.shift[:cout] = shift.detach().to(device=device, dtype=torch.float32)
         self.device = device
         self._ktabs = {}
         self._cfgs = {}
@@ -156,53 +172,78 @@ class PackedConv:
             self._ktabs[key] = tab
         return tab
 
-    def _autotune(self, d, args):
+    def _autotune(self, d, args, stats=None):
         L = _lib.lib()
         best, best_ms = 0, float("inf")
         stream = _stream_ptr()
+        keep = stats.clone() if stats is not None else None   # timing runs must not pollute the accumulator
         for cfg in range(0, L.tedspad_conv_num_tile_cfgs() + 1):
             d.tile_cfg = cfg
-            if L.tedspad_conv_fwd(*args, stream) != 0:   # configuration not applicable to this K
+            if L.tedspad_conv_fwd_ex(*args, stream) != 0:   # configuration not applicable to this conv
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                L.tedspad_conv_fwd(*args, stream)
+                L.tedspad_conv_fwd_ex(*args, stream)
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1)
             if ms < best_ms * 0.97:  # prefer the heuristic / earlier entry on ties
                 best, best_ms = cfg, ms
+        if keep is not None:
+            stats.copy_(keep)
         return best
 
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
-                 residual: Optional[Act] = None, relu=True, sigmoid=False) -> Act:
-        """pads: FRONT zero padding (t,h,w); pads_back defaults to pads (symmetric, as nn.Conv3d)."""
+                 residual: Optional[Act] = None, relu=True, sigmoid=False, mask: Optional[Act] = None,
+                 stats: Optional[torch.Tensor] = None, out_dims=None, out_map=None) -> Act:
+        """pads: FRONT zero padding (t,h,w); pads_back defaults to pads (symmetric, as nn.Conv3d).
+        out_dims: explicit output extent (instead of the one implied by pads_back).
+        out_map = ((ost,osh,osw), (oot,ooh,oow)): output pixel (to,ho,wo) lands at (to*ost+oot, ...) of `out`
+        (which then is the full, larger tensor; residual / mask are indexed the same way).
+        mask: out = mask > 0 ? out : 0.  stats: fp32 (2, >=cout) batch-statistics accumulator."""
         n, t, h, w = x.dims
         assert x.c == self.cin, "conv expects %d input channels, got %d" % (self.cin, x.c)
         pb = pads if pads_back is None else pads_back
         kt, kh, kw = self.k
         st, sh, sw = self.stride
-        o = (conv_out(t, kt, st, pads[0], pb[0]), conv_out(h, kh, sh, pads[1], pb[1]), conv_out(w, kw, sw, pads[2], pb[2]))
+        o = tuple(out_dims) if out_dims is not None else (
+            conv_out(t, kt, st, pads[0], pb[0]), conv_out(h, kh, sh, pads[1], pb[1]), conv_out(w, kw, sw, pads[2], pb[2]))
         if out is None:
+            assert out_map is None
             out = Act.empty(n, o[0], o[1], o[2], self.cout, self.torch_dtype, x.buf.device)
-        assert out.dims == (n,) + o and out.c == self.cout, (out.dims, (n,) + o, out.c, self.cout)
-        if residual is not None:
-            assert residual.dims == out.dims and residual.c == self.cout
+        if out_map is None:
+            assert out.dims == (n,) + o, (out.dims, (n,) + o)
+        assert out.c == self.cout, (out.c, self.cout)
+        for other in (residual, mask):
+            if other is not None:
+                assert other.dims == out.dims and other.c == self.cout
         d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
+        ex = None
+        if mask is not None or stats is not None or out_map is not None:
+            ex = _lib.ConvExtras()
+            if mask is not None:
+                ex.mask, ex.ldmask = mask.ptr, mask.ld
+            if stats is not None:
+                assert stats.dtype == torch.float32 and stats.dim() == 2 and stats.shape[0] == 2 and stats.shape[1] >= self.cout
+                ex.stats, ex.stats_ld = stats.data_ptr(), stats.shape[1]
+            if out_map is not None:
+                (ex.ost, ex.osh, ex.osw), (ex.oot, ex.ooh, ex.oow) = out_map
+                ex.out_strided = 1
+                _, ex.tf, ex.hf, ex.wf = out.dims
         args = (C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                residual.ptr if residual is not None else None, out.ptr, int(sigmoid))
-        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None)
+                residual.ptr if residual is not None else None, out.ptr, int(sigmoid), C.byref(ex) if ex is not None else None)
+        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map)
         cfg = self._cfgs.get(key)
         if cfg is None:
-            cfg = self._autotune(d, args) if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else 0
+            cfg = self._autotune(d, args, stats) if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else 0
             self._cfgs[key] = cfg
         d.tile_cfg = cfg
-        check(_lib.lib().tedspad_conv_fwd(*args, _stream_ptr()), "tedspad_conv_fwd")
+        check(_lib.lib().tedspad_conv_fwd_ex(*args, _stream_ptr()), "tedspad_conv_fwd")
         return out
 
 
-def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: Optional[Act] = None) -> Act:
+def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: Optional[Act] = None, return_idx=False):
     n, t, h, w = x.dims
     pb = pads if pads_back is None else pads_back
     o = tuple(conv_out(sz, kk, ss, pf, pbk) for sz, kk, ss, pf, pbk in zip((t, h, w), k, s, pads, pb))
@@ -211,8 +252,10 @@ def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: O
     code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
     d = PoolDesc(n=n, t=t, h=h, w=w, c=x.c, ldx=x.ld, ldy=out.ld, kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2],
                  pt=pads[0], ph=pads[1], pw=pads[2], to=o[0], ho=o[1], wo=o[2], pad_zero=int(pad_zero), dtype=code)
-    check(_lib.lib().tedspad_maxpool_fwd(C.byref(d), x.ptr, out.ptr, _stream_ptr()), "tedspad_maxpool_fwd")
-    return out
+    idx = torch.empty((n, o[0], o[1], o[2], x.c), dtype=torch.uint8, device=x.buf.device) if return_idx else None
+    check(_lib.lib().tedspad_maxpool_fwd_idx(C.byref(d), x.ptr, out.ptr, idx.data_ptr() if return_idx else None, _stream_ptr()),
+          "tedspad_maxpool_fwd")
+    return (out, idx) if return_idx else out
 
 
 def global_avgpool(x: Act) -> torch.Tensor:

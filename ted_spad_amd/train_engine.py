@@ -1,0 +1,302 @@
+"""Training-path plumbing on top of `engine`: a trainable convolution (forward with batch
+statistics, data gradient, weight gradient), train-mode BatchNorm, and the backward launchers
+of the pooling / resize ops. All arithmetic is in libtedspad_hip.so; torch holds the buffers.
+
+Backward of the reference's torch.nn modules inside `loss.backward()`
+(anonymization_training/train_anonymizer.py:122,190-191):
+
+  * data gradient of a convolution = a convolution of dY with the spatially flipped, channel-
+    transposed weights; a stride-s conv splits into s^d dense sub-convolutions, one per parity class
+    of the input position, each writing its results interleaved in place (tedspad_conv_extras.out_*).
+    It runs on the SAME implicit-GEMM kernel as the forward pass.
+  * the ReLU backward is folded into the data-gradient conv that produces d(input): the input IS
+    the ReLU output, so the conv's epilogue masks with it (tedspad_conv_extras.mask).
+  * eval-mode BatchNorm backward (phase 1: frozen ft, train_anonymizer.py:73-75) is the folded
+    scale, multiplied into the data-gradient weights.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib, engine as E
+from ._lib import PoolDesc, check
+from .engine import Act, PackedConv, _stream_ptr
+
+
+def _code(t: torch.Tensor) -> int:
+    return _lib.F16 if t.dtype == torch.float16 else _lib.BF16
+
+
+def _ceil_div(a, b):
+    return -(-a // b)
+
+
+class DgradPlan:
+    """The data gradient of one convolution as dense sub-convolutions over dY."""
+
+    def __init__(self, w_k: torch.Tensor, scale: Optional[torch.Tensor], stride, pads_front, in_dims, out_dims, dtype):
+        co, ci, kt, kh, kw = w_k.shape
+        ws = w_k if scale is None else w_k * scale.view(-1, 1, 1, 1, 1).to(w_k.dtype)
+        self.ci = (ci + 7) // 8 * 8
+        self.in_dims, self.out_dims = tuple(in_dims), tuple(out_dims)
+        self.subs: List[Tuple] = []
+        self.need_zero = False
+        ks, ones, zeros = (kt, kh, kw), torch.ones(ci, device=w_k.device), torch.zeros(ci, device=w_k.device)
+        for rt in range(stride[0]):
+            for rh in range(stride[1]):
+                for rw in range(stride[2]):
+                    r = (rt, rh, rw)
+                    idx, pf2, J = [], [], []
+                    empty = False
+                    for dim in range(3):
+                        s, k, pf, n_in, n_out = stride[dim], ks[dim], pads_front[dim], in_dims[dim], out_dims[dim]
+                        c, q = (r[dim] + pf) % s, (r[dim] + pf) // s
+                        e_n = _ceil_div(k - c, s) if k > c else 0
+                        j_n = _ceil_div(n_in - r[dim], s) if n_in > r[dim] else 0
+                        if e_n == 0 or j_n == 0:
+                            empty = True
+                            break
+                        p2 = e_n - 1 - q
+                        assert p2 >= 0, "unsupported padding/stride combination in dgrad"
+                        if j_n > n_out + p2:      # trailing input the forward conv never read
+                            j_n = n_out + p2
+                            self.need_zero = True
+                        idx.append([c + s * (e_n - 1 - e) for e in range(e_n)])   # flipped taps of this class
+                        pf2.append(p2)
+                        J.append(j_n)
+                    if empty:
+                        self.need_zero = True
+                        continue
+                    wsub = ws[:, :, idx[0]][:, :, :, idx[1]][:, :, :, :, idx[2]].permute(1, 0, 2, 3, 4)   # (ci, co, Et, Eh, Ew)
+                    pc = PackedConv(wsub, ones, zeros, dtype=dtype, device=w_k.device)
+                    self.subs.append((r, pc, tuple(pf2), tuple(J)))
+        self.stride = tuple(stride)
+
+    def run(self, dy: Act, residual: Optional[Act] = None, mask: Optional[Act] = None, out: Optional[Act] = None) -> Act:
+        n = dy.dims[0]
+        assert dy.dims[1:] == self.out_dims, (dy.dims, self.out_dims)
+        if out is None:
+            out = Act.empty(n, *self.in_dims, self.ci, dy.buf.dtype, dy.buf.device)
+        if self.need_zero:
+            if residual is not None:
+                raise NotImplementedError("dgrad with a fused residual needs every input position covered by the conv "
+                                          "(not the case for this stride/kernel); add the residual separately")
+            out.buf.zero_()
+        dense = self.stride == (1, 1, 1)
+        for r, pc, pf2, J in self.subs:
+            pc(dy, pads=pf2, out=out, out_dims=J, residual=residual, mask=mask, relu=False,
+               out_map=None if dense and J == self.in_dims else (self.stride, r))
+        return out
+
+
+class ConvLayer:
+    """A trainable convolution bound to its fp32 parameter(s) (reference layout (co,ci,*k)).
+    Repacks the 16-bit kernel-layout copies whenever the parameter was updated."""
+
+    def __init__(self, weight, bias=None, stride=(1, 1, 1), pads=(0, 0, 0), pads_back=None, pair_w=None, dtype=E.DEFAULT_DTYPE):
+        self.weight, self.bias = weight, bias
+        self.stride, self.pads = tuple(stride), tuple(pads)
+        self.pads_back = self.pads if pads_back is None else tuple(pads_back)
+        self.pair_w, self.dtype = pair_w, dtype
+        self._fwd = None
+        self._fwd_sig = None
+        self._dgrad = {}
+
+    # ---- kernel-form weights ------------------------------------------------------------------------
+    def _w5(self):
+        w = self.weight.detach()
+        return w.unsqueeze(2) if w.dim() == 4 else w
+
+    def kernel_form(self):
+        """(w_k, stride_k, pads_k, pads_back_k): the conv as the kernel sees it (stem: pixel-pair form)."""
+        w = self._w5().float()
+        if self.pair_w is None:
+            return w, self.stride, self.pads, self.pads_back
+        w2, kw2, pw2 = E.stem_pair_form(w, self.pair_w)
+        return w2, (self.stride[0], self.stride[1], 1), (self.pads[0], self.pads[1], pw2), (self.pads_back[0], self.pads_back[1], kw2 - 1 - pw2)
+
+    def _sig(self, scale, shift):
+        def v(t):
+            return None if t is None else (t.data_ptr(), t._version)
+        return (v(self.weight), v(self.bias), v(scale), v(shift))
+
+    def fwd_conv(self, scale=None, shift=None) -> PackedConv:
+        """scale/shift None -> (1, bias): the raw conv of the train-mode path."""
+        sig = self._sig(scale, shift)
+        if self._fwd is None or self._fwd_sig != sig:
+            w = self._w5()
+            co = w.shape[0]
+            sc = torch.ones(co, device=w.device) if scale is None else scale
+            sf = (self.bias.detach() if self.bias is not None else torch.zeros(co, device=w.device)) if shift is None else shift
+            old = self._fwd
+            self._fwd = PackedConv(w, sc, sf, stride=self.stride, dtype=self.dtype, device=w.device, pair_w=self.pair_w)
+            if old is not None:   # same geometry: keep the gather tables and the tuned tile choice
+                self._fwd._ktabs, self._fwd._cfgs = old._ktabs, old._cfgs
+            self._fwd_sig = sig
+        return self._fwd
+
+    def _pads_k(self, pc: PackedConv):
+        if self.pair_w is None:
+            return self.pads, self.pads_back
+        return (self.pads[0], self.pads[1], pc.pair_pw), (self.pads_back[0], self.pads_back[1], pc.k[2] - 1 - pc.pair_pw)
+
+    def forward(self, x: Act, scale=None, shift=None, relu=False, residual=None, stats=None, out=None, sigmoid=False) -> Act:
+        pc = self.fwd_conv(scale, shift)
+        pk, pbk = self._pads_k(pc)
+        return pc(x, pads=pk, pads_back=pbk, relu=relu, residual=residual, stats=stats, out=out, sigmoid=sigmoid)
+
+    # ---- backward -----------------------------------------------------------------------------------
+    def dgrad(self, dy: Act, x_dims, scale=None, residual=None, mask=None, out=None) -> Act:
+        """d(input) (kernel-form channels: the stem returns the (n,t,h,w/2,8) pixel-pair tensor == (n,t,h,w,4))."""
+        key = (tuple(x_dims), dy.dims[1:])
+        sig = self._sig(scale, None)
+        plan = self._dgrad.get(key)
+        if plan is None or plan[0] != sig:
+            w_k, s_k, p_k, _ = self.kernel_form()
+            new = DgradPlan(w_k, scale, s_k, p_k, x_dims, dy.dims[1:], self.dtype)
+            if plan is not None:
+                for (_, pc_new, _, _), (_, pc_old, _, _) in zip(new.subs, plan[1].subs):
+                    pc_new._ktabs, pc_new._cfgs = pc_old._ktabs, pc_old._cfgs
+            plan = (sig, new)
+            self._dgrad[key] = plan
+        return plan[1].run(dy, residual=residual, mask=mask, out=out)
+
+    def wgrad(self, x: Act, dy: Act):
+        """Accumulates d(weight) (and d(bias) = per-channel sum of dy) into `.grad` in the parameter layout."""
+        pc = self.fwd_conv()
+        n, t, h, w = x.dims
+        pk, _ = self._pads_k(pc)
+        d = pc._desc(n, t, h, w, x.ld, pk, dy.dims[1:], dy.ld, 0, False)
+        dwp = torch.zeros((pc.cpad, pc.kpad), dtype=torch.float32, device=x.buf.device)
+        check(_lib.lib().tedspad_conv_wgrad(C.byref(d), x.ptr, dy.ptr, pc._ktab(d).data_ptr(), dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
+        w5 = self._w5()
+        co, ci, kt, kh, kw = w5.shape
+        kt_, kh_, kw_ = pc.k
+        g = dwp[:co, :pc.K].view(co, kt_, kh_, kw_, pc.cin).permute(0, 4, 1, 2, 3)
+        g = E.stem_pair_grad(g, ci, kw, self.pair_w) if self.pair_w is not None else g[:, :ci]
+        g = g.reshape(self.weight.shape)
+        self.weight.grad = g.contiguous() if self.weight.grad is None else self.weight.grad + g
+        if self.bias is not None:
+            db = channel_sums(dy)[0, :co]
+            self.bias.grad = db.clone() if self.bias.grad is None else self.bias.grad + db
+
+
+# ---- per-channel reductions / BatchNorm ---------------------------------------------------------------
+
+def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[Act] = None, mean=None, invstd=None, relu=False) -> torch.Tensor:
+    """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu)."""
+    n, t, h, w = dy.dims
+    sums = torch.zeros((2, dy.c), dtype=torch.float32, device=dy.buf.device)
+    check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.ptr if z is not None else None,
+                                           mean.data_ptr() if mean is not None else None, invstd.data_ptr() if invstd is not None else None,
+                                           sums.data_ptr(), dy.c, n * t * h * w, dy.c, dy.ld, y.ld if y is not None else 0,
+                                           z.ld if z is not None else 0, int(relu), _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
+    return sums
+
+
+class BNTrainCtx:
+    __slots__ = ("x", "z", "y", "mean", "invstd", "bn", "conv", "relu", "has_res")
+
+
+def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional[Act] = None, out: Optional[Act] = None):
+    """conv -> BatchNorm(batch statistics, running stats updated) -> (+residual) -> ReLU. Returns (y, ctx)."""
+    cpad = conv.fwd_conv().cpad
+    stats = torch.zeros((2, cpad), dtype=torch.float32, device=x.buf.device)
+    z = conv.forward(x, stats=stats)
+    n, t, h, w = z.dims
+    c = bn.weight.shape[0]
+    scale, shift, mean, invstd = (torch.zeros(z.c, dtype=torch.float32, device=x.buf.device) for _ in range(4))
+    check(_lib.lib().tedspad_bn_finalize(stats.data_ptr(), cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                         C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                         scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), c, _stream_ptr()),
+          "tedspad_bn_finalize")
+    bn.num_batches_tracked += 1
+    y = out if out is not None else Act.empty(n, t, h, w, z.c, z.buf.dtype, z.buf.device)
+    check(_lib.lib().tedspad_scale_shift_act(z.ptr, scale.data_ptr(), shift.data_ptr(), residual.ptr if residual is not None else None,
+                                             y.ptr, n * t * h * w, z.c, z.ld, residual.ld if residual is not None else 0, y.ld,
+                                             int(relu), _code(z.buf), _stream_ptr()), "tedspad_scale_shift_act")
+    ctx = BNTrainCtx()
+    ctx.x, ctx.z, ctx.y, ctx.mean, ctx.invstd, ctx.bn, ctx.conv, ctx.relu, ctx.has_res = x, z, y, mean, invstd, bn, conv, relu, residual is not None
+    return y, ctx
+
+
+def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: Optional[Act] = None, dx_mask: Optional[Act] = None,
+                          x_dims=None):
+    """Backward of `conv_bn_act_train`: accumulates d(gamma), d(beta), d(weight), d(bias) into .grad and returns
+    (dx or None, dres or None). dx = dgrad(dz) (+ dx_residual) masked by dx_mask."""
+    bn, z = ctx.bn, ctx.z
+    n, t, h, w = z.dims
+    c = bn.weight.shape[0]
+    sums = channel_sums(dy, ctx.y, z, ctx.mean, ctx.invstd, relu=ctx.relu)
+    dz = Act.empty(n, t, h, w, z.c, z.buf.dtype, z.buf.device)
+    dres = Act.empty(n, t, h, w, z.c, z.buf.dtype, z.buf.device) if ctx.has_res else None
+    gam = torch.zeros(z.c, dtype=torch.float32, device=z.buf.device)
+    gam[:c] = bn.weight.detach()
+    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ctx.y.ptr, z.ptr, ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
+                                          sums.data_ptr(), z.c, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w, z.c,
+                                          dy.ld, ctx.y.ld, z.ld, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu),
+                                          _code(z.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
+    bn.bias.grad = sums[0, :c].clone() if bn.bias.grad is None else bn.bias.grad + sums[0, :c]
+    bn.weight.grad = sums[1, :c].clone() if bn.weight.grad is None else bn.weight.grad + sums[1, :c]
+    ctx.conv.wgrad(ctx.x, dz)
+    dx = None
+    if need_dx:
+        dx = ctx.conv.dgrad(dz, ctx.x.dims[1:] if x_dims is None else x_dims, residual=dx_residual, mask=dx_mask)
+    return dx, dres
+
+
+# ---- pooling / resize backward -----------------------------------------------------------------------
+
+def maxpool_bwd(x: Act, idx: torch.Tensor, dy: Act, k, s, pads=(0, 0, 0), add: Optional[Act] = None, relu_mask=False) -> Act:
+    """idx: the argmax tensor `engine.maxpool(..., return_idx=True)` recorded in the forward pass."""
+    n, t, h, w = x.dims
+    _, to, ho, wo = dy.dims
+    dx = Act.empty(n, t, h, w, x.c, x.buf.dtype, x.buf.device)
+    d = PoolDesc(n=n, t=t, h=h, w=w, c=x.c, ldx=x.ld, ldy=dy.ld, kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2],
+                 pt=pads[0], ph=pads[1], pw=pads[2], to=to, ho=ho, wo=wo, pad_zero=0, dtype=_code(x.buf))
+    check(_lib.lib().tedspad_maxpool_bwd(C.byref(d), x.ptr, idx.data_ptr(), dy.ptr, dy.ld, add.ptr if add is not None else None,
+                                         add.ld if add is not None else 0, dx.ptr, dx.ld, int(relu_mask), _stream_ptr()), "tedspad_maxpool_bwd")
+    return dx
+
+
+def global_avgpool_bwd(dfeat: torch.Tensor, like: Act, mask: Optional[Act] = None) -> Act:
+    n, t, h, w = like.dims
+    dx = Act.empty(n, t, h, w, like.c, like.buf.dtype, like.buf.device)
+    dfeat = dfeat.contiguous().float()
+    check(_lib.lib().tedspad_global_avgpool_bwd(dfeat.data_ptr(), mask.ptr if mask is not None else None, mask.ld if mask is not None else 0,
+                                                dx.ptr, n, t * h * w, like.c, dx.ld, _code(like.buf), _stream_ptr()), "tedspad_global_avgpool_bwd")
+    return dx
+
+
+def upsample2x_bwd(dy_slice: Act, h: int, w: int, pad_top=0, pad_left=0) -> Act:
+    n, _, ho, wo = dy_slice.dims
+    dx = Act.empty(n, 1, h, w, dy_slice.c, dy_slice.buf.dtype, dy_slice.buf.device)
+    check(_lib.lib().tedspad_upsample_bilinear2x_bwd(dy_slice.ptr, dx.ptr, n, h, w, dy_slice.c, dy_slice.ld, dx.ld, ho, wo, pad_top, pad_left,
+                                                     _code(dx.buf), _stream_ptr()), "tedspad_upsample_bilinear2x_bwd")
+    return dx
+
+
+def nchw_grad_to_act(dy: torch.Tensor, y_sigmoid: Optional[torch.Tensor], dims, dtype=E.DEFAULT_DTYPE) -> Act:
+    """fp32 (n,c,*spatial) gradient -> 16-bit (n,t,h,w,8); with y_sigmoid also the sigmoid backward."""
+    n, c = dy.shape[:2]
+    t, h, w = dims
+    tdt, code = E.DTYPES[dtype]
+    out = Act.empty(n, t, h, w, 8, tdt, dy.device)
+    dy = dy.contiguous().float()
+    ys = y_sigmoid.contiguous().float() if y_sigmoid is not None else None
+    check(_lib.lib().tedspad_nchw_grad_to_channels_last(dy.data_ptr(), ys.data_ptr() if ys is not None else None, out.ptr, n, c, t * h * w,
+                                                        code, _stream_ptr()), "tedspad_nchw_grad_to_channels_last")
+    return out
+
+
+def act_to_nchw_into(x: Act, c: int, dst: torch.Tensor):
+    """x (n,t,h,w,ld) first c channels -> fp32 `dst` (n,c,t,h,w) view with arbitrary strides."""
+    n, t, h, w = x.dims
+    assert tuple(dst.shape) == (n, c, t, h, w) and dst.dtype == torch.float32
+    sn, sc, st, sh, sw = dst.stride()
+    check(_lib.lib().tedspad_channels_last_to_nchw_strided(x.ptr, dst.data_ptr(), n, c, t, h, w, x.ld, sn, sc, st, sh, sw, _code(x.buf),
+                                                           _stream_ptr()), "tedspad_channels_last_to_nchw_strided")
+    return dst
