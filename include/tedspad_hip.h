@@ -101,7 +101,10 @@ int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *
 typedef struct tedspad_conv_extras {
     const void *mask;
     float      *stats;
-    int32_t     ldmask, stats_ld;
+    float      *y32;     /* optional fp32 output (pixel stride ldy32); `y` may then be NULL. Train-mode BatchNorm keeps
+                            the pre-normalisation conv output in fp32: rounding it to 16 bits before subtracting the
+                            batch mean flips ReLU branches (DESIGN.md "training precision"). */
+    int32_t     ldmask, stats_ld, ldy32;
     int32_t     out_strided, ost, osh, osw, oot, ooh, oow, tf, hf, wf;
 } tedspad_conv_extras;
 
@@ -185,19 +188,19 @@ int32_t tedspad_bn_finalize(const float *stats, int32_t stats_ld, int64_t count,
                             float eps, float momentum, float *running_mean, float *running_var, float *scale,
                             float *shift, float *mean, float *invstd, int32_t C, void *stream);
 
-/* y = act(z*scale[c] + shift[c] (+ res)), 16-bit channels-last, `pixels` rows with strides ldz/ldres/ldy. */
-int32_t tedspad_scale_shift_act(const void *z, const float *scale, const float *shift, const void *res, void *y,
+/* y = act(z*scale[c] + shift[c] (+ res)); z fp32 (pixel stride ldz), res / y 16-bit channels-last. */
+int32_t tedspad_scale_shift_act(const float *z, const float *scale, const float *shift, const void *res, void *y,
                                 int64_t pixels, int32_t C, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
                                 int32_t dtype, void *stream);
 
 /* sums[0][c] += sum_px g, sums[1][c] += sum_px g*xhat  with g = dy*(y>0 if relu), xhat = (z-mean)*invstd
  * (second row skipped when z == NULL: plain per-channel sum = bias gradient). `sums` pre-zeroed. */
-int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, const float *mean, const float *invstd,
+int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
                               float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
                               int32_t ldz, int32_t relu, int32_t dtype, void *stream);
 
 /* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input). */
-int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, const float *mean, const float *invstd,
+int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
                              const float *gamma, const float *sums, int32_t sums_ld, void *dz, void *dres,
                              int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
                              int32_t lddres, int32_t relu, int32_t dtype, void *stream);
@@ -226,6 +229,20 @@ int32_t tedspad_nchw_grad_to_channels_last(const float *dy, const float *y_sigmo
 int32_t tedspad_channels_last_to_nchw_strided(const void *x, float *y, int32_t n, int32_t c, int32_t t, int32_t h,
                                               int32_t w, int32_t ldx, int64_t sn, int64_t sc, int64_t st_, int64_t sh,
                                               int64_t sw, int32_t dtype, void *stream);
+
+/* ---- fp32 head ops of the training step (B x C matrices with tiny B): mlp / fc of wrapper_i3d ---- */
+/* nn.BatchNorm1d in train mode (+ ReLU): model_loaders.py:252-253 under ft_model.train(). */
+int32_t tedspad_bn1d_train_fwd(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                               float *running_mean, float *running_var, float *y, float *mean, float *invstd,
+                               int32_t B, int32_t C, int32_t relu, void *stream);
+int32_t tedspad_bn1d_train_bwd(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
+                               const float *gamma, float *dx, float *dgamma, float *dbeta, int32_t B, int32_t C,
+                               int32_t relu, void *stream);
+/* backward of tedspad_l2_normalize_rows (x = its INPUT). */
+int32_t tedspad_l2_normalize_rows_bwd(const float *x, const float *dy, float *dx, int32_t B, int32_t N, float eps,
+                                      void *stream);
+/* out = a * b * scale (dropout mask application: I3Res50.drop, large_i3d.py:148,242). */
+int32_t tedspad_mul_f32(const float *a, const float *b, float *out, int64_t n, float scale, void *stream);
 
 #ifdef __cplusplus
 }

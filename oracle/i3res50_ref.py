@@ -65,7 +65,7 @@ def bottleneck(x, sd, p, stride, temp_conv, has_down, q=_id, bn=_bn_eval):
     out = bn(F.conv3d(out, q(sd[p + "conv3.weight"], "w")), sd, p + "bn3.")
     if has_down:
         res = F.conv3d(xin, q(sd[p + "downsample.0.weight"], "w"), stride=(1, stride, stride))
-        res = bn(res, sd, p + "downsample.1.")
+        res = q(bn(res, sd, p + "downsample.1."), "act")
     else:
         res = x
     return q(F.relu(out + res), "res")

@@ -1,0 +1,56 @@
+"""ORACLE (test infrastructure, never shipped): CPU restatement of one iteration of the
+anonymizer training loss algebra with torch autograd (float32), on the oracle networks.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Pinned by tests/test_oracle_golden.py::test_train_step_* against loss values and gradient norms
+captured by running the REFERENCE modules (model_loaders.load_fa_model('unet'),
+load_ft_model('largei3d')) through the same lines of train_anonymizer.py (tests/golden/make_golden.py g7).
+
+Follows anonymization_training/train_anonymizer.py:
+  feed (Q2)           :57,87-92        split :94       ft x3 :99,111-112
+  loss_ft             :107,115-116     loss_fa :119 (the fb / NT-Xent term needs torchvision's ResNet-50: absent)
+  phase 2             :137-183
+"""
+import torch
+
+from . import i3res50_ref, losses_ref, unet_ref
+
+
+def _grad_sd(sd):
+    return {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+            for k, v in sd.items()}
+
+
+def _utility(ft_sd, clips, labels, train, tlw=0.1):
+    heads = [i3res50_ref.wrapper_forward(c, ft_sd, train=train) for c in clips]
+    ce = losses_ref.cross_entropy_torch(heads[0][0], labels)
+    trip = losses_ref.triplet_torch(heads[0][1], heads[1][1], heads[2][1])
+    return ce + tlw * trip, ce, trip
+
+
+def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_frames=16):
+    """Returns (losses dict, grads of fa parameters dict, d(loss)/d(anon))."""
+    fa = _grad_sd(fa_sd)
+    v = video_b48.permute(0, 2, 1, 3, 4)
+    b, c, t, h, w = v.shape
+    anon = unet_ref.forward(v.reshape(-1, c, h, w), fa, train=True).reshape(b, c, t, h, w)
+    anon.retain_grad()
+    clips = torch.split(anon, [num_frames] * 3, dim=2)
+    loss_ft, ce, trip = _utility(ft_sd, clips, labels, train=False, tlw=tlw)
+    loss_fa = ft_loss_weight * loss_ft
+    loss_fa.backward()
+    grads = {k: p.grad for k, p in fa.items() if p.requires_grad and p.grad is not None}
+    return dict(loss_fa=loss_fa.item(), loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads, anon.grad
+
+
+def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
+    ft = _grad_sd(ft_sd)
+    v = video_b48.permute(0, 2, 1, 3, 4)
+    b, c, t, h, w = v.shape
+    with torch.no_grad():
+        anon = unet_ref.forward(v.reshape(-1, c, h, w), fa_sd, train=False).reshape(b, c, t, h, w)
+    clips = torch.split(anon, [num_frames] * 3, dim=2)
+    loss_ft, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw)
+    loss_ft.backward()
+    grads = {k: p.grad for k, p in ft.items() if p.requires_grad and p.grad is not None}
+    return dict(loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads

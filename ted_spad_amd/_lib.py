@@ -20,8 +20,8 @@ class ConvDesc(C.Structure):
 
 
 class ConvExtras(C.Structure):
-    _fields_ = [("mask", C.c_void_p), ("stats", C.c_void_p)] + [(n, C.c_int32) for n in (
-        "ldmask", "stats_ld", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf")]
+    _fields_ = [("mask", C.c_void_p), ("stats", C.c_void_p), ("y32", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf")]
 
 
 class PoolDesc(C.Structure):
@@ -62,6 +62,10 @@ SYMBOLS = {
     "tedspad_upsample_bilinear2x_bwd": (_I32, [_P, _P] + [_I32] * 11 + [_P]),
     "tedspad_nchw_grad_to_channels_last": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I32, _P]),
     "tedspad_channels_last_to_nchw_strided": (_I32, [_P, _P] + [_I32] * 6 + [_I64] * 5 + [_I32, _P]),
+    "tedspad_bn1d_train_fwd": (_I32, [_P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "tedspad_bn1d_train_bwd": (_I32, [_P] * 9 + [_I32, _I32, _I32, _P]),
+    "tedspad_l2_normalize_rows_bwd": (_I32, [_P, _P, _P, _I32, _I32, C.c_float, _P]),
+    "tedspad_mul_f32": (_I32, [_P, _P, _P, _I64, C.c_float, _P]),
     "tedspad_linear_fwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "tedspad_l2_normalize_rows": (_I32, [_P, _P, _I32, _I32, C.c_float, _P]),
 }

@@ -47,7 +47,8 @@ struct ConvKP {
     // optional epilogue extras (training path)
     const uint16_t *mask;   // out = mask > 0 ? out : 0   (ReLU backward fused into the dgrad that produces d(input))
     float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)
-    int ldmask, stats_ld;
+    float *y32;             // optional fp32 copy of the output (train-mode BN keeps the pre-normalisation conv output exact)
+    int ldmask, stats_ld, ldy32;
     int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
     int ost, osh, osw, oot, ooh, oow, TF, HF, WF;
 };
@@ -253,7 +254,11 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
             }
-            *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
+            if (p.y) *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
+            if (p.y32) {
+                *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
         }
     }
     if (p.stats) {   // block-level reduction of the batch statistics, then one atomic per channel
@@ -567,7 +572,7 @@ extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x
                                        const float *scale, const float *shift, const void *residual, void *y, int32_t sigmoid,
                                        const tedspad_conv_extras *ex, void *stream) {
     TS_REQUIRE(desc_ok(d), "tedspad_conv_fwd: bad descriptor (cin/cout/ld* multiples of 8, kernel dims <= 7)");
-    TS_REQUIRE(x && w_packed && ktab && scale && shift && y, "tedspad_conv_fwd: null pointer");
+    TS_REQUIRE(x && w_packed && ktab && scale && shift && (y || (ex && ex->y32)), "tedspad_conv_fwd: null pointer");
     TS_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) % 16 == 0,
                "tedspad_conv_fwd: pointers must be 16-byte aligned");
     TS_REQUIRE(!residual || (d->ldres % 8 == 0 && d->ldres >= d->cout), "tedspad_conv_fwd: bad ldres");
@@ -591,13 +596,15 @@ extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x
     p.pointwise = (d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
                    d->ph == 0 && d->pw == 0 && d->to == d->t && d->ho == d->h && d->wo == d->w);
     p.tiles_n = 0;
-    p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0;
+    p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
     bool extras = false;
     if (ex) {
         TS_REQUIRE(!ex->mask || (ex->ldmask % 8 == 0 && ex->ldmask >= d->cout && (uintptr_t)ex->mask % 16 == 0), "tedspad_conv_fwd_ex: bad mask");
         TS_REQUIRE(!ex->stats || ex->stats_ld >= d->cout, "tedspad_conv_fwd_ex: stats_ld must be >= cout");
+        TS_REQUIRE(!ex->y32 || (ex->ldy32 % 4 == 0 && ex->ldy32 >= d->cout && (uintptr_t)ex->y32 % 16 == 0), "tedspad_conv_fwd_ex: bad y32");
         p.mask = (const uint16_t *)ex->mask; p.ldmask = ex->ldmask; p.stats = ex->stats; p.stats_ld = ex->stats_ld;
+        p.y32 = ex->y32; p.ldy32 = ex->ldy32;
         if (ex->out_strided) {
             TS_REQUIRE(ex->ost > 0 && ex->osh > 0 && ex->osw > 0 && ex->oot >= 0 && ex->ooh >= 0 && ex->oow >= 0 &&
                            (d->to - 1) * ex->ost + ex->oot < ex->tf && (d->ho - 1) * ex->osh + ex->ooh < ex->hf &&
@@ -606,7 +613,7 @@ extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x
             p.ostrided = 1; p.ost = ex->ost; p.osh = ex->osh; p.osw = ex->osw; p.oot = ex->oot; p.ooh = ex->ooh; p.oow = ex->oow;
             p.TF = ex->tf; p.HF = ex->hf; p.WF = ex->wf;
         }
-        extras = p.mask || p.stats || p.ostrided;
+        extras = p.mask || p.stats || p.ostrided || p.y32;
     }
     hipStream_t s = (hipStream_t)stream;
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);

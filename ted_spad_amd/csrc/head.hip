@@ -48,10 +48,102 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float *x, float *y, i
     for (int i = lane; i < N; i += 64) y[(size_t)wave * N + i] = px[i] * inv;
 }
 
+// BatchNorm1d in train mode on a (B, C) fp32 matrix (B is tiny: one thread per feature walks the batch).
+__global__ void bn1d_train_fwd_kernel(const float *x, const float *gamma, const float *beta, float eps, float momentum, float *rmean,
+                                      float *rvar, float *y, float *mean_o, float *invstd_o, int B, int C, int relu) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, ss = 0.f;
+    for (int b = 0; b < B; ++b) { const float v = x[(size_t)b * C + c]; s += v; }
+    const float mean = s / B;
+    for (int b = 0; b < B; ++b) { const float d = x[(size_t)b * C + c] - mean; ss += d * d; }
+    const float var = ss / B;
+    const float invstd = rsqrtf(var + eps);
+    for (int b = 0; b < B; ++b) {
+        float v = (x[(size_t)b * C + c] - mean) * invstd * gamma[c] + beta[c];
+        if (relu) v = __builtin_fmaxf(v, 0.f);
+        y[(size_t)b * C + c] = v;
+    }
+    mean_o[c] = mean; invstd_o[c] = invstd;
+    if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (B > 1 ? var * B / (B - 1) : var);
+    }
+}
+
+__global__ void bn1d_train_bwd_kernel(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
+                                      const float *gamma, float *dx, float *dgamma, float *dbeta, int B, int C, int relu) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sb = 0.f, sg = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float g = dy[(size_t)b * C + c];
+        if (relu && !(y[(size_t)b * C + c] > 0.f)) g = 0.f;
+        sb += g; sg += g * (x[(size_t)b * C + c] - mean[c]) * invstd[c];
+    }
+    dbeta[c] = sb; dgamma[c] = sg;
+    for (int b = 0; b < B; ++b) {
+        float g = dy[(size_t)b * C + c];
+        if (relu && !(y[(size_t)b * C + c] > 0.f)) g = 0.f;
+        const float xh = (x[(size_t)b * C + c] - mean[c]) * invstd[c];
+        dx[(size_t)b * C + c] = gamma[c] * invstd[c] * (g - sb / B - xh * sg / B);
+    }
+}
+
+// y = x / max(|x|, eps)  ->  dx = (dy - y (y . dy)) / max(|x|, eps)   (rows with |x| < eps: dx = dy / eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *x, const float *dy, float *dx, int B, int N, float eps) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    const float *px = x + (size_t)wave * N, *pg = dy + (size_t)wave * N;
+    float s = 0.f, d = 0.f;
+    for (int i = lane; i < N; i += 64) { s += px[i] * px[i]; d += px[i] * pg[i]; }
+    s = wave_sum(s); d = wave_sum(d);
+    const float nr = sqrtf(s);
+    if (nr < eps) {
+        for (int i = lane; i < N; i += 64) dx[(size_t)wave * N + i] = pg[i] / eps;
+    } else {
+        const float inv = 1.f / nr;
+        for (int i = lane; i < N; i += 64) dx[(size_t)wave * N + i] = (pg[i] - px[i] * d * inv * inv) * inv;
+    }
+}
+
+__global__ void mul_kernel(const float *a, const float *b, float *o, long n, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) o[i] = a[i] * b[i] * scale;
+}
+
 }  // namespace
 }  // namespace tedspad
 
 using namespace tedspad;
+
+extern "C" int32_t tedspad_bn1d_train_fwd(const float *x, const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                          float *running_var, float *y, float *mean, float *invstd, int32_t B, int32_t C, int32_t relu, void *stream) {
+    TS_REQUIRE(x && gamma && beta && y && mean && invstd && B > 0 && C > 0, "tedspad_bn1d_train_fwd: bad arguments");
+    hipLaunchKernelGGL(bn1d_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, momentum, running_mean,
+                       running_var, y, mean, invstd, B, C, relu);
+    return check_launch("tedspad_bn1d_train_fwd");
+}
+
+extern "C" int32_t tedspad_bn1d_train_bwd(const float *dy, const float *x, const float *y, const float *mean, const float *invstd, const float *gamma,
+                                          float *dx, float *dgamma, float *dbeta, int32_t B, int32_t C, int32_t relu, void *stream) {
+    TS_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && B > 0 && C > 0 && (!relu || y), "tedspad_bn1d_train_bwd: bad arguments");
+    hipLaunchKernelGGL(bn1d_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, x, y, mean, invstd, gamma, dx, dgamma, dbeta, B, C, relu);
+    return check_launch("tedspad_bn1d_train_bwd");
+}
+
+extern "C" int32_t tedspad_l2_normalize_rows_bwd(const float *x, const float *dy, float *dx, int32_t B, int32_t N, float eps, void *stream) {
+    TS_REQUIRE(x && dy && dx && B > 0 && N > 0, "tedspad_l2_normalize_rows_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, N, eps);
+    return check_launch("tedspad_l2_normalize_rows_bwd");
+}
+
+extern "C" int32_t tedspad_mul_f32(const float *a, const float *b, float *out, int64_t n, float scale, void *stream) {
+    TS_REQUIRE(a && b && out && n > 0, "tedspad_mul_f32: bad arguments");
+    long g = (n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, scale);
+    return check_launch("tedspad_mul_f32");
+}
 
 extern "C" int32_t tedspad_linear_fwd(const float *x, const float *w, const float *scale, const float *shift, float *y,
                                       int32_t B, int32_t K, int32_t N, int32_t relu, void *stream) {

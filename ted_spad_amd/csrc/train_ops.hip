@@ -42,14 +42,18 @@ __global__ void bn_finalize_kernel(const float *stats, int stats_ld, float count
 
 // y = act(z * scale + shift (+ res))
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t *z, const float *scale, const float *shift, const uint16_t *res,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *z, const float *scale, const float *shift, const uint16_t *res,
                                                         uint16_t *y, long pixels, int C8, int ldz, int ldres, int ldy, int relu) {
     const long total = pixels * C8;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c8 = (int)(idx % C8);
         const long px = idx / C8;
         float v[8];
-        unpack8<T>(*reinterpret_cast<const uint4 *>(z + px * ldz + c8 * 8), v);
+        {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), b = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] * scale[c8 * 8 + i] + shift[c8 * 8 + i];
         if (res) {
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t *z, const 
 //   g = dy * (y > 0 if relu),  xhat = (z - mean) * invstd  (xhat term skipped when z == nullptr)
 // block = 256 threads = (256 / C8L) pixel lanes x C8L channel chunks, C8L = min(C8, 32)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const uint16_t *z, const float *mean,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const float *z, const float *mean,
                                                              const float *invstd, float *out, int out_ld, long pixels, int C8, int lddy,
                                                              int ldy, int ldz, int relu) {
     __shared__ float red[2][256][8];
@@ -100,10 +104,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) s0[i] += g[i];
             if (z) {
-                float zz[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(z + px * ldz + c8 * 8), zz);
+                const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s1[i] += g[i] * (zz[i] - mu[i]) * is[i];
+                for (int i = 0; i < 4; ++i) { s1[i] += g[i] * (za[i] - mu[i]) * is[i]; s1[i + 4] += g[i + 4] * (zb[i] - mu[i + 4]) * is[i + 4]; }
             }
         }
     }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 // dz = k[c] * (g - a[c] - xhat * b[c]),  g = dy * (y > 0 if relu);  optionally dres = g
 //   train BN: k = gamma*invstd, a = dbeta/M, b = dgamma/M
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const uint16_t *z, const float *mean,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const float *z, const float *mean,
                                                             const float *invstd, const float *gamma, const float *sums, int sums_ld,
                                                             float inv_count, uint16_t *dz, uint16_t *dres, long pixels, int C8, int lddy,
                                                             int ldy, int ldz, int lddz, int lddres, int relu) {
@@ -143,7 +146,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
             for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
         }
         if (dres) *reinterpret_cast<uint4 *>(dres + px * lddres + c8 * 8) = pack8<T>(g);
-        unpack8<T>(*reinterpret_cast<const uint4 *>(z + px * ldz + c8 * 8), zz);
+        {
+            const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = c8 * 8 + i;
@@ -329,15 +336,15 @@ extern "C" int32_t tedspad_bn_finalize(const float *stats, int32_t stats_ld, int
     return check_launch("tedspad_bn_finalize");
 }
 
-extern "C" int32_t tedspad_scale_shift_act(const void *z, const float *scale, const float *shift, const void *res, void *y, int64_t pixels,
+extern "C" int32_t tedspad_scale_shift_act(const float *z, const float *scale, const float *shift, const void *res, void *y, int64_t pixels,
                                            int32_t C, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu, int32_t dtype, void *stream) {
-    TS_REQUIRE(z && scale && shift && y && pixels > 0 && C > 0 && C % 8 == 0 && ldz % 8 == 0 && ldy % 8 == 0 && TS_DT(dtype), "tedspad_scale_shift_act: bad arguments");
+    TS_REQUIRE(z && scale && shift && y && pixels > 0 && C > 0 && C % 8 == 0 && ldz % 4 == 0 && ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0, "tedspad_scale_shift_act: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_apply_kernel, dim3(grid_for(pixels * (C / 8))), (const uint16_t *)z, scale, shift, (const uint16_t *)res, (uint16_t *)y, (long)pixels, C / 8, ldz, ldres, ldy, relu);
+    LAUNCH_T(dtype, bn_apply_kernel, dim3(grid_for(pixels * (C / 8))), z, scale, shift, (const uint16_t *)res, (uint16_t *)y, (long)pixels, C / 8, ldz, ldres, ldy, relu);
     return check_launch("tedspad_scale_shift_act");
 }
 
-extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, const float *mean, const float *invstd, float *sums,
+extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, float *sums,
                                          int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t relu,
                                          int32_t dtype, void *stream) {
     TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && (!z || (mean && invstd)) && sums_ld >= C,
@@ -347,18 +354,18 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
     if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups)), (const uint16_t *)dy, (const uint16_t *)y, (const uint16_t *)z, mean, invstd,
+    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups)), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd,
              sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
     return check_launch("tedspad_bn_bwd_reduce");
 }
 
-extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, const float *mean, const float *invstd, const float *gamma,
+extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, const float *gamma,
                                         const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
                                         int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t dtype, void *stream) {
     TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y),
                "tedspad_bn_bwd_apply: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8))), (const uint16_t *)dy, (const uint16_t *)y, (const uint16_t *)z, mean, invstd, gamma,
+    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8))), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd, gamma,
              sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
     return check_launch("tedspad_bn_bwd_apply");
 }

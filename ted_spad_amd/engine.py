@@ -196,12 +196,13 @@ class PackedConv:
 
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
                  residual: Optional[Act] = None, relu=True, sigmoid=False, mask: Optional[Act] = None,
-                 stats: Optional[torch.Tensor] = None, out_dims=None, out_map=None) -> Act:
+                 stats: Optional[torch.Tensor] = None, out_dims=None, out_map=None, y32: bool = False):
         """pads: FRONT zero padding (t,h,w); pads_back defaults to pads (symmetric, as nn.Conv3d).
         out_dims: explicit output extent (instead of the one implied by pads_back).
         out_map = ((ost,osh,osw), (oot,ooh,oow)): output pixel (to,ho,wo) lands at (to*ost+oot, ...) of `out`
         (which then is the full, larger tensor; residual / mask are indexed the same way).
-        mask: out = mask > 0 ? out : 0.  stats: fp32 (2, >=cout) batch-statistics accumulator."""
+        mask: out = mask > 0 ? out : 0.  stats: fp32 (2, >=cout) batch-statistics accumulator.
+        y32=True: the result is returned as an fp32 (n,to,ho,wo,cout) tensor instead of a 16-bit Act."""
         n, t, h, w = x.dims
         assert x.c == self.cin, "conv expects %d input channels, got %d" % (self.cin, x.c)
         pb = pads if pads_back is None else pads_back
@@ -209,6 +210,11 @@ class PackedConv:
         st, sh, sw = self.stride
         o = tuple(out_dims) if out_dims is not None else (
             conv_out(t, kt, st, pads[0], pb[0]), conv_out(h, kh, sh, pads[1], pb[1]), conv_out(w, kw, sw, pads[2], pb[2]))
+        z32 = None
+        if y32:
+            assert out is None and out_map is None and residual is None and mask is None
+            z32 = torch.empty((n,) + o + (self.cout,), dtype=torch.float32, device=x.buf.device)
+            out = Act(z32, self.cout)      # geometry carrier only; the 16-bit pointer is not passed
         if out is None:
             assert out_map is None
             out = Act.empty(n, o[0], o[1], o[2], self.cout, self.torch_dtype, x.buf.device)
@@ -220,8 +226,10 @@ class PackedConv:
                 assert other.dims == out.dims and other.c == self.cout
         d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
         ex = None
-        if mask is not None or stats is not None or out_map is not None:
+        if mask is not None or stats is not None or out_map is not None or y32:
             ex = _lib.ConvExtras()
+            if y32:
+                ex.y32, ex.ldy32 = z32.data_ptr(), self.cout
             if mask is not None:
                 ex.mask, ex.ldmask = mask.ptr, mask.ld
             if stats is not None:
@@ -232,15 +240,16 @@ class PackedConv:
                 ex.out_strided = 1
                 _, ex.tf, ex.hf, ex.wf = out.dims
         args = (C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                residual.ptr if residual is not None else None, out.ptr, int(sigmoid), C.byref(ex) if ex is not None else None)
-        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map)
+                residual.ptr if residual is not None else None, None if y32 else out.ptr, int(sigmoid),
+                C.byref(ex) if ex is not None else None)
+        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map, y32)
         cfg = self._cfgs.get(key)
         if cfg is None:
             cfg = self._autotune(d, args, stats) if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else 0
             self._cfgs[key] = cfg
         d.tile_cfg = cfg
         check(_lib.lib().tedspad_conv_fwd_ex(*args, _stream_ptr()), "tedspad_conv_fwd")
-        return out
+        return z32 if y32 else out
 
 
 def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: Optional[Act] = None, return_idx=False):

@@ -143,3 +143,12 @@ def synth_state_dict(template: "OrderedDict[str, torch.Tensor]", seed: int = 0,
             raise KeyError("synth_state_dict: no rule for %s %s" % (k, shape))
         out[k] = v.to(t.dtype)
     return out
+
+
+def synth_train_video(seed: int, name: str, shape, device="cpu") -> torch.Tensor:
+    """(B,48,3,H,W) training batch in [0,1]: i.i.d. noise frames with a per-sample brightness gain
+    (b+1)/B. Pure i.i.d. noise makes the pooled features of all samples nearly identical, and a
+    train-mode BatchNorm over such a batch amplifies rounding noise instead of signal."""
+    b = shape[0]
+    gain = (torch.arange(1, b + 1, dtype=torch.float32, device=device) / b).view(b, 1, 1, 1, 1)
+    return synth_tensor(seed, name, shape, device=device) * gain

@@ -143,10 +143,10 @@ class ConvLayer:
             return self.pads, self.pads_back
         return (self.pads[0], self.pads[1], pc.pair_pw), (self.pads_back[0], self.pads_back[1], pc.k[2] - 1 - pc.pair_pw)
 
-    def forward(self, x: Act, scale=None, shift=None, relu=False, residual=None, stats=None, out=None, sigmoid=False) -> Act:
+    def forward(self, x: Act, scale=None, shift=None, relu=False, residual=None, stats=None, out=None, sigmoid=False, y32=False):
         pc = self.fwd_conv(scale, shift)
         pk, pbk = self._pads_k(pc)
-        return pc(x, pads=pk, pads_back=pbk, relu=relu, residual=residual, stats=stats, out=out, sigmoid=sigmoid)
+        return pc(x, pads=pk, pads_back=pbk, relu=relu, residual=residual, stats=stats, out=out, sigmoid=sigmoid, y32=y32)
 
     # ---- backward -----------------------------------------------------------------------------------
     def dgrad(self, dy: Act, x_dims, scale=None, residual=None, mask=None, out=None) -> Act:
@@ -186,14 +186,15 @@ class ConvLayer:
 
 # ---- per-channel reductions / BatchNorm ---------------------------------------------------------------
 
-def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[Act] = None, mean=None, invstd=None, relu=False) -> torch.Tensor:
-    """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu)."""
+def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = None, mean=None, invstd=None, relu=False) -> torch.Tensor:
+    """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu).
+    z: the fp32 (n,t,h,w,C) pre-normalisation conv output."""
     n, t, h, w = dy.dims
     sums = torch.zeros((2, dy.c), dtype=torch.float32, device=dy.buf.device)
-    check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.ptr if z is not None else None,
+    check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.data_ptr() if z is not None else None,
                                            mean.data_ptr() if mean is not None else None, invstd.data_ptr() if invstd is not None else None,
                                            sums.data_ptr(), dy.c, n * t * h * w, dy.c, dy.ld, y.ld if y is not None else 0,
-                                           z.ld if z is not None else 0, int(relu), _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
+                                           z.shape[-1] if z is not None else 0, int(relu), _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
     return sums
 
 
@@ -202,22 +203,24 @@ class BNTrainCtx:
 
 
 def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional[Act] = None, out: Optional[Act] = None):
-    """conv -> BatchNorm(batch statistics, running stats updated) -> (+residual) -> ReLU. Returns (y, ctx)."""
-    cpad = conv.fwd_conv().cpad
-    stats = torch.zeros((2, cpad), dtype=torch.float32, device=x.buf.device)
-    z = conv.forward(x, stats=stats)
-    n, t, h, w = z.dims
+    """conv -> BatchNorm(batch statistics, running stats updated) -> (+residual) -> ReLU. Returns (y, ctx).
+    The pre-normalisation conv output z stays in fp32 (it is re-read by the BN apply and by the backward)."""
+    pc = conv.fwd_conv()
+    stats = torch.zeros((2, pc.cpad), dtype=torch.float32, device=x.buf.device)
+    z = conv.forward(x, stats=stats, y32=True)                       # (n,t,h,w,cout) fp32
+    n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
-    scale, shift, mean, invstd = (torch.zeros(z.c, dtype=torch.float32, device=x.buf.device) for _ in range(4))
-    check(_lib.lib().tedspad_bn_finalize(stats.data_ptr(), cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
+    scale, shift, mean, invstd = (torch.zeros(cz, dtype=torch.float32, device=x.buf.device) for _ in range(4))
+    check(_lib.lib().tedspad_bn_finalize(stats.data_ptr(), pc.cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                          C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), c, _stream_ptr()),
           "tedspad_bn_finalize")
     bn.num_batches_tracked += 1
-    y = out if out is not None else Act.empty(n, t, h, w, z.c, z.buf.dtype, z.buf.device)
-    check(_lib.lib().tedspad_scale_shift_act(z.ptr, scale.data_ptr(), shift.data_ptr(), residual.ptr if residual is not None else None,
-                                             y.ptr, n * t * h * w, z.c, z.ld, residual.ld if residual is not None else 0, y.ld,
-                                             int(relu), _code(z.buf), _stream_ptr()), "tedspad_scale_shift_act")
+    tdt = E.DTYPES[conv.dtype][0]
+    y = out if out is not None else Act.empty(n, t, h, w, cz, tdt, z.device)
+    check(_lib.lib().tedspad_scale_shift_act(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), residual.ptr if residual is not None else None,
+                                             y.ptr, n * t * h * w, cz, cz, residual.ld if residual is not None else 0, y.ld,
+                                             int(relu), _code(y.buf), _stream_ptr()), "tedspad_scale_shift_act")
     ctx = BNTrainCtx()
     ctx.x, ctx.z, ctx.y, ctx.mean, ctx.invstd, ctx.bn, ctx.conv, ctx.relu, ctx.has_res = x, z, y, mean, invstd, bn, conv, relu, residual is not None
     return y, ctx
@@ -227,18 +230,18 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
                           x_dims=None):
     """Backward of `conv_bn_act_train`: accumulates d(gamma), d(beta), d(weight), d(bias) into .grad and returns
     (dx or None, dres or None). dx = dgrad(dz) (+ dx_residual) masked by dx_mask."""
-    bn, z = ctx.bn, ctx.z
-    n, t, h, w = z.dims
+    bn, z, y = ctx.bn, ctx.z, ctx.y
+    n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
-    sums = channel_sums(dy, ctx.y, z, ctx.mean, ctx.invstd, relu=ctx.relu)
-    dz = Act.empty(n, t, h, w, z.c, z.buf.dtype, z.buf.device)
-    dres = Act.empty(n, t, h, w, z.c, z.buf.dtype, z.buf.device) if ctx.has_res else None
-    gam = torch.zeros(z.c, dtype=torch.float32, device=z.buf.device)
+    sums = channel_sums(dy, y, z, ctx.mean, ctx.invstd, relu=ctx.relu)
+    dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
+    dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
+    gam = torch.zeros(cz, dtype=torch.float32, device=z.device)
     gam[:c] = bn.weight.detach()
-    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ctx.y.ptr, z.ptr, ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
-                                          sums.data_ptr(), z.c, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w, z.c,
-                                          dy.ld, ctx.y.ld, z.ld, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu),
-                                          _code(z.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
+    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, y.ptr, z.data_ptr(), ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
+                                          sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w, cz,
+                                          dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu),
+                                          _code(y.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
     bn.bias.grad = sums[0, :c].clone() if bn.bias.grad is None else bn.bias.grad + sums[0, :c]
     bn.weight.grad = sums[1, :c].clone() if bn.weight.grad is None else bn.weight.grad + sums[1, :c]
     ctx.conv.wgrad(ctx.x, dz)

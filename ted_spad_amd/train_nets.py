@@ -1,0 +1,331 @@
+"""Forward-with-tape and backward of the three networks of the anonymizer training step on
+MI355X: the reference relies on torch autograd through its nn.Modules
+(anonymization_training/train_anonymizer.py:71-132 phase 1, :135-198 phase 2); here each network
+has an explicit launch sequence for both directions (all arithmetic in libtedspad_hip.so).
+
+  I3DTrainer  -- wrapper_i3d (I3Res50 + fc + mlp):
+       mode 'eval'  (phase 1, ft frozen: BN folded, gradient flows to the INPUT only; the unused
+                     weight gradients of the reference are skipped)
+       mode 'train' (phase 2: batch-statistics BN, running stats updated once per forward (Q14),
+                     weight gradients, dropout before fc)
+  UNetTrainer -- UNet anonymizer in train mode (phase 1).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib, engine as E, head, train_engine as TE
+from ._lib import check
+from .engine import Act, _stream_ptr
+
+
+def _acc_grad(p, g):
+    p.grad = g.clone() if p.grad is None else p.grad + g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fp32 head: Linear / BatchNorm1d(train) / L2-normalise with explicit backward (B x C matrices, B tiny)
+# ------------------------------------------------------------------------------------------------------------------
+
+def _linear_bwd(x, w, dy, want_dx=True):
+    """y = x w^T (+b): returns (dx, dw, db); the three products reuse the forward GEMV kernel."""
+    dx = head.linear(dy, w.detach().t().contiguous()) if want_dx else None            # (B,N) x (N,K)
+    dw = head.linear(dy.t().contiguous(), x.t().contiguous())                          # (N,B) x (B,K)
+    db = head.linear(torch.ones((1, dy.shape[0]), device=dy.device), dy.t().contiguous())[0]
+    return dx, dw, db
+
+
+def _bn1d_train(x, bn, relu):
+    B, Cn = x.shape
+    y = torch.empty_like(x)
+    mean, invstd = torch.empty(Cn, device=x.device), torch.empty(Cn, device=x.device)
+    check(_lib.lib().tedspad_bn1d_train_fwd(x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), C.c_float(bn.eps), C.c_float(bn.momentum),
+                                            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                            invstd.data_ptr(), B, Cn, int(relu), _stream_ptr()), "tedspad_bn1d_train_fwd")
+    bn.num_batches_tracked += 1
+    return y, (x, y, mean, invstd, relu)
+
+
+def _bn1d_train_bwd(ctx, bn, dy):
+    x, y, mean, invstd, relu = ctx
+    B, Cn = x.shape
+    dy = dy.contiguous()
+    dx, dg, db = torch.empty_like(x), torch.empty(Cn, device=x.device), torch.empty(Cn, device=x.device)
+    check(_lib.lib().tedspad_bn1d_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                            bn.weight.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), B, Cn, int(relu),
+                                            _stream_ptr()), "tedspad_bn1d_train_bwd")
+    return dx, dg, db
+
+
+def _l2norm_bwd(x, dy, eps=1e-12):
+    dx = torch.empty_like(x)
+    dy = dy.contiguous().float()
+    check(_lib.lib().tedspad_l2_normalize_rows_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1], C.c_float(eps),
+                                                   _stream_ptr()), "tedspad_l2_normalize_rows_bwd")
+    return dx
+
+
+def _mul(a, b, scale):
+    out = torch.empty_like(a)
+    check(_lib.lib().tedspad_mul_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), C.c_float(scale), _stream_ptr()), "tedspad_mul_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# wrapper_i3d
+# ------------------------------------------------------------------------------------------------------------------
+
+class I3DTrainer:
+    def __init__(self, wrapper):
+        self.m = wrapper
+        i3d = wrapper.i3d
+        dt = i3d.compute_dtype
+        self.stem = TE.ConvLayer(i3d.conv1.weight, None, (2, 2, 2), (2, 3, 3), pair_w=3, dtype=dt)
+        self.blocks = []
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(i3d, "layer%d" % li)):
+                s = blk.stride
+                d = dict(li=li, bi=bi, blk=blk,
+                         c1=TE.ConvLayer(blk.conv1.weight, None, (1, 1, 1), (blk.temp_conv, 0, 0), dtype=dt),
+                         c2=TE.ConvLayer(blk.conv2.weight, None, (1, s, s), (0, 1, 1), dtype=dt),
+                         c3=TE.ConvLayer(blk.conv3.weight, None, (1, 1, 1), (0, 0, 0), dtype=dt),
+                         cd=TE.ConvLayer(blk.downsample[0].weight, None, (1, s, s), (0, 0, 0), dtype=dt) if blk.downsample is not None else None)
+                self.blocks.append(d)
+        self._folds = {}
+
+    def _fold(self, bn):
+        """Eval-mode BN as fp32 (scale, shift); cached while the BN tensors are unchanged."""
+        sig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        hit = self._folds.get(id(bn))
+        if hit is None or hit[0] != sig:
+            hit = (sig,) + E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            self._folds[id(bn)] = hit
+        return hit[1], hit[2]
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, mode: str, drop_mask: Optional[torch.Tensor] = None):
+        """x: (B,3,T,H,W) fp32 (any strides: a `torch.split` view is fine).
+        Returns (pred (B,nc), feat (B,128), tape)."""
+        assert mode in ("eval", "train")
+        i3d, mlp = self.m.i3d, self.m.mlp
+        E.require_cuda(x, "I3DTrainer")
+        if x.shape[0] < 2:
+            raise ValueError("wrapper_i3d.forward needs B >= 2 (BatchNorm1d; SURVEY.md Q3)")
+        train = mode == "train"
+        tape = dict(mode=mode, x_shape=tuple(x.shape), units=[])
+        a = E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype)
+        tape["clip"] = a
+
+        def unit(conv, bn, xin, relu=True, residual=None):
+            if train:
+                y, ctx = TE.conv_bn_act_train(conv, bn, xin, relu=relu, residual=residual)
+                return y, ctx
+            s, b = self._fold(bn)
+            return conv.forward(xin, scale=s, shift=b, relu=relu, residual=residual), (conv, s)
+
+        y, tape["stem"] = unit(self.stem, i3d.bn1, a)
+        tape["stem_y"] = y
+        a, tape["idx1"] = E.maxpool(y, (2, 3, 3), (2, 2, 2), return_idx=True)
+        for d in self.blocks:
+            blk = d["blk"]
+            rec = dict(d=d)
+            if d["li"] == 2 and d["bi"] == 0:
+                rec["pool_in"] = a
+                a, rec["pool_idx"] = E.maxpool(a, (2, 1, 1), (2, 1, 1), return_idx=True)
+            rec["a_in"] = a
+            h1, rec["u1"] = unit(d["c1"], blk.bn1, a)
+            h2, rec["u2"] = unit(d["c2"], blk.bn2, h1)
+            if d["cd"] is not None:
+                r, rec["ud"] = unit(d["cd"], blk.downsample[1], a, relu=False)
+            else:
+                r = a
+            a, rec["u3"] = unit(d["c3"], blk.bn3, h2, relu=True, residual=r)
+            rec["h1"], rec["h2"], rec["out"] = h1, h2, a
+            tape["units"].append(rec)
+        f = E.global_avgpool(a)                                   # (B,2048) fp32; feat = x.squeeze() BEFORE dropout
+        tape["f"] = f
+        # ---- head: fc on dropout(f) ; mlp on f ---------------------------------------------------------------------
+        fd = f
+        if train and i3d.drop_p > 0:
+            if drop_mask is None:
+                drop_mask = (torch.rand_like(f) >= i3d.drop_p).float()
+            fd = _mul(f, drop_mask, 1.0 / (1.0 - i3d.drop_p))
+        tape["drop_mask"], tape["fd"] = drop_mask, fd
+        pred = head.linear(fd, i3d.fc.weight, i3d.fc.bias)
+        if train:
+            z1 = head.linear(f, mlp.fc1.weight, mlp.fc1.bias)
+            h, tape["bn1"] = _bn1d_train(z1, mlp.bn1, relu=True)
+            z2 = head.linear(h, mlp.fc2.weight, None)
+            g, tape["bn2"] = _bn1d_train(z2, mlp.bn2, relu=False)
+            tape["h"], tape["g"] = h, g
+            feat = head.l2_normalize(g)
+        else:
+            h = head.linear(f, mlp.fc1.weight, mlp.fc1.bias, bn=mlp.bn1, relu=True)
+            g = head.linear(h, mlp.fc2.weight, None, bn=mlp.bn2, relu=False)
+            tape["h"], tape["g"] = h, g
+            feat = head.l2_normalize(g)
+        return pred, feat, tape
+
+    # ---- backward --------------------------------------------------------------------------------------------------
+    def backward(self, tape, dpred: Optional[torch.Tensor], dfeat: Optional[torch.Tensor], dx_out: Optional[torch.Tensor] = None):
+        """Accumulates parameter gradients (mode 'train') and/or writes d(loss)/d(clip) into `dx_out`
+        ((B,3,T,H,W) fp32 view, any strides; mode 'eval')."""
+        i3d, mlp = self.m.i3d, self.m.mlp
+        train = tape["mode"] == "train"
+        f, h, g = tape["f"], tape["h"], tape["g"]
+        df = torch.zeros_like(f)
+        if dpred is not None:
+            dpred = dpred.contiguous().float()
+            dfd, dw, db = _linear_bwd(tape["fd"], i3d.fc.weight, dpred)
+            if train:
+                _acc_grad(i3d.fc.weight, dw)
+                _acc_grad(i3d.fc.bias, db)
+                if tape["drop_mask"] is not None and i3d.drop_p > 0:
+                    dfd = _mul(dfd, tape["drop_mask"], 1.0 / (1.0 - i3d.drop_p))
+            df = df + dfd
+        if dfeat is not None:
+            dg = _l2norm_bwd(g, dfeat)
+            if train:
+                dz2, dgam, dbet = _bn1d_train_bwd(tape["bn2"], mlp.bn2, dg)
+                _acc_grad(mlp.bn2.weight, dgam); _acc_grad(mlp.bn2.bias, dbet)
+                dh, dw2, _ = _linear_bwd(h, mlp.fc2.weight, dz2)
+                _acc_grad(mlp.fc2.weight, dw2)
+                dz1, dgam, dbet = _bn1d_train_bwd(tape["bn1"], mlp.bn1, dh)
+                _acc_grad(mlp.bn1.weight, dgam); _acc_grad(mlp.bn1.bias, dbet)
+                dfm, dw1, db1 = _linear_bwd(f, mlp.fc1.weight, dz1)
+                _acc_grad(mlp.fc1.weight, dw1); _acc_grad(mlp.fc1.bias, db1)
+            else:
+                s2, _ = self._fold(mlp.bn2)
+                dz2 = dg * s2
+                dh = head.linear(dz2, mlp.fc2.weight.detach().t().contiguous())
+                s1, _ = self._fold(mlp.bn1)
+                dz1 = _mul(dh, (h > 0).float(), 1.0) * s1
+                dfm = head.linear(dz1, mlp.fc1.weight.detach().t().contiguous())
+            df = df + dfm
+        last = tape["units"][-1]["out"]
+        if train:
+            da = TE.global_avgpool_bwd(df, last)
+            for rec in reversed(tape["units"]):
+                dh2, dres = TE.conv_bn_act_train_bwd(rec["u3"], da)
+                dh1, _ = TE.conv_bn_act_train_bwd(rec["u2"], dh2)
+                t = TE.conv_bn_act_train_bwd(rec["ud"], dres)[0] if "ud" in rec else dres
+                da, _ = TE.conv_bn_act_train_bwd(rec["u1"], dh1, dx_residual=t)
+                if "pool_idx" in rec:
+                    da = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], da, (2, 1, 1), (2, 1, 1))
+            da = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], da, (2, 3, 3), (2, 2, 2))
+            TE.conv_bn_act_train_bwd(tape["stem"], da, need_dx=False)
+            return None
+        # eval mode: only d(input). delta = gradient w.r.t. a block output's PRE-activation (already ReLU-masked).
+        delta = TE.global_avgpool_bwd(df, last, mask=last)
+        for rec in reversed(tape["units"]):
+            d = rec["d"]
+            (c3, s3), (c2, s2), (c1, s1) = rec["u3"], rec["u2"], rec["u1"]
+            du2 = c3.dgrad(delta, rec["h2"].dims[1:], scale=s3, mask=rec["h2"])
+            du1 = c2.dgrad(du2, rec["h1"].dims[1:], scale=s2, mask=rec["h1"])
+            t = rec["ud"][0].dgrad(delta, rec["a_in"].dims[1:], scale=rec["ud"][1]) if "ud" in rec else delta
+            first_after_pool = (d["li"], d["bi"]) in ((1, 0), (2, 0))     # block input is a max-pool output, not a ReLU output
+            delta = c1.dgrad(du1, rec["a_in"].dims[1:], scale=s1, residual=t, mask=None if first_after_pool else rec["a_in"])
+            if "pool_idx" in rec:
+                delta = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], delta, (2, 1, 1), (2, 1, 1), relu_mask=True)
+        delta = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], delta, (2, 3, 3), (2, 2, 2), relu_mask=True)
+        conv, s = tape["stem"]
+        dclip = conv.dgrad(delta, tape["clip"].dims[1:], scale=s)            # (B,T,H,W/2,8) == (B,T,H,W,4)
+        B, _, T, Hh, Ww = tape["x_shape"]
+        dview = Act(dclip.buf.view(B, T, Hh, Ww, 4), 4)
+        if dx_out is None:
+            dx_out = torch.empty(tape["x_shape"], dtype=torch.float32, device=dclip.buf.device)
+        TE.act_to_nchw_into(dview, 3, dx_out)
+        return dx_out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# UNet (train mode)
+# ------------------------------------------------------------------------------------------------------------------
+
+class UNetTrainer:
+    ENC = (64, 128, 256, 512)
+
+    def __init__(self, unet):
+        self.m = unet
+        dt = unet.compute_dtype
+
+        def dc(module):
+            seq = module.double_conv
+            return [(TE.ConvLayer(seq[i].weight, seq[i].bias, (1, 1, 1), (0, 1, 1), dtype=dt), seq[i + 1]) for i in (0, 3)]
+
+        self.inc = dc(unet.inc)
+        self.down = [dc(getattr(unet, "down%d" % i).maxpool_conv[1]) for i in (1, 2, 3, 4)]
+        self.up = [dc(getattr(unet, "up%d" % i).conv) for i in (1, 2, 3, 4)]
+        self.outc = TE.ConvLayer(unet.outc.conv.weight, unet.outc.conv.bias, (1, 1, 1), (0, 0, 0), dtype=dt)
+
+    def forward(self, x: torch.Tensor):
+        """x: (N,3,H,W) fp32 -> (y (N,3,H,W) fp32, tape). BatchNorm2d uses the batch statistics of this call
+        and updates the running stats once (the reference calls fa on the B*48 pseudo-images at once, Q2/Q14)."""
+        m = self.m
+        E.require_cuda(x, "UNetTrainer")
+        n, _, H, W = x.shape
+        tdt = E.DTYPES[m.compute_dtype][0]
+        a = E.clip_to_act(x.unsqueeze(2), cpad=8, dtype=m.compute_dtype)
+        tape = dict(n=n, H=H, W=W, enc=[], dec=[])
+        cats, cur, h, w = [], a, H, W
+        for lvl in range(4):
+            units = self.inc if lvl == 0 else self.down[lvl - 1]
+            rec = {}
+            if lvl > 0:
+                rec["pool_in"] = cur
+                cur, rec["pool_idx"] = E.maxpool(cur, (1, 2, 2), (1, 2, 2), return_idx=True)
+                h, w = h // 2, w // 2
+            cat = Act.empty(n, 1, h, w, 2 * self.ENC[lvl], tdt, x.device)
+            mid, rec["u1"] = TE.conv_bn_act_train(units[0][0], units[0][1], cur)
+            skip, rec["u2"] = TE.conv_bn_act_train(units[1][0], units[1][1], mid, out=cat.slice(0, self.ENC[lvl]))
+            cats.append(cat)
+            tape["enc"].append(rec)
+            cur = skip
+        rec = dict(pool_in=cur)
+        cur, rec["pool_idx"] = E.maxpool(cur, (1, 2, 2), (1, 2, 2), return_idx=True)
+        mid, rec["u1"] = TE.conv_bn_act_train(self.down[3][0][0], self.down[3][0][1], cur)
+        cur, rec["u2"] = TE.conv_bn_act_train(self.down[3][1][0], self.down[3][1][1], mid)
+        tape["bottom"] = rec
+        for i, lvl in zip((0, 1, 2, 3), (3, 2, 1, 0)):
+            cat = cats[lvl]
+            _, _, sh_, sw_ = cat.dims
+            _, _, ch, cw = cur.dims
+            dy, dx = sh_ - 2 * ch, sw_ - 2 * cw
+            E.upsample2x_into(cur, cat.slice(self.ENC[lvl], self.ENC[lvl]), dy // 2, dx // 2)
+            rec = dict(lvl=lvl, in_hw=(ch, cw), pad=(dy // 2, dx // 2))
+            mid, rec["u1"] = TE.conv_bn_act_train(self.up[i][0][0], self.up[i][0][1], cat)
+            cur, rec["u2"] = TE.conv_bn_act_train(self.up[i][1][0], self.up[i][1][1], mid)
+            tape["dec"].append(rec)
+        tape["u4"] = cur
+        logits = self.outc.forward(cur, relu=False, sigmoid=True)       # 1x1 conv + bias + sigmoid fused
+        y = E.act_to_nchw(logits, m.n_classes).squeeze(2)
+        tape["y"] = y
+        return y, tape
+
+    def backward(self, tape, dy: torch.Tensor):
+        """dy: (N,3,H,W) fp32 gradient w.r.t. the UNet output; accumulates every parameter's .grad."""
+        n, H, W = tape["n"], tape["H"], tape["W"]
+        dlogit = TE.nchw_grad_to_act(dy, tape["y"], (1, H, W), dtype=self.m.compute_dtype)     # sigmoid backward fused
+        self.outc.wgrad(tape["u4"], dlogit)
+        d = self.outc.dgrad(dlogit, tape["u4"].dims[1:])
+        dskip = {}
+        for rec in reversed(tape["dec"]):
+            lvl = rec["lvl"]
+            dmid, _ = TE.conv_bn_act_train_bwd(rec["u2"], d)
+            dcat, _ = TE.conv_bn_act_train_bwd(rec["u1"], dmid)
+            c = self.ENC[lvl]
+            dskip[lvl] = dcat.slice(0, c)
+            d = TE.upsample2x_bwd(dcat.slice(c, c), rec["in_hw"][0], rec["in_hw"][1], rec["pad"][0], rec["pad"][1])
+        rec = tape["bottom"]
+        dmid, _ = TE.conv_bn_act_train_bwd(rec["u2"], d)
+        d, _ = TE.conv_bn_act_train_bwd(rec["u1"], dmid)
+        d = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], d, (1, 2, 2), (1, 2, 2), add=dskip[3])
+        for lvl in (3, 2, 1, 0):
+            rec = tape["enc"][lvl]
+            dmid, _ = TE.conv_bn_act_train_bwd(rec["u2"], d)
+            d, _ = TE.conv_bn_act_train_bwd(rec["u1"], dmid, need_dx=lvl > 0)
+            if lvl > 0:
+                d = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], d, (1, 2, 2), (1, 2, 2), add=dskip[lvl - 1])

@@ -1,0 +1,139 @@
+"""One iteration of the alternating min-max anonymizer training on MI355X: the build's
+counterpart of `train_epoch` (anonymization_training/train_anonymizer.py:32-212).
+
+    phase 1 (even iterations, :71-132): fa.train(), ft.eval()
+        loss_fa = -fb_loss_weight * NTXent(fb(fa(v0)), fb(fa(v1))) + ft_loss_weight * (CE + temporal_loss_weight * Triplet)
+        gradients flow through the frozen ft into fa; optimizer_fa.step()
+    phase 2 (odd iterations, :135-198): fa.eval() under no_grad, ft.train()
+        loss_ft = CE + temporal_loss_weight * Triplet ; optimizer_ft.step()   (three train-mode ft forwards, Q14)
+
+Video batch layout as the reference loader delivers it: (B, 48, 3, H, W) fp32 in [0,1] = 3 clips x 16
+frames stacked on dim 1 (ucf101_dl.py:368-379); labels int64 (B,). The feed reproduces quirk Q2
+(`(B,3,48,H,W).reshape(-1,3,H,W)` pseudo-images, train_anonymizer.py:87-92).
+
+The privacy branch fb is torchvision's ResNet-50 (third-party): not built, so the
+NT-Xent term is only available from precomputed embeddings (see `ntxent_from_embeddings`); with
+`fb_model=None` the step optimises the utility term alone and says so in its result.
+
+Data parallel: one process per GPU, per-rank BatchNorm statistics (what nn.DataParallel does in the
+reference), gradients of the network being updated averaged with ONE flat RCCL all-reduce.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+from .losses import CrossEntropyLoss, NTXentLoss, TripletMarginLoss
+from .train_nets import I3DTrainer, UNetTrainer
+
+# anonymization_training/params_anonymization.py:28-62
+DEFAULT_PARAMS = SimpleNamespace(num_frames=16, learning_rate=1e-5, learning_rate_fa=0.4e-5, learning_rate_fb=1e-5,
+                                 learning_rate_ft=1e-5, ft_loss_weight=0.7, fb_loss_weight=1.0, temporal_loss_weight=0.1,
+                                 triplet_loss_margin=1, loss="ce", temporal_loss="trip", batch_size=8, batch_size_vispr=12)
+
+
+def allreduce_mean_grads(params, group=None):
+    """Average .grad over the ranks with one flat all-reduce (RCCL over xGMI; gloo in the CPU tests)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def ntxent_from_embeddings(z0, z1, temperature=0.1):
+    """loss_fb of train_anonymizer.py:82-84 given the two views' fb embeddings (N,128)."""
+    return NTXentLoss(z0.device, z0.shape[0], temperature, False)(z0, z1)
+
+
+class AnonymizerTrainStep:
+    def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None):
+        if fb_model is not None:
+            raise NotImplementedError("fb (torchvision ResNet-50) is out of scope; pass fb_model=None")
+        self.fa, self.ft, self.params, self.group = fa_model, ft_model, params, group
+        self.fa_tr, self.ft_tr = UNetTrainer(fa_model), I3DTrainer(ft_model)
+        self.opt_fa = torch.optim.Adam(fa_model.parameters(), lr=params.learning_rate_fa)     # train_anonymizer.py:377-380
+        self.opt_ft = torch.optim.Adam(ft_model.parameters(), lr=params.learning_rate_ft)
+        self.ce = CrossEntropyLoss()
+        self.trip = TripletMarginLoss(margin=params.triplet_loss_margin)
+        self.iteration = 0
+
+    # ---- shared pieces -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _feed(inputs_video):
+        """(B,48,3,H,W) -> the (B*48,3,H,W) pseudo-image batch fa sees (Q2) and the shape to restore."""
+        v = inputs_video.permute(0, 2, 1, 3, 4)                       # :57
+        b, c, t, h, w = v.shape
+        return v.reshape(-1, c, h, w), (b, c, t, h, w)                # :89 (copy: the permuted tensor is not viewable)
+
+    def _utility_losses(self, heads, labels):
+        """heads: [(pred, feat)] x3 as leaf tensors -> (loss_ft, loss_ce, loss_trip)."""
+        p = self.params
+        loss_ce = self.ce(heads[0][0], labels)                        # :107
+        loss_trip = self.trip(heads[0][1], heads[1][1], heads[2][1])  # :115
+        return loss_ce + p.temporal_loss_weight * loss_trip, loss_ce, loss_trip
+
+    # ---- phase 1 --------------------------------------------------------------------------------------------------
+    def step_fa(self, inputs_video, labels):
+        """Update fa (phase 1). Returns a dict of python floats."""
+        p = self.params
+        self.fa.train(); self.ft.eval()
+        for opt in (self.opt_fa, self.opt_ft):
+            opt.zero_grad(set_to_none=True)
+        frames, shape = self._feed(inputs_video)
+        anon_flat, tape_fa = self.fa_tr.forward(frames)
+        anon = anon_flat.reshape(shape)                               # :92
+        clips = torch.split(anon, [p.num_frames] * 3, dim=2)          # :94 (non-contiguous views, Q15)
+        tapes, leaves = [], []
+        for c in clips:
+            pred, feat, tape = self.ft_tr.forward(c, "eval")
+            tapes.append(tape)
+            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
+        loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
+        loss_fa = p.ft_loss_weight * loss_ft                          # :119 with the fb term absent
+        loss_fa.backward()
+        danon = torch.zeros(shape, dtype=torch.float32, device=anon.device)
+        for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
+            self.ft_tr.backward(tape, pl.grad, fl.grad, dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
+        self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape))
+        allreduce_mean_grads(list(self.fa.parameters()), self.group)
+        self.opt_fa.step()                                            # :123
+        self.iteration += 1
+        return dict(phase=1, loss_fa=float(loss_fa.detach()), loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
+                    loss_fb=None)
+
+    # ---- phase 2 --------------------------------------------------------------------------------------------------
+    def step_ft(self, inputs_video, labels, drop_masks=None):
+        """Update ft (phase 2)."""
+        p = self.params
+        self.fa.eval(); self.ft.train()
+        for opt in (self.opt_fa, self.opt_ft):
+            opt.zero_grad(set_to_none=True)
+        frames, shape = self._feed(inputs_video)
+        with torch.no_grad():
+            anon = self.fa(frames).reshape(shape)                     # :144-148
+        clips = torch.split(anon, [p.num_frames] * 3, dim=2)
+        tapes, leaves = [], []
+        for k, c in enumerate(clips):
+            pred, feat, tape = self.ft_tr.forward(c, "train", drop_mask=None if drop_masks is None else drop_masks[k])
+            tapes.append(tape)
+            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
+        loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
+        loss_ft.backward()                                            # :191
+        for tape, (pl, fl) in zip(tapes, leaves):
+            self.ft_tr.backward(tape, pl.grad, fl.grad)
+        allreduce_mean_grads(list(self.ft.parameters()), self.group)
+        self.opt_ft.step()                                            # :193
+        self.iteration += 1
+        return dict(phase=2, loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()), loss_fb=None)
+
+    def step(self, inputs_video, labels):
+        """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft."""
+        return self.step_fa(inputs_video, labels) if self.iteration % 2 == 0 else self.step_ft(inputs_video, labels)

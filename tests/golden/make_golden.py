@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
 from _refimport import REFERENCE_ROOT, import_reference, _stub  # noqa: E402
-from ted_spad_amd.synth import synth_clips, synth_state_dict, synth_tensor  # noqa: E402
+from ted_spad_amd.synth import synth_clips, synth_state_dict, synth_tensor, synth_train_video  # noqa: E402
 
 SEED = 0
 
@@ -237,5 +237,61 @@ def main():
     print("wrote", {k: v.shape for k, v in out.items()})
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--train-step" not in sys.argv:
     main()
+    sys.argv.append("--train-step")
+
+
+def train_step_golden():
+    """g7: the REFERENCE modules through the loss lines of train_anonymizer.py (phase 1 :87-123, phase 2 :137-191)
+    at tiny size (B=2, 48 frames of 32x32), fb term absent (torchvision ResNet-50 is not available). Appended to
+    golden.npz / golden_meta.json."""
+    ml, _ = import_reference()
+    torch.set_num_threads(os.cpu_count())
+    fa = ml.load_fa_model(arch="unet")
+    ft = ml.load_ft_model("largei3d", num_classes=102, kin_pretrained=False)
+    fa.load_state_dict(synth_state_dict(fa.state_dict(), SEED))
+    ft.load_state_dict(synth_state_dict(ft.state_dict(), SEED))
+    ft.i3d.drop.p = 0.0
+    video = synth_train_video(SEED, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    crit, trip = torch.nn.CrossEntropyLoss(), torch.nn.TripletMarginLoss(margin=1)
+    meta = {}
+    # ---- phase 1 (train_anonymizer.py:71-123) ----
+    fa.train(); ft.eval()
+    iv = video.permute(0, 2, 1, 3, 4)
+    ori = iv.shape
+    anon = fa(iv.reshape(-1, ori[1], ori[3], ori[4])).reshape(ori)
+    i1, i2, i3 = torch.split(anon, [16, 16, 16], dim=2)
+    out, f1 = ft(i1); _, f2 = ft(i2); _, f3 = ft(i3)
+    loss_ft = crit(out, labels) + 0.1 * trip(f1, f2, f3)
+    loss_fa = 0.7 * loss_ft
+    loss_fa.backward()
+    meta["phase1"] = dict(loss_fa=loss_fa.item(), loss_ft=loss_ft.item(),
+                          grad_l2={k: float(p.grad.norm()) for k, p in fa.named_parameters()})
+    # ---- phase 2 (train_anonymizer.py:135-191) on fresh modules; 64x64 so the last stage still has 2x2x2 positions
+    #      (at 32x32 layer4's train-mode BN would normalise over 2 values: analytically zero gradients, pure noise) ----
+    fa.load_state_dict(synth_state_dict(fa.state_dict(), SEED)); fa.zero_grad(); ft.zero_grad()
+    fa.eval(); ft.train()
+    # B = 4: with B = 2 the mlp's train-mode BatchNorm1d normalises over two values (analytically zero gradient).
+    video = synth_train_video(SEED, "train_video64", (4, 48, 3, 64, 64))
+    labels = torch.tensor([5, 77, 101, 1])
+    iv = video.permute(0, 2, 1, 3, 4)
+    ori = iv.shape
+    with torch.no_grad():
+        anon = fa(iv.reshape(-1, ori[1], ori[3], ori[4])).reshape(ori)
+    i1, i2, i3 = torch.split(anon, [16, 16, 16], dim=2)
+    out, f1 = ft(i1); _, f2 = ft(i2); _, f3 = ft(i3)
+    loss_ft = crit(out, labels) + 0.1 * trip(f1, f2, f3)
+    loss_ft.backward()
+    meta["phase2"] = dict(loss_ft=loss_ft.item(), grad_l2={k: float(p.grad.norm()) for k, p in ft.named_parameters()},
+                          num_batches_tracked=int(ft.i3d.bn1.num_batches_tracked))
+    path = os.path.join(HERE, "golden_meta.json")
+    full = json.load(open(path))
+    full["train_step"] = meta
+    json.dump(full, open(path, "w"), indent=1, sort_keys=True)
+    print("train-step golden:", meta["phase1"]["loss_fa"], meta["phase2"]["loss_ft"])
+
+
+if __name__ == "__main__" and "--train-step" in sys.argv:
+    train_step_golden()

@@ -1,0 +1,181 @@
+"""-m gpu: one iteration of each phase of the anonymizer training step on MI355X against the CPU
+oracle (oracle/train_step_ref.py, itself pinned to the reference modules): loss values, the gradient
+handed from ft to fa, and the parameter gradients, then the Adam update."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_state_dict, synth_tensor, synth_train_video
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(beta=None):
+    from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
+    fa, ft = load_fa_model(arch="unet"), load_ft_model("largei3d", num_classes=102)
+    sd_u, sd_l = synth_state_dict(fa.state_dict(), 0), synth_state_dict(ft.state_dict(), 0)
+    if beta is not None:   # push every BatchNorm output far above 0: the ReLUs become (almost) the identity
+        for sd in (sd_u, sd_l):
+            for k in sd:
+                if k.rsplit(".", 1)[0] + ".running_mean" in sd and k.endswith(".bias"):
+                    sd[k] = torch.full_like(sd[k], beta)
+    fa.load_state_dict(sd_u); ft.load_state_dict(sd_l)
+    ft.i3d.drop_p = 0.0       # Q13: dropout is stochastic; parity runs with p = 0
+    return fa.cuda(), ft.cuda(), sd_u, sd_l
+
+
+# Gradient tolerance. Every kernel of the backward chain is checked tightly on its own
+# (tests/test_hip_train_ops.py, 1e-3 .. 5e-3). End to end the comparison is against an fp32 CPU path while
+# the GPU stores activations in 16 bits: a pre-activation within one rounding step of 0 takes the other ReLU
+# branch (about 2.4e-4 of the elements per layer), and each flip is an O(1) difference in that element's
+# gradient, i.e. ~2 % rel-L2 per ReLU layer, sqrt(L) x 2 % over L layers (18 in the UNet, 53 in I3Res50):
+# 10-16 %. (The reference's own fp16-autocast training has the same property w.r.t. its fp32 path.)
+# So: rel-L2 bounds of that size PLUS a direction check (cosine), plus loss parity at 5e-3.
+def _report(name, got, ref, min_cos=0.93, med_cos=0.97):
+    errs, cos = {}, {}
+    for k in ref:
+        if float(ref[k].norm()) > 1e-4:
+            g, r = got[k].detach().cpu().double().flatten(), ref[k].double().flatten()
+            errs[k] = rel_l2(g, r)
+            cos[k] = float(g @ r / (g.norm() * r.norm()))
+    if os.environ.get("TEDSPAD_VERBOSE"):
+        for k in errs:
+            print("   %-50s rel %.3e cos %.5f |g| %.3e" % (k, errs[k], cos[k], float(ref[k].norm())))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print(name, "median rel-L2 %.3e, min cosine %.4f, worst %s" % (float(np.median(list(errs.values()))), min(cos.values()), worst))
+    assert min(cos.values()) > min_cos and float(np.median(list(cos.values()))) > med_cos
+    return errs
+
+
+def test_phase1_update_fa_vs_oracle():
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, ref_danon = train_step_ref.phase1(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    ft_before = {k: v.detach().clone() for k, v in ft.state_dict().items()}
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert out["phase"] == 1 and out["loss_fb"] is None
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 5e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * abs(ref_l["loss_fa"])
+    errs = _report("phase1 fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.25 and max(errs.values()) < 0.4
+    # Adam moved every fa parameter by ~lr (first step: |delta| = lr * sign(grad)); ft is untouched in phase 1
+    moved = [float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()]
+    assert 0 < max(moved) <= 1.05 * step.params.learning_rate_fa   # fp32 rounding of p - lr*sign
+    assert all(torch.equal(v, ft_before[k]) for k, v in ft.state_dict().items())
+    assert int(fa.inc.double_conv[1].num_batches_tracked) == 1   # UNet BN saw the B*48 pseudo-images once (Q14)
+
+
+def test_phase2_update_ft_vs_oracle():
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
+    labels = torch.tensor([5, 77, 101, 1])
+    ref_l, ref_g = train_step_ref.phase2(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft)
+    fa_before = {k: v.detach().clone() for k, v in fa.state_dict().items()}
+    out = step.step_ft(video.cuda(), labels.cuda())
+    assert out["phase"] == 2
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 5e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 2e-2 * abs(ref_l["loss_temporal"])
+    # train-mode BN at this tiny size normalises over as few as 32 values per channel (layer4: 4x2x2x2), which
+    # amplifies the 16-bit storage error ~5x w.r.t. the eval-mode chain of phase 1 -> proportionally more ReLU flips
+    errs = _report("phase2 ft grads", {k: p.grad for k, p in ft.named_parameters()}, ref_g, min_cos=0.7, med_cos=0.85)
+    assert float(np.median(list(errs.values()))) < 0.55 and max(errs.values()) < 0.75
+    assert int(ft.i3d.bn1.num_batches_tracked) == 3 and int(ft.mlp.bn1.num_batches_tracked) == 3   # Q14
+    assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())                     # fa frozen in phase 2
+
+
+def _smooth(sd, beta=4.0):
+    """Every BatchNorm bias = +4: almost no pre-activation is near 0, so the ReLUs are (nearly) the identity and
+    the networks are smooth -- the end-to-end gradient error of the tests above (ReLU branch flips) disappears and
+    the WHOLE backward chain must agree with the fp32 oracle to 16-bit rounding accuracy."""
+    for k in sd:
+        if k.rsplit(".", 1)[0] + ".running_mean" in sd and k.endswith(".bias"):
+            sd[k] = torch.full_like(sd[k], beta)
+    return sd
+
+
+def _grad_sd(sd):
+    return {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+
+
+def test_unet_backward_chain_tight_on_a_smooth_network():
+    """UNetTrainer (train-mode BN, skip/concat, max-pool routing, upsample, sigmoid, dgrad + wgrad of all 19 convs)."""
+    from oracle import unet_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.train_nets import UNetTrainer
+    fa = load_fa_model(arch="unet")
+    sd = _smooth(synth_state_dict(fa.state_dict(), 0))
+    fa.load_state_dict(sd)
+    fa = fa.cuda().train()
+    x = synth_tensor(0, "dbgu", (6, 3, 32, 32))
+    sdg = _grad_sd(sd)
+    y = unet_ref.forward(x, sdg, train=True)
+    dy = synth_tensor(0, "dyu", tuple(y.shape), -1, 1)
+    (y * dy).sum().backward()
+    tr = UNetTrainer(fa)
+    yy, tape = tr.forward(x.cuda())
+    assert rel_l2(yy.cpu(), y.detach()) < 2e-3
+    tr.backward(tape, dy.cuda())
+    errs = _report("unet chain (smooth)", {k: p.grad for k, p in fa.named_parameters()}, {k: v.grad for k, v in sdg.items() if v.requires_grad},
+                   min_cos=0.998, med_cos=0.9998)
+    assert max(errs.values()) < 5e-2 and float(np.median(list(errs.values()))) < 8e-3
+
+
+def test_i3d_backward_chains_tight_on_a_smooth_network():
+    """I3DTrainer: train-mode chain (parameter gradients) and eval-mode chain (gradient w.r.t. the clip)."""
+    from oracle import i3res50_ref
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.train_nets import I3DTrainer
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = _smooth(synth_state_dict(ft.state_dict(), 0))
+    ft.load_state_dict(sd)
+    ft = ft.cuda()
+    ft.i3d.drop_p = 0.0
+    x = synth_tensor(0, "dbgx", (4, 3, 16, 64, 64)) * (torch.arange(1, 5).float() / 4).view(4, 1, 1, 1, 1)
+    dp, dfe = synth_tensor(0, "dp", (4, 102), -1, 1), synth_tensor(0, "df", (4, 128), -1, 1)
+    tr = I3DTrainer(ft)
+    # ---- train mode: parameter gradients ----
+    sdg = _grad_sd(sd)
+    pred, feat = i3res50_ref.wrapper_forward(x, sdg, train=True)
+    ((pred * dp).sum() + (feat * dfe).sum()).backward()
+    ft.train()
+    p, f, tape = tr.forward(x.cuda(), "train")
+    assert rel_l2(p.cpu(), pred.detach()) < 5e-3
+    tr.backward(tape, dp.cuda(), dfe.cuda())
+    errs = _report("i3d train chain (smooth)", {k: q.grad for k, q in ft.named_parameters()}, {k: v.grad for k, v in sdg.items() if v.requires_grad},
+                   min_cos=0.95, med_cos=0.998)   # min: BN biases whose gradient is ~0 (|g| ~ 2e-3); layer1 sits behind two max-pools whose
+    assert float(np.median(list(errs.values()))) < 4e-2   # arg-max can differ between 16-bit and fp32 values (2-8 % there, < 2 % elsewhere)
+    # ---- eval mode: gradient w.r.t. the input clip (what phase 1 hands to the anonymizer) ----
+    ft.load_state_dict(sd)      # the train-mode forward above updated the running statistics
+    ft.eval()
+    xg = x.clone().requires_grad_()
+    pred, feat = i3res50_ref.wrapper_forward(xg, sd, train=False)
+    ((pred * dp).sum() + (feat * dfe).sum()).backward()
+    p, f, tape = tr.forward(x.cuda(), "eval")
+    dx = tr.backward(tape, dp.cuda(), dfe.cuda())
+    e = rel_l2(dx.cpu(), xg.grad)
+    print("i3d eval chain: d(clip) rel-L2 %.3e" % e)
+    # eval-mode BN does not re-normalise, so the +4 bias does not keep the deeper pre-activations away from 0: this
+    # chain keeps its ReLU-flip error (53 ReLU layers + 2 max-pools, sqrt(L) x ~2 %); its pieces are checked tightly
+    # in test_hip_train_ops.py (dgrad incl. strided / pixel-pair form, mask + residual epilogue, max-pool routing).
+    assert e < 0.25
+
+
+def test_step_alternates_phases():
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, _, _ = _models()
+    step = AnonymizerTrainStep(fa, ft)
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64)).cuda()
+    labels = torch.tensor([5, 77, 101, 1]).cuda()
+    phases = [step.step(video, labels)["phase"] for _ in range(4)]
+    assert phases == [1, 2, 1, 2]
