@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=50, help="clips per forward")
     ap.add_argument("--clip-times", type=int, default=225, help="clip times per GPU (7200 frames / 32)")
     ap.add_argument("--crops", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the clip batches alternate over (fills the tail of one forward with the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,16 +82,24 @@ def main():
     feats = torch.empty((n_local, F), dtype=torch.float32, device=dev)
     ev = []
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+
     def step(timed):
-        for i in range(0, n_local, args.batch):
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            f = fx(clips[i:i + args.batch]).flatten(1)
-            if timed:
-                e1.record()
-                ev.append((e0, e1, f.shape[0]))
-            feats[i:i + f.shape[0]] = f
+        main = torch.cuda.current_stream()
+        if timed:   # HIP events on the launching (main) stream around the fork/join of the forward streams
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+        for st in streams:
+            st.wait_stream(main)
+        for j, i in enumerate(range(0, n_local, args.batch)):
+            with torch.cuda.stream(streams[j % len(streams)]):
+                f = fx(clips[i:i + args.batch]).flatten(1)
+                feats[i:i + f.shape[0]] = f
+        for st in streams:
+            main.wait_stream(st)
+        if timed:
+            e1.record(main)
+            ev.append((e0, e1, n_local))
         full = sharding.gather_video_features(feats.view(hi - lo, args.crops, F), T_total)
         return full.cpu() if rank == 0 else full  # the .npy rows reach the host on rank 0
 
@@ -119,10 +128,17 @@ def main():
     fwd_ms = sum(a.elapsed_time(b) for a, b, _ in ev)
     fwd_clips = sum(n for _, _, n in ev)
     achieved = fwd_clips * GFLOP_PER_CLIP[args.arch] / fwd_ms  # GFLOP / ms == TFLOP/s
+    n_fwd = len(ev) * ((n_local + args.batch - 1) // args.batch)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # PMC result of the same command (scripts/summarize_rocprof.py)
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("arch") == args.arch and tj.get("batch") == args.batch and tj.get("dtype") == args.dtype:
+            traffic = tj["conv_traffic_bytes_per_forward"]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": "conv_igemm_kernel (all conv launches of one batch forward)",
-                "ms_per_forward": round(fwd_ms / len(ev), 3), "clips_per_forward": args.batch}
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "kernel": "conv stack of one batch forward (conv_igemm_kernel x52 + conv_stem_halo_kernel; pools/layout included in the time)",
+                "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}
 
     if rank != 0:
         if world > 1:

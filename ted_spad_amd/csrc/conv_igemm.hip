@@ -59,6 +59,15 @@ constexpr int KTAB_SMALL_BYTES = 1024;  // "short-K" configs: Kpad <= 1024, smal
 
 __device__ uint4 g_zero16;              // zero page for padded taps (zero-initialised by the loader)
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2). Remap the block id so that every
+// XCD walks a CONTIGUOUS range of logical tiles: the N tiles of one pixel tile, and pixel tiles that share halo
+// rows, then hit the same L2 instead of re-reading HBM (profiles/r01: 272 MB/clip of traffic vs 129 MB minimal).
+// Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
 __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p) {
     constexpr int NT = WM * WN * 64;
@@ -82,8 +91,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % p.tiles_n;
+    const int tile_m = lid / p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = b % tiles_w; b /= tiles_w;
     const int th = b % tiles_h; b /= tiles_h;
     const int to = b % p.To;

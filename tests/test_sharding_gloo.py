@@ -62,3 +62,35 @@ def test_gather_video_features_world2(T):
 def test_world1_passthrough():
     x = torch.randn(5, 2, 4)
     assert sharding.gather_video_features(x, 5) is x
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ted_spad_amd.train_step import allreduce_mean_grads
+        ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+        ps[0].grad = torch.full((3, 4), float(rank + 1))
+        ps[1].grad = torch.arange(5, dtype=torch.float32) * (rank + 1)
+        # ps[2] has no gradient on any rank (a frozen parameter): skipped consistently
+        allreduce_mean_grads(ps)
+        ok = bool(torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[1].grad, torch.arange(5.) * 1.5) and ps[2].grad is None)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    """The data-parallel exchange of the training step (one flat all-reduce of the updated net's grads)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
