@@ -104,6 +104,15 @@ def main():
         return full.cpu() if rank == 0 else full  # the .npy rows reach the host on rank 0
 
     with torch.no_grad():
+        # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are
+        # chosen in context during the first ~45 forwards of every conv geometry; do that before the counted warm-up
+        from ted_spad_amd import engine as _E
+        for i in range(0, min(n_local, args.batch * 48), args.batch):
+            if not _E.AUTOTUNE:
+                break
+            with torch.cuda.stream(streams[(i // args.batch) % len(streams)]):
+                fx(clips[:args.batch])
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             step(False)
         if world > 1:
@@ -137,7 +146,7 @@ def main():
             traffic = tj["conv_traffic_bytes_per_forward"]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "kernel": "conv stack of one batch forward (conv_igemm_kernel x52 + conv_stem_halo_kernel; pools/layout included in the time)",
+                "kernel": "conv stack of one batch forward (conv_igemm_kernel launches + conv_stem_halo_kernel; pools/layout included in the time)",
                 "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}
 
     if rank != 0:

@@ -489,7 +489,12 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //   7  128 x  64          2x2    2      50 KB   short K, N <= 64: 3 WG/CU
 //   8   64 x 128          2x2    2      50 KB   short K, small M
 //   9  1x8x32 patch, halo-direct (cin == 8 stems only): input patch resident in LDS, 2 WG/CU
-constexpr int NUM_CFGS = 9;
+//  10   64 x  64          2x2    2      33 KB   short K, streaming: 4 WG/CU
+//  11  128 x 128          2x2    4     138 KB   long K, deeper ring
+//  12  128 x  64          2x2    4     108 KB   long K, N <= 64, deeper ring
+//  13  128 x 128          2x2    2      76 KB   long K, 2 WG/CU (one WG's prologue/epilogue under the other's MFMAs)
+//  14  128 x  64          2x2    2      59 KB   long K, N <= 64, 2 WG/CU
+constexpr int NUM_CFGS = 14;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, hipStream_t s) {
@@ -503,6 +508,11 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, hipStream_t s) {
         case 6: return launch<T, 128, 128, 2, 2, 2, KTAB_SMALL_BYTES>(p, s);
         case 7: return launch<T, 128, 64, 2, 2, 2, KTAB_SMALL_BYTES>(p, s);
         case 8: return launch<T, 64, 128, 2, 2, 2, KTAB_SMALL_BYTES>(p, s);
+        case 10: return launch<T, 64, 64, 2, 2, 2, KTAB_SMALL_BYTES>(p, s);
+        case 11: return launch<T, 128, 128, 2, 2, 4, KTAB_MAX_BYTES>(p, s);
+        case 12: return launch<T, 128, 64, 2, 2, 4, KTAB_MAX_BYTES>(p, s);
+        case 13: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES>(p, s);
+        case 14: return launch<T, 128, 64, 2, 2, 2, KTAB_MAX_BYTES>(p, s);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
     return TEDSPAD_EINVAL;

@@ -129,6 +129,39 @@ __global__ __launch_bounds__(256) void to_channels_last_kernel(const float *x, u
     }
 }
 
+// Fast path of the above for W-contiguous clips (sw == 1, w % 8 == 0, 16-byte aligned rows): a thread converts
+// 8 consecutive pixels of one row: two 16-byte loads per channel plane, 64 (cpad 4) or 128 (cpad 8) bytes stored.
+template <typename T, int CPAD>
+__global__ __launch_bounds__(256) void to_channels_last_w8_kernel(const float *x, uint16_t *y, int c, int t, int h, int w8, long sn, long sc,
+                                                                   long st, long sh, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int iw8 = (int)(r % w8); r /= w8;
+        const int ih = (int)(r % h); r /= h;
+        const int it = (int)(r % t);
+        const long n = r / t;
+        const float *px = x + n * sn + it * st + ih * sh + iw8 * 8;
+        float v[8][CPAD];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int ch = 0; ch < CPAD; ++ch) v[p][ch] = 0.f;
+        for (int ch = 0; ch < c; ++ch) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(px + ch * sc), b = *reinterpret_cast<const f32x4 *>(px + ch * sc + 4);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { v[p][ch] = a[p]; v[p + 4][ch] = b[p]; }
+        }
+        uint16_t *py = y + idx * 8 * CPAD;
+#pragma unroll
+        for (int q = 0; q < CPAD; ++q) {   // CPAD chunks of 8 output elements
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[(q * 8 + e) / CPAD][(q * 8 + e) % CPAD];
+            *reinterpret_cast<uint4 *>(py + q * 8) = pack8<T>(o);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void to_nchw_kernel(const uint16_t *x, float *y, int c, long thw, int ldx, long total) {
     // idx over (n, c, thw): writes coalesced along thw, reads strided (tiny tensors only)
@@ -244,6 +277,18 @@ extern "C" int32_t tedspad_clip_to_channels_last(const float *x, void *y, int32_
     TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_clip_to_channels_last: bad dtype");
     const long total8 = (long)n * t * h * w * cpad / 8;
     hipStream_t s = (hipStream_t)stream;
+    if (sw == 1 && w % 8 == 0 && c <= 4 && ((uintptr_t)x % 16 == 0) && sn % 4 == 0 && sc % 4 == 0 && st_ % 4 == 0 && sh % 4 == 0) {
+        const long tot = (long)n * t * h * (w / 8);
+        const dim3 g(grid_for(tot));
+        if (cpad == 4) {
+            if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((to_channels_last_w8_kernel<F16, 4>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+            else hipLaunchKernelGGL((to_channels_last_w8_kernel<BF16, 4>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+        } else {
+            if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((to_channels_last_w8_kernel<F16, 8>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+            else hipLaunchKernelGGL((to_channels_last_w8_kernel<BF16, 8>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+        }
+        return check_launch("tedspad_clip_to_channels_last");
+    }
     if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(to_channels_last_kernel<F16>, dim3(grid_for(total8)), dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, cpad, total8);
     else hipLaunchKernelGGL(to_channels_last_kernel<BF16>, dim3(grid_for(total8)), dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, cpad, total8);
     return check_launch("tedspad_clip_to_channels_last");

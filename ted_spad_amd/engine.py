@@ -20,10 +20,10 @@ from ._lib import ConvDesc, PoolDesc, check
 DTYPES = {"f16": (torch.float16, _lib.F16), "bf16": (torch.bfloat16, _lib.BF16)}
 DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e-3 feature gate
 
-# Tile autotuning (the reference sets cudnn.benchmark = True, train_anonymizer.py:28): on the first
-# call of a conv on a new geometry every tile configuration of the kernel is timed with HIP events
-# and the fastest is kept. Same arithmetic for every configuration (K order per output is fixed), so
-# results do not depend on the choice. Off inside hipGraph capture: warm up first.
+# Tile autotuning (the reference sets cudnn.benchmark = True, train_anonymizer.py:28): during the first
+# calls of a conv on a new geometry the tile configurations of the kernel take turns, timed in context with
+# HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
+# (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 
 
@@ -172,27 +172,64 @@ class PackedConv:
             self._ktabs[key] = tab
         return tab
 
-    def _autotune(self, d, args, stats=None):
+    # ---- in-context tile tuning -------------------------------------------------------------------------------
+    # Every call during the tuning phase IS a real call (any tile configuration gives the same result), launched
+    # with the next candidate and bracketed by HIP events; after TUNE_REPS passes over the candidates the
+    # fastest (median) is kept. Timing each configuration inside the running network -- cold caches, the other
+    # stream's kernels alongside -- ranks them as they will actually run; replaying one launch in isolation
+    # (first version) favoured L2-hungry configurations that lose in context.
+    TUNE_REPS = 3
+
+    def _launch_tuned(self, key, d, args):
         L = _lib.lib()
-        best, best_ms = 0, float("inf")
         stream = _stream_ptr()
-        keep = stats.clone() if stats is not None else None   # timing runs must not pollute the accumulator
-        for cfg in range(0, L.tedspad_conv_num_tile_cfgs() + 1):
+        st = self._cfgs.get(key)
+        if isinstance(st, int):
+            d.tile_cfg = st
+            check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd")
+            return
+        if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            d.tile_cfg = 0
+            check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd")
+            return
+        if st is None:
+            st = {"cands": list(range(0, L.tedspad_conv_num_tile_cfgs() + 1)), "pos": 0, "rep": 0, "rec": {}}
+            self._cfgs[key] = st
+        while True:
+            cfg = st["cands"][st["pos"]]
             d.tile_cfg = cfg
-            if L.tedspad_conv_fwd_ex(*args, stream) != 0:   # configuration not applicable to this conv
-                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(3):
-                L.tedspad_conv_fwd_ex(*args, stream)
+            rc = L.tedspad_conv_fwd_ex(*args, stream)
+            if rc != 0:                                   # configuration not applicable to this conv: drop it
+                st["cands"].pop(st["pos"])
+                if not st["cands"]:
+                    check(rc, "tedspad_conv_fwd")
+                if st["pos"] >= len(st["cands"]):
+                    st["pos"] = 0
+                    st["rep"] += 1
+                continue
             e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if ms < best_ms * 0.97:  # prefer the heuristic / earlier entry on ties
-                best, best_ms = cfg, ms
-        if keep is not None:
-            stats.copy_(keep)
-        return best
+            st["rec"].setdefault(cfg, []).append((e0, e1))
+            break
+        st["pos"] += 1
+        if st["pos"] >= len(st["cands"]):
+            st["pos"] = 0
+            st["rep"] += 1
+        if st["rep"] >= self.TUNE_REPS:
+            best, best_ms = 0, float("inf")
+            for cfg in st["cands"]:
+                ts = []
+                for a, b in st["rec"].get(cfg, []):
+                    b.synchronize()
+                    ts.append(a.elapsed_time(b))
+                if not ts:
+                    continue
+                ts.sort()
+                ms = ts[len(ts) // 2]
+                if ms < best_ms * 0.98:
+                    best, best_ms = cfg, ms
+            self._cfgs[key] = best
 
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
                  residual: Optional[Act] = None, relu=True, sigmoid=False, mask: Optional[Act] = None,
@@ -243,12 +280,7 @@ class PackedConv:
                 residual.ptr if residual is not None else None, None if y32 else out.ptr, int(sigmoid),
                 C.byref(ex) if ex is not None else None)
         key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map, y32)
-        cfg = self._cfgs.get(key)
-        if cfg is None:
-            cfg = self._autotune(d, args, stats) if (AUTOTUNE and not torch.cuda.is_current_stream_capturing()) else 0
-            self._cfgs[key] = cfg
-        d.tile_cfg = cfg
-        check(_lib.lib().tedspad_conv_fwd_ex(*args, _stream_ptr()), "tedspad_conv_fwd")
+        self._launch_tuned(key, d, args)
         return z32 if y32 else out
 
 
