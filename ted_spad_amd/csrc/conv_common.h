@@ -1,0 +1,49 @@
+// Shared between the conv kernels (conv_igemm.hip, conv_halo.hip): kernel parameter block, constants.
+#pragma once
+#include "common.h"
+
+namespace tedspad {
+
+struct ConvKP {
+    const uint16_t *x;
+    const uint16_t *w;
+    const int2 *ktab;
+    const float *scale;
+    const float *shift;
+    const uint16_t *res;
+    uint16_t *y;
+    int M, Cout, Kpad, nk;
+    int Ti, Hi, Wi, ldx;
+    int To, Ho, Wo, ldy, ldres;
+    int kt, kh, kw;
+    int st, sh, sw, pt, ph, pw;
+    int relu, sigmoid, pointwise;
+    int tiles_n;
+    // optional epilogue extras (training path)
+    const uint16_t *mask;   // out = mask > 0 ? out : 0   (ReLU backward fused into the dgrad that produces d(input))
+    float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)
+    float *y32;             // optional fp32 copy of the output (train-mode BN keeps the pre-normalisation conv output exact)
+    int ldmask, stats_ld, ldy32;
+    int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
+    int ost, osh, osw, oot, ooh, oow, TF, HF, WF;
+};
+
+constexpr int BK = 64;                  // K elements per LDS tile row (8 chunks of 16 bytes)
+constexpr int KTAB_MAX_BYTES = 10240;   // Kpad <= 10240 (one int2 per 8 K elements)
+constexpr int KTAB_SMALL_BYTES = 1024;  // "short-K" configs: Kpad <= 1024, smaller LDS -> 2-3 workgroups per CU
+
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2). Remap the block id so that every
+// XCD walks a CONTIGUOUS range of logical tiles: the N tiles of one pixel tile, and pixel tiles that share halo
+// rows, then hit the same L2 instead of re-reading HBM (profiles/r01: 272 MB/clip of traffic vs 129 MB minimal).
+// Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+
+// conv_halo.hip: halo-direct kernel for stride-1 multi-tap convolutions with cin % 64 == 0 (tile_cfg 15 / 16).
+int32_t launch_conv_halo(int dtype, const ConvKP &p, int N, int cin, int bn, hipStream_t s);
+
+}  // namespace tedspad

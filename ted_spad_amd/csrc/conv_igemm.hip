@@ -24,49 +24,12 @@
 //     per 16-byte load; padded taps (and rows past M) are redirected to a 16-byte zero page;
 //   * the fp32 tile is staged through LDS so the final stores (and the residual loads)
 //     are full 16-byte-per-lane coalesced rows of the NTHWC tensor.
-#include "common.h"
+#include "conv_common.h"
 
 namespace tedspad {
 namespace {
 
-struct ConvKP {
-    const uint16_t *x;
-    const uint16_t *w;
-    const int2 *ktab;
-    const float *scale;
-    const float *shift;
-    const uint16_t *res;
-    uint16_t *y;
-    int M, Cout, Kpad, nk;
-    int Ti, Hi, Wi, ldx;
-    int To, Ho, Wo, ldy, ldres;
-    int kt, kh, kw;
-    int st, sh, sw, pt, ph, pw;
-    int relu, sigmoid, pointwise;
-    int tiles_n;
-    // optional epilogue extras (training path)
-    const uint16_t *mask;   // out = mask > 0 ? out : 0   (ReLU backward fused into the dgrad that produces d(input))
-    float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)
-    float *y32;             // optional fp32 copy of the output (train-mode BN keeps the pre-normalisation conv output exact)
-    int ldmask, stats_ld, ldy32;
-    int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
-    int ost, osh, osw, oot, ooh, oow, TF, HF, WF;
-};
-
-constexpr int BK = 64;                  // K elements per LDS tile row (8 chunks of 16 bytes)
-constexpr int KTAB_MAX_BYTES = 10240;   // Kpad <= 10240 (one int2 per 8 K elements)
-constexpr int KTAB_SMALL_BYTES = 1024;  // "short-K" configs: Kpad <= 1024, smaller LDS -> 2-3 workgroups per CU
-
 __device__ uint4 g_zero16;              // zero page for padded taps (zero-initialised by the loader)
-
-// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2). Remap the block id so that every
-// XCD walks a CONTIGUOUS range of logical tiles: the N tiles of one pixel tile, and pixel tiles that share halo
-// rows, then hit the same L2 instead of re-reading HBM (profiles/r01: 272 MB/clip of traffic vs 129 MB minimal).
-// Bijective for any grid size; affects speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
 __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p) {
@@ -494,12 +457,16 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  12  128 x  64          2x2    4     108 KB   long K, N <= 64, deeper ring
 //  13  128 x 128          2x2    2      76 KB   long K, 2 WG/CU (one WG's prologue/epilogue under the other's MFMAs)
 //  14  128 x  64          2x2    2      59 KB   long K, N <= 64, 2 WG/CU
-constexpr int NUM_CFGS = 14;
+//  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
+//  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
+constexpr int NUM_CFGS = 16;
 
 template <typename T>
-int32_t launch_cfg(int cfg, const ConvKP &p, int N, hipStream_t s) {
+int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
     switch (cfg) {
         case 9: return launch_stem_halo<T>(p, N, s);
+        case 15: return launch_conv_halo(T::kDtype, p, N, cin, 128, s);
+        case 16: return launch_conv_halo(T::kDtype, p, N, cin, 64, s);
         case 1: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 2: return launch<T, 256, 64, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 3: return launch<T, 128, 128, 2, 2, 3, KTAB_MAX_BYTES>(p, s);
@@ -641,7 +608,7 @@ extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
         TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
     }
-    return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, s) : launch_cfg<BF16>(cfg, p, d->n, s);
+    return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, d->cin, s) : launch_cfg<BF16>(cfg, p, d->n, d->cin, s);
 }
 
 extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,

@@ -25,6 +25,8 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
+PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
+FORCE_TILE_CFG = None   # tests: run every conv with this tile configuration (error if it does not apply)
 
 
 def _stream_ptr():
@@ -183,6 +185,15 @@ class PackedConv:
     def _launch_tuned(self, key, d, args):
         L = _lib.lib()
         stream = _stream_ptr()
+        if FORCE_TILE_CFG is not None:
+            d.tile_cfg = FORCE_TILE_CFG
+            check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd(cfg %d)" % FORCE_TILE_CFG)
+            return
+        if PREFER_TILE_CFG:          # experiments: use this configuration wherever it applies
+            d.tile_cfg = PREFER_TILE_CFG
+            if L.tedspad_conv_fwd_ex(*args, stream) == 0:
+                self._cfgs[key] = PREFER_TILE_CFG
+                return
         st = self._cfgs.get(key)
         if isinstance(st, int):
             d.tile_cfg = st

@@ -150,3 +150,53 @@ def test_bad_arguments_fail_loudly():
     pc = E.PackedConv(torch.zeros(8, 8, 1, 1, 1), torch.ones(8), torch.zeros(8), device="cuda")
     with pytest.raises(AssertionError):
         pc(E.Act(torch.zeros(1, 1, 2, 2, 16, dtype=torch.float16, device="cuda"), 16))
+
+
+HALO_CASES = [
+    # name, (n,t,h,w), cin, cout, k, pads, residual+mask
+    ("halo_3x1x1", (2, 4, 9, 10), 256, 64, (3, 1, 1), (1, 0, 0), False),
+    ("halo_1x3x3_55", (1, 2, 55, 55), 64, 64, (1, 3, 3), (0, 1, 1), True),
+    ("halo_1x3x3_28", (3, 2, 28, 28), 128, 128, (1, 3, 3), (0, 1, 1), False),
+    ("halo_1x3x3_14", (2, 2, 14, 14), 256, 256, (1, 3, 3), (0, 1, 1), True),
+    ("halo_1x3x3_7", (2, 2, 7, 7), 512, 512, (1, 3, 3), (0, 1, 1), False),
+    ("halo_unet_112", (2, 1, 112, 112), 64, 64, (1, 3, 3), (0, 1, 1), False),
+    ("halo_unet_cat_1024", (1, 1, 14, 14), 1024, 512, (1, 3, 3), (0, 1, 1), False),
+    ("halo_3x3x3", (1, 4, 14, 14), 128, 256, (3, 3, 3), (1, 1, 1), False),
+    ("halo_3x1x1_big_k", (2, 2, 7, 7), 2048, 512, (3, 1, 1), (1, 0, 0), False),
+]
+
+
+@pytest.mark.parametrize("cfg", [15, 16])
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_halo_direct_conv(case, cfg):
+    """tile_cfg 15/16 (conv_halo.hip): the patch/halo kernel must give the same result as the oracle for every
+    patch shape the host picks (ragged patches, padding on all sides, 1-3 cin chunks ... 32 chunks)."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import _lib, engine as E
+    name, dims, cin, cout, k, pads, extras = case
+    tdt = torch.float16
+    n, t, h, w = dims
+    x = _round(synth_tensor(6, name + "x", (n, t, h, w, cin), -1, 1), tdt)
+    wgt = _round(synth_tensor(6, name + "w", (cout, cin) + k, -1, 1) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5, tdt)
+    scale = synth_tensor(6, name + "s", (cout,), 0.5, 1.5)
+    shift = synth_tensor(6, name + "b", (cout,), -0.3, 0.3)
+    res = _round(synth_tensor(6, name + "r", (n, t, h, w, cout), -1, 1), tdt) if extras else None
+    mask = _round(synth_tensor(6, name + "m", (n, t, h, w, cout), -1, 1), tdt) if extras else None
+    ref = conv_cl(x, wgt, scale, shift, (1, 1, 1), pads, pads, res, relu=True)
+    if extras:
+        ref = ref * (mask > 0)
+    pc = E.PackedConv(wgt, scale, shift, dtype="f16", device="cuda")
+    E.FORCE_TILE_CFG = cfg
+    try:
+        out = pc(E.Act(x.to(tdt).cuda(), cin), pads=pads, relu=True,
+                 residual=E.Act(res.to(tdt).cuda(), cout) if extras else None, mask=E.Act(mask.to(tdt).cuda(), cout) if extras else None)
+    except _lib.TedSpadHipError as e:
+        assert "no patch fits" in str(e) or "does not fit" in str(e), str(e)
+        return
+    finally:
+        E.FORCE_TILE_CFG = None
+    torch.cuda.synchronize()
+    got = out.buf.float().cpu()
+    err = (got - ref).abs()
+    assert bool((err <= 2.0 ** -10 * ref.abs() + 1e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < 4e-4
