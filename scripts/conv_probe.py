@@ -4,13 +4,17 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dir
 from ted_spad_amd import engine as E
 ap = argparse.ArgumentParser()
 ap.add_argument('--dims', default='100,2,14,14'); ap.add_argument('--cin', type=int, default=256); ap.add_argument('--cout', type=int, default=256)
-ap.add_argument('--k', default='1,3,3'); ap.add_argument('--pads', default='0,1,1'); ap.add_argument('--cfg', type=int, default=1); ap.add_argument('--reps', type=int, default=20)
+ap.add_argument('--k', default='1,3,3'); ap.add_argument('--pads', default='0,1,1'); ap.add_argument('--cfg', type=int, default=1); ap.add_argument('--reps', type=int, default=20); ap.add_argument('--dbg', type=int, default=0)
 a = ap.parse_args()
 n, t, h, w = map(int, a.dims.split(',')); k = tuple(map(int, a.k.split(','))); pads = tuple(map(int, a.pads.split(',')))
 x = E.Act((torch.rand(n, t, h, w, a.cin, device='cuda') - 0.5).half(), a.cin)
 wt = (torch.rand(a.cout, a.cin, *k) - 0.5) * 0.05
 pc = E.PackedConv(wt, torch.ones(a.cout), torch.zeros(a.cout), device='cuda')
 E.FORCE_TILE_CFG = a.cfg
+_orig = pc._desc
+def _d(*aa, **kk):
+    d = _orig(*aa, **kk); d.relu = d.relu | (a.dbg << 8); return d
+pc._desc = _d
 out = pc(x, pads=pads)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,6 +19,8 @@ struct ConvKP {
     int st, sh, sw, pt, ph, pw;
     int relu, sigmoid, pointwise;
     int tiles_n;
+    float inv_wo, inv_ho, inv_to;   // fp32 reciprocals for the row decode
+    int cin, utap;                  // utap: cin % 64 == 0, K-tile -> tap is arithmetic (no table)
     // optional epilogue extras (training path)
     const uint16_t *mask;   // out = mask > 0 ? out : 0   (ReLU backward fused into the dgrad that produces d(input))
     float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)

@@ -31,6 +31,15 @@ namespace {
 
 __device__ uint4 g_zero16;              // zero page for padded taps (zero-initialised by the loader)
 
+// n / d for 0 <= n < 2^24, d >= 1 via the fp32 reciprocal (both exactly representable), corrected to the exact quotient.
+__device__ __forceinline__ int fdiv(int n, int d, float inv_d) {
+    int q = (int)((float)n * inv_d);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
 __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p) {
     constexpr int NT = WM * WN * 64;
@@ -60,8 +69,6 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    for (int i = tid; i < p.nk * 8; i += NT) ktab_lds[i] = p.ktab[i];
-
     // ---- DMA roles: 8 consecutive lanes fetch the eight 16-byte chunks of one tile row ------
     const int rsub = wave * 8 + (lane >> 3);                            // row inside a slot
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);  // SOURCE chunk (swizzle on the source)
@@ -77,9 +84,16 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
                 a_base[i] = m * p.ldx;
                 a_mask[i] = 0x010101u;
             } else {
-                const int wo = m % p.Wo; const int r1 = m / p.Wo;
-                const int ho = r1 % p.Ho; const int r2 = r1 / p.Ho;
-                const int to = r2 % p.To; const int n = r2 / p.To;
+                int wo, ho, to, n;
+                if (p.M < (1 << 24)) {   // exact in fp32: reciprocal estimate + one correction step instead of six integer divisions
+                    const int r1 = fdiv(m, p.Wo, p.inv_wo); wo = m - r1 * p.Wo;
+                    const int r2 = fdiv(r1, p.Ho, p.inv_ho); ho = r1 - r2 * p.Ho;
+                    n = fdiv(r2, p.To, p.inv_to); to = r2 - n * p.To;
+                } else {
+                    wo = m % p.Wo; const int r1 = m / p.Wo;
+                    ho = r1 % p.Ho; const int r2 = r1 / p.Ho;
+                    to = r2 % p.To; n = r2 / p.To;
+                }
                 const int t0 = to * p.st - p.pt, h0 = ho * p.sh - p.ph, w0 = wo * p.sw - p.pw;
                 a_base[i] = (((n * p.Ti + t0) * p.Hi + h0) * p.Wi + w0) * p.ldx;
                 unsigned mk = 0;
@@ -92,12 +106,38 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     }
     const uint16_t *wsrc = p.w + (size_t)(n0 + rsub) * p.Kpad + kc * 8;
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
-    __syncthreads();  // ktab_lds visible
-
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;  // LDS byte address of the ring
+    auto issue_a = [&](int2 e, int slot) {
+        const unsigned stage = lds0 + slot * STAGE + wave * 8 * (BK * 2);
+        const unsigned s_t = e.y & 255, s_h = (e.y >> 8) & 255, s_w = (unsigned)e.y >> 16;
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            const unsigned ok = (a_mask[i] >> s_t) & (a_mask[i] >> s_h) & (a_mask[i] >> s_w) & 1u;
+            const uint16_t *src = ok ? p.x + (ptrdiff_t)(a_base[i] + e.x) : zero;
+            lds_dma16(src, stage + i * RPS * (BK * 2));
+        }
+    };
+    auto issue_w = [&](int kt, int slot) {
+        const unsigned stage = lds0 + slot * STAGE + wave * 8 * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < SW; ++j)
+            lds_dma16(wsrc + (size_t)(j * RPS) * p.Kpad + kt * BK, stage + BM * BK * 2 + j * RPS * (BK * 2));
+    };
+    // Uniform-tap layers (cin % 64 == 0: a 64-deep K tile never straddles a tap): the table entry of K tile kt is
+    // plain arithmetic on wave-uniform counters that advance with the issue order -- no table loads in the prologue
+    // (two dependent global-load latencies per workgroup, measured ~2-3 us of a ~4 us ramp).
+    int u_dt = 0, u_dh = 0, u_dw = 0, u_c = 0;
+    auto next_entry = [&]() -> int2 {
+        int2 e;
+        e.x = ((u_dt * p.Hi + u_dh) * p.Wi + u_dw) * p.ldx + u_c + kc * 8;
+        e.y = u_dt | ((8 + u_dh) << 8) | ((16 + u_dw) << 16);
+        u_c += BK;
+        if (u_c == p.cin) { u_c = 0; if (++u_dw == p.kw) { u_dw = 0; if (++u_dh == p.kh) { u_dh = 0; ++u_dt; } } }
+        return e;
+    };
     auto issue = [&](int kt, int slot) {
         const unsigned stage = lds0 + slot * STAGE + wave * 8 * (BK * 2);
-        const int2 e = ktab_lds[kt * 8 + kc];
+        const int2 e = p.utap ? next_entry() : ktab_lds[kt * 8 + kc];
         const unsigned s_t = e.y & 255, s_h = (e.y >> 8) & 255, s_w = (unsigned)e.y >> 16;
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
@@ -122,9 +162,27 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Prologue, ordered to shorten the per-workgroup ramp (measured: prologue + epilogue were 30-55 % of these kernels):
+    // the weight DMAs of the first S-1 stages need no geometry and go out first, this thread's K-table entries for those
+    // stages come straight from global memory, and the LDS copy of the table (used from the first in-loop issue on) is
+    // written last; the first barrier of the loop publishes it.
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
-        if (s < p.nk) issue(s, s);
+        if (s < p.nk) issue_w(s, s);
+    if (p.utap) {
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < p.nk) issue_a(next_entry(), s);
+    } else {
+        int2 e0[S - 1];
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s) e0[s] = p.ktab[(s < p.nk ? s : 0) * 8 + kc];
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < p.nk) issue_a(e0[s], s);
+        for (int i = tid; i < p.nk * 8; i += NT) ktab_lds[i] = p.ktab[i];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // table in LDS (and, once, the whole prologue) before barrier 0
+    }
 
     int rd = 0, wr = S - 1;  // ring slots: stage kt is read from `rd`, stage kt+S-1 is written to `wr`
     for (int kt = 0; kt < p.nk; ++kt) {
@@ -428,8 +486,8 @@ int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
 
 template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
 int32_t launch(const ConvKP &p, hipStream_t s) {
-    if (p.Kpad > KT) {
-        set_error("tedspad_conv_fwd: tile_cfg needs Kpad <= %d, got %d", KT, p.Kpad);
+    if (KT == 0 ? !p.utap : p.Kpad > KT) {
+        set_error("tedspad_conv_fwd: tile_cfg needs %s", KT == 0 ? "cin % 64 == 0" : "a shorter K");
         return TEDSPAD_EINVAL;
     }
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -457,9 +515,11 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  12  128 x  64          2x2    4     108 KB   long K, N <= 64, deeper ring
 //  13  128 x 128          2x2    2      76 KB   long K, 2 WG/CU (one WG's prologue/epilogue under the other's MFMAs)
 //  14  128 x  64          2x2    2      59 KB   long K, N <= 64, 2 WG/CU
+//  17  256 x  64          4x2    2      80 KB   cin % 64 == 0 (no K table): TWO 8-wave WGs per CU
+//  18  128 x 128          2x2    2      68 KB   cin % 64 == 0
 //  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
-constexpr int NUM_CFGS = 16;
+constexpr int NUM_CFGS = 18;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -480,6 +540,8 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 12: return launch<T, 128, 64, 2, 2, 4, KTAB_MAX_BYTES>(p, s);
         case 13: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES>(p, s);
         case 14: return launch<T, 128, 64, 2, 2, 2, KTAB_MAX_BYTES>(p, s);
+        case 17: return launch<T, 256, 64, 4, 2, 2, 0>(p, s);
+        case 18: return launch<T, 128, 128, 2, 2, 2, 0>(p, s);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
     return TEDSPAD_EINVAL;
@@ -583,6 +645,8 @@ extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x
     p.pointwise = (d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
                    d->ph == 0 && d->pw == 0 && d->to == d->t && d->ho == d->h && d->wo == d->w);
     p.tiles_n = 0;
+    p.cin = d->cin; p.utap = (d->cin % BK == 0) ? 1 : 0;
+    p.inv_wo = 1.0f / (float)d->wo; p.inv_ho = 1.0f / (float)d->ho; p.inv_to = 1.0f / (float)d->to;
     p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
     bool extras = false;
