@@ -244,6 +244,17 @@ int32_t tedspad_l2_normalize_rows_bwd(const float *x, const float *dy, float *dx
 /* out = a * b * scale (dropout mask application: I3Res50.drop, large_i3d.py:148,242). */
 int32_t tedspad_mul_f32(const float *a, const float *b, float *out, int64_t n, float scale, void *stream);
 
+/* Device-side weight packing: fp32 (co, ci, kt, kh, kw) parameter -> the 16-bit [rows_pad][kpad] matrix of
+ * tedspad_conv_fwd. mode 0: forward matrix (rows = co; K ordered (dt,dh,dw,c) over the kernel-form channels
+ * cink / width taps kwk; pair_shift >= 0 selects the stem's pixel-pair form, -1 plain zero-padded channels).
+ * mode 1: data-gradient matrix of one parity class (rows = kernel-form input channels, K ordered (et,eh,ew,co));
+ * dgrad_geo = host int32[9] {Et,Eh,Ew, ct,ch,cw, st,sh,sw}: tap = c + s*(E-1-e) per dim. `scale` (per co, may be
+ * NULL) is multiplied in (folded eval-mode BatchNorm). */
+int32_t tedspad_pack_conv_weights(const float *w, const float *scale, void *out, int32_t co, int32_t ci, int32_t kt,
+                                  int32_t kh, int32_t kw, int32_t cink, int32_t kwk, int32_t pair_shift, int32_t mode,
+                                  int32_t rows, int32_t rows_pad, int32_t kpad, const int32_t *dgrad_geo, int32_t dtype,
+                                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--res', type=int, default=112)
 ap.add_argument('--steps', type=int, default=6)
-ap.add_argument('--warmup', type=int, default=2)
+ap.add_argument('--warmup', type=int, default=30)   # the tile tuner needs ~30 calls per conv geometry
 a = ap.parse_args()
 import contextlib, io
 with contextlib.redirect_stdout(io.StringIO()):

@@ -66,6 +66,7 @@ SYMBOLS = {
     "tedspad_bn1d_train_bwd": (_I32, [_P] * 9 + [_I32, _I32, _I32, _P]),
     "tedspad_l2_normalize_rows_bwd": (_I32, [_P, _P, _P, _I32, _I32, C.c_float, _P]),
     "tedspad_mul_f32": (_I32, [_P, _P, _P, _I64, C.c_float, _P]),
+    "tedspad_pack_conv_weights": (_I32, [_P, _P, _P] + [_I32] * 12 + [_P, _I32, _P]),
     "tedspad_linear_fwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "tedspad_l2_normalize_rows": (_I32, [_P, _P, _I32, _I32, C.c_float, _P]),
 }

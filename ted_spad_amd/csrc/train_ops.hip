@@ -350,7 +350,7 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const fl
     TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && (!z || (mean && invstd)) && sums_ld >= C,
                "tedspad_bn_bwd_reduce: bad arguments");
     const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
-    long pblocks = (pixels + (long)PL * 64 - 1) / ((long)PL * 64);
+    long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
     if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;

@@ -37,22 +37,30 @@ def _ceil_div(a, b):
 class DgradPlan:
     """The data gradient of one convolution as dense sub-convolutions over dY."""
 
-    def __init__(self, w_k: torch.Tensor, scale: Optional[torch.Tensor], stride, pads_front, in_dims, out_dims, dtype):
-        co, ci, kt, kh, kw = w_k.shape
-        ws = w_k if scale is None else w_k * scale.view(-1, 1, 1, 1, 1).to(w_k.dtype)
-        self.ci = (ci + 7) // 8 * 8
+    def __init__(self, w5: torch.Tensor, scale: Optional[torch.Tensor], stride_k, pads_front_k, in_dims, out_dims, dtype, pair_w=None):
+        """w5: the fp32 (co,ci,kt,kh,kw) parameter; stride_k / pads_front_k / in_dims describe the conv in KERNEL form
+        (the stem: pixel-pair form, stride (2,2,1))."""
+        co, ci, kt, kh, kw = w5.shape
+        if pair_w is not None:
+            pw2 = (pair_w + 1) // 2
+            kw = (kw + 2 * pw2 - pair_w + 1) // 2
+            cin_k = 8
+        else:
+            cin_k = (ci + 7) // 8 * 8
+        self.ci = cin_k
         self.in_dims, self.out_dims = tuple(in_dims), tuple(out_dims)
         self.subs: List[Tuple] = []
         self.need_zero = False
-        ks, ones, zeros = (kt, kh, kw), torch.ones(ci, device=w_k.device), torch.zeros(ci, device=w_k.device)
-        for rt in range(stride[0]):
-            for rh in range(stride[1]):
-                for rw in range(stride[2]):
+        ks = (kt, kh, kw)
+        wscale = None if scale is None else scale.detach().float().contiguous()
+        for rt in range(stride_k[0]):
+            for rh in range(stride_k[1]):
+                for rw in range(stride_k[2]):
                     r = (rt, rh, rw)
-                    idx, pf2, J = [], [], []
+                    E, cs, pf2, J = [], [], [], []
                     empty = False
                     for dim in range(3):
-                        s, k, pf, n_in, n_out = stride[dim], ks[dim], pads_front[dim], in_dims[dim], out_dims[dim]
+                        s, k, pf, n_in, n_out = stride_k[dim], ks[dim], pads_front_k[dim], in_dims[dim], out_dims[dim]
                         c, q = (r[dim] + pf) % s, (r[dim] + pf) // s
                         e_n = _ceil_div(k - c, s) if k > c else 0
                         j_n = _ceil_div(n_in - r[dim], s) if n_in > r[dim] else 0
@@ -64,16 +72,14 @@ class DgradPlan:
                         if j_n > n_out + p2:      # trailing input the forward conv never read
                             j_n = n_out + p2
                             self.need_zero = True
-                        idx.append([c + s * (e_n - 1 - e) for e in range(e_n)])   # flipped taps of this class
-                        pf2.append(p2)
-                        J.append(j_n)
+                        E.append(e_n); cs.append(c); pf2.append(p2); J.append(j_n)
                     if empty:
                         self.need_zero = True
                         continue
-                    wsub = ws[:, :, idx[0]][:, :, :, idx[1]][:, :, :, :, idx[2]].permute(1, 0, 2, 3, 4)   # (ci, co, Et, Eh, Ew)
-                    pc = PackedConv(wsub, ones, zeros, dtype=dtype, device=w_k.device)
+                    geo = tuple(E) + tuple(cs) + tuple(stride_k)            # tap = c + s*(E-1-e): the flipped taps of this class
+                    pc = PackedConv.dgrad_sub(w5, wscale, geo, pair_w, dtype)
                     self.subs.append((r, pc, tuple(pf2), tuple(J)))
-        self.stride = tuple(stride)
+        self.stride = tuple(stride_k)
 
     def run(self, dy: Act, residual: Optional[Act] = None, mask: Optional[Act] = None, out: Optional[Act] = None) -> Act:
         n = dy.dims[0]
@@ -109,14 +115,6 @@ class ConvLayer:
     def _w5(self):
         w = self.weight.detach()
         return w.unsqueeze(2) if w.dim() == 4 else w
-
-    def kernel_form(self):
-        """(w_k, stride_k, pads_k, pads_back_k): the conv as the kernel sees it (stem: pixel-pair form)."""
-        w = self._w5().float()
-        if self.pair_w is None:
-            return w, self.stride, self.pads, self.pads_back
-        w2, kw2, pw2 = E.stem_pair_form(w, self.pair_w)
-        return w2, (self.stride[0], self.stride[1], 1), (self.pads[0], self.pads[1], pw2), (self.pads_back[0], self.pads_back[1], kw2 - 1 - pw2)
 
     def _sig(self, scale, shift):
         def v(t):
@@ -155,8 +153,9 @@ class ConvLayer:
         sig = self._sig(scale, None)
         plan = self._dgrad.get(key)
         if plan is None or plan[0] != sig:
-            w_k, s_k, p_k, _ = self.kernel_form()
-            new = DgradPlan(w_k, scale, s_k, p_k, x_dims, dy.dims[1:], self.dtype)
+            pc = self.fwd_conv()
+            p_k, _ = self._pads_k(pc)
+            new = DgradPlan(self._w5().float(), scale, pc.stride, p_k, x_dims, dy.dims[1:], self.dtype, pair_w=self.pair_w)
             if plan is not None:
                 for (_, pc_new, _, _), (_, pc_old, _, _) in zip(new.subs, plan[1].subs):
                     pc_new._ktabs, pc_new._cfgs = pc_old._ktabs, pc_old._cfgs
