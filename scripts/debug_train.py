@@ -37,5 +37,6 @@ if which in ('unet','both'):
     yy, tape = tr.forward(x.cuda())
     print('unet fwd', rel(yy, y.detach()))
     tr.backward(tape, dy.cuda())
+    tr.flush_grads()
     errs = {k: rel(p.grad, sdg[k].grad) for k,p in fa.named_parameters() if float(sdg[k].grad.norm())>1e-4}
     for k,v in errs.items(): print('%-45s %.3e  |g|=%.3e' % (k, v, float(sdg[k].grad.norm())))

@@ -15,6 +15,7 @@ tr = I3DTrainer(ft)
 p, f, tape = tr.forward(x.cuda(), 'train')
 print('fwd pred', rel(p, pred.detach()), 'feat', rel(f, feat.detach()))
 tr.backward(tape, dp.cuda(), dfe.cuda())
+tr.flush_grads()
 keys = [k for k,_ in ft.named_parameters()]
 for k in reversed(keys):
     if float(sdg[k].grad.norm()) > 1e-5 and ('layer4' in k or 'layer3.5' in k or 'mlp' in k or 'fc' in k or k.startswith('i3d.conv1') or k.startswith('i3d.bn1') or 'layer1.0' in k):

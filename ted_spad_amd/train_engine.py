@@ -17,6 +17,7 @@ Backward of the reference's torch.nn modules inside `loss.backward()`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -24,6 +25,46 @@ import torch
 from . import _lib, engine as E
 from ._lib import PoolDesc, check
 from .engine import Act, PackedConv, _stream_ptr
+
+
+class ZeroArena:
+    """One big pre-zeroed fp32 buffer per training step for every atomic-accumulation target (BatchNorm batch
+    statistics, per-channel gradient sums, packed weight-gradient matrices): ONE memset per step instead of one
+    torch.zeros launch per request (~1500 per step). The request sequence repeats every step, so slices are
+    handed out bump-style; `reset()` re-zeroes what the previous step used."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.high = 0
+        self.gen = 0
+
+    def reset(self, device):
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(64 << 20, dtype=torch.float32, device=device)     # 256 MB, grows on demand
+        elif self.high:
+            self.buf[: self.high].zero_()
+        self.used, self.high = 0, 0
+        self.gen += 1
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n4 = (n + 3) // 4 * 4                                   # keep 16-byte alignment
+        if os.environ.get('TEDSPAD_NO_ARENA'):
+            return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.reset(device)
+        if self.used + n4 > self.buf.numel():                   # outgrown: fresh zeros for this request
+            return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        out = self.buf[self.used: self.used + n].view(tuple(shape))
+        self.used += n4
+        self.high = max(self.high, self.used)
+        return out
+
+
+ARENA = ZeroArena()
 
 
 def _code(t: torch.Tensor) -> int:
@@ -164,23 +205,37 @@ class ConvLayer:
         return plan[1].run(dy, residual=residual, mask=mask, out=out)
 
     def wgrad(self, x: Act, dy: Act):
-        """Accumulates d(weight) (and d(bias) = per-channel sum of dy) into `.grad` in the parameter layout."""
+        """Accumulates d(weight) in the packed [cout_pad][kpad] fp32 layout (float atomics); several calls per step
+        (the three clips) add into the same matrix. `flush_grad()` converts it to the parameter layout once."""
         pc = self.fwd_conv()
         n, t, h, w = x.dims
         pk, _ = self._pads_k(pc)
         d = pc._desc(n, t, h, w, x.ld, pk, dy.dims[1:], dy.ld, 0, False)
-        dwp = torch.zeros((pc.cpad, pc.kpad), dtype=torch.float32, device=x.buf.device)
-        check(_lib.lib().tedspad_conv_wgrad(C.byref(d), x.ptr, dy.ptr, pc._ktab(d).data_ptr(), dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
+        if getattr(self, "_dwp_gen", -1) != ARENA.gen:
+            self._dwp = ARENA.take((pc.cpad, pc.kpad), x.buf.device)
+            self._dwp_gen = ARENA.gen
+            self._db = None
+        check(_lib.lib().tedspad_conv_wgrad(C.byref(d), x.ptr, dy.ptr, pc._ktab(d).data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
+        if self.bias is not None:
+            db = channel_sums(dy)[0]
+            self._db = db if self._db is None else self._db + db
+
+    def flush_grad(self):
+        """d(weight) / d(bias) of this step -> `.grad` in the parameter layout (no-op if wgrad was not called)."""
+        if getattr(self, "_dwp_gen", -1) != ARENA.gen or self._dwp is None:
+            return
+        pc = self.fwd_conv()
         w5 = self._w5()
         co, ci, kt, kh, kw = w5.shape
         kt_, kh_, kw_ = pc.k
-        g = dwp[:co, :pc.K].view(co, kt_, kh_, kw_, pc.cin).permute(0, 4, 1, 2, 3)
+        g = self._dwp[:co, :pc.K].view(co, kt_, kh_, kw_, pc.cin).permute(0, 4, 1, 2, 3)
         g = E.stem_pair_grad(g, ci, kw, self.pair_w) if self.pair_w is not None else g[:, :ci]
         g = g.reshape(self.weight.shape)
         self.weight.grad = g.contiguous() if self.weight.grad is None else self.weight.grad + g
-        if self.bias is not None:
-            db = channel_sums(dy)[0, :co]
+        if self.bias is not None and self._db is not None:
+            db = self._db[:co]
             self.bias.grad = db.clone() if self.bias.grad is None else self.bias.grad + db
+        self._dwp = None
 
 
 # ---- per-channel reductions / BatchNorm ---------------------------------------------------------------
@@ -189,7 +244,7 @@ def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = N
     """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu).
     z: the fp32 (n,t,h,w,C) pre-normalisation conv output."""
     n, t, h, w = dy.dims
-    sums = torch.zeros((2, dy.c), dtype=torch.float32, device=dy.buf.device)
+    sums = ARENA.take((2, dy.c), dy.buf.device)
     check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.data_ptr() if z is not None else None,
                                            mean.data_ptr() if mean is not None else None, invstd.data_ptr() if invstd is not None else None,
                                            sums.data_ptr(), dy.c, n * t * h * w, dy.c, dy.ld, y.ld if y is not None else 0,
@@ -205,11 +260,11 @@ def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional
     """conv -> BatchNorm(batch statistics, running stats updated) -> (+residual) -> ReLU. Returns (y, ctx).
     The pre-normalisation conv output z stays in fp32 (it is re-read by the BN apply and by the backward)."""
     pc = conv.fwd_conv()
-    stats = torch.zeros((2, pc.cpad), dtype=torch.float32, device=x.buf.device)
+    stats = ARENA.take((2, pc.cpad), x.buf.device)
     z = conv.forward(x, stats=stats, y32=True)                       # (n,t,h,w,cout) fp32
     n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
-    scale, shift, mean, invstd = (torch.zeros(cz, dtype=torch.float32, device=x.buf.device) for _ in range(4))
+    scale, shift, mean, invstd = ARENA.take((4, cz), x.buf.device).unbind(0)
     check(_lib.lib().tedspad_bn_finalize(stats.data_ptr(), pc.cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                          C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), c, _stream_ptr()),
@@ -235,8 +290,11 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
     sums = channel_sums(dy, y, z, ctx.mean, ctx.invstd, relu=ctx.relu)
     dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
     dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
-    gam = torch.zeros(cz, dtype=torch.float32, device=z.device)
-    gam[:c] = bn.weight.detach()
+    if cz == c:
+        gam = bn.weight.detach()
+    else:
+        gam = torch.zeros(cz, dtype=torch.float32, device=z.device)
+        gam[:c] = bn.weight.detach()
     check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, y.ptr, z.data_ptr(), ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
                                           sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w, cz,
                                           dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu),

@@ -96,6 +96,17 @@ class I3DTrainer:
                 self.blocks.append(d)
         self._folds = {}
 
+    def conv_layers(self):
+        out = [self.stem]
+        for d in self.blocks:
+            out += [d[k] for k in ("c1", "c2", "c3", "cd") if d[k] is not None]
+        return out
+
+    def flush_grads(self):
+        """Convert the packed weight-gradient accumulators of this step into the parameters' .grad."""
+        for c in self.conv_layers():
+            c.flush_grad()
+
     def _fold(self, bn):
         """Eval-mode BN as fp32 (scale, shift); cached while the BN tensors are unchanged."""
         sig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
@@ -260,6 +271,16 @@ class UNetTrainer:
         self.down = [dc(getattr(unet, "down%d" % i).maxpool_conv[1]) for i in (1, 2, 3, 4)]
         self.up = [dc(getattr(unet, "up%d" % i).conv) for i in (1, 2, 3, 4)]
         self.outc = TE.ConvLayer(unet.outc.conv.weight, unet.outc.conv.bias, (1, 1, 1), (0, 0, 0), dtype=dt)
+
+    def conv_layers(self):
+        out = [c for c, _ in self.inc] + [self.outc]
+        for units in self.down + self.up:
+            out += [c for c, _ in units]
+        return out
+
+    def flush_grads(self):
+        for c in self.conv_layers():
+            c.flush_grad()
 
     def forward(self, x: torch.Tensor):
         """x: (N,3,H,W) fp32 -> (y (N,3,H,W) fp32, tape). BatchNorm2d uses the batch statistics of this call

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from .losses import CrossEntropyLoss, NTXentLoss, TripletMarginLoss
+from . import train_engine as TE
 from .train_nets import I3DTrainer, UNetTrainer
 
 # anonymization_training/params_anonymization.py:28-62
@@ -87,6 +88,7 @@ class AnonymizerTrainStep:
         self.fa.train(); self.ft.eval()
         for opt in (self.opt_fa, self.opt_ft):
             opt.zero_grad(set_to_none=True)
+        TE.ARENA.reset(inputs_video.device)
         frames, shape = self._feed(inputs_video)
         anon_flat, tape_fa = self.fa_tr.forward(frames)
         anon = anon_flat.reshape(shape)                               # :92
@@ -103,6 +105,7 @@ class AnonymizerTrainStep:
         for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
             self.ft_tr.backward(tape, pl.grad, fl.grad, dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
         self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape))
+        self.fa_tr.flush_grads()
         allreduce_mean_grads(list(self.fa.parameters()), self.group)
         self.opt_fa.step()                                            # :123
         self.iteration += 1
@@ -116,6 +119,7 @@ class AnonymizerTrainStep:
         self.fa.eval(); self.ft.train()
         for opt in (self.opt_fa, self.opt_ft):
             opt.zero_grad(set_to_none=True)
+        TE.ARENA.reset(inputs_video.device)
         frames, shape = self._feed(inputs_video)
         with torch.no_grad():
             anon = self.fa(frames).reshape(shape)                     # :144-148
@@ -129,6 +133,7 @@ class AnonymizerTrainStep:
         loss_ft.backward()                                            # :191
         for tape, (pl, fl) in zip(tapes, leaves):
             self.ft_tr.backward(tape, pl.grad, fl.grad)
+        self.ft_tr.flush_grads()
         allreduce_mean_grads(list(self.ft.parameters()), self.group)
         self.opt_ft.step()                                            # :193
         self.iteration += 1

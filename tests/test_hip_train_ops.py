@@ -58,6 +58,7 @@ def test_dgrad_and_wgrad_vs_autograd(case):
     assert rel_l2(nc(dx2), x.grad) < 1e-3
     # weight gradient
     layer.wgrad(cl(x.detach()), cl(dy))
+    layer.flush_grad()
     assert rel_l2(wp.grad.cpu(), w.grad) < 1e-3
 
 
@@ -78,6 +79,7 @@ def test_stem_pair_form_backward():
     dx = dxp.buf.float().cpu().reshape(2, 8, 32, 32, 4)[..., :3].permute(0, 4, 1, 2, 3)
     assert rel_l2(dx, x.grad) < 1e-3
     layer.wgrad(xa, cl(dy))
+    layer.flush_grad()
     assert rel_l2(wp.grad.cpu(), w.grad) < 1e-3
 
 
@@ -114,6 +116,7 @@ def test_conv_bn_relu_train_fwd_bwd(with_res):
     assert rel_l2(bn.running_mean.cpu(), rm_ref) < 1e-3 and rel_l2(bn.running_var.cpu(), rv_ref) < 1e-3
     assert int(bn.num_batches_tracked) == 1
     dx, dres = TE.conv_bn_act_train_bwd(ctx, cl(dy))
+    layer.flush_grad()
     assert rel_l2(nc(dx), x.grad) < 5e-3
     assert rel_l2(wp.grad.cpu(), w.grad) < 5e-3
     assert rel_l2(bn.weight.grad.cpu(), g.grad) < 5e-3 and rel_l2(bn.bias.grad.cpu(), be.grad) < 5e-3
