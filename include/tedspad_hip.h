@@ -255,6 +255,31 @@ int32_t tedspad_pack_conv_weights(const float *w, const float *scale, void *out,
                                   int32_t rows, int32_t rows_pad, int32_t kpad, const int32_t *dgrad_geo, int32_t dtype,
                                   void *stream);
 
+/* ---- the steps either side of the encoder ---------------------------------------- */
+/* Antialiased bilinear resize weights of one axis, as torch builds them for F.interpolate(mode='bilinear',
+ * antialias=True, align_corners=False) -- the call behind torchvision F.resize(antialias=True) on a float tensor
+ * (feature_extraction/dali_extraction.py:49). Host functions: `table` receives out_size entries of
+ * (2 + taps) 32-bit words {first input index, tap count, float weights[taps]}; copy it to the device. */
+int32_t tedspad_resize_aa_taps(int32_t in_size, int32_t out_size);
+int32_t tedspad_resize_aa_table(int32_t in_size, int32_t out_size, int32_t *table);
+
+/* DALIDataloader.val_augmentations (dali_extraction.py:38-50) for one crop box: frames (T,H,W,C) interleaved,
+ * uint8 or float (in_is_float) -> value / divisor (255) -> crop [y0,y0+ch) x [x0,x0+cw) -> antialiased bilinear
+ * resize to (oh,ow) with the two device tables above (for ch->oh and cw->ow) -> optional horizontal flip (ten-crop)
+ * -> fp32 out[t*so_t + c*so_c + y*so_h + x*so_w] (element strides: (T,C,h,w) as the reference returns it, or
+ * straight into a (C,T,h,w) clip of the encoder's batch). */
+int32_t tedspad_frames_crop_resize(const void *frames, int32_t in_is_float, int32_t T, int32_t H, int32_t W, int32_t C,
+                                   int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t oh, int32_t ow,
+                                   const int32_t *ytab, const int32_t *xtab, float divisor, int32_t flip, float *out,
+                                   int64_t so_t, int64_t so_c, int64_t so_h, int64_t so_w, void *stream);
+
+/* MGFN feature feed (anomaly_detection_mgfn/datasets/dataset.py:65-100): feat (T, ncrops, F) fp32.
+ * length > 0 (train): out (ncrops, length, F+1) = process_feat (utils/utils.py:34-42: means over the
+ * numpy.linspace(0,T,length+1,dtype=int) segments, a single row where a segment is empty) + L2 magnitude channel.
+ * length == 0 (test_mode): out (T, ncrops, F+1) = the rows + magnitude channel. */
+int32_t tedspad_segment_pool_mag(const float *feat, int32_t T, int32_t ncrops, int32_t F, int32_t length, float *out,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

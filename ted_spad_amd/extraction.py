@@ -109,3 +109,20 @@ def save_video_features(save_dir: str, video_path: str, feats) -> str:
         arr = arr[:, 0]
     np.save(path, np.ascontiguousarray(arr, dtype=np.float64))
     return path
+
+
+def save_features_batched(save_dir: str, items) -> list:
+    """Batched `.npy` writer: items = [(video_path, feats (T,F) or (T,ncrops,F) tensor), ...] of several videos.
+    All features cross PCIe in ONE device-to-host copy (one sync instead of one per clip as in
+    st_feature_extraction.py:31-37), then each video is written with the reference's naming / float64 layout."""
+    items = list(items)
+    if not items:
+        return []
+    flat = torch.cat([f.detach().reshape(-1).to(torch.float32) for _, f in items])
+    host = flat.cpu().numpy()
+    paths, off = [], 0
+    for path, f in items:
+        n = f.numel()
+        paths.append(save_video_features(save_dir, path, host[off:off + n].reshape(tuple(f.shape))))
+        off += n
+    return paths

@@ -137,3 +137,42 @@ def test_no_cpu_fallback():
     for holder in (ft.i3d.conv1, ft.i3d.bn1, ft.mlp.fc1):
         with pytest.raises(RuntimeError):
             holder(torch.zeros(1))
+
+
+def test_resize_aa_table_matches_torch_antialias_weights():
+    """Host builder of the antialiased-resize weights (tedspad_resize_aa_table, no GPU involved) against the dense
+    resize matrix read off torch.nn.functional.interpolate(antialias=True) itself -- the call behind
+    torchvision F.resize in dali_extraction.py:49. Tolerance: 2e-6 absolute on weights in [0,1] (fp32 rounding)."""
+    from oracle import preprocess_ref
+    from ted_spad_amd import preprocess
+    for n_in, n_out in [(864, 224), (576, 224), (224, 224), (100, 224), (1080, 7), (5, 3), (3, 5)]:
+        tab = preprocess.aa_table_host(n_in, n_out)
+        dense = np.zeros((n_out, n_in), np.float32)
+        for i in range(n_out):
+            lo, cnt = int(tab[i, 0]), int(tab[i, 1])
+            assert 0 <= lo and lo + cnt <= n_in and cnt <= tab.shape[1] - 2
+            dense[i, lo:lo + cnt] = tab[i, 2:2 + cnt].view(np.float32)
+        ref = preprocess_ref.resize_matrix(n_in, n_out).numpy()
+        assert np.abs(dense - ref).max() < 2e-6, (n_in, n_out, np.abs(dense - ref).max())
+        assert np.allclose(dense.sum(1), 1.0, atol=1e-5)
+
+
+def test_crop_boxes():
+    from ted_spad_amd import preprocess
+    assert preprocess.center_crop_box(1080, 1920, 864, 1536) == (108, 192, 864, 1536)
+    assert preprocess.center_crop_box(241, 321, 192, 256) == (24, 32, 192, 256)       # 24.5 -> 24, 32.5 -> 32: half to even
+    boxes = preprocess.ten_crop_boxes(256, 340, 224, 224)
+    assert len(boxes) == 10 and boxes[0] == (0, 0, 224, 224, False) and boxes[4][:2] == (16, 58)
+    assert boxes[5] == (0, 116, 224, 224, True) and boxes[6] == (0, 0, 224, 224, True)  # flipped tl = right edge of the frame
+    with pytest.raises(ValueError):
+        preprocess.center_crop_box(100, 100, 120, 50)
+
+
+def test_save_features_batched(tmp_path):
+    from ted_spad_amd.extraction import save_features_batched
+    a, b = synth_tensor(0, "fa", (5, 16)), synth_tensor(0, "fb", (3, 10, 8))
+    paths = save_features_batched(str(tmp_path), [("/x/y/Abuse001_x264.mp4", a), ("Normal_7.avi", b)])
+    assert [os.path.basename(p) for p in paths] == ["Abuse001_x264.npy", "Normal_7.npy"]
+    la, lb = np.load(paths[0]), np.load(paths[1])
+    assert la.dtype == np.float64 and la.shape == (5, 16) and np.array_equal(la, a.numpy().astype(np.float64))
+    assert lb.shape == (3, 10, 8) and np.array_equal(lb, b.numpy().astype(np.float64))
