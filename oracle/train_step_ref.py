@@ -8,12 +8,14 @@ load_ft_model('largei3d')) through the same lines of train_anonymizer.py (tests/
 
 Follows anonymization_training/train_anonymizer.py:
   feed (Q2)           :57,87-92        split :94       ft x3 :99,111-112
-  loss_ft             :107,115-116     loss_fa :119 (the fb / NT-Xent term needs torchvision's ResNet-50: absent)
+  loss_ft             :107,115-116     loss_fa :119
+  fb / NT-Xent term   :80-84 (phase 1: through the frozen fb into fa), :147,153-157,190 (phase 2: updates fb);
+                      fb = oracle/resnet50_ref.py (torchvision ResNet-50 restated: that trunk's parity is unpinned)
   phase 2             :137-183
 """
 import torch
 
-from . import i3res50_ref, losses_ref, unet_ref
+from . import i3res50_ref, losses_ref, resnet50_ref, unet_ref
 
 
 def _grad_sd(sd):
@@ -28,9 +30,15 @@ def _utility(ft_sd, clips, labels, train, tlw=0.1):
     return ce + tlw * trip, ce, trip
 
 
-def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_frames=16):
-    """Returns (losses dict, grads of fa parameters dict, d(loss)/d(anon))."""
+def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_frames=16, vispr=None, fb_sd=None, fb_loss_weight=1.0):
+    """Returns (losses dict, grads of fa parameters dict, d(loss)/d(anon)). With `vispr` = [view0, view1] (N,3,H,W)
+    and `fb_sd`, the privacy term -fb_loss_weight * NTXent(fb(fa(v0)), fb(fa(v1))) is included (fa in train mode on
+    each view separately, fb in eval mode: :73-84)."""
     fa = _grad_sd(fa_sd)
+    loss_fb = None
+    if vispr is not None:
+        z = [resnet50_ref.forward(unet_ref.forward(x, fa, train=True), fb_sd, train=False) for x in vispr]
+        loss_fb = losses_ref.nt_xent_torch(z[0], z[1], 0.1)
     v = video_b48.permute(0, 2, 1, 3, 4)
     b, c, t, h, w = v.shape
     anon = unet_ref.forward(v.reshape(-1, c, h, w), fa, train=True).reshape(b, c, t, h, w)
@@ -38,9 +46,24 @@ def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_fra
     clips = torch.split(anon, [num_frames] * 3, dim=2)
     loss_ft, ce, trip = _utility(ft_sd, clips, labels, train=False, tlw=tlw)
     loss_fa = ft_loss_weight * loss_ft
+    if loss_fb is not None:
+        loss_fa = -fb_loss_weight * loss_fb + loss_fa
     loss_fa.backward()
     grads = {k: p.grad for k, p in fa.items() if p.requires_grad and p.grad is not None}
-    return dict(loss_fa=loss_fa.item(), loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads, anon.grad
+    return dict(loss_fa=loss_fa.item(), loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item(),
+                loss_fb=None if loss_fb is None else loss_fb.item()), grads, anon.grad
+
+
+def phase2_fb(vispr, fa_sd, fb_sd):
+    """The fb half of phase 2 (:147,153-157,190): fa eval / no grad on each view, fb in train mode per view, NT-Xent.
+    Returns (loss_fb, grads of fb parameters)."""
+    fb = _grad_sd(fb_sd)
+    with torch.no_grad():
+        x = [unet_ref.forward(v, fa_sd, train=False) for v in vispr]
+    z = [resnet50_ref.forward(xi, fb, train=True) for xi in x]
+    loss_fb = losses_ref.nt_xent_torch(z[0], z[1], 0.1)
+    loss_fb.backward()
+    return loss_fb.item(), {k: p.grad for k, p in fb.items() if p.requires_grad and p.grad is not None}
 
 
 def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):

@@ -8,9 +8,9 @@ the networks running on MI355X HIP kernels (libtedspad_hip.so).
     mlp, wrapper_i3d                                                          model_loaders.py:235-268
 
 In scope: arch 'largei3d' and 'i3d' for ft, 'unet' for fa (the architectures whose source
-is part of the reference). 'unet++', 'r3d_18', 'mvitv2' and fb 'r50' are third-party models
-(segmentation_models_pytorch / torchvision) that are out of scope: they
-raise NotImplementedError rather than silently falling back.
+is part of the reference) and 'r50' for fb (torchvision's ResNet-50, restated: resnet50.py). 'unet++', 'r3d_18'
+and 'mvitv2' are third-party models (segmentation_models_pytorch / torchvision) that are out of scope
+(SURVEY.md §2 row 5): they raise NotImplementedError rather than silently falling back.
 """
 from __future__ import annotations
 
@@ -149,9 +149,25 @@ def load_ft_model(arch="r3d", saved_model_file=None, num_classes=400, kin_pretra
 
 
 def load_fb_model(arch="r50", saved_model_file=None, num_pa=7, ssl=False, pretrained=True):
-    """model_loaders.py:94-120. fb is torchvision's ResNet-50 (third-party): not built."""
-    if arch != "r50":
+    """model_loaders.py:94-120: ResNet-50 privacy branch (ssl=True: + projection MLP, what train_anonymizer.py:338 uses).
+    `pretrained=True` asks torchvision for its ImageNet download in the reference; offline, the weights come from
+    `saved_model_file` (or stay randomly initialised, and the message says so)."""
+    from .resnet50 import build_resnet_predictor, load_privacy_ssl
+    if arch == "r50":
+        fb_model = load_privacy_ssl() if ssl else build_resnet_predictor(num_classes=num_pa, pretrained=pretrained)
+    else:
         print(f"Architecture {arch} invalid for fb_model. Try 'r50'")
         return
-    raise NotImplementedError("fb 'r50' is torchvision's resnet50 (third-party): out of scope for this path; the "
-                              "training step takes fb embeddings as an input (DESIGN.md).")
+    if saved_model_file:
+        saved_dict = torch.load(saved_model_file, map_location="cpu")
+        try:
+            fb_model.load_state_dict(saved_dict["fb_model_state_dict"], strict=True)
+        except Exception:
+            new_state_dict = OrderedDict((k[7:], v) for k, v in saved_dict["fb_model_state_dict"].items())   # 'module.' (:110-113)
+            fb_model.load_state_dict(new_state_dict, strict=True)
+        print(f"fb_model loaded from {saved_model_file} successfully!")
+    else:
+        # the reference prints `Pretrained: {pretrained}` after torchvision downloaded the ImageNet weights; offline
+        # nothing was downloaded, so the message states what actually happened
+        print("fb_model freshly initialized! Pretrained: False")
+    return fb_model

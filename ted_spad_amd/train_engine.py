@@ -41,7 +41,7 @@ class ZeroArena:
 
     def reset(self, device):
         if self.buf is None or self.buf.device != torch.device(device):
-            self.buf = torch.zeros(64 << 20, dtype=torch.float32, device=device)     # 256 MB, grows on demand
+            self.buf = torch.zeros(160 << 20, dtype=torch.float32, device=device)    # 640 MB (all three nets' packed weight gradients fit)
         elif self.high:
             self.buf[: self.high].zero_()
         self.used, self.high = 0, 0

@@ -75,25 +75,20 @@ def _mul(a, b, scale):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# wrapper_i3d
+# bottleneck trunk shared by wrapper_i3d (I3Res50) and the privacy branch fb (ResNet-50 == the same blocks with
+# 2-D kernels: an image is a clip with T = 1)
 # ------------------------------------------------------------------------------------------------------------------
 
-class I3DTrainer:
-    def __init__(self, wrapper):
-        self.m = wrapper
-        i3d = wrapper.i3d
-        dt = i3d.compute_dtype
-        self.stem = TE.ConvLayer(i3d.conv1.weight, None, (2, 2, 2), (2, 3, 3), pair_w=3, dtype=dt)
-        self.blocks = []
-        for li in range(1, 5):
-            for bi, blk in enumerate(getattr(i3d, "layer%d" % li)):
-                s = blk.stride
-                d = dict(li=li, bi=bi, blk=blk,
-                         c1=TE.ConvLayer(blk.conv1.weight, None, (1, 1, 1), (blk.temp_conv, 0, 0), dtype=dt),
-                         c2=TE.ConvLayer(blk.conv2.weight, None, (1, s, s), (0, 1, 1), dtype=dt),
-                         c3=TE.ConvLayer(blk.conv3.weight, None, (1, 1, 1), (0, 0, 0), dtype=dt),
-                         cd=TE.ConvLayer(blk.downsample[0].weight, None, (1, s, s), (0, 0, 0), dtype=dt) if blk.downsample is not None else None)
-                self.blocks.append(d)
+class BottleneckTrunk:
+    """stem conv + BN + ReLU -> max-pool -> bottleneck blocks (optionally a max-pool in front of a block) -> global
+    average pool, forward with tape and both backward flavours:
+       'train': batch-statistics BN, parameter gradients (+ nothing w.r.t. the input)
+       'eval' : BN folded, gradient w.r.t. the INPUT only (the network is frozen in that phase)."""
+
+    def __init__(self, stem, stem_bn, pool1, blocks):
+        """pool1 = (kernel, stride, pads); blocks = dicts with c1,c2,c3,cd (ConvLayer | None), bn1,bn2,bn3,bnd,
+        pre_pool ((kernel, stride) | None)."""
+        self.stem, self.stem_bn, self.pool1, self.blocks = stem, stem_bn, pool1, blocks
         self._folds = {}
 
     def conv_layers(self):
@@ -107,7 +102,7 @@ class I3DTrainer:
         for c in self.conv_layers():
             c.flush_grad()
 
-    def _fold(self, bn):
+    def fold(self, bn):
         """Eval-mode BN as fp32 (scale, shift); cached while the BN tensors are unchanged."""
         sig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
         hit = self._folds.get(id(bn))
@@ -115,6 +110,119 @@ class I3DTrainer:
             hit = (sig,) + E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             self._folds[id(bn)] = hit
         return hit[1], hit[2]
+
+    def forward(self, a: Act, train: bool):
+        """a: the pixel-pair input Act. Returns (f (B,C) fp32 pooled feature, tape)."""
+        tape = dict(train=train, units=[], clip=a)
+
+        def unit(conv, bn, xin, relu=True, residual=None):
+            if train:
+                return TE.conv_bn_act_train(conv, bn, xin, relu=relu, residual=residual)
+            s, b = self.fold(bn)
+            return conv.forward(xin, scale=s, shift=b, relu=relu, residual=residual), (conv, s)
+
+        y, tape["stem"] = unit(self.stem, self.stem_bn, a)
+        tape["stem_y"] = y
+        k, s, pads = self.pool1
+        a, tape["idx1"] = E.maxpool(y, k, s, pads=pads, return_idx=True)
+        after_pool = True
+        for d in self.blocks:
+            rec = dict(d=d)
+            if d["pre_pool"] is not None:
+                rec["pool_in"] = a
+                a, rec["pool_idx"] = E.maxpool(a, d["pre_pool"][0], d["pre_pool"][1], return_idx=True)
+                after_pool = True
+            rec["a_in"], rec["after_pool"] = a, after_pool       # after_pool: the block input is a max-pool output, not a ReLU output
+            after_pool = False
+            h1, rec["u1"] = unit(d["c1"], d["bn1"], a)
+            h2, rec["u2"] = unit(d["c2"], d["bn2"], h1)
+            if d["cd"] is not None:
+                r, rec["ud"] = unit(d["cd"], d["bnd"], a, relu=False)
+            else:
+                r = a
+            a, rec["u3"] = unit(d["c3"], d["bn3"], h2, relu=True, residual=r)
+            rec["h1"], rec["h2"], rec["out"] = h1, h2, a
+            tape["units"].append(rec)
+        f = E.global_avgpool(a)
+        tape["f"] = f
+        return f, tape
+
+    def backward(self, tape, df: torch.Tensor):
+        """df: (B,C) fp32 gradient w.r.t. the pooled feature. 'train' tape: accumulates the parameter gradients,
+        returns None. 'eval' tape: returns d(input) as the stem's pixel-pair Act."""
+        last = tape["units"][-1]["out"]
+        k1, s1, p1 = self.pool1
+        if tape["train"]:
+            da = TE.global_avgpool_bwd(df, last)
+            for rec in reversed(tape["units"]):
+                dh2, dres = TE.conv_bn_act_train_bwd(rec["u3"], da)
+                dh1, _ = TE.conv_bn_act_train_bwd(rec["u2"], dh2)
+                t = TE.conv_bn_act_train_bwd(rec["ud"], dres)[0] if "ud" in rec else dres
+                da, _ = TE.conv_bn_act_train_bwd(rec["u1"], dh1, dx_residual=t)
+                if "pool_idx" in rec:
+                    pk, ps = rec["d"]["pre_pool"]
+                    da = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], da, pk, ps)
+            da = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], da, k1, s1, pads=p1)
+            TE.conv_bn_act_train_bwd(tape["stem"], da, need_dx=False)
+            return None
+        # eval mode: only d(input). delta = gradient w.r.t. a block output's PRE-activation (already ReLU-masked).
+        delta = TE.global_avgpool_bwd(df, last, mask=last)
+        for rec in reversed(tape["units"]):
+            (c3, s3), (c2, s2), (c1, sc1) = rec["u3"], rec["u2"], rec["u1"]
+            du2 = c3.dgrad(delta, rec["h2"].dims[1:], scale=s3, mask=rec["h2"])
+            du1 = c2.dgrad(du2, rec["h1"].dims[1:], scale=s2, mask=rec["h1"])
+            t = rec["ud"][0].dgrad(delta, rec["a_in"].dims[1:], scale=rec["ud"][1]) if "ud" in rec else delta
+            delta = c1.dgrad(du1, rec["a_in"].dims[1:], scale=sc1, residual=t, mask=None if rec["after_pool"] else rec["a_in"])
+            if "pool_idx" in rec:
+                pk, ps = rec["d"]["pre_pool"]
+                delta = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], delta, pk, ps, relu_mask=True)
+        delta = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], delta, k1, s1, pads=p1, relu_mask=True)
+        conv, s = tape["stem"]
+        return conv.dgrad(delta, tape["clip"].dims[1:], scale=s)             # (B,T,H,W/2,8) == (B,T,H,W,4)
+
+
+def _bottleneck_blocks(layers, dt, temporal):
+    """ConvLayers of a list of `nn.Sequential` bottleneck stages (parameter names conv1..3 / bn1..3 / downsample)."""
+    blocks = []
+    for li, layer in enumerate(layers, 1):
+        for bi, blk in enumerate(layer):
+            s = blk.stride
+            tc = blk.temp_conv if temporal else 0
+            blocks.append(dict(
+                li=li, bi=bi, bn1=blk.bn1, bn2=blk.bn2, bn3=blk.bn3, bnd=blk.downsample[1] if blk.downsample is not None else None,
+                c1=TE.ConvLayer(blk.conv1.weight, None, (1, 1, 1), (tc, 0, 0), dtype=dt),
+                c2=TE.ConvLayer(blk.conv2.weight, None, (1, s, s), (0, 1, 1), dtype=dt),
+                c3=TE.ConvLayer(blk.conv3.weight, None, (1, 1, 1), (0, 0, 0), dtype=dt),
+                cd=TE.ConvLayer(blk.downsample[0].weight, None, (1, s, s), (0, 0, 0), dtype=dt) if blk.downsample is not None else None,
+                pre_pool=None))
+    return blocks
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# wrapper_i3d
+# ------------------------------------------------------------------------------------------------------------------
+
+class I3DTrainer:
+    def __init__(self, wrapper):
+        self.m = wrapper
+        i3d = wrapper.i3d
+        dt = i3d.compute_dtype
+        stem = TE.ConvLayer(i3d.conv1.weight, None, (2, 2, 2), (2, 3, 3), pair_w=3, dtype=dt)
+        blocks = _bottleneck_blocks([getattr(i3d, "layer%d" % li) for li in range(1, 5)], dt, temporal=True)
+        for d in blocks:
+            if (d["li"], d["bi"]) == (2, 0):
+                d["pre_pool"] = ((2, 1, 1), (2, 1, 1))                            # large_i3d.py:139
+        self.trunk = BottleneckTrunk(stem, i3d.bn1, ((2, 3, 3), (2, 2, 2), (0, 0, 0)), blocks)     # large_i3d.py:138
+        self.stem, self.blocks = stem, blocks
+
+    def conv_layers(self):
+        return self.trunk.conv_layers()
+
+    def flush_grads(self):
+        self.trunk.flush_grads()
+
+    def _fold(self, bn):
+        return self.trunk.fold(bn)
 
     # ---- forward ---------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, mode: str, drop_mask: Optional[torch.Tensor] = None):
@@ -126,38 +234,8 @@ class I3DTrainer:
         if x.shape[0] < 2:
             raise ValueError("wrapper_i3d.forward needs B >= 2 (BatchNorm1d; SURVEY.md Q3)")
         train = mode == "train"
-        tape = dict(mode=mode, x_shape=tuple(x.shape), units=[])
-        a = E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype)
-        tape["clip"] = a
-
-        def unit(conv, bn, xin, relu=True, residual=None):
-            if train:
-                y, ctx = TE.conv_bn_act_train(conv, bn, xin, relu=relu, residual=residual)
-                return y, ctx
-            s, b = self._fold(bn)
-            return conv.forward(xin, scale=s, shift=b, relu=relu, residual=residual), (conv, s)
-
-        y, tape["stem"] = unit(self.stem, i3d.bn1, a)
-        tape["stem_y"] = y
-        a, tape["idx1"] = E.maxpool(y, (2, 3, 3), (2, 2, 2), return_idx=True)
-        for d in self.blocks:
-            blk = d["blk"]
-            rec = dict(d=d)
-            if d["li"] == 2 and d["bi"] == 0:
-                rec["pool_in"] = a
-                a, rec["pool_idx"] = E.maxpool(a, (2, 1, 1), (2, 1, 1), return_idx=True)
-            rec["a_in"] = a
-            h1, rec["u1"] = unit(d["c1"], blk.bn1, a)
-            h2, rec["u2"] = unit(d["c2"], blk.bn2, h1)
-            if d["cd"] is not None:
-                r, rec["ud"] = unit(d["cd"], blk.downsample[1], a, relu=False)
-            else:
-                r = a
-            a, rec["u3"] = unit(d["c3"], blk.bn3, h2, relu=True, residual=r)
-            rec["h1"], rec["h2"], rec["out"] = h1, h2, a
-            tape["units"].append(rec)
-        f = E.global_avgpool(a)                                   # (B,2048) fp32; feat = x.squeeze() BEFORE dropout
-        tape["f"] = f
+        f, tape = self.trunk.forward(E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype), train)   # feat = x.squeeze() BEFORE dropout
+        tape["mode"], tape["x_shape"] = mode, tuple(x.shape)
         # ---- head: fc on dropout(f) ; mlp on f ---------------------------------------------------------------------
         fd = f
         if train and i3d.drop_p > 0:
@@ -216,39 +294,71 @@ class I3DTrainer:
                 dz1 = _mul(dh, (h > 0).float(), 1.0) * s1
                 dfm = head.linear(dz1, mlp.fc1.weight.detach().t().contiguous())
             df = df + dfm
-        last = tape["units"][-1]["out"]
+        dclip = self.trunk.backward(tape, df)
         if train:
-            da = TE.global_avgpool_bwd(df, last)
-            for rec in reversed(tape["units"]):
-                dh2, dres = TE.conv_bn_act_train_bwd(rec["u3"], da)
-                dh1, _ = TE.conv_bn_act_train_bwd(rec["u2"], dh2)
-                t = TE.conv_bn_act_train_bwd(rec["ud"], dres)[0] if "ud" in rec else dres
-                da, _ = TE.conv_bn_act_train_bwd(rec["u1"], dh1, dx_residual=t)
-                if "pool_idx" in rec:
-                    da = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], da, (2, 1, 1), (2, 1, 1))
-            da = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], da, (2, 3, 3), (2, 2, 2))
-            TE.conv_bn_act_train_bwd(tape["stem"], da, need_dx=False)
             return None
-        # eval mode: only d(input). delta = gradient w.r.t. a block output's PRE-activation (already ReLU-masked).
-        delta = TE.global_avgpool_bwd(df, last, mask=last)
-        for rec in reversed(tape["units"]):
-            d = rec["d"]
-            (c3, s3), (c2, s2), (c1, s1) = rec["u3"], rec["u2"], rec["u1"]
-            du2 = c3.dgrad(delta, rec["h2"].dims[1:], scale=s3, mask=rec["h2"])
-            du1 = c2.dgrad(du2, rec["h1"].dims[1:], scale=s2, mask=rec["h1"])
-            t = rec["ud"][0].dgrad(delta, rec["a_in"].dims[1:], scale=rec["ud"][1]) if "ud" in rec else delta
-            first_after_pool = (d["li"], d["bi"]) in ((1, 0), (2, 0))     # block input is a max-pool output, not a ReLU output
-            delta = c1.dgrad(du1, rec["a_in"].dims[1:], scale=s1, residual=t, mask=None if first_after_pool else rec["a_in"])
-            if "pool_idx" in rec:
-                delta = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], delta, (2, 1, 1), (2, 1, 1), relu_mask=True)
-        delta = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], delta, (2, 3, 3), (2, 2, 2), relu_mask=True)
-        conv, s = tape["stem"]
-        dclip = conv.dgrad(delta, tape["clip"].dims[1:], scale=s)            # (B,T,H,W/2,8) == (B,T,H,W,4)
         B, _, T, Hh, Ww = tape["x_shape"]
         dview = Act(dclip.buf.view(B, T, Hh, Ww, 4), 4)
         if dx_out is None:
             dx_out = torch.empty(tape["x_shape"], dtype=torch.float32, device=dclip.buf.device)
         TE.act_to_nchw_into(dview, 3, dx_out)
+        return dx_out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fb: the privacy branch, ResNet-50 + MLP (model_loaders.py:124-153)
+# ------------------------------------------------------------------------------------------------------------------
+
+class FBTrainer:
+    """nn.Sequential(ResNet50(fc = Identity), MLP(2048 -> 2048 -> 128, L2-normalised)) with tape:
+       mode 'eval'  (phase 1, train_anonymizer.py:75-84: fb frozen, the NT-Xent gradient flows through it into fa)
+       mode 'train' (phase 2, :138-157,190-192: fb is updated with the NT-Xent loss of the anonymised views)."""
+
+    def __init__(self, fb_model):
+        self.m = fb_model
+        r = fb_model[0]
+        dt = r.compute_dtype
+        stem = TE.ConvLayer(r.conv1.weight, None, (1, 2, 2), (0, 3, 3), pair_w=3, dtype=dt)
+        blocks = _bottleneck_blocks([getattr(r, "layer%d" % li) for li in range(1, 5)], dt, temporal=False)
+        self.trunk = BottleneckTrunk(stem, r.bn1, ((1, 3, 3), (1, 2, 2), (0, 1, 1)), blocks)
+
+    def conv_layers(self):
+        return self.trunk.conv_layers()
+
+    def flush_grads(self):
+        self.trunk.flush_grads()
+
+    def forward(self, x: torch.Tensor, mode: str):
+        """x: (N,3,H,W) fp32 -> (embedding (N,128) unit-norm, tape)."""
+        assert mode in ("eval", "train")
+        E.require_cuda(x, "FBTrainer")
+        r, mlp = self.m[0], self.m[1]
+        f, tape = self.trunk.forward(E.clip_to_act(x.unsqueeze(2), cpad=4, dtype=r.compute_dtype), mode == "train")
+        tape["mode"], tape["x_shape"] = mode, tuple(x.shape)
+        h = head.linear(f, mlp.fc1.weight, mlp.fc1.bias, relu=True)
+        g = head.linear(h, mlp.fc2.weight, mlp.fc2.bias)
+        tape["h"], tape["g"] = h, g
+        return head.l2_normalize(g), tape
+
+    def backward(self, tape, demb: torch.Tensor, dx_out: Optional[torch.Tensor] = None):
+        mlp = self.m[1]
+        train = tape["mode"] == "train"
+        f, h, g = tape["f"], tape["h"], tape["g"]
+        dg = _l2norm_bwd(g, demb)
+        dh, dw2, db2 = _linear_bwd(h, mlp.fc2.weight, dg)
+        dz1 = _mul(dh, (h > 0).float(), 1.0)
+        df, dw1, db1 = _linear_bwd(f, mlp.fc1.weight, dz1)
+        if train:
+            _acc_grad(mlp.fc2.weight, dw2); _acc_grad(mlp.fc2.bias, db2)
+            _acc_grad(mlp.fc1.weight, dw1); _acc_grad(mlp.fc1.bias, db1)
+        dimg = self.trunk.backward(tape, df)
+        if train:
+            return None
+        N, _, Hh, Ww = tape["x_shape"]
+        dview = Act(dimg.buf.view(N, 1, Hh, Ww, 4), 4)
+        if dx_out is None:
+            dx_out = torch.empty(tape["x_shape"], dtype=torch.float32, device=dimg.buf.device)
+        TE.act_to_nchw_into(dview, 3, dx_out.unsqueeze(2))
         return dx_out
 
 

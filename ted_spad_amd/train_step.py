@@ -11,9 +11,9 @@ Video batch layout as the reference loader delivers it: (B, 48, 3, H, W) fp32 in
 frames stacked on dim 1 (ucf101_dl.py:368-379); labels int64 (B,). The feed reproduces quirk Q2
 (`(B,3,48,H,W).reshape(-1,3,H,W)` pseudo-images, train_anonymizer.py:87-92).
 
-The privacy branch fb is torchvision's ResNet-50 (third-party): not built, so the
-NT-Xent term is only available from precomputed embeddings (see `ntxent_from_embeddings`); with
-`fb_model=None` the step optimises the utility term alone and says so in its result.
+The privacy branch fb (ResNet-50 + MLP, resnet50.py) is optional: with `fb_model` and the two
+VISPR views (`inputs_vispr`, 2 x (N,3,H,W)) the step is the whole `train_epoch` body; with `fb_model=None` it
+optimises the utility term alone and says so in its result (`loss_fb` None).
 
 Data parallel: one process per GPU, per-rank BatchNorm statistics (what nn.DataParallel does in the
 reference), gradients of the network being updated averaged with ONE flat RCCL all-reduce.
@@ -27,7 +27,7 @@ import torch.distributed as dist
 
 from .losses import CrossEntropyLoss, NTXentLoss, TripletMarginLoss
 from . import train_engine as TE
-from .train_nets import I3DTrainer, UNetTrainer
+from .train_nets import FBTrainer, I3DTrainer, UNetTrainer
 
 # anonymization_training/params_anonymization.py:28-62
 DEFAULT_PARAMS = SimpleNamespace(num_frames=16, learning_rate=1e-5, learning_rate_fa=0.4e-5, learning_rate_fb=1e-5,
@@ -56,12 +56,12 @@ def ntxent_from_embeddings(z0, z1, temperature=0.1):
 
 class AnonymizerTrainStep:
     def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None):
-        if fb_model is not None:
-            raise NotImplementedError("fb (torchvision ResNet-50) is out of scope; pass fb_model=None")
-        self.fa, self.ft, self.params, self.group = fa_model, ft_model, params, group
+        self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
         self.fa_tr, self.ft_tr = UNetTrainer(fa_model), I3DTrainer(ft_model)
+        self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
         self.opt_fa = torch.optim.Adam(fa_model.parameters(), lr=params.learning_rate_fa)     # train_anonymizer.py:377-380
         self.opt_ft = torch.optim.Adam(ft_model.parameters(), lr=params.learning_rate_ft)
+        self.opt_fb = torch.optim.Adam(fb_model.parameters(), lr=params.learning_rate_fb) if fb_model is not None else None
         self.ce = CrossEntropyLoss()
         self.trip = TripletMarginLoss(margin=params.triplet_loss_margin)
         self.iteration = 0
@@ -81,14 +81,34 @@ class AnonymizerTrainStep:
         loss_trip = self.trip(heads[0][1], heads[1][1], heads[2][1])  # :115
         return loss_ce + p.temporal_loss_weight * loss_trip, loss_ce, loss_trip
 
+    def _opts(self):
+        return [o for o in (self.opt_fa, self.opt_fb, self.opt_ft) if o is not None]
+
+    def _views(self, inputs_vispr):
+        if self.fb is None:
+            return None
+        if inputs_vispr is None or len(inputs_vispr) != 2:
+            raise ValueError("a step with fb_model needs inputs_vispr = [view0, view1], each (N,3,H,W) (train_anonymizer.py:56)")
+        return inputs_vispr
+
     # ---- phase 1 --------------------------------------------------------------------------------------------------
-    def step_fa(self, inputs_video, labels):
+    def step_fa(self, inputs_video, labels, inputs_vispr=None):
         """Update fa (phase 1). Returns a dict of python floats."""
         p = self.params
+        views = self._views(inputs_vispr)
         self.fa.train(); self.ft.eval()
-        for opt in (self.opt_fa, self.opt_ft):
+        if self.fb is not None:
+            self.fb.eval()
+        for opt in self._opts():
             opt.zero_grad(set_to_none=True)
         TE.ARENA.reset(inputs_video.device)
+        fb_ctx, loss_fb = [], None
+        if views is not None:                                         # :80-84: fa (train mode) on each view, frozen fb
+            for v in views:
+                y, tape_u = self.fa_tr.forward(v)
+                emb, tape_b = self.fb_tr.forward(y, "eval")
+                fb_ctx.append((tape_u, tape_b, emb.detach().requires_grad_()))
+            loss_fb = NTXentLoss(inputs_video.device, fb_ctx[0][2].shape[0], 0.1, False)(fb_ctx[0][2], fb_ctx[1][2])
         frames, shape = self._feed(inputs_video)
         anon_flat, tape_fa = self.fa_tr.forward(frames)
         anon = anon_flat.reshape(shape)                               # :92
@@ -99,8 +119,12 @@ class AnonymizerTrainStep:
             tapes.append(tape)
             leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
         loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
-        loss_fa = p.ft_loss_weight * loss_ft                          # :119 with the fb term absent
+        loss_fa = p.ft_loss_weight * loss_ft                          # :119
+        if loss_fb is not None:
+            loss_fa = -p.fb_loss_weight * loss_fb + loss_fa
         loss_fa.backward()
+        for tape_u, tape_b, z in fb_ctx:
+            self.fa_tr.backward(tape_u, self.fb_tr.backward(tape_b, z.grad))
         danon = torch.zeros(shape, dtype=torch.float32, device=anon.device)
         for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
             self.ft_tr.backward(tape, pl.grad, fl.grad, dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
@@ -110,19 +134,36 @@ class AnonymizerTrainStep:
         self.opt_fa.step()                                            # :123
         self.iteration += 1
         return dict(phase=1, loss_fa=float(loss_fa.detach()), loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
-                    loss_fb=None)
+                    loss_fb=None if loss_fb is None else float(loss_fb.detach()))
 
     # ---- phase 2 --------------------------------------------------------------------------------------------------
-    def step_ft(self, inputs_video, labels, drop_masks=None):
-        """Update ft (phase 2)."""
+    def step_ft(self, inputs_video, labels, drop_masks=None, inputs_vispr=None):
+        """Update ft and fb (phase 2)."""
         p = self.params
+        views = self._views(inputs_vispr)
         self.fa.eval(); self.ft.train()
-        for opt in (self.opt_fa, self.opt_ft):
+        if self.fb is not None:
+            self.fb.train()
+        for opt in self._opts():
             opt.zero_grad(set_to_none=True)
         TE.ARENA.reset(inputs_video.device)
         frames, shape = self._feed(inputs_video)
         with torch.no_grad():
+            anon_views = [self.fa(v) for v in views] if views is not None else []      # :147
             anon = self.fa(frames).reshape(shape)                     # :144-148
+        loss_fb = None
+        if views is not None:                                         # :153-157,190,192
+            ctx = []
+            for x in anon_views:
+                emb, tape_b = self.fb_tr.forward(x, "train")
+                ctx.append((tape_b, emb.detach().requires_grad_()))
+            loss_fb = NTXentLoss(inputs_video.device, ctx[0][1].shape[0], 0.1, False)(ctx[0][1], ctx[1][1])
+            loss_fb.backward()
+            for tape_b, z in ctx:
+                self.fb_tr.backward(tape_b, z.grad)
+            self.fb_tr.flush_grads()
+            allreduce_mean_grads(list(self.fb.parameters()), self.group)
+            self.opt_fb.step()
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)
         tapes, leaves = [], []
         for k, c in enumerate(clips):
@@ -137,8 +178,11 @@ class AnonymizerTrainStep:
         allreduce_mean_grads(list(self.ft.parameters()), self.group)
         self.opt_ft.step()                                            # :193
         self.iteration += 1
-        return dict(phase=2, loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()), loss_fb=None)
+        return dict(phase=2, loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
+                    loss_fb=None if loss_fb is None else float(loss_fb.detach()))
 
-    def step(self, inputs_video, labels):
-        """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft."""
-        return self.step_fa(inputs_video, labels) if self.iteration % 2 == 0 else self.step_ft(inputs_video, labels)
+    def step(self, inputs_video, labels, inputs_vispr=None):
+        """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft (and fb)."""
+        if self.iteration % 2 == 0:
+            return self.step_fa(inputs_video, labels, inputs_vispr)
+        return self.step_ft(inputs_video, labels, inputs_vispr=inputs_vispr)

@@ -176,3 +176,19 @@ def test_save_features_batched(tmp_path):
     la, lb = np.load(paths[0]), np.load(paths[1])
     assert la.dtype == np.float64 and la.shape == (5, 16) and np.array_equal(la, a.numpy().astype(np.float64))
     assert lb.shape == (3, 10, 8) and np.array_equal(lb, b.numpy().astype(np.float64))
+
+
+def test_fb_model_has_torchvision_resnet50_keys():
+    """fb = nn.Sequential(resnet50(fc=Identity), MLP) (model_loaders.py:124-153): key names / counts of
+    torchvision.models.resnet50 so `fb_model_state_dict` checkpoints load strict=True (incl. the 'module.' fallback)."""
+    from ted_spad_amd.model_loaders import load_fb_model
+    fb = load_fb_model(arch="r50", ssl=True)
+    sd = fb.state_dict()
+    assert len(sd) == 322 and sum(p.numel() for p in fb.parameters()) == 23508032 + 2048 * 2048 + 2048 + 2048 * 128 + 128
+    for k, shape in {"0.conv1.weight": (64, 3, 7, 7), "0.bn1.running_var": (64,), "0.layer1.0.conv1.weight": (64, 64, 1, 1),
+                     "0.layer1.0.downsample.0.weight": (256, 64, 1, 1), "0.layer2.0.conv2.weight": (128, 128, 3, 3),
+                     "0.layer4.2.bn3.num_batches_tracked": (), "1.fc1.bias": (2048,), "1.fc2.weight": (128, 2048)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert not any(k.startswith("0.fc") for k in sd)                      # fc = nn.Identity()
+    pred = load_fb_model(arch="r50", ssl=False, num_pa=7)
+    assert tuple(pred.state_dict()["fc.weight"].shape) == (7, 2048) and len(pred.state_dict()) == 320
