@@ -85,6 +85,78 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
     }
 }
 
+// 8-lane 16-bit max without leaving the packed form where the ISA has it (v_pk_max_f16); bf16 goes through fp32.
+template <typename T> __device__ __forceinline__ uint4 max8(uint4 a, uint4 b);
+template <> __device__ __forceinline__ uint4 max8<F16>(uint4 a, uint4 b) {
+    return __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b)));
+}
+template <> __device__ __forceinline__ uint4 max8<BF16>(uint4 a, uint4 b) {
+    float fa[8], fb[8];
+    unpack8<BF16>(a, fa);
+    unpack8<BF16>(b, fb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = __builtin_fmaxf(fa[i], fb[i]);
+    return pack8<BF16>(fa);
+}
+
+// 3x3x3 / stride 1 / pad 1 max-pool (the pool branch of every InceptionModule, i3d.py:133-134,148: 9 of the 13 pools of
+// InceptionI3d). The generic kernel above reads 27 taps per output; here one thread walks a W row for TWO output rows
+// (h0, h0+1) of one 8-channel group: per column it loads the 3(t) x 4(h) inputs once, reduces them to the two column
+// maxima, and an output is the max of three consecutive column maxima kept in registers: 6 loads per output instead of
+// 27, all of them independent 16-byte loads that are contiguous across the lanes (channel-minor).
+// `padv` is what an out-of-range tap contributes: 0 (MaxPool3dSamePadding pads with zeros) or -inf (nn.MaxPool3d).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_k3s1_kernel(const uint16_t *x, uint16_t *y, int N, int Tn, int H, int W, int C8, int ldx, int ldy,
+                                                           uint32_t padw, int segs, int seglen, long total) {
+    const uint4 padv = make_uint4(padw, padw, padw, padw);
+    const int H2 = (H + 1) / 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long r = idx / C8;
+        const int seg = (int)(r % segs); r /= segs;          // a row is cut into `segs` runs of `seglen` columns (+1 halo column each side)
+        const int h0 = (int)(r % H2) * 2; r /= H2;
+        const int t = (int)(r % Tn);
+        const int n = (int)(r / Tn);
+        const int w0 = seg * seglen, w1 = min(W, w0 + seglen);
+        if (w0 >= W) continue;
+        const uint16_t *row[12];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int dh = 0; dh < 4; ++dh) {
+                const int it = t + dt - 1, ih = h0 + dh - 1;
+                row[dh * 3 + dt] = ((unsigned)it < (unsigned)Tn && (unsigned)ih < (unsigned)H)
+                                       ? x + (((size_t)n * Tn + it) * H + ih) * (size_t)W * ldx + c8 * 8 : nullptr;
+            }
+        uint16_t *o0 = y + (((size_t)n * Tn + t) * H + h0) * (size_t)W * ldy + c8 * 8;
+        uint16_t *o1 = o0 + (size_t)W * ldy;
+        const bool two = h0 + 1 < H;
+        uint4 cur[12], nxt[12];
+        auto load_col = [&](int w, uint4 (&v)[12]) {
+            const bool in = (unsigned)w < (unsigned)W;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) v[i] = (in && row[i]) ? *reinterpret_cast<const uint4 *>(row[i] + (size_t)w * ldx) : padv;
+        };
+        load_col(w0 - 1, cur);
+        uint4 a1 = padv, a2 = padv, b1 = padv, b2 = padv;        // column maxima at w-1 and w-2 (rows h0 / h0+1)
+        for (int w = w0 - 1; w <= w1; ++w) {
+            if (w < w1) load_col(w + 1, nxt);                     // in flight while column w is reduced
+            uint4 rm[4];
+#pragma unroll
+            for (int dh = 0; dh < 4; ++dh) rm[dh] = max8<T>(max8<T>(cur[dh * 3], cur[dh * 3 + 1]), cur[dh * 3 + 2]);
+            const uint4 mid = max8<T>(rm[1], rm[2]);
+            const uint4 a0 = max8<T>(rm[0], mid), b0 = max8<T>(mid, rm[3]);
+            if (w >= w0 + 1) {
+                *reinterpret_cast<uint4 *>(o0 + (size_t)(w - 1) * ldy) = max8<T>(max8<T>(a2, a1), a0);
+                if (two) *reinterpret_cast<uint4 *>(o1 + (size_t)(w - 1) * ldy) = max8<T>(max8<T>(b2, b1), b0);
+            }
+            a2 = a1; a1 = a0; b2 = b1; b1 = b0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) cur[i] = nxt[i];
+        }
+    }
+}
+
 // mean over `spatial` pixels; one thread per (n, 8-channel chunk), fp32 accumulate + output.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_kernel(const uint16_t *x, float *y, int n, int spatial, int c8n, int ldx) {
@@ -250,6 +322,20 @@ extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const voi
     p.pad_zero = d->pad_zero;
     p.total = (long)d->n * d->to * d->ho * d->wo * p.C8;
     hipStream_t s = (hipStream_t)stream;
+    if (!idx && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 && d->ph == 1 && d->pw == 1 &&
+        d->to == d->t && d->ho == d->h && d->wo == d->w) {
+        long rows = (long)d->n * d->t * ((d->h + 1) / 2) * p.C8;
+        int segs = 1;                                             // enough threads for ~8 waves per SIMD on 256 CUs
+        while (rows * segs < 256L * 2048 && (d->w + segs - 1) / segs > 4) ++segs;
+        const int seglen = (d->w + segs - 1) / segs;
+        const long tot = rows * segs;
+        // a row whose window is entirely padding cannot occur (pad 1 < 3), so with "skip" semantics -inf never survives
+        const uint32_t ninf = d->dtype == TEDSPAD_F16 ? 0xFC00FC00u : 0xFF80FF80u;
+        const uint32_t padw = d->pad_zero ? 0u : ninf;
+        if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_k3s1_kernel<F16>, dim3(grid_for(tot)), dim3(256), 0, s, p.x, p.y, d->n, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw, segs, seglen, tot);
+        else hipLaunchKernelGGL(maxpool_k3s1_kernel<BF16>, dim3(grid_for(tot)), dim3(256), 0, s, p.x, p.y, d->n, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw, segs, seglen, tot);
+        return check_launch("tedspad_maxpool_fwd");
+    }
     if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_kernel<F16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(maxpool_kernel<BF16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
     return check_launch("tedspad_maxpool_fwd");

@@ -108,6 +108,9 @@ POOLS = [
     ("res_maxpool2", (2, 4, 9, 9), 256, (2, 1, 1), (2, 1, 1), (0, 0, 0), (0, 0, 0), False),
     ("inc_1x3x3_s2_same", (1, 8, 28, 28), 64, (1, 3, 3), (1, 2, 2), (0, 0, 0), (0, 1, 1), True),
     ("inc_3x3x3_s1_same", (1, 4, 14, 14), 480, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),
+    ("inc_3x3x3_s1_odd_hw", (2, 2, 7, 7), 832, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),
+    ("k3s1_skip_padding", (2, 3, 5, 6), 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), False),
+    ("k3s1_degenerate", (1, 1, 1, 1), 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),
     ("inc_3x3x3_s2_same", (1, 8, 28, 28), 32, (3, 3, 3), (2, 2, 2), (0, 0, 0), (1, 1, 1), True),
     ("inc_2x2x2_s2_odd", (1, 4, 7, 7), 64, (2, 2, 2), (2, 2, 2), (0, 0, 0), (0, 1, 1), True),
     ("unet_2x2", (3, 1, 14, 14), 128, (1, 2, 2), (1, 2, 2), (0, 0, 0), (0, 0, 0), False),
@@ -125,6 +128,17 @@ def test_maxpool_bit_exact(case):
     out = E.maxpool(E.Act(x.cuda(), c), k, s, pf, pb, pad_zero=pz)
     torch.cuda.synchronize()
     assert torch.equal(out.buf.float().cpu(), ref)
+
+
+def test_maxpool_k3s1_bf16_bit_exact():
+    """The 3x3x3 / stride 1 fast path in bf16 storage (max goes through fp32 there)."""
+    from oracle.conv_ref import maxpool_cl
+    from ted_spad_amd import engine as E
+    x = synth_tensor(4, "k3s1bf", (2, 4, 9, 10, 24), -1, 1).bfloat16()
+    for pz in (True, False):
+        ref = maxpool_cl(x.float(), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), pad_zero=pz)
+        out = E.maxpool(E.Act(x.cuda(), 24), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), pad_zero=pz)
+        assert torch.equal(out.buf.float().cpu(), ref)
 
 
 def test_avgpool_and_layouts():
