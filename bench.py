@@ -110,7 +110,8 @@ def main():
         for i in range(0, args.batch * 64, args.batch):   # > TUNE_REPS x number of tile configurations
             if not _E.AUTOTUNE:
                 break
-            with torch.cuda.stream(streams[(i // args.batch) % len(streams)]):
+            multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
+            with torch.cuda.stream(streams[(i // args.batch) % len(streams) if multi and i else 0]):
                 fx(clips[:args.batch])
         torch.cuda.synchronize()
         for _ in range(args.warmup):

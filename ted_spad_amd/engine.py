@@ -27,6 +27,14 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
 FORCE_TILE_CFG = None   # tests: run every conv with this tile configuration (error if it does not apply)
+_TUNING = set()         # (id(PackedConv), geometry key) of the convs whose configurations are still taking turns
+
+
+def tuning_pending() -> bool:
+    """True while any conv geometry seen so far is still being tuned. Callers that overlap forwards on several
+    streams stay on ONE stream until this is False: a candidate timed while other streams' kernels share the CUs
+    is measured with their interference and can lose to a slower configuration."""
+    return bool(_TUNING)
 
 
 def _stream_ptr():
@@ -268,6 +276,7 @@ class PackedConv:
         if st is None:
             st = {"cands": list(range(0, L.tedspad_conv_num_tile_cfgs() + 1)), "pos": 0, "rep": 0, "rec": {}}
             self._cfgs[key] = st
+            _TUNING.add((id(self), key))
         while True:
             cfg = st["cands"][st["pos"]]
             d.tile_cfg = cfg
@@ -309,6 +318,7 @@ class PackedConv:
                 if med[cfg] < best_ms * 0.98:
                     best, best_ms = cfg, med[cfg]
             self._cfgs[key] = best
+            _TUNING.discard((id(self), key))
 
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
                  residual: Optional[Act] = None, relu=True, sigmoid=False, mask: Optional[Act] = None,

@@ -60,8 +60,10 @@ def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 50, o
     main = torch.cuda.current_stream(dev)
     for st in pool:
         st.wait_stream(main)
+    from . import engine as E
     for j, i in enumerate(range(0, n, batch)):
-        with torch.cuda.stream(pool[j % len(pool)]):
+        # while the conv tile tuner is still timing candidates, stay on one stream (engine.tuning_pending)
+        with torch.cuda.stream(pool[0 if E.tuning_pending() else j % len(pool)]):
             f = fx(clips_cthw[i:i + batch]).flatten(1)
             out[i:i + f.shape[0]] = f
     for st in pool:
