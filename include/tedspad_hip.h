@@ -255,6 +255,11 @@ int32_t tedspad_pack_conv_weights(const float *w, const float *scale, void *out,
                                   int32_t rows, int32_t rows_pad, int32_t kpad, const int32_t *dgrad_geo, int32_t dtype,
                                   void *stream);
 
+/* Eval-mode BatchNorm folded to y = x*scale + shift (fp64 inside, rounded once): scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale (+ conv_bias*scale). FrozenBN / .eval() semantics (large_i3d.py:8-38, i3d.py:113-116). */
+int32_t tedspad_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, const float *conv_bias,
+                        double eps, int32_t C, float *scale, float *shift, void *stream);
+
 /* ---- the steps either side of the encoder ---------------------------------------- */
 /* Antialiased bilinear resize weights of one axis, as torch builds them for F.interpolate(mode='bilinear',
  * antialias=True, align_corners=False) -- the call behind torchvision F.resize(antialias=True) on a float tensor

@@ -18,5 +18,10 @@ for name, fn in (('phase1', step.step_fa), ('phase2', step.step_ft)):
     ev = prof.key_averages()
     rows = sorted(ev, key=lambda e: -e.device_time_total)[:14]
     tot = sum(e.device_time_total for e in ev)
-    print(name, 'total device time ms', tot/1e3, 'kernels', sum(e.count for e in ev if e.device_time_total>0))
-    for e in rows: print('   %-70s n=%4d  %8.2f ms' % (e.key[:70], e.count, e.device_time_total/1e3))
+    from torch.autograd import DeviceType
+    kern = [e for e in ev if e.device_type == DeviceType.CUDA]
+    print(name, 'GPU kernels per step: %d launches, %.2f ms device time' % (sum(e.count for e in kern), sum(e.device_time_total for e in kern) / 1e3))
+    print('  -- by device time')
+    for e in sorted(kern, key=lambda e: -e.device_time_total)[:16]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
+    print('  -- by launch count')
+    for e in sorted(kern, key=lambda e: -e.count)[:16]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))

@@ -327,6 +327,31 @@ using namespace tedspad;
         else hipLaunchKernelGGL(KERN<BF16>, grid, dim3(256), 0, s, __VA_ARGS__);                       \
     } while (0)
 
+namespace tedspad {
+namespace {
+// eval-mode BatchNorm as y = x*scale + shift, folded in fp64 and rounded once (engine.fold_bn; one launch per BN
+// instead of ~6 elementwise torch launches: the frozen network is re-folded after every optimizer step of the other phase)
+__global__ void bn_fold_kernel(const float *gamma, const float *beta, const float *mean, const float *var, const float *conv_bias,
+                               double eps, int C, float *scale, float *shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double inv = (double)gamma[c] / sqrt((double)var[c] + eps);
+    double sh = (double)beta[c] - (double)mean[c] * inv;
+    if (conv_bias) sh += (double)conv_bias[c] * inv;
+    scale[c] = (float)inv;
+    shift[c] = (float)sh;
+}
+}  // namespace
+}  // namespace tedspad
+
+extern "C" int32_t tedspad_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, const float *conv_bias,
+                                   double eps, int32_t C, float *scale, float *shift, void *stream) {
+    TS_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, "tedspad_bn_fold: bad arguments");
+    hipLaunchKernelGGL(tedspad::bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, conv_bias, eps, C,
+                       scale, shift);
+    return tedspad::check_launch("tedspad_bn_fold");
+}
+
 extern "C" int32_t tedspad_bn_finalize(const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
                                        float eps, float momentum, float *running_mean, float *running_var, float *scale,
                                        float *shift, float *mean, float *invstd, int32_t C, void *stream) {

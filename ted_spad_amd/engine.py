@@ -88,7 +88,15 @@ def same_pads(size, k, s):
 
 
 def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
-    """y = gamma*(x + b - mean)/sqrt(var+eps) + beta  ==  x*scale + shift   (fp64 -> fp32)."""
+    """y = gamma*(x + b - mean)/sqrt(var+eps) + beta  ==  x*scale + shift   (fp64 -> fp32).
+    On the GPU one launch of tedspad_bn_fold; host tensors (weight-layout tests, before .cuda()) use the same formula."""
+    if gamma.is_cuda:
+        g, b, m, v = (t.detach().float().contiguous() for t in (gamma, beta, mean, var))
+        cb = conv_bias.detach().float().contiguous() if conv_bias is not None else None
+        scale, shift = torch.empty_like(g), torch.empty_like(g)
+        check(_lib.lib().tedspad_bn_fold(g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), cb.data_ptr() if cb is not None else None,
+                                         C.c_double(eps), g.numel(), scale.data_ptr(), shift.data_ptr(), _stream_ptr()), "tedspad_bn_fold")
+        return scale, shift
     inv = gamma.double() / torch.sqrt(var.double() + eps)
     shift = beta.double() - mean.double() * inv
     if conv_bias is not None:
@@ -109,9 +117,8 @@ def _padded_vec(v, n, npad, device, fill):
             t[:n] = fill
             _CONST_VECS[key] = t
         return t
-    out = torch.zeros(npad, dtype=torch.float32, device=device)
-    out[:n] = v.detach().to(device=device, dtype=torch.float32)
-    return out
+    v = v.detach().to(device=device, dtype=torch.float32)
+    return v.contiguous() if npad == n else torch.nn.functional.pad(v, (0, npad - n))     # at most one launch
 
 
 def stem_pair_form(w: torch.Tensor, pair_w: int):

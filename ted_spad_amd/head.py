@@ -17,11 +17,8 @@ def linear(x, weight, bias=None, bn=None, relu=False):
     N = w.shape[0]
     scale = shift = None
     if bn is not None:
-        inv = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
-        sh = bn.bias.detach().double() - bn.running_mean.double() * inv
-        if bias is not None:
-            sh = sh + bias.detach().double() * inv
-        scale, shift = inv.float().contiguous(), sh.float().contiguous()
+        from .engine import fold_bn
+        scale, shift = fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, conv_bias=bias)
     elif bias is not None:
         shift = bias.detach().float().contiguous()
     y = torch.empty((B, N), dtype=torch.float32, device=x.device)

@@ -40,6 +40,7 @@ class ZeroArena:
         self.gen = 0
 
     def reset(self, device):
+        flush_deferred()                                        # pending gradients are views of the buffer zeroed below
         if self.buf is None or self.buf.device != torch.device(device):
             self.buf = torch.zeros(160 << 20, dtype=torch.float32, device=device)    # 640 MB (all three nets' packed weight gradients fit)
         elif self.high:
@@ -65,6 +66,49 @@ class ZeroArena:
 
 
 ARENA = ZeroArena()
+
+# Tiny per-BatchNorm updates are collected and applied with multi-tensor launches: `num_batches_tracked += 1`
+# (one launch per BN per forward otherwise) and d(gamma) / d(beta), whose per-call sums live in the arena (one clone
+# or add launch per tensor per clip otherwise).
+_PENDING_COUNT = {}     # id(tensor) -> [tensor, increments]
+_PENDING_GRAD = {}      # id(param)  -> [param, [arena slices]]
+
+
+def bump_counter(t: torch.Tensor):
+    e = _PENDING_COUNT.setdefault(id(t), [t, 0])
+    e[1] += 1
+
+
+def defer_grad(p, g: torch.Tensor):
+    _PENDING_GRAD.setdefault(id(p), [p, []])[1].append(g)
+
+
+def flush_counters():
+    if _PENDING_COUNT:
+        ent = list(_PENDING_COUNT.values())
+        _PENDING_COUNT.clear()
+        torch._foreach_add_([e[0] for e in ent], [e[1] for e in ent])
+
+
+def flush_deferred():
+    """Apply the collected counter increments and BN parameter gradients (must run before the arena is reset)."""
+    flush_counters()
+    if not _PENDING_GRAD:
+        return
+    ent = list(_PENDING_GRAD.values())
+    _PENDING_GRAD.clear()
+    fresh = [e for e in ent if e[0].grad is None]
+    if fresh:                                               # .grad = copy of the first slice (one multi-tensor launch)
+        for e, g in zip(fresh, torch._foreach_mul([e[1][0] for e in fresh], 1.0)):
+            e[0].grad = g
+            e[1] = e[1][1:]
+    r = 0
+    while True:
+        todo = [e for e in ent if len(e[1]) > r]
+        if not todo:
+            break
+        torch._foreach_add_([e[0].grad for e in todo], [e[1][r] for e in todo])
+        r += 1
 
 
 def _code(t: torch.Tensor) -> int:
@@ -167,9 +211,8 @@ class ConvLayer:
         sig = self._sig(scale, shift)
         if self._fwd is None or self._fwd_sig != sig:
             w = self._w5()
-            co = w.shape[0]
-            sc = torch.ones(co, device=w.device) if scale is None else scale
-            sf = (self.bias.detach() if self.bias is not None else torch.zeros(co, device=w.device)) if shift is None else shift
+            sc = scale                                                          # None: the cached all-ones vector (no launch)
+            sf = (self.bias.detach() if self.bias is not None else None) if shift is None else shift
             old = self._fwd
             self._fwd = PackedConv(w, sc, sf, stride=self.stride, dtype=self.dtype, device=w.device, pair_w=self.pair_w)
             if old is not None:   # same geometry: keep the gather tables and the tuned tile choice
@@ -222,6 +265,7 @@ class ConvLayer:
 
     def flush_grad(self):
         """d(weight) / d(bias) of this step -> `.grad` in the parameter layout (no-op if wgrad was not called)."""
+        flush_deferred()
         if getattr(self, "_dwp_gen", -1) != ARENA.gen or self._dwp is None:
             return
         pc = self.fwd_conv()
@@ -269,7 +313,7 @@ def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional
                                          C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), c, _stream_ptr()),
           "tedspad_bn_finalize")
-    bn.num_batches_tracked += 1
+    bump_counter(bn.num_batches_tracked)
     tdt = E.DTYPES[conv.dtype][0]
     y = out if out is not None else Act.empty(n, t, h, w, cz, tdt, z.device)
     check(_lib.lib().tedspad_scale_shift_act(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), residual.ptr if residual is not None else None,
@@ -299,8 +343,8 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
                                           sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w, cz,
                                           dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu),
                                           _code(y.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
-    bn.bias.grad = sums[0, :c].clone() if bn.bias.grad is None else bn.bias.grad + sums[0, :c]
-    bn.weight.grad = sums[1, :c].clone() if bn.weight.grad is None else bn.weight.grad + sums[1, :c]
+    defer_grad(bn.bias, sums[0, :c])
+    defer_grad(bn.weight, sums[1, :c])
     ctx.conv.wgrad(ctx.x, dz)
     dx = None
     if need_dx:

@@ -45,7 +45,7 @@ def _bn1d_train(x, bn, relu):
     check(_lib.lib().tedspad_bn1d_train_fwd(x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), C.c_float(bn.eps), C.c_float(bn.momentum),
                                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                             invstd.data_ptr(), B, Cn, int(relu), _stream_ptr()), "tedspad_bn1d_train_fwd")
-    bn.num_batches_tracked += 1
+    TE.bump_counter(bn.num_batches_tracked)
     return y, (x, y, mean, invstd, relu)
 
 
@@ -145,6 +145,8 @@ class BottleneckTrunk:
             tape["units"].append(rec)
         f = E.global_avgpool(a)
         tape["f"] = f
+        if train:
+            TE.flush_counters()
         return f, tape
 
     def backward(self, tape, df: torch.Tensor):
@@ -434,6 +436,7 @@ class UNetTrainer:
         logits = self.outc.forward(cur, relu=False, sigmoid=True)       # 1x1 conv + bias + sigmoid fused
         y = E.act_to_nchw(logits, m.n_classes).squeeze(2)
         tape["y"] = y
+        TE.flush_counters()
         return y, tape
 
     def backward(self, tape, dy: torch.Tensor):

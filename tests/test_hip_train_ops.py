@@ -114,6 +114,7 @@ def test_conv_bn_relu_train_fwd_bwd(with_res):
     ya, ctx = TE.conv_bn_act_train(layer, bn, cl(x.detach()), relu=True, residual=cl(res.detach()) if with_res else None)
     assert rel_l2(nc(ya), y.detach()) < 2e-3
     assert rel_l2(bn.running_mean.cpu(), rm_ref) < 1e-3 and rel_l2(bn.running_var.cpu(), rv_ref) < 1e-3
+    TE.flush_deferred()      # counters / BN gradients are applied in multi-tensor batches
     assert int(bn.num_batches_tracked) == 1
     dx, dres = TE.conv_bn_act_train_bwd(ctx, cl(dy))
     layer.flush_grad()
