@@ -214,3 +214,50 @@ def test_halo_direct_conv(case, cfg):
     err = (got - ref).abs()
     assert bool((err <= 2.0 ** -10 * ref.abs() + 1e-3).all()), "max err %g" % float(err.max())
     assert rel_l2(got, ref) < 4e-4
+
+
+AGREE = [
+    ("a_1x3x3_c64", (3, 2, 19, 23), 64, 64, (1, 3, 3), (0, 1, 1), True),
+    ("a_3x1x1_c128", (2, 4, 9, 11), 128, 256, (3, 1, 1), (1, 0, 0), False),
+    ("a_1x1x1_c256", (5, 2, 7, 9), 256, 128, (1, 1, 1), (0, 0, 0), True),
+    ("a_3x3_cin24", (2, 1, 21, 17), 24, 40, (1, 3, 3), (0, 1, 1), False),
+]
+
+
+@pytest.mark.parametrize("case", AGREE, ids=[c[0] for c in AGREE])
+def test_every_tile_configuration_gives_the_same_result(case):
+    """The tile tuner may pick any applicable configuration, so the choice must not change results: every generic
+    implicit-GEMM configuration accumulates K in the same order and must agree BIT-EXACTLY with the others; the
+    halo-direct ones (15, 16) walk K as (channel chunk, tap) instead of (tap, channel chunk) -- an fp32 reassociation --
+    and must stay within one f16 rounding step of them (and inside the oracle bound of test_conv_fused)."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import _lib, engine as E
+    name, dims, cin, cout, k, pf, use_res = case
+    n, t, h, w = dims
+    x = synth_tensor(7, name + "x", (n, t, h, w, cin), -1, 1).half().float()
+    wgt = (synth_tensor(7, name + "w", (cout, cin) + k, -1, 1) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5).half().float()
+    scale, shift = synth_tensor(7, name + "s", (cout,), 0.5, 1.5), synth_tensor(7, name + "b", (cout,), -0.3, 0.3)
+    res = synth_tensor(7, name + "r", (n, t, h, w, cout), -1, 1).half().float() if use_res else None
+    ref = conv_cl(x, wgt, scale, shift, (1, 1, 1), pf, pf, res, relu=True)
+    pc = E.PackedConv(wgt, scale, shift, dtype="f16", device="cuda")
+    xa, ra = E.Act(x.half().cuda(), cin), (E.Act(res.half().cuda(), cout) if use_res else None)
+    outs = {}
+    try:
+        for cfg in range(1, _lib.lib().tedspad_conv_num_tile_cfgs() + 1):
+            E.FORCE_TILE_CFG = cfg
+            try:
+                outs[cfg] = pc(xa, pads=pf, residual=ra, relu=True).buf.float().cpu()
+            except _lib.TedSpadHipError:
+                continue                                   # configuration not applicable to this geometry
+    finally:
+        E.FORCE_TILE_CFG = None
+    generic = {c: o for c, o in outs.items() if c not in (15, 16)}
+    assert len(generic) >= 4, sorted(outs)
+    first = next(iter(generic.values()))
+    for c, o in generic.items():
+        assert torch.equal(o, first), "configuration %d differs from configuration %d" % (c, next(iter(generic)))
+    assert bool(((first - ref).abs() <= 2.0 ** -10 * ref.abs() + 1e-3).all())
+    for c in (15, 16):
+        if c in outs:
+            assert bool(((outs[c] - first).abs() <= 2.0 ** -10 * first.abs() + 1e-4).all()), c
+    print(name, "configurations run:", sorted(outs))
