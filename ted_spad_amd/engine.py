@@ -27,6 +27,20 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
 FORCE_TILE_CFG = None   # tests: run every conv with this tile configuration (error if it does not apply)
+# The kernels index with 32-bit element offsets (and the weight gradient decodes < 2^23 pixels): larger tensors
+# (cfg5: 384 frames of 224x224) are processed in chunks of whole samples along n, transparently to the callers.
+MAX_ELEMS = (1 << 31) - (1 << 20)
+MAX_WGRAD_PIXELS = (1 << 23) - 64
+
+
+def batch_chunk(n: int, per_sample_sizes, limit: int) -> int:
+    """Largest number of samples per launch so that every per-sample size x samples stays below `limit`."""
+    worst = max(int(v) for v in per_sample_sizes)
+    if worst >= limit:
+        raise _lib.TedSpadHipError("a single sample has %d elements: too large for the 32-bit offsets of the kernels" % worst)
+    return max(1, min(n, limit // worst))
+
+
 _TUNING = set()         # (id(PackedConv), geometry key) of the convs whose configurations are still taking turns
 
 
@@ -327,6 +341,31 @@ class PackedConv:
             self._cfgs[key] = best
             _TUNING.discard((id(self), key))
 
+    def _run(self, x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid):
+        """One launch (through the tuner) on tensors small enough for the kernel's 32-bit offsets."""
+        n, t, h, w = x.dims
+        y32 = z32 is not None
+        d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
+        ex = None
+        if mask is not None or stats is not None or out_map is not None or y32:
+            ex = _lib.ConvExtras()
+            if y32:
+                ex.y32, ex.ldy32 = z32.data_ptr(), self.cout
+            if mask is not None:
+                ex.mask, ex.ldmask = mask.ptr, mask.ld
+            if stats is not None:
+                assert stats.dtype == torch.float32 and stats.dim() == 2 and stats.shape[0] == 2 and stats.shape[1] >= self.cout
+                ex.stats, ex.stats_ld = stats.data_ptr(), stats.shape[1]
+            if out_map is not None:
+                (ex.ost, ex.osh, ex.osw), (ex.oot, ex.ooh, ex.oow) = out_map
+                ex.out_strided = 1
+                _, ex.tf, ex.hf, ex.wf = out.dims
+        args = (C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                residual.ptr if residual is not None else None, None if y32 else out.ptr, int(sigmoid),
+                C.byref(ex) if ex is not None else None)
+        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map, y32)
+        self._launch_tuned(key, d, args)
+
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
                  residual: Optional[Act] = None, relu=True, sigmoid=False, mask: Optional[Act] = None,
                  stats: Optional[torch.Tensor] = None, out_dims=None, out_map=None, y32: bool = False):
@@ -357,26 +396,15 @@ class PackedConv:
         for other in (residual, mask):
             if other is not None:
                 assert other.dims == out.dims and other.c == self.cout
-        d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
-        ex = None
-        if mask is not None or stats is not None or out_map is not None or y32:
-            ex = _lib.ConvExtras()
-            if y32:
-                ex.y32, ex.ldy32 = z32.data_ptr(), self.cout
-            if mask is not None:
-                ex.mask, ex.ldmask = mask.ptr, mask.ld
-            if stats is not None:
-                assert stats.dtype == torch.float32 and stats.dim() == 2 and stats.shape[0] == 2 and stats.shape[1] >= self.cout
-                ex.stats, ex.stats_ld = stats.data_ptr(), stats.shape[1]
-            if out_map is not None:
-                (ex.ost, ex.osh, ex.osw), (ex.oot, ex.ooh, ex.oow) = out_map
-                ex.out_strided = 1
-                _, ex.tf, ex.hf, ex.wf = out.dims
-        args = (C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                residual.ptr if residual is not None else None, None if y32 else out.ptr, int(sigmoid),
-                C.byref(ex) if ex is not None else None)
-        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map, y32)
-        self._launch_tuned(key, d, args)
+        per = [t * h * w * x.ld, out.dims[1] * out.dims[2] * out.dims[3] * max(out.ld, self.cout)]
+        for other in (residual, mask):
+            if other is not None:
+                per.append(other.dims[1] * other.dims[2] * other.dims[3] * other.ld)
+        nc = batch_chunk(n, per, MAX_ELEMS)
+        for n0 in range(0, n, nc):
+            n1 = min(n, n0 + nc)
+            sub = (lambda a: None if a is None else Act(a.buf[n0:n1], a.c, a.coff)) if nc < n else (lambda a: a)
+            self._run(sub(x), pads, o, sub(out), sub(residual), sub(mask), stats, out_map, None if z32 is None else z32[n0:n1], relu, sigmoid)
         return z32 if y32 else out
 
 

@@ -253,12 +253,17 @@ class ConvLayer:
         pc = self.fwd_conv()
         n, t, h, w = x.dims
         pk, _ = self._pads_k(pc)
-        d = pc._desc(n, t, h, w, x.ld, pk, dy.dims[1:], dy.ld, 0, False)
         if getattr(self, "_dwp_gen", -1) != ARENA.gen:
             self._dwp = ARENA.take((pc.cpad, pc.kpad), x.buf.device)
             self._dwp_gen = ARENA.gen
             self._db = None
-        check(_lib.lib().tedspad_conv_wgrad(C.byref(d), x.ptr, dy.ptr, pc._ktab(d).data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
+        to, ho, wo = dy.dims[1:]
+        nc = min(E.batch_chunk(n, [t * h * w * x.ld, to * ho * wo * dy.ld], E.MAX_ELEMS), E.batch_chunk(n, [to * ho * wo], E.MAX_WGRAD_PIXELS))
+        for n0 in range(0, n, nc):                      # chunks of whole samples accumulate into the same matrix
+            n1 = min(n, n0 + nc)
+            xs, ds = (Act(x.buf[n0:n1], x.c, x.coff), Act(dy.buf[n0:n1], dy.c, dy.coff)) if nc < n else (x, dy)
+            d = pc._desc(n1 - n0, t, h, w, xs.ld, pk, dy.dims[1:], ds.ld, 0, False)
+            check(_lib.lib().tedspad_conv_wgrad(C.byref(d), xs.ptr, ds.ptr, pc._ktab(d).data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
         if self.bias is not None:
             db = channel_sums(dy)[0]
             self._db = db if self._db is None else self._db + db

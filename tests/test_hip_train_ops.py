@@ -161,3 +161,37 @@ def test_pool_and_upsample_backward():
     a = TE.nchw_grad_to_act(gy.cuda(), yv.cuda(), (1, 5, 6))
     got = a.buf.float().cpu()[:, 0, :, :, :3].permute(0, 3, 1, 2)
     assert rel_l2(got, gy * yv * (1 - yv)) < 1e-3 and float(a.buf[..., 3:].abs().max()) == 0.0
+
+
+def test_batch_chunking_matches_single_launch(monkeypatch):
+    """Tensors beyond the kernels' 32-bit offsets (cfg5: 384 frames of 224x224) are processed in chunks of whole
+    samples (engine.batch_chunk). With the limits lowered so that a 6-sample batch splits into 3 + 3 (forward / data
+    gradient) and 2 + 2 + 2 (weight gradient), the results must equal the single-launch ones: bit-exact outputs,
+    BatchNorm statistics and weight gradients up to float-atomic order (1e-5)."""
+    from ted_spad_amd import engine as E, train_engine as TE
+    n, cin, cout = 6, 16, 24
+    x = cl(synth_tensor(9, "cx", (n, cin, 1, 12, 10), -1, 1))
+    dy = cl(synth_tensor(9, "cdy", (n, cout, 1, 12, 10), -1, 1))
+    res = cl(synth_tensor(9, "cr", (n, cout, 1, 12, 10), -1, 1))
+    wp = torch.nn.Parameter(synth_tensor(9, "cw", (cout, cin, 3, 3), -0.2, 0.2).cuda())
+
+    def run():
+        layer = TE.ConvLayer(wp, None, (1, 1, 1), (0, 1, 1))
+        stats = torch.zeros((2, layer.fwd_conv().cpad), device="cuda")
+        y = layer.forward(x, relu=True, residual=res, stats=stats)
+        dx = layer.dgrad(dy, x.dims[1:], mask=x)
+        wp.grad = None
+        layer.wgrad(x, dy)
+        layer.flush_grad()
+        return y.buf.clone(), stats.clone(), dx.buf.clone(), wp.grad.clone()
+
+    one = run()
+    per_sample = 12 * 10 * 24
+    monkeypatch.setattr(E, "MAX_ELEMS", 3 * per_sample + 1)
+    monkeypatch.setattr(E, "MAX_WGRAD_PIXELS", 2 * 12 * 10 + 1)
+    assert E.batch_chunk(n, [per_sample], E.MAX_ELEMS) == 3
+    many = run()
+    assert torch.equal(one[0], many[0]) and torch.equal(one[2], many[2])
+    assert torch.allclose(one[1], many[1], rtol=1e-5, atol=1e-5) and torch.allclose(one[3], many[3], rtol=1e-5, atol=1e-5)
+    with pytest.raises(Exception):
+        E.batch_chunk(2, [1 << 31], E.MAX_ELEMS)          # a single sample that does not fit fails loudly
