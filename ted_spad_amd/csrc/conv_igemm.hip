@@ -517,6 +517,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  14  128 x  64          2x2    2      59 KB   long K, N <= 64, 2 WG/CU
 //  17  256 x  64          4x2    2      80 KB   cin % 64 == 0 (no K table): TWO 8-wave WGs per CU
 //  18  128 x 128          2x2    2      68 KB   cin % 64 == 0
+// (table-free 128x64 / 64x64 / 64x128 tiles with 3-5 WG/CU were measured for the HBM-bound 1x1 layers: no faster than 17
+//  -- every tile shape plateaus at ~3.1-3.3 TB/s of a 4.8 TB/s copy, the per-WG load -> MFMA -> store phases do not overlap)
 //  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
 constexpr int NUM_CFGS = 18;
