@@ -15,6 +15,12 @@ The privacy branch fb (ResNet-50 + MLP, resnet50.py) is o
 VISPR views (`inputs_vispr`, 2 x (N,3,H,W)) the step is the whole `train_epoch` body; with `fb_model=None` it
 optimises the utility term alone and says so in its result (`loss_fb` None).
 
+Gradient range: activations AND activation gradients are stored in f16 (fp32 accumulate). The reference's
+train_anonymizer.py back-propagates its fp16-autocast graph without a GradScaler; its action-training scripts use one
+(train_anonymized_action.py:92-94). `loss_scale` (default 1 = the reference's behaviour) multiplies the loss gradients
+entering the networks and is divided out of every parameter gradient before the optimizer step; a step whose gradients
+are not finite is skipped and reported (`skipped: True`), like `GradScaler.step`.
+
 Data parallel: one process per GPU, per-rank BatchNorm statistics (what nn.DataParallel does in the
 reference), gradients of the network being updated averaged with ONE flat RCCL all-reduce.
 """
@@ -55,8 +61,9 @@ def ntxent_from_embeddings(z0, z1, temperature=0.1):
 
 
 class AnonymizerTrainStep:
-    def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None):
+    def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 1.0):
         self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
+        self.loss_scale = float(loss_scale)
         self.fa_tr, self.ft_tr = UNetTrainer(fa_model), I3DTrainer(ft_model)
         self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
         self.opt_fa = torch.optim.Adam(fa_model.parameters(), lr=params.learning_rate_fa)     # train_anonymizer.py:377-380
@@ -80,6 +87,18 @@ class AnonymizerTrainStep:
         loss_ce = self.ce(heads[0][0], labels)                        # :107
         loss_trip = self.trip(heads[0][1], heads[1][1], heads[2][1])  # :115
         return loss_ce + p.temporal_loss_weight * loss_trip, loss_ce, loss_trip
+
+    def _scaled(self, g):
+        return g if (g is None or self.loss_scale == 1.0) else g * self.loss_scale
+
+    def _unscale(self, module) -> bool:
+        """Divide the loss scale out of `module`'s gradients; False if they are not finite (the step is skipped)."""
+        if self.loss_scale == 1.0:
+            return True
+        grads = [p.grad for p in module.parameters() if p.grad is not None]
+        found_inf = torch.zeros(1, device=grads[0].device)
+        torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, torch.full((1,), 1.0 / self.loss_scale, device=grads[0].device))
+        return float(found_inf) == 0.0
 
     def _opts(self):
         return [o for o in (self.opt_fa, self.opt_fb, self.opt_ft) if o is not None]
@@ -124,17 +143,19 @@ class AnonymizerTrainStep:
             loss_fa = -p.fb_loss_weight * loss_fb + loss_fa
         loss_fa.backward()
         for tape_u, tape_b, z in fb_ctx:
-            self.fa_tr.backward(tape_u, self.fb_tr.backward(tape_b, z.grad))
+            self.fa_tr.backward(tape_u, self.fb_tr.backward(tape_b, self._scaled(z.grad)))
         danon = torch.zeros(shape, dtype=torch.float32, device=anon.device)
         for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
-            self.ft_tr.backward(tape, pl.grad, fl.grad, dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
+            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad), dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
         self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape))
         self.fa_tr.flush_grads()
+        ok = self._unscale(self.fa)
         allreduce_mean_grads(list(self.fa.parameters()), self.group)
-        self.opt_fa.step()                                            # :123
+        if ok:
+            self.opt_fa.step()                                        # :123
         self.iteration += 1
         return dict(phase=1, loss_fa=float(loss_fa.detach()), loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
-                    loss_fb=None if loss_fb is None else float(loss_fb.detach()))
+                    loss_fb=None if loss_fb is None else float(loss_fb.detach()), skipped=not ok)
 
     # ---- phase 2 --------------------------------------------------------------------------------------------------
     def step_ft(self, inputs_video, labels, drop_masks=None, inputs_vispr=None):
@@ -160,10 +181,12 @@ class AnonymizerTrainStep:
             loss_fb = NTXentLoss(inputs_video.device, ctx[0][1].shape[0], 0.1, False)(ctx[0][1], ctx[1][1])
             loss_fb.backward()
             for tape_b, z in ctx:
-                self.fb_tr.backward(tape_b, z.grad)
+                self.fb_tr.backward(tape_b, self._scaled(z.grad))
             self.fb_tr.flush_grads()
+            ok_fb = self._unscale(self.fb)
             allreduce_mean_grads(list(self.fb.parameters()), self.group)
-            self.opt_fb.step()
+            if ok_fb:
+                self.opt_fb.step()
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)
         tapes, leaves = [], []
         for k, c in enumerate(clips):
@@ -173,13 +196,15 @@ class AnonymizerTrainStep:
         loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
         loss_ft.backward()                                            # :191
         for tape, (pl, fl) in zip(tapes, leaves):
-            self.ft_tr.backward(tape, pl.grad, fl.grad)
+            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad))
         self.ft_tr.flush_grads()
+        ok = self._unscale(self.ft)
         allreduce_mean_grads(list(self.ft.parameters()), self.group)
-        self.opt_ft.step()                                            # :193
+        if ok:
+            self.opt_ft.step()                                        # :193
         self.iteration += 1
         return dict(phase=2, loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
-                    loss_fb=None if loss_fb is None else float(loss_fb.detach()))
+                    loss_fb=None if loss_fb is None else float(loss_fb.detach()), skipped=not ok)
 
     def step(self, inputs_video, labels, inputs_vispr=None):
         """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft (and fb)."""
