@@ -519,9 +519,10 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  18  128 x 128          2x2    2      68 KB   cin % 64 == 0
 // (table-free 128x64 / 64x64 / 64x128 tiles with 3-5 WG/CU were measured for the HBM-bound 1x1 layers: no faster than 17
 //  -- every tile shape plateaus at ~3.1-3.3 TB/s of a 4.8 TB/s copy, the per-WG load -> MFMA -> store phases do not overlap)
+//  19  128 x 64, PERSISTENT pointwise (conv_pw.hip): 1x1x1 convs with cin = 64 / 128, next tile prefetched under the stores
 //  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
-constexpr int NUM_CFGS = 18;
+constexpr int NUM_CFGS = 19;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -544,6 +545,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 14: return launch<T, 128, 64, 2, 2, 2, KTAB_MAX_BYTES>(p, s);
         case 17: return launch<T, 256, 64, 4, 2, 2, 0>(p, s);
         case 18: return launch<T, 128, 128, 2, 2, 2, 0>(p, s);
+        case 19: return launch_conv_pw(T::kDtype, p, s);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
     return TEDSPAD_EINVAL;

@@ -1,0 +1,199 @@
+// Persistent pointwise convolution for gfx950 (tile_cfg 19): 1x1x1 / stride 1 convs with cin = 64 or 128 -- the conv3
+// / downsample layers of the first two bottleneck stages (64 -> 256 on 900 k pixels, 128 -> 512), which write 4x the bytes
+// they read and do almost no arithmetic.
+//
+// Measured on the generic kernel (scripts/conv_probe.py --sweep): every tile shape, at 2..5 workgroups per CU, needs the
+// same ~185 us for 64 -> 256 at 907 k pixels = 2.5 TB/s of stores, while a copy kernel moves 4.8 TB/s: a workgroup's
+// life there is dispatch -> DMA round trip -> 16 MFMAs -> staging -> stores, all serial, ~6.6 us per 32 KB of output.
+// Here a workgroup is PERSISTENT: it owns one 64-channel slice of the output (its [64][cin] weight slice is DMA'd into
+// LDS once) and walks 128-pixel tiles; the activations of tile i+1 (LDS-DMA, double buffered) are in flight while
+// tile i is multiplied, staged and stored, and the row stores are never waited for inside the loop. Every wave owns 32 pixels x 64 channels end to end (MFMA -> its own fp32 staging rows -> 16-byte row stores):
+// one barrier per tile. Same K order, same epilogue arithmetic as conv_igemm (results are bit-identical to it).
+#include "conv_common.h"
+
+namespace tedspad {
+namespace {
+
+__device__ uint4 g_zero16p;
+
+constexpr int PW_BM = 128, PW_BN = 64, PW_STG_LD = PW_BN + 4;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+}
+
+template <typename T, int KB, bool RES>   // KB = cin / 64; RES: fused residual input
+__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int tiles_m, const int nworkers) {
+    constexpr int XSUB = PW_BM * BK * 2;        // one [128 px][64] sub-tile
+    constexpr int WSUB = PW_BN * BK * 2;        // one [64 co][64] sub-tile
+    constexpr int XBUF = KB * XSUB;
+    constexpr int RBUF = RES ? PW_BM * PW_BN * 2 : 0;   // the tile's residual rows [128 px][64 co], plain row-major
+    constexpr int OFF_X = KB * WSUB, OFF_RES = OFF_X + 2 * XBUF, OFF_STG = OFF_RES + 2 * RBUF;
+    constexpr int LDS = OFF_STG + 4 * 32 * PW_STG_LD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % p.tiles_n, worker = lid / p.tiles_n;
+    const int n0 = tile_n * PW_BN;
+
+    // ---- DMA roles (as conv_igemm: 8 consecutive lanes fetch the eight 16-byte chunks of one row, swizzled source) ----
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16p);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    const unsigned wrow = wave * 8 * (BK * 2);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            lds_dma16(p.w + (size_t)(n0 + i * 32 + rsub) * p.Kpad + kb * BK + kc * 8, lds0 + kb * WSUB + i * 32 * (BK * 2) + wrow);
+    auto issue_x = [&](int mt, int buf) {
+        const int mb = mt * PW_BM;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mb + i * 32 + rsub;
+                const uint16_t *src = m < p.M ? p.x + (size_t)m * p.ldx + kb * BK + kc * 8 : zero;
+                lds_dma16(src, lds0 + OFF_X + buf * XBUF + kb * XSUB + i * 32 * (BK * 2) + wrow);
+            }
+        if (RES) {   // residual rows ride the same DMA stream (ordinary loads inside this loop would make hipcc drain it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mb + i * 32 + rsub;
+                const int nn = n0 + (lane & 7) * 8;
+                const uint16_t *src = (m < p.M && nn < p.Cout) ? p.res + (size_t)m * p.ldres + nn : zero;
+                lds_dma16(src, lds0 + OFF_RES + buf * RBUF + i * 32 * (PW_BN * 2) + wave * 8 * (PW_BN * 2));
+            }
+        }
+    };
+
+    // ---- row roles of the epilogue: lane -> (row = j*8 + lane/8 of the wave's 32 pixels, 8 channels cc*8..) -----------
+    const int cc = lane & 7, rrow = lane >> 3;
+    const int n = n0 + cc * 8;
+    const bool active = n < p.Cout;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = 0.f; sf[i] = 0.f; }
+    if (active) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sc[i]), "+v"(sf[i]));   // hipcc's wait for these loads happens HERE, not in the loop
+    // ---- MFMA roles: the wave's 32 pixels x 64 channels (2 accumulator tiles) ---------------------------------------
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    float *stg = reinterpret_cast<float *>(smem + OFF_STG) + wave * 32 * PW_STG_LD;
+
+    // The row STORES are issued from inline asm, like the LDS-DMA: hipcc cannot count vector-memory operations across asm
+    // statements and answers every store in such a loop with `s_waitcnt vmcnt(0)` (seen in the ISA of the first version:
+    // four serialised store round trips per tile -- the same 2.5 TB/s as the generic kernel); an ordinary load in the
+    // loop gets the same treatment (a full drain right after it), and asm-issued register loads are not an option
+    // (hipcc copies their destination registers before the data has arrived) -- hence the residual goes through LDS.
+    // The one wait on the DMA is counted by hand; vector-memory operations retire in issue order on gfx9 (one counter
+    // for loads and stores; hipcc's own counted waits rely on it).
+    int mt = worker;
+    if (mt < tiles_m) issue_x(mt, 0);
+    int buf = 0;
+    bool stores_pending = false;            // the previous tile issued exactly 4 store instructions per wave (a full tile)
+    for (; mt < tiles_m; mt += nworkers) {
+        // this tile's activations were issued BEFORE the previous tile's 4 row stores: those may stay in flight
+        if (stores_pending) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // ... of every wave; the other buffer is no longer read by anyone
+        asm volatile("" ::: "memory");
+        const int nxt = mt + nworkers;
+        if (nxt < tiles_m) issue_x(nxt, buf ^ 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const uint16_t *A = reinterpret_cast<const uint16_t *>(smem + OFF_X + buf * XBUF + kb * XSUB) + (wave * 32 + l31) * BK;
+            const uint16_t *W = reinterpret_cast<const uint16_t *>(smem + kb * WSUB) + l31 * BK;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int coff = (((ks << 1) | lh) ^ swz) << 3;
+                const uint4 fa = *reinterpret_cast<const uint4 *>(A + coff);
+                const uint4 fw0 = *reinterpret_cast<const uint4 *>(W + coff), fw1 = *reinterpret_cast<const uint4 *>(W + 32 * BK + coff);
+                acc[0] = T::mfma(fw0, fa, acc[0]);
+                acc[1] = T::mfma(fw1, fa, acc[1]);
+            }
+        }
+        // wave-private staging: lane (pixel l31) holds channels a*32 + 8g + 4lh + {0..3}
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(stg + l31 * PW_STG_LD + a * 32 + 8 * g + 4 * lh) = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = j * 8 + rrow;
+            const int m = mt * PW_BM + wave * 32 + row;
+            if (active && m < p.M) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + row * PW_STG_LD + cc * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + row * PW_STG_LD + cc * 8 + 4);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+                if (RES) {
+                    float rr[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(smem + OFF_RES + buf * RBUF + (wave * 32 + row) * (PW_BN * 2) + cc * 16), rr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += rr[i];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+                }
+                gstore16(p.y + (size_t)m * p.ldy + n, __builtin_bit_cast(u32x4, pack8<T>(v)));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();    // the wave's staging rows are rewritten by its next tile
+        stores_pending = (mt + 1) * PW_BM <= p.M;   // every row exists: all 4 store instructions were issued by every wave
+        buf ^= 1;
+    }
+}
+
+template <typename T, int KB, bool RES>
+int32_t launch_pw2(const ConvKP &p, int tiles_m, hipStream_t s) {
+    const int per_cu = (KB == 1 && !RES) ? 2 : 1;        // LDS per workgroup: 75 KB (cin 64, no residual) .. 147 KB
+    int nworkers = (256 * per_cu + p.tiles_n - 1) / p.tiles_n;
+    if (nworkers > tiles_m) nworkers = tiles_m;
+    hipLaunchKernelGGL((conv_pw_kernel<T, KB, RES>), dim3(p.tiles_n * nworkers), dim3(256), 0, s, p, tiles_m, nworkers);
+    return check_launch("tedspad_conv_fwd(pointwise persistent)");
+}
+
+template <typename T, int KB>
+int32_t launch_pw(const ConvKP &pin, hipStream_t s) {
+    ConvKP p = pin;
+    p.tiles_n = (p.Cout + PW_BN - 1) / PW_BN;
+    const int tiles_m = (p.M + PW_BM - 1) / PW_BM;
+    return p.res ? launch_pw2<T, KB, true>(p, tiles_m, s) : launch_pw2<T, KB, false>(p, tiles_m, s);
+}
+
+}  // namespace
+
+int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s) {
+    if (!p.pointwise || (p.cin != 64 && p.cin != 128) || p.Kpad != p.cin || p.mask || p.stats || p.y32 || p.ostrided || p.sigmoid || !p.y) {
+        set_error("tedspad_conv_fwd: tile_cfg 19 (persistent pointwise) needs a 1x1x1 stride-1 conv with cin 64 or 128 and a plain epilogue");
+        return TEDSPAD_EINVAL;
+    }
+    if (p.cin == 64) return dtype == TEDSPAD_F16 ? launch_pw<F16, 1>(p, s) : launch_pw<BF16, 1>(p, s);
+    return dtype == TEDSPAD_F16 ? launch_pw<F16, 2>(p, s) : launch_pw<BF16, 2>(p, s);
+}
+
+}  // namespace tedspad

@@ -221,6 +221,9 @@ AGREE = [
     ("a_3x1x1_c128", (2, 4, 9, 11), 128, 256, (3, 1, 1), (1, 0, 0), False),
     ("a_1x1x1_c256", (5, 2, 7, 9), 256, 128, (1, 1, 1), (0, 0, 0), True),
     ("a_3x3_cin24", (2, 1, 21, 17), 24, 40, (1, 3, 3), (0, 1, 1), False),
+    ("a_1x1x1_c64_res", (7, 3, 13, 11), 64, 256, (1, 1, 1), (0, 0, 0), True),        # persistent pointwise (19): ragged M
+    ("a_1x1x1_c128", (3, 2, 9, 10), 128, 72, (1, 1, 1), (0, 0, 0), False),            # ... cin 128, ragged N
+    ("a_1x1x1_c64_big", (40, 2, 28, 28), 64, 64, (1, 1, 1), (0, 0, 0), True),         # ... many tiles per persistent workgroup
 ]
 
 
