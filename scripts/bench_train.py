@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--res', type=int, default=112)
 ap.add_argument('--steps', type=int, default=6)
-ap.add_argument('--warmup', type=int, default=30)   # the tile tuner needs ~30 calls per conv geometry
+ap.add_argument('--warmup', type=int, default=45)   # the tile tuner needs up to ~40 calls per conv geometry (convs called once per step)
 ap.add_argument('--fb', action='store_true', help='include the privacy branch (2 x (12,3,224,224) VISPR views)')
 ap.add_argument('--vispr-batch', type=int, default=12)
 ap.add_argument('--vispr-res', type=int, default=224)

@@ -396,15 +396,18 @@ class PackedConv:
         for other in (residual, mask):
             if other is not None:
                 assert other.dims == out.dims and other.c == self.cout
-        per = [t * h * w * x.ld, out.dims[1] * out.dims[2] * out.dims[3] * max(out.ld, self.cout)]
-        for other in (residual, mask):
-            if other is not None:
-                per.append(other.dims[1] * other.dims[2] * other.dims[3] * other.ld)
-        nc = batch_chunk(n, per, MAX_ELEMS)
-        for n0 in range(0, n, nc):
-            n1 = min(n, n0 + nc)
-            sub = (lambda a: None if a is None else Act(a.buf[n0:n1], a.c, a.coff)) if nc < n else (lambda a: a)
-            self._run(sub(x), pads, o, sub(out), sub(residual), sub(mask), stats, out_map, None if z32 is None else z32[n0:n1], relu, sigmoid)
+        od = out.dims
+        worst = max(t * h * w * x.ld, od[1] * od[2] * od[3] * max(out.ld, self.cout if residual is None else residual.ld,
+                                                                  0 if mask is None else mask.ld))
+        if n * worst < MAX_ELEMS:               # the common case: one launch
+            self._run(x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid)
+        else:
+            nc = batch_chunk(n, [worst], MAX_ELEMS)
+            sub = lambda a, n0, n1: None if a is None else Act(a.buf[n0:n1], a.c, a.coff)
+            for n0 in range(0, n, nc):
+                n1 = min(n, n0 + nc)
+                self._run(sub(x, n0, n1), pads, o, sub(out, n0, n1), sub(residual, n0, n1), sub(mask, n0, n1), stats, out_map,
+                          None if z32 is None else z32[n0:n1], relu, sigmoid)
         return z32 if y32 else out
 
 

@@ -258,7 +258,9 @@ class ConvLayer:
             self._dwp_gen = ARENA.gen
             self._db = None
         to, ho, wo = dy.dims[1:]
-        nc = min(E.batch_chunk(n, [t * h * w * x.ld, to * ho * wo * dy.ld], E.MAX_ELEMS), E.batch_chunk(n, [to * ho * wo], E.MAX_WGRAD_PIXELS))
+        nc = n
+        if n * max(t * h * w * x.ld, to * ho * wo * dy.ld) >= E.MAX_ELEMS or n * to * ho * wo >= E.MAX_WGRAD_PIXELS:
+            nc = min(E.batch_chunk(n, [t * h * w * x.ld, to * ho * wo * dy.ld], E.MAX_ELEMS), E.batch_chunk(n, [to * ho * wo], E.MAX_WGRAD_PIXELS))
         for n0 in range(0, n, nc):                      # chunks of whole samples accumulate into the same matrix
             n1 = min(n, n0 + nc)
             xs, ds = (Act(x.buf[n0:n1], x.c, x.coff), Act(dy.buf[n0:n1], dy.c, dy.coff)) if nc < n else (x, dy)
