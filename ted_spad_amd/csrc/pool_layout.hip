@@ -30,6 +30,20 @@ struct PoolKP {
     long total;  // n*to*ho*wo*C8
 };
 
+// 8-lane 16-bit max without leaving the packed form where the ISA has it (v_pk_max_f16); bf16 goes through fp32.
+template <typename T> __device__ __forceinline__ uint4 max8(uint4 a, uint4 b);
+template <> __device__ __forceinline__ uint4 max8<F16>(uint4 a, uint4 b) {
+    return __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b)));
+}
+template <> __device__ __forceinline__ uint4 max8<BF16>(uint4 a, uint4 b) {
+    float fa[8], fb[8];
+    unpack8<BF16>(a, fa);
+    unpack8<BF16>(b, fb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = __builtin_fmaxf(fa[i], fb[i]);
+    return pack8<BF16>(fa);
+}
+
 // max over the window, 8 channels per thread. Padded taps contribute 0 when pad_zero
 // (MaxPool3dSamePadding pads with zeros BEFORE pooling, i3d.py:41-45), else are skipped
 // (nn.MaxPool3d semantics, large_i3d.py:138-139).
@@ -85,18 +99,37 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
     }
 }
 
-// 8-lane 16-bit max without leaving the packed form where the ISA has it (v_pk_max_f16); bf16 goes through fp32.
-template <typename T> __device__ __forceinline__ uint4 max8(uint4 a, uint4 b);
-template <> __device__ __forceinline__ uint4 max8<F16>(uint4 a, uint4 b) {
-    return __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b)));
-}
-template <> __device__ __forceinline__ uint4 max8<BF16>(uint4 a, uint4 b) {
-    float fa[8], fb[8];
-    unpack8<BF16>(a, fa);
-    unpack8<BF16>(b, fb);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = __builtin_fmaxf(fa[i], fb[i]);
-    return pack8<BF16>(fa);
+// Forward-only variant (no arg-max record): the maximum stays in packed 16-bit form (v_pk_max_f16), ~6x fewer vector
+// instructions per tap than the fp32 compare-and-select above -- the inference pools are then bound by HBM, not by the VALU.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_noidx_kernel(const PoolKP p, const uint32_t ninf) {
+    const uint4 lo = make_uint4(ninf, ninf, ninf, ninf), zero = make_uint4(0, 0, 0, 0);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % p.C8);
+        long r = idx / p.C8;
+        const int wo = (int)(r % p.Wo); r /= p.Wo;
+        const int ho = (int)(r % p.Ho); r /= p.Ho;
+        const int to = (int)(r % p.To);
+        const int n = (int)(r / p.To);
+        uint4 m = lo;
+        bool padded = false;
+        for (int dt = 0; dt < p.kt; ++dt) {
+            const int it = to * p.st - p.pt + dt;
+            for (int dh = 0; dh < p.kh; ++dh) {
+                const int ih = ho * p.sh - p.ph + dh;
+                const bool rowok = (unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi;
+                const uint16_t *row = p.x + ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi) * p.ldx + c8 * 8;
+                for (int dw = 0; dw < p.kw; ++dw) {
+                    const int iw = wo * p.sw - p.pw + dw;
+                    if (rowok && (unsigned)iw < (unsigned)p.Wi) m = max8<T>(m, *reinterpret_cast<const uint4 *>(row + (size_t)iw * p.ldx));
+                    else padded = true;
+                }
+            }
+        }
+        if (padded && p.pad_zero) m = max8<T>(m, zero);
+        const size_t opix = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+        *reinterpret_cast<uint4 *>(p.y + opix * p.ldy + c8 * 8) = m;
+    }
 }
 
 // 3x3x3 / stride 1 / pad 1 max-pool (the pool branch of every InceptionModule, i3d.py:133-134,148: 9 of the 13 pools of
@@ -334,6 +367,11 @@ extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const voi
         const uint32_t padw = d->pad_zero ? 0u : ninf;
         if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_k3s1_kernel<F16>, dim3(grid_for(tot)), dim3(256), 0, s, p.x, p.y, d->n, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw, segs, seglen, tot);
         else hipLaunchKernelGGL(maxpool_k3s1_kernel<BF16>, dim3(grid_for(tot)), dim3(256), 0, s, p.x, p.y, d->n, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw, segs, seglen, tot);
+        return check_launch("tedspad_maxpool_fwd");
+    }
+    if (!idx) {
+        if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_noidx_kernel<F16>, dim3(grid_for(p.total)), dim3(256), 0, s, p, 0xFC00FC00u);
+        else hipLaunchKernelGGL(maxpool_noidx_kernel<BF16>, dim3(grid_for(p.total)), dim3(256), 0, s, p, 0xFF80FF80u);
         return check_launch("tedspad_maxpool_fwd");
     }
     if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_kernel<F16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
