@@ -113,6 +113,14 @@ int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const voi
                             const void *residual, void *y, int32_t sigmoid,
                             const tedspad_conv_extras *ex, void *stream);
 
+/* Bottleneck tail + temporal max-pool in one launch: y = MaxPool3d((2,1,1), stride (2,1,1)) of
+ * ReLU(conv1x1x1(x)*scale + shift + residual) -- `bn3 / += residual / relu` of the last layer1 block followed by
+ * `maxpool2` (large_i3d.py:77-84,139,235). `d` describes the convolution (1x1x1, stride 1, cin 64 or 128, to/ho/wo = its
+ * own output extent); y is (n, t/2, h, w) with pixel stride d->ldy. Persistent kernel of tile_cfg 19: the un-pooled
+ * tensor is never written. */
+int32_t tedspad_conv_pool_t2_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                 const float *shift, const void *residual, void *y, void *stream);
+
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
  * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be
  * zeroed by the caller (hipMemsetAsync on the same stream); accumulation uses float atomics.

@@ -49,6 +49,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 int32_t launch_conv_halo(int dtype, const ConvKP &p, int N, int cin, int bn, hipStream_t s);
 
 // conv_pw.hip: persistent pointwise kernel for 1x1x1 stride-1 convolutions with cin = 64 / 128 (tile_cfg 19).
-int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s);
+int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t = false);
 
 }  // namespace tedspad

@@ -621,9 +621,9 @@ extern "C" int32_t tedspad_conv_build_ktab(const tedspad_conv_desc *d, int32_t *
     return TEDSPAD_OK;
 }
 
-extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
+static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
                                        const float *scale, const float *shift, const void *residual, void *y, int32_t sigmoid,
-                                       const tedspad_conv_extras *ex, void *stream) {
+                                       const tedspad_conv_extras *ex, void *stream, int pool_t) {
     TS_REQUIRE(desc_ok(d), "tedspad_conv_fwd: bad descriptor (cin/cout/ld* multiples of 8, kernel dims <= 7)");
     TS_REQUIRE(x && w_packed && ktab && scale && shift && (y || (ex && ex->y32)), "tedspad_conv_fwd: null pointer");
     TS_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) % 16 == 0,
@@ -671,12 +671,28 @@ extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x
         extras = p.mask || p.stats || p.ostrided || p.y32;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (pool_t) {
+        TS_REQUIRE(!extras && !sigmoid, "tedspad_conv_pool_t2_fwd: no mask / stats / fp32 / strided-output epilogue");
+        return launch_conv_pw(d->dtype, p, s, true);
+    }
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
     if (cfg == 9) {
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
         TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
     }
     return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, d->cin, s) : launch_cfg<BF16>(cfg, p, d->n, d->cin, s);
+}
+
+extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
+                                       const float *scale, const float *shift, const void *residual, void *y, int32_t sigmoid,
+                                       const tedspad_conv_extras *ex, void *stream) {
+    return conv_fwd_impl(d, x, w_packed, ktab, scale, shift, residual, y, sigmoid, ex, stream, 0);
+}
+
+extern "C" int32_t tedspad_conv_pool_t2_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                            const float *shift, const void *residual, void *y, void *stream) {
+    static const int32_t dummy_ktab[2] = {0, 0};   // the pointwise path never reads the table
+    return conv_fwd_impl(d, x, w_packed, dummy_ktab, scale, shift, residual, y, 0, nullptr, stream, 1);
 }
 
 extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,

@@ -24,8 +24,11 @@ __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
 }
 
-template <typename T, int KB, bool RES>   // KB = cin / 64; RES: fused residual input
-__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int tiles_m, const int nworkers) {
+// POOLT: the conv output additionally goes through MaxPool3d((2,1,1), stride (2,1,1)) before it is written: the sequence
+// of tiles is (frame 2k, frame 2k+1) of the same 128 pixels, the first result stays in registers, the second is max-ed
+// with it and stored at the pooled position (tiles never straddle a frame: `hw` pixels per frame, `jt` tiles per frame).
+template <typename T, int KB, bool RES, bool POOLT>   // KB = cin / 64; RES: fused residual input
+__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int tiles_m, const int nworkers, const int hw, const int jt) {
     constexpr int XSUB = PW_BM * BK * 2;        // one [128 px][64] sub-tile
     constexpr int WSUB = PW_BN * BK * 2;        // one [64 co][64] sub-tile
     constexpr int XBUF = KB * XSUB;
@@ -51,14 +54,29 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             lds_dma16(p.w + (size_t)(n0 + i * 32 + rsub) * p.Kpad + kb * BK + kc * 8, lds0 + kb * WSUB + i * 32 * (BK * 2) + wrow);
-    auto issue_x = [&](int mt, int buf) {
-        const int mb = mt * PW_BM;
+    // sequence index q -> first input row of the tile and the number of valid rows in it
+    auto tile_rows = [&](int q, int &mb, int &valid) {
+        if (POOLT) {            // q = 2 * (frame pair * jt + j) + f
+            const int f = q & 1, u = q >> 1;
+            const int j = u % jt, fp = u / jt;               // fp = n * (T/2) + tp
+            const int tp = fp % (p.Ti >> 1), nb = fp / (p.Ti >> 1);
+            mb = ((nb * p.Ti + 2 * tp + f) * hw) + j * PW_BM;
+            valid = min(PW_BM, hw - j * PW_BM);
+        } else {
+            mb = q * PW_BM;
+            valid = min(PW_BM, p.M - mb);
+        }
+    };
+    auto issue_x = [&](int q, int buf) {
+        int mb, valid;
+        tile_rows(q, mb, valid);
+        const int mend = mb + valid;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = mb + i * 32 + rsub;
-                const uint16_t *src = m < p.M ? p.x + (size_t)m * p.ldx + kb * BK + kc * 8 : zero;
+                const uint16_t *src = m < mend ? p.x + (size_t)m * p.ldx + kb * BK + kc * 8 : zero;
                 lds_dma16(src, lds0 + OFF_X + buf * XBUF + kb * XSUB + i * 32 * (BK * 2) + wrow);
             }
         if (RES) {   // residual rows ride the same DMA stream (ordinary loads inside this loop would make hipcc drain it)
@@ -66,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
             for (int i = 0; i < 4; ++i) {
                 const int m = mb + i * 32 + rsub;
                 const int nn = n0 + (lane & 7) * 8;
-                const uint16_t *src = (m < p.M && nn < p.Cout) ? p.res + (size_t)m * p.ldres + nn : zero;
+                const uint16_t *src = (m < mend && nn < p.Cout) ? p.res + (size_t)m * p.ldres + nn : zero;
                 lds_dma16(src, lds0 + OFF_RES + buf * RBUF + i * 32 * (PW_BN * 2) + wave * 8 * (PW_BN * 2));
             }
         }
@@ -99,18 +117,29 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
     // (hipcc copies their destination registers before the data has arrived) -- hence the residual goes through LDS.
     // The one wait on the DMA is counted by hand; vector-memory operations retire in issue order on gfx9 (one counter
     // for loads and stores; hipcc's own counted waits rely on it).
-    int mt = worker;
-    if (mt < tiles_m) issue_x(mt, 0);
+    // sequence of tiles of this worker: plain: q = worker, worker + nworkers, ...; POOLT: units u = worker, worker +
+    // nworkers, ... each expanding to q = 2u (even frame) and 2u + 1 (odd frame)
+    const int nseq = POOLT ? 2 * tiles_m : tiles_m;           // tiles_m counts UNITS when POOLT
+    int q = POOLT ? 2 * worker : worker;
+    auto next_q = [&](int c) { return POOLT ? ((c & 1) ? c + 2 * nworkers - 1 : c + 1) : c + nworkers; };
+    if (q < nseq) issue_x(q, 0);
     int buf = 0;
     bool stores_pending = false;            // the previous tile issued exactly 4 store instructions per wave (a full tile)
-    for (; mt < tiles_m; mt += nworkers) {
-        // this tile's activations were issued BEFORE the previous tile's 4 row stores: those may stay in flight
+    float keep[4][8];                        // POOLT: the even frame's rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep[j][i] = 0.f;
+    for (; q < nseq; q = next_q(q)) {
+        // this tile's activations were issued BEFORE the previous tile's row stores (if any): those may stay in flight
         if (stores_pending) wait_vmcnt<4>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();       // ... of every wave; the other buffer is no longer read by anyone
         asm volatile("" ::: "memory");
-        const int nxt = mt + nworkers;
-        if (nxt < tiles_m) issue_x(nxt, buf ^ 1);
+        const int nxt = next_q(q);
+        if (nxt < nseq) issue_x(nxt, buf ^ 1);
+        int mb, valid;
+        tile_rows(q, mb, valid);
         f32x16 acc[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -139,19 +168,24 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const bool second = POOLT && (q & 1);
+        size_t obase = (size_t)mb;                                  // first OUTPUT row of the tile
+        if (POOLT) {
+            const int u = q >> 1, j = u % jt, fp = u / jt;
+            obase = (size_t)fp * hw + (size_t)j * PW_BM;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = j * 8 + rrow;
-            const int m = mt * PW_BM + wave * 32 + row;
-            if (active && m < p.M) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + row * PW_STG_LD + cc * 8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + row * PW_STG_LD + cc * 8 + 4);
+            const int row = wave * 32 + j * 8 + rrow;
+            if (active && row < valid) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + (j * 8 + rrow) * PW_STG_LD + cc * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + (j * 8 + rrow) * PW_STG_LD + cc * 8 + 4);
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
                 if (RES) {
                     float rr[8];
-                    unpack8<T>(*reinterpret_cast<const uint4 *>(smem + OFF_RES + buf * RBUF + (wave * 32 + row) * (PW_BN * 2) + cc * 16), rr);
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(smem + OFF_RES + buf * RBUF + row * (PW_BN * 2) + cc * 16), rr);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += rr[i];
                 }
@@ -159,41 +193,59 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
                 }
-                gstore16(p.y + (size_t)m * p.ldy + n, __builtin_bit_cast(u32x4, pack8<T>(v)));
+                if (POOLT && !second) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) keep[j][i] = v[i];
+                } else {
+                    if (POOLT) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], keep[j][i]);
+                    }
+                    gstore16(p.y + (obase + row) * p.ldy + n, __builtin_bit_cast(u32x4, pack8<T>(v)));
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();    // the wave's staging rows are rewritten by its next tile
-        stores_pending = (mt + 1) * PW_BM <= p.M;   // every row exists: all 4 store instructions were issued by every wave
+        stores_pending = valid == PW_BM && (!POOLT || second);   // all 4 store instructions were issued by every wave
         buf ^= 1;
     }
 }
 
-template <typename T, int KB, bool RES>
-int32_t launch_pw2(const ConvKP &p, int tiles_m, hipStream_t s) {
+template <typename T, int KB, bool RES, bool POOLT>
+int32_t launch_pw2(const ConvKP &p, int tiles_m, int hw, int jt, hipStream_t s) {
     const int per_cu = (KB == 1 && !RES) ? 2 : 1;        // LDS per workgroup: 75 KB (cin 64, no residual) .. 147 KB
     int nworkers = (256 * per_cu + p.tiles_n - 1) / p.tiles_n;
     if (nworkers > tiles_m) nworkers = tiles_m;
-    hipLaunchKernelGGL((conv_pw_kernel<T, KB, RES>), dim3(p.tiles_n * nworkers), dim3(256), 0, s, p, tiles_m, nworkers);
+    hipLaunchKernelGGL((conv_pw_kernel<T, KB, RES, POOLT>), dim3(p.tiles_n * nworkers), dim3(256), 0, s, p, tiles_m, nworkers, hw, jt);
     return check_launch("tedspad_conv_fwd(pointwise persistent)");
 }
 
 template <typename T, int KB>
-int32_t launch_pw(const ConvKP &pin, hipStream_t s) {
+int32_t launch_pw(const ConvKP &pin, bool pool_t, hipStream_t s) {
     ConvKP p = pin;
     p.tiles_n = (p.Cout + PW_BN - 1) / PW_BN;
+    if (pool_t) {
+        const int hw = p.Hi * p.Wi, jt = (hw + PW_BM - 1) / PW_BM;
+        const int units = (p.M / (p.Ti * hw)) * (p.Ti / 2) * jt;      // (batch) x (frame pairs) x (tiles per frame)
+        return p.res ? launch_pw2<T, KB, true, true>(p, units, hw, jt, s) : launch_pw2<T, KB, false, true>(p, units, hw, jt, s);
+    }
     const int tiles_m = (p.M + PW_BM - 1) / PW_BM;
-    return p.res ? launch_pw2<T, KB, true>(p, tiles_m, s) : launch_pw2<T, KB, false>(p, tiles_m, s);
+    return p.res ? launch_pw2<T, KB, true, false>(p, tiles_m, 0, 1, s) : launch_pw2<T, KB, false, false>(p, tiles_m, 0, 1, s);
 }
 
 }  // namespace
 
-int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s) {
+int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t) {
     if (!p.pointwise || (p.cin != 64 && p.cin != 128) || p.Kpad != p.cin || p.mask || p.stats || p.y32 || p.ostrided || p.sigmoid || !p.y) {
         set_error("tedspad_conv_fwd: tile_cfg 19 (persistent pointwise) needs a 1x1x1 stride-1 conv with cin 64 or 128 and a plain epilogue");
         return TEDSPAD_EINVAL;
     }
-    if (p.cin == 64) return dtype == TEDSPAD_F16 ? launch_pw<F16, 1>(p, s) : launch_pw<BF16, 1>(p, s);
-    return dtype == TEDSPAD_F16 ? launch_pw<F16, 2>(p, s) : launch_pw<BF16, 2>(p, s);
+    if (pool_t && p.Ti < 2) {
+        set_error("tedspad_conv_pool_t2_fwd: needs at least two frames");
+        return TEDSPAD_EINVAL;
+    }
+    if (p.cin == 64) return dtype == TEDSPAD_F16 ? launch_pw<F16, 1>(p, pool_t, s) : launch_pw<BF16, 1>(p, pool_t, s);
+    return dtype == TEDSPAD_F16 ? launch_pw<F16, 2>(p, pool_t, s) : launch_pw<BF16, 2>(p, pool_t, s);
 }
 
 }  // namespace tedspad

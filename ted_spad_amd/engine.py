@@ -341,6 +341,27 @@ class PackedConv:
             self._cfgs[key] = best
             _TUNING.discard((id(self), key))
 
+    def pool_t2_supported(self, x: Act) -> bool:
+        return self.k == (1, 1, 1) and self.stride == (1, 1, 1) and self.cin in (64, 128) and x.dims[1] >= 2
+
+    def call_pool_t2(self, x: Act, residual: Optional[Act] = None, relu=True) -> Act:
+        """conv (1x1x1) + scale/shift + residual + ReLU + MaxPool3d((2,1,1),(2,1,1)) in one persistent launch
+        (tedspad_conv_pool_t2_fwd): the un-pooled tensor is never written."""
+        n, t, h, w = x.dims
+        assert self.pool_t2_supported(x) and x.c == self.cin
+        if residual is not None:
+            assert residual.dims == x.dims and residual.c == self.cout
+        out = Act.empty(n, t // 2, h, w, self.cout, self.torch_dtype, x.buf.device)
+        worst = max(t * h * w * x.ld, t * h * w * (residual.ld if residual is not None else self.cout))
+        nc = n if n * worst < MAX_ELEMS else batch_chunk(n, [worst], MAX_ELEMS)
+        for n0 in range(0, n, nc):
+            n1 = min(n, n0 + nc)
+            xs, rs, os_ = (Act(a.buf[n0:n1], a.c, a.coff) if a is not None else None for a in (x, residual, out))
+            d = self._desc(n1 - n0, t, h, w, xs.ld, (0, 0, 0), (t, h, w), os_.ld, rs.ld if rs is not None else 0, relu)
+            check(_lib.lib().tedspad_conv_pool_t2_fwd(C.byref(d), xs.ptr, self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                                      rs.ptr if rs is not None else None, os_.ptr, _stream_ptr()), "tedspad_conv_pool_t2_fwd")
+        return out
+
     def _run(self, x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid):
         """One launch (through the tuner) on tensors small enough for the kernel's 32-bit offsets."""
         n, t, h, w = x.dims

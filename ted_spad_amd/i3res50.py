@@ -104,15 +104,23 @@ class I3Res50(nn.Module):
         a = E.maxpool(a, (2, 3, 3), (2, 2, 2))                           # large_i3d.py:138
         if taps is not None:
             taps["maxpool1"] = a
+        pooled = False
         for li in range(1, 5):
-            if li == 2:
+            if li == 2 and not pooled:
                 a = E.maxpool(a, (2, 1, 1), (2, 1, 1))                   # large_i3d.py:139
-            for i, blk in enumerate(getattr(self, "layer%d" % li)):
+            layer = getattr(self, "layer%d" % li)
+            for i, blk in enumerate(layer):
                 p = "layer%d.%d." % (li, i)
                 h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
                 h = P[p + "conv2"](h, pads=(0, 1, 1))
                 res = P[p + "down"](a, relu=False) if blk.downsample is not None else a
-                a = P[p + "conv3"](h, residual=res, relu=True)           # bn3 + (+= residual) + ReLU fused
+                if li == 1 and i == len(layer) - 1 and taps is None and P[p + "conv3"].pool_t2_supported(h):
+                    # the block's tail and maxpool2 (large_i3d.py:139) in one launch: the 256-channel tensor is only
+                    # written after the temporal pooling (half the bytes, no separate pool pass)
+                    a = P[p + "conv3"].call_pool_t2(h, residual=res, relu=True)
+                    pooled = True
+                else:
+                    a = P[p + "conv3"](h, residual=res, relu=True)       # bn3 + (+= residual) + ReLU fused
             if taps is not None:
                 taps["layer%d" % li] = a
         return a

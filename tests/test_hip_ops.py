@@ -264,3 +264,24 @@ def test_every_tile_configuration_gives_the_same_result(case):
         if c in outs:
             assert bool(((outs[c] - first).abs() <= 2.0 ** -10 * first.abs() + 1e-4).all()), c
     print(name, "configurations run:", sorted(outs))
+
+
+@pytest.mark.parametrize("dims,cin,cout,use_res", [((3, 4, 11, 13), 64, 256, True), ((2, 5, 7, 9), 128, 72, False),
+                                                   ((2, 2, 16, 16), 64, 64, True), ((1, 8, 30, 30), 64, 256, True)])
+def test_conv_pool_t2_fused_equals_conv_then_pool(dims, cin, cout, use_res):
+    """tedspad_conv_pool_t2_fwd (1x1x1 conv + BN + residual + ReLU + MaxPool3d((2,1,1),(2,1,1)) in one persistent launch)
+    must equal the two separate launches BIT-EXACTLY: rounding to f16 is monotonic, so max-then-round == round-then-max.
+    Covers frames whose pixel count is not a multiple of the 128-pixel tile, an odd frame count (last frame dropped,
+    as nn.MaxPool3d does) and a ragged channel tile."""
+    from ted_spad_amd import engine as E
+    n, t, h, w = dims
+    x = synth_tensor(11, "ptx", (n, t, h, w, cin), -1, 1).half()
+    wgt = (synth_tensor(11, "ptw", (cout, cin, 1, 1, 1), -1, 1) * (2.0 / cin) ** 0.5)
+    scale, shift = synth_tensor(11, "pts", (cout,), 0.5, 1.5), synth_tensor(11, "ptb", (cout,), -0.3, 0.3)
+    res = synth_tensor(11, "ptr", (n, t, h, w, cout), -1, 1).half() if use_res else None
+    pc = E.PackedConv(wgt, scale, shift, dtype="f16", device="cuda")
+    xa, ra = E.Act(x.cuda(), cin), (E.Act(res.cuda(), cout) if use_res else None)
+    two = E.maxpool(pc(xa, residual=ra, relu=True), (2, 1, 1), (2, 1, 1))
+    one = pc.call_pool_t2(xa, residual=ra, relu=True)
+    assert one.dims == two.dims == (n, t // 2, h, w)
+    assert torch.equal(one.buf, two.buf)
