@@ -107,7 +107,7 @@ def main():
         # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are
         # chosen in context during the first ~45 forwards of every conv geometry; do that before the counted warm-up
         from ted_spad_amd import engine as _E
-        for i in range(0, args.batch * 64, args.batch):   # > TUNE_REPS x number of tile configurations
+        for i in range(0, args.batch * 96, args.batch):   # > number of tile configurations + TUNE_REPS pruned passes
             if not _E.AUTOTUNE:
                 break
             multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()

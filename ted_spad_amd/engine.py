@@ -271,7 +271,7 @@ class PackedConv:
     # fastest (median) is kept. Timing each configuration inside the running network -- cold caches, the other
     # stream's kernels alongside -- ranks them as they will actually run; replaying one launch in isolation
     # (first version) favoured L2-hungry configurations that lose in context.
-    TUNE_REPS = 3
+    TUNE_REPS = int(os.environ.get("TEDSPAD_TUNE_REPS", "3"))
 
     def _launch_tuned(self, key, d, args):
         L = _lib.lib()
