@@ -325,27 +325,45 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
 constexpr int ST_TH = 8, ST_TW = 32;          // output patch (rows x cols); ST_TW = one MFMA pixel group
 constexpr int ST_WSTAGE = 64 * BK * 2;        // 64 channels x 64 k x 2 B
 
-template <typename T>
-__global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, const int HH, const int WH, const int tiles_h, const int tiles_w) {
+// FR = output frames per patch (1: 4 waves, 256 pixels; 2: 8 waves, 512 pixels on frames to, to+1). The kernel is bound
+// by the L2 -> LDS stream (per 256-pixel patch: 147 KB of weights + 61 KB of halo); with FR = 2 every weight stage
+// serves twice the pixels and the two frames share most of their temporal halo (7 input frames instead of 2 x 5):
+// 229 KB instead of 416 KB of DMA per 512 pixels.
+// KS = 2: split-K inside the workgroup. Measured with s_memtime stamps (FR = 1, KS = 1): a workgroup lives 36 k cycles =
+// prologue 10 k (halo DMA) + K loop 19 k + epilogue 7 k, and the loop takes 19 k whether or not the CU's other workgroup
+// is also in its loop: ONE wave per SIMD issues its 4-MFMA groups at ~50 % duty (dependent LDS fragment reads), two fill
+// the pipe. With 8 waves per patch -- waves 4-7 take the k16 sub-steps 2,3 of every K step, waves 0-3 the sub-steps 0,1,
+// partial sums added through the staging tile -- a single workgroup saturates the matrix cores, so the other workgroup's
+// prologue / epilogue no longer idles them. (fp32 partial sums are re-associated: results within one f16 rounding step
+// of KS = 1, like the halo-direct trunk kernels.)
+template <typename T, int FR, int KS>
+__global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const ConvKP p, const int HH, const int WH, const int tiles_h, const int tiles_w) {
+    constexpr int NT = 256 * FR * KS;
+    constexpr int WS = (FR == 1) ? 2 : 4;    // weight ring slots: FR = 2 has the LDS for four (its staging tile is larger anyway)
+    constexpr int WL = NT == 256 ? 2 : 1;    // weight DMA instructions per thread and stage
+    static_assert(FR * KS <= 2, "8 waves at most");
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tgroups = (p.To + FR - 1) / FR;
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = b % tiles_w; b /= tiles_w;
     const int th = b % tiles_h; b /= tiles_h;
-    const int to = b % p.To;
-    const int n = b / p.To;
+    const int to = (b % tgroups) * FR;
+    const int n = b / tgroups;
     const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
-    const int P = p.kt * HH * WH;                       // halo positions
-    const int NH = (P + 255) / 256;                     // DMA instructions per thread for the halo
-    const int halo_bytes = NH * 256 * 16;
-    unsigned char *wring = dsm + halo_bytes;            // [2][64][64] 16-bit
-    int *tapd = reinterpret_cast<int *>(wring + 2 * ST_WSTAGE);  // byte delta of every K chunk (= tap)
+    const int HT = p.kt + (FR - 1) * p.st;              // input frames under the patch
+    const int P = HT * HH * WH;                         // halo positions
+    const int NH = (P + NT - 1) / NT;                   // DMA instructions per thread for the halo
+    const int Pr = (P + 63) / 64 * 64;                  // positions rounded to whole wave instructions
+    const int halo_bytes = Pr * 16;
+    unsigned char *wring = dsm + halo_bytes;            // [WS][64][64] 16-bit
+    int *tapd = reinterpret_cast<int *>(wring + WS * ST_WSTAGE);  // byte delta of every K chunk (= tap)
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
 
-    for (int i = tid; i < p.nk * 8; i += 256) {
+    for (int i = tid; i < p.nk * 8; i += NT) {
         const int y = p.ktab[i].y;
         const int dt = y & 255, dh = ((y >> 8) & 255) - 8, dw = (y >> 16) - 16;
         tapd[i] = dt < 8 ? ((dt * HH + dh) * WH + dw) * 16 : 0;   // K padding: zero weights, any in-range address
@@ -354,13 +372,14 @@ __global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, con
     // ---- halo: one 16-byte DMA per position, lane-linear in LDS --------------------------------
     const int t0 = to * p.st - p.pt, h0 = ho0 * p.sh - p.ph, w0 = wo0 * p.sw - p.pw;
     for (int i = 0; i < NH; ++i) {
-        const int idx = i * 256 + tid;
+        if (i * NT + wave * 64 >= Pr) break;             // wave-uniform: nothing of this instruction is inside the halo
+        const int idx = i * NT + tid;
         const int ww = idx % WH; const int r = idx / WH;
         const int hh = r % HH; const int dt = r / HH;
         const int it = t0 + dt, ih = h0 + hh, iw = w0 + ww;
         const bool ok = idx < P && (unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
         const uint16_t *src = ok ? p.x + ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.ldx : zero;
-        lds_dma16(src, lds0 + (i * 256 + wave * 64) * 16);
+        lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
     }
     // ---- weights: [64][64] tile per K step, swizzled on the source like the generic kernel ------
     const int rsub = wave * 8 + (lane >> 3);
@@ -369,16 +388,20 @@ __global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, con
     auto issue_w = [&](int kt, int slot) {
         const unsigned dst = lds0 + halo_bytes + slot * ST_WSTAGE + wave * 8 * (BK * 2);
         lds_dma16(wsrc + kt * BK, dst);
-        lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));
+        if (NT == 256) lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));   // 8 waves cover the 64 rows in one pass
     };
-    issue_w(0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < WS - 1; ++s0)
+        if (s0 < p.nk) issue_w(s0, s0);
 
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
-    // wave `wave` owns output rows 2*wave, 2*wave+1 of the patch; B-fragment base of pixel (row, l31)
+    // wave (f, wq) = (wave / 4, wave % 4) owns output rows 2*wq, 2*wq+1 of frame to+f; B-fragment base of pixel (row, l31)
+    const int wf = FR == 2 ? wave >> 2 : 0, wq = wave & 3;
+    const int kh2 = KS == 2 ? wave >> 2 : 0;        // which half of the k16 sub-steps this wave multiplies
     int pixb[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) pixb[g] = ((2 * wave + g) * p.sh * WH + l31 * p.sw) * 16;
+    for (int g = 0; g < 2; ++g) pixb[g] = ((wf * p.st * HH + (2 * wq + g) * p.sh) * WH + l31 * p.sw) * 16;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -388,13 +411,18 @@ __global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, con
             for (int r = 0; r < 16; ++r) acc[a][g][r] = 0.f;
 
     for (int kt = 0; kt < p.nk; ++kt) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // weight stage kt (+ halo, tap table on kt = 0) visible; other slot free
+        // stage kt must have landed (the halo was issued before stage 0); up to WS-2 later stages stay in flight
+        const int later = p.nk - 1 - kt;
+        if (WS >= 4 && later >= 2) wait_vmcnt<(WS >= 4 ? 2 : 0) * WL>();
+        else if (WS >= 3 && later >= 1) wait_vmcnt<(WS >= 3 ? 1 : 0) * WL>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // weight stage kt (+ halo, tap table on kt = 0) visible; the slot of stage kt-1 is free
         asm volatile("" ::: "memory");
-        if (kt + 1 < p.nk) issue_w(kt + 1, (kt + 1) & 1);
-        const uint16_t *W = reinterpret_cast<const uint16_t *>(wring + (kt & 1) * ST_WSTAGE) + l31 * BK;
+        if (kt + WS - 1 < p.nk) issue_w(kt + WS - 1, (kt + WS - 1) % WS);
+        const uint16_t *W = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * ST_WSTAGE) + l31 * BK;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int kq = 0; kq < BK / 16 / KS; ++kq) {
+            const int ks = kq + kh2 * (BK / 16 / KS);
             const int d = tapd[kt * 8 + ks * 2 + lh];
             const int coff = (((ks << 1) | lh) ^ swz) << 3;
             uint4 fa[2], fw[2];
@@ -410,32 +438,54 @@ __global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, con
     }
     __syncthreads();
 
-    // ---- epilogue: fp32 patch [256 pixels][64 channels] -> LDS -> coalesced rows -----------------
+    // ---- epilogue: fp32 patch [256*FR pixels][64 channels] -> LDS -> coalesced rows -----------------
     constexpr int STG_LD = 64 + 4;
     float *stg = reinterpret_cast<float *>(dsm);
+    const int wrow = KS == 2 ? (wave & 3) : wave;          // patch row pair of this wave
+    if (KS == 1 || kh2 == 1) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int ml = (2 * wave + g) * 32 + l31;
+            for (int g = 0; g < 2; ++g) {
+                const int ml = (2 * wrow + g) * 32 + l31;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = a * 32 + 8 * q + 4 * lh;
-                f32x4 v = {acc[a][g][4 * q], acc[a][g][4 * q + 1], acc[a][g][4 * q + 2], acc[a][g][4 * q + 3]};
-                *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = a * 32 + 8 * q + 4 * lh;
+                    f32x4 v = {acc[a][g][4 * q], acc[a][g][4 * q + 1], acc[a][g][4 * q + 2], acc[a][g][4 * q + 3]};
+                    *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
+                }
             }
-        }
+    }
     __syncthreads();
-    const int cc = tid & 7, r0 = tid >> 3;     // 8 chunks of 8 channels per pixel, 32 pixels per pass
+    if (KS == 2) {
+        if (kh2 == 0) {      // first half: add the partner wave's partial sums (same lanes, same addresses)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int ml = (2 * wrow + g) * 32 + l31;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = a * 32 + 8 * q + 4 * lh;
+                        f32x4 *ptr = reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl);
+                        const f32x4 o = *ptr;
+                        f32x4 v = {acc[a][g][4 * q] + o[0], acc[a][g][4 * q + 1] + o[1], acc[a][g][4 * q + 2] + o[2], acc[a][g][4 * q + 3] + o[3]};
+                        *ptr = v;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    const int cc = tid & 7, r0 = tid >> 3;     // 8 chunks of 8 channels per pixel, NT/8 pixels per pass
     const int nch = cc * 8;
     if (nch >= p.Cout) return;
     float sc[8], sf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
-    for (int r = r0; r < 256; r += 32) {
-        const int ho = ho0 + (r >> 5), wo = wo0 + (r & 31);
-        if (ho >= p.Ho || wo >= p.Wo) continue;
-        const size_t m = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+    for (int r = r0; r < 256 * FR; r += NT / 8) {
+        const int tf = to + (r >> 8), ho = ho0 + ((r & 255) >> 5), wo = wo0 + (r & 31);
+        if (tf >= p.To || ho >= p.Ho || wo >= p.Wo) continue;
+        const size_t m = (((size_t)n * p.To + tf) * p.Ho + ho) * p.Wo + wo;
         const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch);
         const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch + 4);
         float v[8];
@@ -455,23 +505,25 @@ __global__ __launch_bounds__(256) void conv_stem_halo_kernel(const ConvKP p, con
     }
 }
 
-template <typename T>
+template <typename T, int FR, int KS>
 int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
     if (p.ldx < 8 || p.Cout > 64 || p.Kpad > 8 * 256 * 8 || p.sw != 1 || p.sigmoid) {
         set_error("tedspad_conv_fwd: halo-direct config needs cin == 8, cout <= 64, sw == 1");
         return TEDSPAD_EINVAL;
     }
+    constexpr int NT = 256 * FR * KS;
     const int HH = (ST_TH - 1) * p.sh + p.kh, WH = (ST_TW - 1) * p.sw + p.kw;
-    const int P = p.kt * HH * WH, NH = (P + 255) / 256;
-    const int main_bytes = NH * 256 * 16 + 2 * ST_WSTAGE + p.nk * 8 * 4;
-    const int stage_bytes = 256 * (64 + 4) * 4;
+    const int HT = p.kt + (FR - 1) * p.st;
+    const int P = HT * HH * WH, NH = (P + NT - 1) / NT;
+    const int main_bytes = (P + 63) / 64 * 64 * 16 + (FR == 1 ? 2 : 4) * ST_WSTAGE + p.nk * 8 * 4;
+    const int stage_bytes = 256 * FR * (64 + 4) * 4;
     const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
     if (lds > 160 * 1024) {
         set_error("tedspad_conv_fwd: halo-direct config: halo does not fit LDS (%d bytes)", lds);
         return TEDSPAD_EINVAL;
     }
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_stem_halo_kernel<T>;
+    auto kfn = conv_stem_halo_kernel<T, FR, KS>;
     if (attr_set[T::kDtype] < lds) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -480,7 +532,8 @@ int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
         attr_set[T::kDtype] = 160 * 1024;
     }
     const int tiles_h = (p.Ho + ST_TH - 1) / ST_TH, tiles_w = (p.Wo + ST_TW - 1) / ST_TW;
-    hipLaunchKernelGGL(kfn, dim3(N * p.To * tiles_h * tiles_w), dim3(256), lds, s, p, HH, WH, tiles_h, tiles_w);
+    const int tgroups = (p.To + FR - 1) / FR;
+    hipLaunchKernelGGL(kfn, dim3(N * tgroups * tiles_h * tiles_w), dim3(NT), lds, s, p, HH, WH, tiles_h, tiles_w);
     return check_launch("tedspad_conv_fwd(halo)");
 }
 
@@ -519,15 +572,19 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  18  128 x 128          2x2    2      68 KB   cin % 64 == 0
 // (table-free 128x64 / 64x64 / 64x128 tiles with 3-5 WG/CU were measured for the HBM-bound 1x1 layers: no faster than 17
 //  -- every tile shape plateaus at ~3.1-3.3 TB/s of a 4.8 TB/s copy, the per-WG load -> MFMA -> store phases do not overlap)
+//  20  2x8x32 patch (two output frames), halo-direct stem with 8 waves sharing every weight stage, 1 WG/CU
+//  21  1x8x32 patch, halo-direct stem with split-K over 8 waves (a single workgroup saturates the MFMA pipe), 2 WG/CU
 //  19  128 x 64, PERSISTENT pointwise (conv_pw.hip): 1x1x1 convs with cin = 64 / 128, next tile prefetched under the stores
 //  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
-constexpr int NUM_CFGS = 19;
+constexpr int NUM_CFGS = 21;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
     switch (cfg) {
-        case 9: return launch_stem_halo<T>(p, N, s);
+        case 9: return launch_stem_halo<T, 1, 1>(p, N, s);
+        case 20: return launch_stem_halo<T, 2, 1>(p, N, s);
+        case 21: return launch_stem_halo<T, 1, 2>(p, N, s);
         case 15: return launch_conv_halo(T::kDtype, p, N, cin, 128, s);
         case 16: return launch_conv_halo(T::kDtype, p, N, cin, 64, s);
         case 1: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
@@ -676,7 +733,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         return launch_conv_pw(d->dtype, p, s, true);
     }
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
-    if (cfg == 9) {
+    if (cfg == 9 || cfg == 20 || cfg == 21) {
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
         TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
     }

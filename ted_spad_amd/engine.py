@@ -286,11 +286,11 @@ class PackedConv:
                 self._cfgs[key] = PREFER_TILE_CFG
                 return
         st = self._cfgs.get(key)
-        if isinstance(st, int):
+        if AUTOTUNE and isinstance(st, int):
             d.tile_cfg = st
             check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd")
             return
-        if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        if not AUTOTUNE or torch.cuda.is_current_stream_capturing():     # built-in heuristic: only K-order-preserving tiles
             d.tile_cfg = 0
             check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd")
             return

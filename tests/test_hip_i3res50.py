@@ -47,11 +47,20 @@ def test_stage_checksums_vs_golden(net, golden_meta):
         assert abs(float(t.mean()) - mean) < 2e-3 * abs(mean) + 1e-4, name
 
 
-def test_batch_invariance_and_determinism(net):
+def test_batch_invariance_and_determinism(net, monkeypatch):
+    """With the built-in tile heuristic (tuner off) only configurations that sum K in the same order run, so a clip's
+    feature is BIT-identical whatever batch it is in and from run to run. With the tuner on, the reassociating
+    configurations (halo-direct 15/16, split-K stem 21: one f16 rounding step on ~0.1 % of a layer's outputs) may be
+    picked for one batch size and not for another: the features then agree to 1e-4 rel-L2 (gate: 1e-3 vs the oracle)."""
+    from ted_spad_amd import engine as E
     x = synth_clips(0, 5, (3, 16, 112, 112), device="cuda")
+    tuned5 = net.i3d.extract_features(x).flatten(1)
+    tuned1 = torch.cat([net.i3d.extract_features(x[i:i + 1]) for i in range(5)]).flatten(1)
+    assert rel_l2(tuned5.cpu(), tuned1.cpu()) < 1e-4
+    monkeypatch.setattr(E, "AUTOTUNE", False)
     f5 = net.i3d.extract_features(x)
     f1 = torch.cat([net.i3d.extract_features(x[i:i + 1]) for i in range(5)])
-    assert torch.equal(f5, f1)  # a clip's feature does not depend on its batch (tile M order is fixed per pixel)
+    assert torch.equal(f5, f1)
     assert torch.equal(f5, net.i3d.extract_features(x))
 
 

@@ -285,3 +285,29 @@ def test_conv_pool_t2_fused_equals_conv_then_pool(dims, cin, cout, use_res):
     one = pc.call_pool_t2(xa, residual=ra, relu=True)
     assert one.dims == two.dims == (n, t // 2, h, w)
     assert torch.equal(one.buf, two.buf)
+
+
+@pytest.mark.parametrize("dims", [(3, 16, 224, 224), (2, 6, 100, 76), (1, 2, 32, 64), (5, 10, 48, 40)])
+def test_two_frame_stem_equals_halo_stem(dims):
+    """tile_cfg 20 (halo-direct stem on two output frames per workgroup, 8 waves sharing each weight stage) against
+    tile_cfg 9 and a generic configuration on the 5x7x7 / stride-2 stem: bit-exact, including an odd number of output
+    frames (the second half of the last patch is masked) and patches that hang over the right / bottom edge."""
+    from ted_spad_amd import engine as E
+    n, t, h, w = dims
+    wgt = synth_tensor(13, "stw", (64, 3, 5, 7, 7), -1, 1) * (2.0 / 735) ** 0.5
+    scale, shift = synth_tensor(13, "sts", (64,), 0.5, 1.5), synth_tensor(13, "stb", (64,), -0.3, 0.3)
+    pc = E.PackedConv(wgt, scale, shift, stride=(2, 2, 2), dtype="f16", device="cuda", pair_w=3)
+    a = E.clip_to_act(synth_tensor(13, "stx", (n, 3, t, h, w), device="cuda"), cpad=4)
+    outs = {}
+    try:
+        for cfg in (9, 20, 21, 2):
+            E.FORCE_TILE_CFG = cfg
+            outs[cfg] = pc(a, pads=(2, 3, pc.pair_pw), pads_back=(2, 3, 1)).buf.clone()
+    finally:
+        E.FORCE_TILE_CFG = None
+    assert torch.equal(outs[9], outs[2])
+    assert torch.equal(outs[20], outs[9])
+    # 21: split-K over 8 waves -- fp32 partial sums re-associated: within one f16 rounding step
+    o21, o9 = outs[21].float(), outs[9].float()
+    assert bool(((o21 - o9).abs() <= 2.0 ** -10 * o9.abs() + 1e-4).all())
+    assert float((o21 != o9).float().mean()) < 0.02
