@@ -411,6 +411,11 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
             for (int r = 0; r < 16; ++r) acc[a][g][r] = 0.f;
 
     for (int kt = 0; kt < p.nk; ++kt) {
+        // this wave's tap deltas of the step (constant table): requested before the wait so they are not on the
+        // fragment-read -> MFMA dependency chain
+        int dk[BK / 16 / KS];
+#pragma unroll
+        for (int kq = 0; kq < BK / 16 / KS; ++kq) dk[kq] = tapd[kt * 8 + (kq + kh2 * (BK / 16 / KS)) * 2 + lh];
         // stage kt must have landed (the halo was issued before stage 0); up to WS-2 later stages stay in flight
         const int later = p.nk - 1 - kt;
         if (WS >= 4 && later >= 2) wait_vmcnt<(WS >= 4 ? 2 : 0) * WL>();
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
 #pragma unroll
         for (int kq = 0; kq < BK / 16 / KS; ++kq) {
             const int ks = kq + kh2 * (BK / 16 / KS);
-            const int d = tapd[kt * 8 + ks * 2 + lh];
+            const int d = dk[kq];
             const int coff = (((ks << 1) | lh) ^ swz) << 3;
             uint4 fa[2], fw[2];
 #pragma unroll
