@@ -21,6 +21,9 @@ namespace tedspad {
 namespace {
 
 __device__ uint4 g_zero16h;
+#ifdef TEDSPAD_DEBUG_TS
+__device__ unsigned long long *g_dbg_ts;   // debug builds only: [workgroup][4] = start, loop start, loop end, steps
+#endif
 
 struct HaloGeo {
     int PT, PH, PW;          // output patch
@@ -138,6 +141,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvKP p, const Ha
     __syncthreads();   // dtab written
 
     const int nsteps = g.ncc * g.ntaps;
+#ifdef TEDSPAD_DEBUG_TS
+    unsigned long long ts0 = __builtin_readcyclecounter(), ts1 = 0;
+#endif
     // DMA instructions issued by this thread so far, and that count right after W(step) .. W(step+3) were issued
     int issued = 0, mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0;
 #pragma unroll
@@ -152,6 +158,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvKP p, const Ha
         wait_vmcnt_n(issued - mk0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef TEDSPAD_DEBUG_TS
+        if (step == 0) ts1 = __builtin_readcyclecounter();
+#endif
         if (tap == 0 && cc + 1 < g.ncc) {      // whole halo of the next chunk, BEFORE this step's weight issue (older => covered)
 #pragma unroll
             for (int i = 0; i < 6; ++i)   // static indices: a runtime-indexed hoff[] would live in scratch
@@ -181,6 +190,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvKP p, const Ha
         mk0 = mk1; mk1 = mk2; mk2 = mk3;
     }
 
+#ifdef TEDSPAD_DEBUG_TS
+    if (g_dbg_ts && tid == 0) { unsigned long long *dbg = g_dbg_ts + (size_t)blockIdx.x * 4; dbg[0] = ts0; dbg[1] = ts1; dbg[2] = __builtin_readcyclecounter(); dbg[3] = nsteps; }
+#endif
     // ---- epilogue, 128 channels at a time: fp32 [256 px][128 ch] -> LDS -> coalesced rows ----------------------------
     float *stg = reinterpret_cast<float *>(dsm);
     const int cc16 = tid & 15, r0 = tid >> 4;     // 16 chunks of 8 channels per pixel row, 32 rows per pass
@@ -317,3 +329,9 @@ int32_t launch_conv_halo(int dtype, const ConvKP &p, int N, int cin, int bn, hip
 }
 
 }  // namespace tedspad
+
+#ifdef TEDSPAD_DEBUG_TS
+extern "C" int32_t tedspad_debug_set_halo_ts(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(tedspad::g_dbg_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
