@@ -40,9 +40,12 @@ __device__ __forceinline__ int fdiv(int n, int d, float inv_d) {
     return q;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
-__global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p) {
-    constexpr int NT = WM * WN * 64;
+// KS = 2: split-K inside the workgroup (as in the stem, tile_cfg 21): a second set of WM*WN waves multiplies the k16
+// sub-steps 2,3 of every 64-deep K step, the first set the sub-steps 0,1; partial sums meet in the staging tile. Twice the
+// waves per SIMD for the same LDS: a single wave issues its MFMA groups at about half rate (dependent fragment reads).
+template <typename T, int BM, int BN, int WM, int WN, int S, int KT, int KS = 1>
+__global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const ConvKP p) {
+    constexpr int NT = WM * WN * 64 * KS;
     constexpr int RPS = NT / 8;           // tile rows filled by one DMA instruction slot of the block
     constexpr int SA = BM / RPS;          // DMA slots per thread per stage: activations
     constexpr int SW = BN / RPS;          //                                  weights
@@ -151,7 +154,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
     };
 
     // ---- MFMA roles ----------------------------------------------------------------------
-    const int wm = wave % WM, wn = wave / WM;
+    const int wsub = KS == 2 ? wave % (WM * WN) : wave;
+    const int kh2 = KS == 2 ? wave / (WM * WN) : 0;     // which half of the k16 sub-steps this wave multiplies
+    const int wm = wsub % WM, wn = wsub / WM;
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
     f32x16 acc[TN][TM];
@@ -197,7 +202,8 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
         const uint16_t *A = reinterpret_cast<const uint16_t *>(smem + rd * STAGE) + (wm * (BM / WM) + l31) * BK;
         const uint16_t *W = reinterpret_cast<const uint16_t *>(smem + rd * STAGE + BM * BK * 2) + (wn * (BN / WN) + l31) * BK;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int kq = 0; kq < BK / 16 / KS; ++kq) {
+            const int ks = kq + kh2 * (BK / 16 / KS);
             const int coff = (((ks << 1) | lh) ^ swz) << 3;
             uint4 fa[TM], fw[TN];
 #pragma unroll
@@ -216,19 +222,40 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_igemm_kernel(const ConvKP p)
 
     // ---- epilogue: fp32 tile -> LDS -> coalesced 16-byte rows --------------------------
     float *stg = reinterpret_cast<float *>(smem);
+    if (KS == 1 || kh2 == 1) {
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const int ml = wm * (BM / WM) + b * 32 + l31;
+            for (int b = 0; b < TM; ++b) {
+                const int ml = wm * (BM / WM) + b * 32 + l31;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wn * (BN / WN) + a * 32 + 8 * g + 4 * lh;
-                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wn * (BN / WN) + a * 32 + 8 * g + 4 * lh;
+                    f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
+                }
             }
-        }
+    }
     __syncthreads();
+    if (KS == 2) {
+        if (kh2 == 0) {      // add the partner wave's partial sums (same lanes, same addresses)
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int ml = wm * (BM / WM) + b * 32 + l31;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = wn * (BN / WN) + a * 32 + 8 * g + 4 * lh;
+                        f32x4 *ptr = reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl);
+                        const f32x4 o = *ptr;
+                        f32x4 v = {acc[a][b][4 * g] + o[0], acc[a][b][4 * g + 1] + o[1], acc[a][b][4 * g + 2] + o[2], acc[a][b][4 * g + 3] + o[3]};
+                        *ptr = v;
+                    }
+                }
+        }
+        __syncthreads();
+    }
 
     constexpr int CPR = BN / 8;          // 16-byte output chunks per tile row
     constexpr int RPP = NT / CPR;        // rows per pass
@@ -542,7 +569,7 @@ int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
     return check_launch("tedspad_conv_fwd(halo)");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int S, int KT>
+template <typename T, int BM, int BN, int WM, int WN, int S, int KT, int KS = 1>
 int32_t launch(const ConvKP &p, hipStream_t s) {
     if (KT == 0 ? !p.utap : p.Kpad > KT) {
         set_error("tedspad_conv_fwd: tile_cfg needs %s", KT == 0 ? "cin % 64 == 0" : "a shorter K");
@@ -551,7 +578,7 @@ int32_t launch(const ConvKP &p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     ConvKP q = p;
     q.tiles_n = (p.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, S, KT>), dim3(tiles_m * q.tiles_n), dim3(WM * WN * 64), 0, s, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, S, KT, KS>), dim3(tiles_m * q.tiles_n), dim3(WM * WN * 64 * KS), 0, s, q);
     return check_launch("tedspad_conv_fwd");
 }
 
@@ -578,11 +605,14 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 // (table-free 128x64 / 64x64 / 64x128 tiles with 3-5 WG/CU were measured for the HBM-bound 1x1 layers: no faster than 17
 //  -- every tile shape plateaus at ~3.1-3.3 TB/s of a 4.8 TB/s copy, the per-WG load -> MFMA -> store phases do not overlap)
 //  20  2x8x32 patch (two output frames), halo-direct stem with 8 waves sharing every weight stage, 1 WG/CU
+//  22  128 x 128, split-K over 8 waves (2 x 2 x 2), ring 2, 2 WG/CU: 4 waves per SIMD
+//  23  the same, table-free (cin % 64 == 0)
+//  24  256 x 128, split-K over 16 waves, ring 3, 1 WG/CU
 //  21  1x8x32 patch, halo-direct stem with split-K over 8 waves (a single workgroup saturates the MFMA pipe), 2 WG/CU
 //  19  128 x 64, PERSISTENT pointwise (conv_pw.hip): 1x1x1 convs with cin = 64 / 128, next tile prefetched under the stores
 //  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
-constexpr int NUM_CFGS = 21;
+constexpr int NUM_CFGS = 24;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -590,6 +620,9 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 9: return launch_stem_halo<T, 1, 1>(p, N, s);
         case 20: return launch_stem_halo<T, 2, 1>(p, N, s);
         case 21: return launch_stem_halo<T, 1, 2>(p, N, s);
+        case 22: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES, 2>(p, s);
+        case 23: return launch<T, 128, 128, 2, 2, 2, 0, 2>(p, s);
+        case 24: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES, 2>(p, s);
         case 15: return launch_conv_halo(T::kDtype, p, N, cin, 128, s);
         case 16: return launch_conv_halo(T::kDtype, p, N, cin, 64, s);
         case 1: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES>(p, s);

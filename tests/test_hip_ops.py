@@ -254,13 +254,14 @@ def test_every_tile_configuration_gives_the_same_result(case):
                 continue                                   # configuration not applicable to this geometry
     finally:
         E.FORCE_TILE_CFG = None
-    generic = {c: o for c, o in outs.items() if c not in (15, 16)}
+    REASSOC = (15, 16, 22, 23, 24)      # halo-direct (K walked chunk-major) and split-K tiles: fp32 sums re-associated
+    generic = {c: o for c, o in outs.items() if c not in REASSOC}
     assert len(generic) >= 4, sorted(outs)
     first = next(iter(generic.values()))
     for c, o in generic.items():
         assert torch.equal(o, first), "configuration %d differs from configuration %d" % (c, next(iter(generic)))
     assert bool(((first - ref).abs() <= 2.0 ** -10 * ref.abs() + 1e-3).all())
-    for c in (15, 16):
+    for c in REASSOC:
         if c in outs:
             assert bool(((outs[c] - first).abs() <= 2.0 ** -10 * first.abs() + 1e-4).all()), c
     print(name, "configurations run:", sorted(outs))
