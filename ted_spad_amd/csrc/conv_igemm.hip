@@ -167,6 +167,24 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Epilogue constants, requested FIRST: loaded where they are used (after the staging barrier) their L2 round trip sat on
+    // the critical path of every workgroup's epilogue; issued before any DMA they retire first (in order) and never disturb
+    // the counted waits of the ring.
+    constexpr int CPR = BN / 8;          // 16-byte output chunks per tile row
+    constexpr int RPP = NT / CPR;        // rows per pass
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 8;
+    const bool active = n < p.Cout;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = 0.f; sf[i] = 0.f; }
+    if (active) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
+    }
+
     // Prologue, ordered to shorten the per-workgroup ramp (measured: prologue + epilogue were 30-55 % of these kernels):
     // the weight DMAs of the first S-1 stages need no geometry and go out first, this thread's K-table entries for those
     // stages come straight from global memory, and the LDS copy of the table (used from the first in-loop issue on) is
@@ -257,20 +275,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         __syncthreads();
     }
 
-    constexpr int CPR = BN / 8;          // 16-byte output chunks per tile row
-    constexpr int RPP = NT / CPR;        // rows per pass
-    const int cc = tid % CPR, r0 = tid / CPR;
-    const int n = n0 + cc * 8;
-    const bool active = n < p.Cout;
-    float sc[8], sf[8], s1[8], s2[8];
+    float s1[8], s2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { sc[i] = 0.f; sf[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
-    if (active) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
-        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
-    }
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
     if (active) {
 #pragma unroll 4
         for (int r = r0; r < BM; r += RPP) {
