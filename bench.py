@@ -165,7 +165,7 @@ def main():
            "roofline": roofline}
 
     # ---- CPU baseline + parity on a bounded sample: the oracle on this box's host cores ------------
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: at N > 1 the other ranks must not wait for it
         from oracle import i3res50_ref, inception_i3d_ref
         cores = min(os.cpu_count(), 32)  # measured on the GPU box's host: 8/16/32/64/128 threads -> 6.6/9.2/10.2/7.7/4.0 clips/s
         torch.set_num_threads(cores)
