@@ -227,8 +227,9 @@ AGREE = [
 ]
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("case", AGREE, ids=[c[0] for c in AGREE])
-def test_every_tile_configuration_gives_the_same_result(case):
+def test_every_tile_configuration_gives_the_same_result(case, dtype):
     """The tile tuner may pick any applicable configuration, so the choice must not change results: every generic
     implicit-GEMM configuration accumulates K in the same order and must agree BIT-EXACTLY with the others; the
     halo-direct ones (15, 16) walk K as (channel chunk, tap) instead of (tap, channel chunk) -- an fp32 reassociation --
@@ -237,13 +238,15 @@ def test_every_tile_configuration_gives_the_same_result(case):
     from ted_spad_amd import _lib, engine as E
     name, dims, cin, cout, k, pf, use_res = case
     n, t, h, w = dims
-    x = synth_tensor(7, name + "x", (n, t, h, w, cin), -1, 1).half().float()
-    wgt = (synth_tensor(7, name + "w", (cout, cin) + k, -1, 1) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5).half().float()
+    tdt = E.DTYPES[dtype][0]
+    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    x = synth_tensor(7, name + "x", (n, t, h, w, cin), -1, 1).to(tdt).float()
+    wgt = (synth_tensor(7, name + "w", (cout, cin) + k, -1, 1) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5).to(tdt).float()
     scale, shift = synth_tensor(7, name + "s", (cout,), 0.5, 1.5), synth_tensor(7, name + "b", (cout,), -0.3, 0.3)
-    res = synth_tensor(7, name + "r", (n, t, h, w, cout), -1, 1).half().float() if use_res else None
+    res = synth_tensor(7, name + "r", (n, t, h, w, cout), -1, 1).to(tdt).float() if use_res else None
     ref = conv_cl(x, wgt, scale, shift, (1, 1, 1), pf, pf, res, relu=True)
-    pc = E.PackedConv(wgt, scale, shift, dtype="f16", device="cuda")
-    xa, ra = E.Act(x.half().cuda(), cin), (E.Act(res.half().cuda(), cout) if use_res else None)
+    pc = E.PackedConv(wgt, scale, shift, dtype=dtype, device="cuda")
+    xa, ra = E.Act(x.to(tdt).cuda(), cin), (E.Act(res.to(tdt).cuda(), cout) if use_res else None)
     outs = {}
     try:
         for cfg in range(1, _lib.lib().tedspad_conv_num_tile_cfgs() + 1):
@@ -260,10 +263,10 @@ def test_every_tile_configuration_gives_the_same_result(case):
     first = next(iter(generic.values()))
     for c, o in generic.items():
         assert torch.equal(o, first), "configuration %d differs from configuration %d" % (c, next(iter(generic)))
-    assert bool(((first - ref).abs() <= 2.0 ** -10 * ref.abs() + 1e-3).all())
+    assert bool(((first - ref).abs() <= ulp * ref.abs() + 1e-3).all())
     for c in REASSOC:
         if c in outs:
-            assert bool(((outs[c] - first).abs() <= 2.0 ** -10 * first.abs() + 1e-4).all()), c
+            assert bool(((outs[c] - first).abs() <= ulp * first.abs() + 1e-4).all()), c
     print(name, "configurations run:", sorted(outs))
 
 
