@@ -315,3 +315,40 @@ def test_two_frame_stem_equals_halo_stem(dims):
     o21, o9 = outs[21].float(), outs[9].float()
     assert bool(((o21 - o9).abs() <= 2.0 ** -10 * o9.abs() + 1e-4).all())
     assert float((o21 != o9).float().mean()) < 0.02
+
+
+def test_hand_counted_waits_are_race_free_over_many_launches():
+    """The persistent pointwise kernel (19, incl. the fused temporal pool), the halo-direct kernels (15) and the split-K
+    stem (21) order their LDS reads behind LDS-DMA with hand-counted `s_waitcnt vmcnt(N)`; a wrong count shows up as a
+    rare stale tile that comes and goes with timing. 60 launches each on large shapes, interleaved with a kernel that
+    thrashes L2, must reproduce the first result bit for bit."""
+    from ted_spad_amd import engine as E
+    junk = torch.empty(64 << 20, dtype=torch.float16, device="cuda")
+
+    def repeat(fn, n=60):
+        first = fn().clone()
+        for i in range(n):
+            if i % 3 == 0:
+                junk.normal_()                        # evict L2 / MALL between launches: different DMA latencies
+            assert torch.equal(fn(), first), "launch %d differs" % i
+
+    x = E.Act(synth_tensor(17, "rx", (24, 4, 55, 55, 64), -1, 1, device="cuda").half(), 64)
+    r = E.Act(synth_tensor(17, "rr", (24, 4, 55, 55, 256), -1, 1, device="cuda").half(), 256)
+    pc = E.PackedConv(synth_tensor(17, "rw", (256, 64, 1, 1, 1), -0.2, 0.2), synth_tensor(17, "rs", (256,), 0.5, 1.5),
+                      synth_tensor(17, "rb", (256,), -0.3, 0.3), dtype="f16", device="cuda")
+    x3 = E.Act(synth_tensor(17, "r3", (24, 2, 14, 14, 256), -1, 1, device="cuda").half(), 256)
+    pc3 = E.PackedConv(synth_tensor(17, "rw3", (256, 256, 1, 3, 3), -0.05, 0.05), synth_tensor(17, "rs3", (256,), 0.5, 1.5),
+                       synth_tensor(17, "rb3", (256,), -0.3, 0.3), dtype="f16", device="cuda")
+    st = E.PackedConv(synth_tensor(17, "rws", (64, 3, 5, 7, 7), -0.1, 0.1), torch.ones(64), torch.zeros(64), stride=(2, 2, 2),
+                      dtype="f16", device="cuda", pair_w=3)
+    clip = E.clip_to_act(synth_tensor(17, "rc", (6, 3, 16, 224, 224), device="cuda"), cpad=4)
+    try:
+        E.FORCE_TILE_CFG = 19
+        repeat(lambda: pc(x, residual=r, relu=True).buf)
+        repeat(lambda: pc.call_pool_t2(x, residual=r, relu=True).buf)
+        E.FORCE_TILE_CFG = 15
+        repeat(lambda: pc3(x3, pads=(0, 1, 1)).buf)
+        E.FORCE_TILE_CFG = 21
+        repeat(lambda: st(clip, pads=(2, 3, st.pair_pw), pads_back=(2, 3, 1)).buf, n=30)
+    finally:
+        E.FORCE_TILE_CFG = None
