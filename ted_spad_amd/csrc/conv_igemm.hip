@@ -29,7 +29,10 @@
 namespace tedspad {
 namespace {
 
-__device__ uint4 g_zero16;              // zero page for padded taps (zero-initialised by the loader)
+__device__ uint4 g_zero16;
+#ifdef TEDSPAD_DEBUG_TS
+__device__ unsigned long long *g_dbg_ts_ig;   // debug builds only: [workgroup][4] = start, loop start, loop end, cycles waited in the loop (wave 0)
+#endif              // zero page for padded taps (zero-initialised by the loader)
 
 // n / d for 0 <= n < 2^24, d >= 1 via the fp32 reciprocal (both exactly representable), corrected to the exact quotient.
 __device__ __forceinline__ int fdiv(int n, int d, float inv_d) {
@@ -207,8 +210,14 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // table in LDS (and, once, the whole prologue) before barrier 0
     }
 
+#ifdef TEDSPAD_DEBUG_TS
+    unsigned long long dbg_t0 = __builtin_readcyclecounter(), dbg_t1 = 0, dbg_wait = 0;
+#endif
     int rd = 0, wr = S - 1;  // ring slots: stage kt is read from `rd`, stage kt+S-1 is written to `wr`
     for (int kt = 0; kt < p.nk; ++kt) {
+#ifdef TEDSPAD_DEBUG_TS
+        const unsigned long long dbg_w0 = __builtin_readcyclecounter();
+#endif
         // stage kt must have landed; up to S-2 later stages stay in flight across the barrier
         const int later = p.nk - 1 - kt;
         if (S >= 4 && later >= 2) wait_vmcnt<(S >= 4 ? 2 : 0) * L>();
@@ -216,6 +225,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // everyone's DMA of stage kt is visible; the slot of stage kt-1 is free
         asm volatile("" ::: "memory");
+#ifdef TEDSPAD_DEBUG_TS
+        if (kt == 0) dbg_t1 = __builtin_readcyclecounter(); else dbg_wait += __builtin_readcyclecounter() - dbg_w0;
+#endif
         if (kt + S - 1 < p.nk) issue(kt + S - 1, wr);
         const uint16_t *A = reinterpret_cast<const uint16_t *>(smem + rd * STAGE) + (wm * (BM / WM) + l31) * BK;
         const uint16_t *W = reinterpret_cast<const uint16_t *>(smem + rd * STAGE + BM * BK * 2) + (wn * (BN / WN) + l31) * BK;
@@ -237,6 +249,12 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         wr = wr + 1 == S ? 0 : wr + 1;
     }
     __syncthreads();  // all waves done with the ring before it is reused as the fp32 staging tile
+#ifdef TEDSPAD_DEBUG_TS
+    if (g_dbg_ts_ig && threadIdx.x == 0) {
+        unsigned long long *dbg = g_dbg_ts_ig + (size_t)blockIdx.x * 4;
+        dbg[0] = dbg_t0; dbg[1] = dbg_t1; dbg[2] = __builtin_readcyclecounter(); dbg[3] = dbg_wait;
+    }
+#endif
 
     // ---- epilogue: fp32 tile -> LDS -> coalesced 16-byte rows --------------------------
     float *stg = reinterpret_cast<float *>(smem);
@@ -802,3 +820,9 @@ extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, c
                                     int32_t sigmoid, void *stream) {
     return tedspad_conv_fwd_ex(d, x, w_packed, ktab, scale, shift, residual, y, sigmoid, nullptr, stream);
 }
+
+#ifdef TEDSPAD_DEBUG_TS
+extern "C" int32_t tedspad_debug_set_igemm_ts(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(tedspad::g_dbg_ts_ig), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
