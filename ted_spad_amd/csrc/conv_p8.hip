@@ -1,0 +1,325 @@
+// Ping-pong implicit-GEMM convolution for gfx950 (tile_cfg 25): 256 pixels x 256 output channels per workgroup, 8 waves
+// (two per SIMD), for convolutions with cin % 64 == 0 (no K table) and cout % 256 == 0.
+//
+// Why a second structure: every tile of conv_igemm.hip runs its steady-state loop at about half the MFMA rate
+// ("Main loop of the generic kernel, measured in cycles") because the two waves of a SIMD run the SAME
+// program between the same barriers: both issue their LDS fragment reads, both wait for them, both want the matrix
+// pipe. Here the two waves of a SIMD (wave w and wave w + 4) are one barrier apart: a K tile is cut into four PHASES,
+// a phase is a LOAD segment (fragment reads of one quadrant + two LDS-DMA instructions of the tile stream) followed by
+// a COMPUTE segment (eight 32x32x16 MFMAs), every segment ends in a raw s_barrier, and waves 4-7 take one extra barrier
+// before the loop -- so while one wave of a SIMD multiplies, its partner reads and issues DMA, and the matrix pipe
+// always has a wave whose operands are already in registers.
+//
+//   wave (g, wn) = (wave >> 2, wave & 3) owns pixels {64g..64g+63} u {128+64g..128+64g+63} x channels {32wn..+31} u
+//   {128+32wn..+31}: its operands of one K tile are two 64-row pixel fragments sets X0, X1 and two 32-row weight
+//   fragment sets W0, W1, each living in its own 16 KB staging UNIT (128 rows x 64 k, the 128-byte-row XOR-swizzled
+//   image of conv_igemm.hip):  Xh0 = pixel rows 0..127, Xh1 = 128..255, Wh0 = channel rows 0..127, Wh1 = 128..255.
+//     phase 1: read W0 (4 x ds_read_b128), X0 (8)   acc[W0][X0] += ...
+//     phase 2: read W1 (4)                           acc[W1][X0]
+//     phase 3: read X1 (8)                           acc[W1][X1]
+//     phase 4: --                                    acc[W0][X1]      (W0 stays in registers)
+//   Every accumulator sums K in the same order as the generic tiles: results are bit-identical to them.
+//
+// Tile stream: 8 unit slots (two K tiles), one unit staged per phase by all 512 threads (2 LDS-DMA instructions each),
+// in the order [phase 1: Wh1(t+1), phase 2: Xh1(t+1), phase 3: Wh0(t+2), phase 4: Xh0(t+2)] -- the gather arithmetic of
+// the pixel units sits in the phases with few fragment reads. A unit is staged >= 5 phases before the phase that reads
+// it and >= 2 phases after the last read of the slot's previous occupant, and every phase ends with a counted
+// s_waitcnt vmcnt(6): all but the three youngest units of this wave have landed. Ordering argument (segments are the
+// barrier-delimited intervals; group 0 runs LOAD of phase k in segment 2k, group 1 in segment 2k+1):
+//   RAW  a unit read in phase n was waited for (by every wave) in phase <= n-2, i.e. before the barrier that ends
+//        segment 2(n-2)+2 = 2n-2, and the earliest read of it is issued in segment 2n;
+//   WAR  reads of phase k have returned (compiler-counted lgkmcnt before the MFMAs that use them) by the end of
+//        segment 2k+2; DMA into their slot is issued in phase >= k+2, i.e. in segment >= 2k+4.
+#include "conv_common.h"
+
+namespace tedspad {
+namespace {
+
+__device__ uint4 g_zero16p;   // zero page for padded taps / rows past M
+
+__device__ __forceinline__ int fdiv_p(int n, int d, float inv_d) {
+    int q = (int)((float)n * inv_d);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int ROWB = BK * 2;                 // 128-byte rows
+    constexpr int UNIT = 128 * ROWB;             // 16 KB
+    constexpr int STG_LD = 128 + 4;              // fp32 staging row stride (floats)
+    constexpr int LDS_MAIN = 8 * UNIT;
+    constexpr int LDS_STAGE = BM * STG_LD * 4;
+    constexpr int LDS_BYTES = LDS_MAIN > LDS_STAGE ? LDS_MAIN : LDS_STAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % p.tiles_n;
+    const int tile_m = lid / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- DMA roles: 8 consecutive lanes fetch the eight 16-byte chunks of one unit row; a wave instruction covers 8 rows,
+    // the block's two instructions per unit cover rows [wave*8 + lane/8] and [64 + ...] --------------------------------
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);   // SOURCE chunk (swizzle (row >> 1) & 7 on the source)
+    int a_base[4];
+    unsigned a_mask[4];   // bits 0..6 valid dt, 8..14 valid dh, 16..22 valid dw
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + i * 64 + rsub;       // i = 2*half + slot
+        a_base[i] = 0;
+        a_mask[i] = 0;
+        if (m < p.M) {
+            if (p.pointwise) {
+                a_base[i] = m * p.ldx;
+                a_mask[i] = 0x010101u;
+            } else {
+                int wo, ho, to, n;
+                if (p.M < (1 << 24)) {
+                    const int r1 = fdiv_p(m, p.Wo, p.inv_wo); wo = m - r1 * p.Wo;
+                    const int r2 = fdiv_p(r1, p.Ho, p.inv_ho); ho = r1 - r2 * p.Ho;
+                    n = fdiv_p(r2, p.To, p.inv_to); to = r2 - n * p.To;
+                } else {
+                    wo = m % p.Wo; const int r1 = m / p.Wo;
+                    ho = r1 % p.Ho; const int r2 = r1 / p.Ho;
+                    to = r2 % p.To; n = r2 / p.To;
+                }
+                const int t0 = to * p.st - p.pt, h0 = ho * p.sh - p.ph, w0 = wo * p.sw - p.pw;
+                a_base[i] = (((n * p.Ti + t0) * p.Hi + h0) * p.Wi + w0) * p.ldx;
+                unsigned mk = 0;
+                for (int d = 0; d < p.kt; ++d) mk |= ((unsigned)(t0 + d) < (unsigned)p.Ti ? 1u : 0u) << d;
+                for (int d = 0; d < p.kh; ++d) mk |= ((unsigned)(h0 + d) < (unsigned)p.Hi ? 1u : 0u) << (8 + d);
+                for (int d = 0; d < p.kw; ++d) mk |= ((unsigned)(w0 + d) < (unsigned)p.Wi ? 1u : 0u) << (16 + d);
+                a_mask[i] = mk;
+            }
+        }
+    }
+    const uint16_t *wsrc = p.w + (size_t)(n0 + rsub) * p.Kpad + kc * 8;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16p);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    const unsigned ldsw = lds0 + wave * 8 * ROWB;      // this wave's 1 KiB piece inside a 64-row half unit
+
+    // K tile -> tap: wave-uniform counters advancing with the staging order (cin % 64 == 0: a tile never straddles a tap)
+    int u_dt = 0, u_dh = 0, u_dw = 0, u_c = 0;
+    auto next_entry = [&]() -> int2 {
+        int2 e;
+        e.x = ((u_dt * p.Hi + u_dh) * p.Wi + u_dw) * p.ldx + u_c + kc * 8;
+        e.y = u_dt | ((8 + u_dh) << 8) | ((16 + u_dw) << 16);
+        u_c += BK;
+        if (u_c == p.cin) { u_c = 0; if (++u_dw == p.kw) { u_dw = 0; if (++u_dh == p.kh) { u_dh = 0; ++u_dt; } } }
+        return e;
+    };
+    // unit slots: slot = (tile & 1) * 4 + {0: Xh0, 1: Wh0, 2: Wh1, 3: Xh1}
+    auto stage_x = [&](int2 e, int half, int slot) {
+        const unsigned dst = ldsw + slot * UNIT;
+        const unsigned s_t = e.y & 255, s_h = (e.y >> 8) & 255, s_w = (unsigned)e.y >> 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned mk = a_mask[half * 2 + i];
+            const unsigned ok = (mk >> s_t) & (mk >> s_h) & (mk >> s_w) & 1u;
+            const uint16_t *src = ok ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + e.x) : zero;
+            lds_dma16(src, dst + i * 64 * ROWB);
+        }
+    };
+    auto stage_w = [&](int kt, int half, int slot) {
+        const unsigned dst = ldsw + slot * UNIT;
+        const uint16_t *src = wsrc + (size_t)(half * 128) * p.Kpad + kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lds_dma16(src + (size_t)(i * 64) * p.Kpad, dst + i * 64 * ROWB);
+    };
+
+    // ---- MFMA roles ------------------------------------------------------------------------------------------------
+    const int grp = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const unsigned xrow = (64 * grp + l31) * ROWB;       // byte offset of this lane's pixel row inside an X unit (+ 32 rows for b = 1)
+    const unsigned wrow = (32 * wn + l31) * ROWB;        //                          weight row inside a W unit
+    unsigned coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = (((ks << 1) | lh) ^ swz) << 4;
+
+    f32x16 acc[2][4];     // [W0 | W1][X0 b0, X0 b1, X1 b0, X1 b1]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- prologue: six units (all of tile 0, Wh0 / Xh0 of tile 1) in the order the loop continues ---------------------
+    int2 eA = next_entry();          // tile 0
+    stage_w(0, 0, 1);
+    stage_x(eA, 0, 0);
+    stage_w(0, 1, 2);
+    stage_x(eA, 1, 3);
+    eA = next_entry();               // tile 1 (nk >= 2 is a launch requirement)
+    stage_w(1, 0, 5);
+    stage_x(eA, 0, 4);
+    wait_vmcnt<6>();                 // Wh0(0), Xh0(0), Wh1(0) of this wave have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: waves 4-7 run one segment behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    uint4 fx[2][4], fw0[4], fw1[4];
+    const int nk = p.nk;
+#define P8_SEG_END()                          \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0)
+#define P8_WAIT(N_STEADY, N_LAST2)                                   \
+    if (t + 1 >= nk) wait_vmcnt<0>();                                \
+    else if (t + 2 >= nk) wait_vmcnt<N_LAST2>();                     \
+    else wait_vmcnt<N_STEADY>()
+
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char *cur = smem + (t & 1) * 4 * UNIT;
+        const int nxt = ((t + 1) & 1) * 4, nn = (t & 1) * 4;     // slot bases of tile t+1 / tile t+2
+        // ---- phase 1 ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw0[ks] = *reinterpret_cast<const uint4 *>(cur + 1 * UNIT + wrow + coff[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fx[b][ks] = *reinterpret_cast<const uint4 *>(cur + 0 * UNIT + xrow + b * 32 * ROWB + coff[ks]);
+        if (t + 1 < nk) stage_w(t + 1, 1, nxt + 2);
+        P8_SEG_END();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[0][b] = T::mfma(fw0[ks], fx[b][ks], acc[0][b]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_WAIT(6, 6);
+        P8_SEG_END();
+        // ---- phase 2 ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw1[ks] = *reinterpret_cast<const uint4 *>(cur + 2 * UNIT + wrow + coff[ks]);
+        if (t + 1 < nk) stage_x(eA, 1, nxt + 3);
+        P8_SEG_END();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[1][b] = T::mfma(fw1[ks], fx[b][ks], acc[1][b]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_WAIT(6, 6);
+        P8_SEG_END();
+        // ---- phase 3 ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fx[b][ks] = *reinterpret_cast<const uint4 *>(cur + 3 * UNIT + xrow + b * 32 * ROWB + coff[ks]);
+        if (t + 2 < nk) stage_w(t + 2, 0, nn + 1);
+        P8_SEG_END();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[1][2 + b] = T::mfma(fw1[ks], fx[b][ks], acc[1][2 + b]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_WAIT(6, 4);
+        P8_SEG_END();
+        // ---- phase 4 ----
+        if (t + 2 < nk) {
+            eA = next_entry();
+            stage_x(eA, 0, nn + 0);
+        }
+        P8_SEG_END();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[0][2 + b] = T::mfma(fw0[ks], fx[b][ks], acc[0][2 + b]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_WAIT(6, 2);
+        P8_SEG_END();
+    }
+#undef P8_SEG_END
+#undef P8_WAIT
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // pairs with the last in-loop barrier of waves 4-7
+    asm volatile("" ::: "memory");
+    __syncthreads();   // ring free: reused as the fp32 staging tile
+
+    // ---- epilogue: two passes of 256 pixels x 128 channels: fp32 -> LDS -> coalesced 16-byte rows ------------------------
+    float *stg = reinterpret_cast<float *>(smem);
+    constexpr int CPR = 16;            // 16-byte output chunks per staged row (128 channels)
+    constexpr int RPP = 512 / CPR;     // rows per pass of the block
+    const int cc = tid % CPR, r0 = tid / CPR;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 128 * j + cc * 8;
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
+        if (j) __syncthreads();        // pass 0's rows have been read
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ml = (b >> 1) * 128 + 64 * grp + (b & 1) * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 32 * wn + 8 * g + 4 * lh;
+                f32x4 v = {acc[j][b][4 * g], acc[j][b][4 * g + 1], acc[j][b][4 * g + 2], acc[j][b][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
+            }
+        }
+        __syncthreads();
+        float sc[8], sf[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
+#pragma unroll 4
+        for (int r = r0; r < BM; r += RPP) {
+            const int m = m0 + r;
+            if (m >= p.M) break;
+            const size_t op = (size_t)m;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+            if (p.res) {
+                float rr[8];
+                unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + op * p.ldres + n), rr);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += rr[i];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+            }
+            *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
+        }
+    }
+}
+
+template <typename T>
+int32_t launch_p8(const ConvKP &p, hipStream_t s) {
+    ConvKP q = p;
+    q.tiles_n = p.Cout / 256;
+    const int tiles_m = (p.M + 255) / 256;
+    hipLaunchKernelGGL((conv_p8_kernel<T>), dim3(tiles_m * q.tiles_n), dim3(512), 0, s, q);
+    return check_launch("tedspad_conv_fwd(p8)");
+}
+
+}  // namespace
+
+int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s) {
+    if (!p.utap || p.nk < 2 || p.Cout % 256 != 0 || p.sigmoid || p.mask || p.stats || p.ostrided || p.y32 || !p.y) {
+        set_error("tedspad_conv_fwd: ping-pong config needs cin %% 64 == 0, K >= 128, cout %% 256 == 0 and the plain epilogue");
+        return TEDSPAD_EINVAL;
+    }
+    return dtype == TEDSPAD_F16 ? launch_p8<F16>(p, s) : launch_p8<BF16>(p, s);
+}
+
+}  // namespace tedspad
