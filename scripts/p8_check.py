@@ -2,11 +2,15 @@
 output, isolated time of both."""
 import os, sys, argparse, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from ted_spad_amd import engine as E, _lib
+from ted_spad_amd import _lib
+if os.environ.get('TEDSPAD_DBG_LIB'):   # ablation build: hipcc -DTEDSPAD_P8_ABLATIONS -> libtedspad_hip_dbg.so (TEDSPAD_P8_ABL selects)
+    _lib.LIB_PATH = _lib.LIB_PATH.replace('libtedspad_hip.so', 'libtedspad_hip_dbg.so')
+from ted_spad_amd import engine as E
 ap = argparse.ArgumentParser()
 ap.add_argument('--clips', type=int, default=300)
 ap.add_argument('--cfgs', default='25,1,13,22,15')
 ap.add_argument('--reps', type=int, default=20)
+ap.add_argument('--only', type=int, default=-1)
 a = ap.parse_args()
 cfgs = [int(c) for c in a.cfgs.split(',')]
 n = a.clips
@@ -23,7 +27,7 @@ shapes = [  # dims (n,t,h,w), cin, cout, k, pads, stride, residual
     ((n, 2, 14, 14), 256, 512, (1, 3, 3), (0, 1, 1), (1, 2, 2), False),
 ]
 torch.manual_seed(0)
-for dims, cin, cout, k, pads, stride, res in shapes:
+for dims, cin, cout, k, pads, stride, res in (shapes if a.only < 0 else shapes[a.only:a.only + 1]):
     x = E.Act((torch.rand(*dims, cin, device='cuda') - 0.5).half(), cin)
     wt = (torch.rand(cout, cin, *k) - 0.5) * 0.05
     pc = E.PackedConv(wt, torch.rand(cout) + 0.5, torch.rand(cout) - 0.5, stride=stride, device='cuda')

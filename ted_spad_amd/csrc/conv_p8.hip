@@ -14,10 +14,10 @@
 //   {128+32wn..+31}: its operands of one K tile are two 64-row pixel fragments sets X0, X1 and two 32-row weight
 //   fragment sets W0, W1, each living in its own 16 KB staging UNIT (128 rows x 64 k, the 128-byte-row XOR-swizzled
 //   image of conv_igemm.hip):  Xh0 = pixel rows 0..127, Xh1 = 128..255, Wh0 = channel rows 0..127, Wh1 = 128..255.
-//     phase 1: read W0 (4 x ds_read_b128), X0 (8)   acc[W0][X0] += ...
+//     phase 1: read X0 (8 x ds_read_b128)            acc[W0][X0] += ...
 //     phase 2: read W1 (4)                           acc[W1][X0]
 //     phase 3: read X1 (8)                           acc[W1][X1]
-//     phase 4: --                                    acc[W0][X1]      (W0 stays in registers)
+//     phase 4: read W0 of the NEXT tile (4)          acc[W0][X1]      (two W0 register sets; evens out the segments)
 //   Every accumulator sums K in the same order as the generic tiles: results are bit-identical to them.
 //
 // Tile stream: 8 unit slots (two K tiles), one unit staged per phase by all 512 threads (2 LDS-DMA instructions each),
@@ -31,6 +31,7 @@
 //   WAR  reads of phase k have returned (compiler-counted lgkmcnt before the MFMAs that use them) by the end of
 //        segment 2k+2; DMA into their slot is issued in phase >= k+2, i.e. in segment >= 2k+4.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace tedspad {
 namespace {
@@ -45,7 +46,11 @@ __device__ __forceinline__ int fdiv_p(int n, int d, float inv_d) {
     return q;
 }
 
-template <typename T>
+__device__ __forceinline__ void keep4(const uint4 &v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+
+// ABL: ablation bits for scripts/p8_check.py (TEDSPAD_P8_ABL; 0 in production): 1 no fragment reads, 2 no DMA in the loop,
+// 4 no MFMAs, 8 no gather arithmetic (pixel units staged from linear addresses) -- results are wrong with any bit set.
+template <typename T, int ABL>
 __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ROWB = BK * 2;                 // 128-byte rows
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
         for (int i = 0; i < 2; ++i) {
             const unsigned mk = a_mask[half * 2 + i];
             const unsigned ok = (mk >> s_t) & (mk >> s_h) & (mk >> s_w) & 1u;
-            const uint16_t *src = ok ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + e.x) : zero;
+            const uint16_t *src = (ABL & 8) ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + (e.x & 1023)) : ok ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + e.x) : zero;
             lds_dma16(src, dst + i * 64 * ROWB);
         }
     };
@@ -168,7 +173,11 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
 
-    uint4 fx[2][4], fw0[4], fw1[4];
+    uint4 fx[2][4], fwa[4], fwb[4], fw1[4];    // W0 lives in two register sets: tile t+1's is read in phase 4 of tile t
+    if (ABL & 1) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fwa[ks] = make_uint4(lane, ks, 3, 4); fwb[ks] = fwa[ks]; fw1[ks] = make_uint4(ks, lane, 1, 2); fx[0][ks] = make_uint4(1, 2, lane, ks); fx[1][ks] = make_uint4(5, lane, 7, ks); }
+    }
     const int nk = p.nk;
 #define P8_SEG_END()                          \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -179,74 +188,71 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     if (t + 1 >= nk) wait_vmcnt<0>();                                \
     else if (t + 2 >= nk) wait_vmcnt<N_LAST2>();                     \
     else wait_vmcnt<N_STEADY>()
+#define P8_MFMA(ACC0, FW)                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                 \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                              \
+            if (ABL & 4) { keep4(FW[ks]); keep4(fx[b][ks]); }                        \
+            else ACC0[b] = T::mfma(FW[ks], fx[b][ks], ACC0[b]);                      \
+        }                                                                            \
+    __builtin_amdgcn_s_setprio(0);                                                   \
+    __builtin_amdgcn_sched_barrier(0)
 
-    for (int t = 0; t < nk; ++t) {
+    // W0 of tile 0 (Wh0(0) was waited for above and the barrier has published it)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) if (!(ABL & 1)) fwa[ks] = *reinterpret_cast<const uint4 *>(smem + 1 * UNIT + wrow + coff[ks]);
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto ktile = [&](const int t, uint4 (&fw0)[4], uint4 (&fw0n)[4]) {
         const unsigned char *cur = smem + (t & 1) * 4 * UNIT;
         const int nxt = ((t + 1) & 1) * 4, nn = (t & 1) * 4;     // slot bases of tile t+1 / tile t+2
-        // ---- phase 1 ----
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw0[ks] = *reinterpret_cast<const uint4 *>(cur + 1 * UNIT + wrow + coff[ks]);
+        // ---- phase 1: X0 | Wh1(t+1) ----
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fx[b][ks] = *reinterpret_cast<const uint4 *>(cur + 0 * UNIT + xrow + b * 32 * ROWB + coff[ks]);
-        if (t + 1 < nk) stage_w(t + 1, 1, nxt + 2);
+            for (int b = 0; b < 2; ++b) if (!(ABL & 1)) fx[b][ks] = *reinterpret_cast<const uint4 *>(cur + 0 * UNIT + xrow + b * 32 * ROWB + coff[ks]);
+        if (!(ABL & 2) && t + 1 < nk) stage_w(t + 1, 1, nxt + 2);
         P8_SEG_END();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[0][b] = T::mfma(fw0[ks], fx[b][ks], acc[0][b]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        P8_MFMA((&acc[0][0]), fw0);
         P8_WAIT(6, 6);
         P8_SEG_END();
-        // ---- phase 2 ----
+        // ---- phase 2: W1 | Xh1(t+1) ----
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw1[ks] = *reinterpret_cast<const uint4 *>(cur + 2 * UNIT + wrow + coff[ks]);
-        if (t + 1 < nk) stage_x(eA, 1, nxt + 3);
+        for (int ks = 0; ks < 4; ++ks) if (!(ABL & 1)) fw1[ks] = *reinterpret_cast<const uint4 *>(cur + 2 * UNIT + wrow + coff[ks]);
+        if (!(ABL & 2) && t + 1 < nk) stage_x(eA, 1, nxt + 3);
         P8_SEG_END();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[1][b] = T::mfma(fw1[ks], fx[b][ks], acc[1][b]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        P8_MFMA((&acc[1][0]), fw1);
         P8_WAIT(6, 6);
         P8_SEG_END();
-        // ---- phase 3 ----
+        // ---- phase 3: X1 | Wh0(t+2) ----
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fx[b][ks] = *reinterpret_cast<const uint4 *>(cur + 3 * UNIT + xrow + b * 32 * ROWB + coff[ks]);
-        if (t + 2 < nk) stage_w(t + 2, 0, nn + 1);
+            for (int b = 0; b < 2; ++b) if (!(ABL & 1)) fx[b][ks] = *reinterpret_cast<const uint4 *>(cur + 3 * UNIT + xrow + b * 32 * ROWB + coff[ks]);
+        if (!(ABL & 2) && t + 2 < nk) stage_w(t + 2, 0, nn + 1);
         P8_SEG_END();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[1][2 + b] = T::mfma(fw1[ks], fx[b][ks], acc[1][2 + b]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        P8_MFMA((&acc[1][2]), fw1);
         P8_WAIT(6, 4);
         P8_SEG_END();
-        // ---- phase 4 ----
-        if (t + 2 < nk) {
+        // ---- phase 4: W0 of tile t+1 | Xh0(t+2) ----
+        if (t + 1 < nk) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) if (!(ABL & 1)) fw0n[ks] = *reinterpret_cast<const uint4 *>(smem + (nxt + 1) * UNIT + wrow + coff[ks]);
+        }
+        if (!(ABL & 2) && t + 2 < nk) {
             eA = next_entry();
             stage_x(eA, 0, nn + 0);
         }
         P8_SEG_END();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[0][2 + b] = T::mfma(fw0[ks], fx[b][ks], acc[0][2 + b]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        P8_MFMA((&acc[0][2]), fw0);
         P8_WAIT(6, 2);
         P8_SEG_END();
+    };
+    for (int t = 0; t < nk; t += 2) {
+        ktile(t, fwa, fwb);
+        if (t + 1 < nk) ktile(t + 1, fwb, fwa);
     }
+#undef P8_MFMA
 #undef P8_SEG_END
 #undef P8_WAIT
     if (grp == 0) __builtin_amdgcn_s_barrier();   // pairs with the last in-loop barrier of waves 4-7
@@ -254,10 +260,24 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     __syncthreads();   // ring free: reused as the fp32 staging tile
 
     // ---- epilogue: two passes of 256 pixels x 128 channels: fp32 -> LDS -> coalesced 16-byte rows ------------------------
+    // The residual rows of both passes are requested BEFORE the staging writes (the fragment registers are dead by now):
+    // their L2 / HBM round trip runs under the staging traffic instead of once per row inside the store loop.
     float *stg = reinterpret_cast<float *>(smem);
     constexpr int CPR = 16;            // 16-byte output chunks per staged row (128 channels)
     constexpr int RPP = 512 / CPR;     // rows per pass of the block
+    constexpr int NR = BM / RPP;       // rows per thread and pass
     const int cc = tid % CPR, r0 = tid / CPR;
+    uint4 rres[2][NR];
+    if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int m = m0 + r0 + i * RPP;
+                rres[j][i] = make_uint4(0, 0, 0, 0);
+                if (m < p.M) rres[j][i] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n0 + 128 * j + cc * 8);
+            }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + 128 * j + cc * 8;
@@ -278,27 +298,28 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
         float sc[8], sf[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
-#pragma unroll 4
-        for (int r = r0; r < BM; r += RPP) {
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int r = r0 + it * RPP;
             const int m = m0 + r;
-            if (m >= p.M) break;
-            const size_t op = (size_t)m;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
-            float v[8];
+            if (m < p.M) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
+                float v[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
-            if (p.res) {
-                float rr[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + op * p.ldres + n), rr);
+                for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+                if (p.res) {
+                    float rr[8];
+                    unpack8<T>(rres[j][it], rr);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += rr[i];
+                    for (int i = 0; i < 8; ++i) v[i] += rr[i];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+                }
+                *reinterpret_cast<uint4 *>(p.y + (size_t)m * p.ldy + n) = pack8<T>(v);
             }
-            if (p.relu) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
-            }
-            *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
         }
     }
 }
@@ -308,7 +329,21 @@ int32_t launch_p8(const ConvKP &p, hipStream_t s) {
     ConvKP q = p;
     q.tiles_n = p.Cout / 256;
     const int tiles_m = (p.M + 255) / 256;
-    hipLaunchKernelGGL((conv_p8_kernel<T>), dim3(tiles_m * q.tiles_n), dim3(512), 0, s, q);
+    const dim3 grid(tiles_m * q.tiles_n), block(512);
+#ifdef TEDSPAD_P8_ABLATIONS
+    static const int abl = getenv("TEDSPAD_P8_ABL") ? atoi(getenv("TEDSPAD_P8_ABL")) : 0;
+    switch (abl) {
+        case 1: hipLaunchKernelGGL((conv_p8_kernel<T, 1>), grid, block, 0, s, q); break;
+        case 2: hipLaunchKernelGGL((conv_p8_kernel<T, 2>), grid, block, 0, s, q); break;
+        case 3: hipLaunchKernelGGL((conv_p8_kernel<T, 3>), grid, block, 0, s, q); break;
+        case 4: hipLaunchKernelGGL((conv_p8_kernel<T, 4>), grid, block, 0, s, q); break;
+        case 6: hipLaunchKernelGGL((conv_p8_kernel<T, 6>), grid, block, 0, s, q); break;
+        case 8: hipLaunchKernelGGL((conv_p8_kernel<T, 8>), grid, block, 0, s, q); break;
+        default: hipLaunchKernelGGL((conv_p8_kernel<T, 0>), grid, block, 0, s, q); break;
+    }
+#else
+    hipLaunchKernelGGL((conv_p8_kernel<T, 0>), grid, block, 0, s, q);
+#endif
     return check_launch("tedspad_conv_fwd(p8)");
 }
 
