@@ -121,6 +121,15 @@ int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const voi
 int32_t tedspad_conv_pool_t2_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                                  const float *shift, const void *residual, void *y, void *stream);
 
+/* First bottleneck of a stage whose two branches are both 1x1x1 stride-1 convs with cin = 64 (layer1.0 of I3Res50):
+ * y = ReLU((conv(x, w)*scale + shift) + (conv(x2, w2)*scale2 + shift2)) -- `bn3(conv3(out))`, `downsample(x)`, `+=`, `relu`
+ * of large_i3d.py:77-84 in one persistent launch (tile_cfg 19's kernel with two sources): the downsample tensor is never
+ * written. `d` describes the first conv (cin = 64; d->relu applies to the sum); x2 has the same pixel grid, pixel stride
+ * ldx2, 64 channels; both weight matrices are packed [cout_pad][64]. Each branch is accumulated and scaled in fp32. */
+int32_t tedspad_conv_pw_dual_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                 const float *shift, const void *x2, int32_t ldx2, const void *w2_packed,
+                                 const float *scale2, const float *shift2, void *y, void *stream);
+
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
  * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be
  * zeroed by the caller (hipMemsetAsync on the same stream); accumulation uses float atomics.

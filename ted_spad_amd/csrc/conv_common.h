@@ -28,6 +28,10 @@ struct ConvKP {
     int ldmask, stats_ld, ldy32;
     int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
     int ost, osh, osw, oot, ooh, oow, TF, HF, WF;
+    // second source of the dual pointwise launch (conv_pw.hip, DUAL): x2 has the pixel grid of x, cin2 = 64
+    const uint16_t *x2, *w2;
+    const float *scale2, *shift2;
+    int ldx2;
 };
 
 constexpr int BK = 64;                  // K elements per LDS tile row (8 chunks of 16 bytes)

@@ -745,7 +745,7 @@ extern "C" int32_t tedspad_conv_build_ktab(const tedspad_conv_desc *d, int32_t *
 
 static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,
                                        const float *scale, const float *shift, const void *residual, void *y, int32_t sigmoid,
-                                       const tedspad_conv_extras *ex, void *stream, int pool_t) {
+                                       const tedspad_conv_extras *ex, void *stream, int pool_t, const ConvKP *dual = nullptr) {
     TS_REQUIRE(desc_ok(d), "tedspad_conv_fwd: bad descriptor (cin/cout/ld* multiples of 8, kernel dims <= 7)");
     TS_REQUIRE(x && w_packed && ktab && scale && shift && (y || (ex && ex->y32)), "tedspad_conv_fwd: null pointer");
     TS_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) % 16 == 0,
@@ -775,6 +775,12 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     p.inv_wo = 1.0f / (float)d->wo; p.inv_ho = 1.0f / (float)d->ho; p.inv_to = 1.0f / (float)d->to;
     p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
+    p.x2 = p.w2 = nullptr; p.scale2 = p.shift2 = nullptr; p.ldx2 = 0;
+    if (dual) {
+        TS_REQUIRE(p.pointwise && d->cin == 64 && !residual && !ex && !sigmoid && !pool_t, "tedspad_conv_pw_dual_fwd: two 1x1x1 stride-1 convs with cin = 64");
+        p.x2 = dual->x2; p.w2 = dual->w2; p.scale2 = dual->scale2; p.shift2 = dual->shift2; p.ldx2 = dual->ldx2;
+        return launch_conv_pw(d->dtype, p, (hipStream_t)stream, false);
+    }
     bool extras = false;
     if (ex) {
         TS_REQUIRE(!ex->mask || (ex->ldmask % 8 == 0 && ex->ldmask >= d->cout && (uintptr_t)ex->mask % 16 == 0), "tedspad_conv_fwd_ex: bad mask");
@@ -815,6 +821,18 @@ extern "C" int32_t tedspad_conv_pool_t2_fwd(const tedspad_conv_desc *d, const vo
                                             const float *shift, const void *residual, void *y, void *stream) {
     static const int32_t dummy_ktab[2] = {0, 0};   // the pointwise path never reads the table
     return conv_fwd_impl(d, x, w_packed, dummy_ktab, scale, shift, residual, y, 0, nullptr, stream, 1);
+}
+
+extern "C" int32_t tedspad_conv_pw_dual_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                                            const float *shift, const void *x2, int32_t ldx2, const void *w2_packed, const float *scale2,
+                                            const float *shift2, void *y, void *stream) {
+    static const int32_t dummy_ktab[2] = {0, 0};
+    TS_REQUIRE(x2 && w2_packed && scale2 && shift2 && ldx2 >= 64 && ldx2 % 8 == 0 &&
+                   ((uintptr_t)x2 | (uintptr_t)w2_packed | (uintptr_t)scale2 | (uintptr_t)shift2) % 16 == 0,
+               "tedspad_conv_pw_dual_fwd: second source: null / misaligned pointer or bad ldx2");
+    ConvKP dual;
+    dual.x2 = (const uint16_t *)x2; dual.w2 = (const uint16_t *)w2_packed; dual.scale2 = scale2; dual.shift2 = shift2; dual.ldx2 = ldx2;
+    return conv_fwd_impl(d, x, w_packed, dummy_ktab, scale, shift, nullptr, y, 0, nullptr, stream, 0, &dual);
 }
 
 extern "C" int32_t tedspad_conv_fwd(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,

@@ -27,7 +27,12 @@ __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
 // POOLT: the conv output additionally goes through MaxPool3d((2,1,1), stride (2,1,1)) before it is written: the sequence
 // of tiles is (frame 2k, frame 2k+1) of the same 128 pixels, the first result stays in registers, the second is max-ed
 // with it and stored at the pooled position (tiles never straddle a frame: `hw` pixels per frame, `jt` tiles per frame).
-template <typename T, int KB, bool RES, bool POOLT>   // KB = cin / 64; RES: fused residual input
+// DUAL: two pointwise convs summed in one launch -- y = act(conv(x, w)*scale + shift + conv(x2, w2)*scale2 + shift2), both with
+// cin = 64 (KB = 2: K block 0 comes from x / w, K block 1 from x2 / w2). The first bottleneck of layer1 (conv3 + bn3 and
+// the downsample conv + bn of large_i3d.py:61-84) runs like this: the 256-channel downsample tensor is never written or
+// re-read (1792 -> 768 bytes per pixel for the two launches it replaces). Each source keeps its own fp32 accumulator and its
+// own fp32 BatchNorm scale (applied in registers before the staging), so nothing is rounded to 16 bits in between.
+template <typename T, int KB, bool RES, bool POOLT, bool DUAL = false>   // KB = cin / 64; RES: fused residual input
 __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int tiles_m, const int nworkers, const int hw, const int jt) {
     constexpr int XSUB = PW_BM * BK * 2;        // one [128 px][64] sub-tile
     constexpr int WSUB = PW_BN * BK * 2;        // one [64 co][64] sub-tile
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            lds_dma16(p.w + (size_t)(n0 + i * 32 + rsub) * p.Kpad + kb * BK + kc * 8, lds0 + kb * WSUB + i * 32 * (BK * 2) + wrow);
+            lds_dma16((DUAL && kb == 1 ? p.w2 + (size_t)(n0 + i * 32 + rsub) * p.Kpad : p.w + (size_t)(n0 + i * 32 + rsub) * p.Kpad + kb * BK) + kc * 8,
+                      lds0 + kb * WSUB + i * 32 * (BK * 2) + wrow);
     // sequence index q -> first input row of the tile and the number of valid rows in it
     auto tile_rows = [&](int q, int &mb, int &valid) {
         if (POOLT) {            // q = 2 * (frame pair * jt + j) + f
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = mb + i * 32 + rsub;
-                const uint16_t *src = m < mend ? p.x + (size_t)m * p.ldx + kb * BK + kc * 8 : zero;
+                const uint16_t *src = m >= mend ? zero : (DUAL && kb == 1) ? p.x2 + (size_t)m * p.ldx2 + kc * 8 : p.x + (size_t)m * p.ldx + kb * BK + kc * 8;
                 lds_dma16(src, lds0 + OFF_X + buf * XBUF + kb * XSUB + i * 32 * (BK * 2) + wrow);
             }
         if (RES) {   // residual rows ride the same DMA stream (ordinary loads inside this loop would make hipcc drain it)
@@ -102,6 +108,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
         const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
+        if (DUAL) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(p.shift2 + n), g1 = *reinterpret_cast<const f32x4 *>(p.shift2 + n + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sc[i] = 1.f; sc[i + 4] = 1.f; sf[i] += g0[i]; sf[i + 4] += g1[i]; }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sc[i]), "+v"(sf[i]));   // hipcc's wait for these loads happens HERE, not in the loop
@@ -109,6 +120,22 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
     float *stg = reinterpret_cast<float *>(smem + OFF_STG) + wave * 32 * PW_STG_LD;
+    f32x4 dsc[DUAL ? 2 : 1][2][4];     // DUAL: per-source BatchNorm scales of the channels this lane accumulates (a*32 + 8g + 4lh + {0..3})
+    if (DUAL) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                dsc[0][a][g] = *reinterpret_cast<const f32x4 *>(p.scale + n0 + a * 32 + 8 * g + 4 * lh);
+                dsc[DUAL ? 1 : 0][a][g] = *reinterpret_cast<const f32x4 *>(p.scale2 + n0 + a * 32 + 8 * g + 4 * lh);
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(dsc[0][a][g][i]), "+v"(dsc[DUAL ? 1 : 0][a][g][i]));
+    }
 
     // The row STORES are issued from inline asm, like the LDS-DMA: hipcc cannot count vector-memory operations across asm
     // statements and answers every store in such a loop with `s_waitcnt vmcnt(0)` (seen in the ISA of the first version:
@@ -140,11 +167,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
         if (nxt < nseq) issue_x(nxt, buf ^ 1);
         int mb, valid;
         tile_rows(q, mb, valid);
-        f32x16 acc[2];
+        f32x16 acc[2], acc2[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[a][r] = 0.f; acc2[a][r] = 0.f; }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const uint16_t *A = reinterpret_cast<const uint16_t *>(smem + OFF_X + buf * XBUF + kb * XSUB) + (wave * 32 + l31) * BK;
@@ -154,9 +181,23 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
                 const int coff = (((ks << 1) | lh) ^ swz) << 3;
                 const uint4 fa = *reinterpret_cast<const uint4 *>(A + coff);
                 const uint4 fw0 = *reinterpret_cast<const uint4 *>(W + coff), fw1 = *reinterpret_cast<const uint4 *>(W + 32 * BK + coff);
-                acc[0] = T::mfma(fw0, fa, acc[0]);
-                acc[1] = T::mfma(fw1, fa, acc[1]);
+                if (DUAL && kb == 1) {
+                    acc2[0] = T::mfma(fw0, fa, acc2[0]);
+                    acc2[1] = T::mfma(fw1, fa, acc2[1]);
+                } else {
+                    acc[0] = T::mfma(fw0, fa, acc[0]);
+                    acc[1] = T::mfma(fw1, fa, acc[1]);
+                }
             }
+        }
+        if (DUAL) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[a][4 * g + i] = acc[a][4 * g + i] * dsc[0][a][g][i] + acc2[a][4 * g + i] * dsc[DUAL ? 1 : 0][a][g][i];
         }
         // wave-private staging: lane (pixel l31) holds channels a*32 + 8g + 4lh + {0..3}
 #pragma unroll
@@ -224,6 +265,13 @@ template <typename T, int KB>
 int32_t launch_pw(const ConvKP &pin, bool pool_t, hipStream_t s) {
     ConvKP p = pin;
     p.tiles_n = (p.Cout + PW_BN - 1) / PW_BN;
+    if (p.x2) {
+        const int tiles = (p.M + PW_BM - 1) / PW_BM;
+        int nworkers = (256 + p.tiles_n - 1) / p.tiles_n;
+        if (nworkers > tiles) nworkers = tiles;
+        hipLaunchKernelGGL((conv_pw_kernel<T, 2, false, false, true>), dim3(p.tiles_n * nworkers), dim3(256), 0, s, p, tiles, nworkers, 0, 1);
+        return check_launch("tedspad_conv_pw_dual_fwd");
+    }
     if (pool_t) {
         const int hw = p.Hi * p.Wi, jt = (hw + PW_BM - 1) / PW_BM;
         const int units = (p.M / (p.Ti * hw)) * (p.Ti / 2) * jt;      // (batch) x (frame pairs) x (tiles per frame)
@@ -236,6 +284,10 @@ int32_t launch_pw(const ConvKP &pin, bool pool_t, hipStream_t s) {
 }  // namespace
 
 int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t) {
+    if (p.x2 && (p.cin != 64 || p.res || pool_t)) {
+        set_error("tedspad_conv_pw_dual_fwd: both convs need cin = 64, no residual");
+        return TEDSPAD_EINVAL;
+    }
     if (!p.pointwise || (p.cin != 64 && p.cin != 128) || p.Kpad != p.cin || p.mask || p.stats || p.y32 || p.ostrided || p.sigmoid || !p.y) {
         set_error("tedspad_conv_fwd: tile_cfg 19 (persistent pointwise) needs a 1x1x1 stride-1 conv with cin 64 or 128 and a plain epilogue");
         return TEDSPAD_EINVAL;
@@ -244,6 +296,7 @@ int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t) {
         set_error("tedspad_conv_pool_t2_fwd: needs at least two frames");
         return TEDSPAD_EINVAL;
     }
+    if (p.x2) return dtype == TEDSPAD_F16 ? launch_pw<F16, 2>(p, false, s) : launch_pw<BF16, 2>(p, false, s);
     if (p.cin == 64) return dtype == TEDSPAD_F16 ? launch_pw<F16, 1>(p, pool_t, s) : launch_pw<BF16, 1>(p, pool_t, s);
     return dtype == TEDSPAD_F16 ? launch_pw<F16, 2>(p, pool_t, s) : launch_pw<BF16, 2>(p, pool_t, s);
 }

@@ -362,6 +362,27 @@ class PackedConv:
                                                       rs.ptr if rs is not None else None, os_.ptr, _stream_ptr()), "tedspad_conv_pool_t2_fwd")
         return out
 
+    def dual_supported(self, other: "PackedConv", x: Act, x2: Act) -> bool:
+        return (self.k == (1, 1, 1) and other.k == (1, 1, 1) and self.stride == (1, 1, 1) and other.stride == (1, 1, 1) and
+                self.cin == 64 and other.cin == 64 and self.cout == other.cout and x.dims == x2.dims and self.dtype_code == other.dtype_code)
+
+    def call_dual(self, x: Act, other: "PackedConv", x2: Act, relu=True) -> Act:
+        """act(self(x) + other(x2)): two 1x1x1 convs with cin = 64 summed in one persistent launch
+        (tedspad_conv_pw_dual_fwd) -- conv3 + bn3 and the downsample branch of the first layer1 bottleneck."""
+        assert self.dual_supported(other, x, x2) and x.c == 64 and x2.c == 64
+        n, t, h, w = x.dims
+        out = Act.empty(n, t, h, w, self.cout, self.torch_dtype, x.buf.device)
+        worst = t * h * w * max(x.ld, x2.ld, self.cout)
+        nc = n if n * worst < MAX_ELEMS else batch_chunk(n, [worst], MAX_ELEMS)
+        for n0 in range(0, n, nc):
+            n1 = min(n, n0 + nc)
+            xs, x2s, os_ = (Act(a.buf[n0:n1], a.c, a.coff) for a in (x, x2, out))
+            d = self._desc(n1 - n0, t, h, w, xs.ld, (0, 0, 0), (t, h, w), os_.ld, 0, relu)
+            check(_lib.lib().tedspad_conv_pw_dual_fwd(C.byref(d), xs.ptr, self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                                      x2s.ptr, x2s.ld, other.w.data_ptr(), other.scale.data_ptr(), other.shift.data_ptr(),
+                                                      os_.ptr, _stream_ptr()), "tedspad_conv_pw_dual_fwd")
+        return out
+
     def _run(self, x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid):
         """One launch (through the tuner) on tensors small enough for the kernel's 32-bit offsets."""
         n, t, h, w = x.dims

@@ -113,6 +113,11 @@ class I3Res50(nn.Module):
                 p = "layer%d.%d." % (li, i)
                 h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
                 h = P[p + "conv2"](h, pads=(0, 1, 1))
+                if blk.downsample is not None and taps is None and P[p + "conv3"].dual_supported(P[p + "down"], h, a):
+                    # layer1.0: conv3 + bn3 and the downsample branch in one launch (the 256-channel downsample tensor
+                    # is never written; both branches stay fp32 until the sum)
+                    a = P[p + "conv3"].call_dual(h, P[p + "down"], a, relu=True)
+                    continue
                 res = P[p + "down"](a, relu=False) if blk.downsample is not None else a
                 if li == 1 and i == len(layer) - 1 and taps is None and P[p + "conv3"].pool_t2_supported(h):
                     # the block's tail and maxpool2 (large_i3d.py:139) in one launch: the 256-channel tensor is only

@@ -224,6 +224,10 @@ AGREE = [
     ("a_1x1x1_c64_res", (7, 3, 13, 11), 64, 256, (1, 1, 1), (0, 0, 0), True),        # persistent pointwise (19): ragged M
     ("a_1x1x1_c128", (3, 2, 9, 10), 128, 72, (1, 1, 1), (0, 0, 0), False),            # ... cin 128, ragged N
     ("a_1x1x1_c64_big", (40, 2, 28, 28), 64, 64, (1, 1, 1), (0, 0, 0), True),         # ... many tiles per persistent workgroup
+    ("a_p8_1x3x3_c256", (3, 2, 14, 13), 256, 256, (1, 3, 3), (0, 1, 1), False),       # ping-pong tile (25): ragged M, 36 K tiles
+    ("a_p8_3x1x1_c128_res", (2, 4, 9, 11), 128, 512, (3, 1, 1), (1, 0, 0), True),     # ... two channel tiles, residual, 6 K tiles
+    ("a_p8_1x1x1_k128", (5, 2, 17, 9), 128, 256, (1, 1, 1), (0, 0, 0), True),         # ... the shortest K it takes (2 K tiles)
+    ("a_p8_1x1x1_k192", (1, 1, 5, 7), 192, 256, (1, 1, 1), (0, 0, 0), False),         # ... odd number of K tiles, one ragged pixel tile
 ]
 
 
@@ -268,6 +272,38 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
         if c in outs:
             assert bool(((outs[c] - first).abs() <= ulp * first.abs() + 1e-4).all()), c
     print(name, "configurations run:", sorted(outs))
+
+
+@pytest.mark.parametrize("dims,cout,ld2", [((3, 4, 11, 13), 256, 64), ((1, 2, 30, 31), 256, 128), ((2, 1, 5, 5), 64, 64)])
+def test_dual_pointwise_equals_two_convs(dims, cout, ld2):
+    """tedspad_conv_pw_dual_fwd (conv3 + bn3 and the downsample branch of layer1.0 in one launch) against the oracle's two
+    convolutions summed in fp32, and against the two-launch path it replaces (which rounds the downsample branch to 16 bits)."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    n, t, h, w = dims
+    tdt = torch.float16
+    x = synth_tensor(11, "dx", (n, t, h, w, 64), -1, 1).to(tdt).float()
+    x2full = synth_tensor(11, "dx2", (n, t, h, w, ld2), -1, 1).to(tdt).float()
+    x2 = x2full[..., ld2 - 64:]                                   # a channel slice of a wider buffer when ld2 > 64
+    w1 = (synth_tensor(11, "dw1", (cout, 64, 1, 1, 1), -1, 1) * (2.0 / 64) ** 0.5).to(tdt).float()
+    w2 = (synth_tensor(11, "dw2", (cout, 64, 1, 1, 1), -1, 1) * (2.0 / 64) ** 0.5).to(tdt).float()
+    s1, b1 = synth_tensor(11, "ds1", (cout,), 0.5, 1.5), synth_tensor(11, "db1", (cout,), -0.3, 0.3)
+    s2, b2 = synth_tensor(11, "ds2", (cout,), 0.5, 1.5), synth_tensor(11, "db2", (cout,), -0.3, 0.3)
+    z = (0, 0, 0)
+    a = conv_cl(x, w1, s1, b1, (1, 1, 1), z, z, None, relu=False)
+    b = conv_cl(x2, w2, s2, b2, (1, 1, 1), z, z, None, relu=False)
+    pc1 = E.PackedConv(w1, s1, b1, dtype="f16", device="cuda")
+    pc2 = E.PackedConv(w2, s2, b2, dtype="f16", device="cuda")
+    xa = E.Act(x.to(tdt).cuda(), 64)
+    x2a = E.Act(x2full.to(tdt).cuda(), 64, ld2 - 64)
+    assert pc1.dual_supported(pc2, xa, x2a)
+    got = pc1.call_dual(xa, pc2, x2a, relu=True).buf.float().cpu()
+    two = pc1(xa, residual=pc2(x2a, relu=False), relu=True).buf.float().cpu()
+    torch.cuda.synchronize()
+    ref = torch.relu(a + b)         # fp32; the fused launch rounds only this sum to f16 (fp32 summation order differs)
+    err = (got - ref).abs()
+    assert bool((err <= 2.0 ** -10 * (a.abs() + b.abs()) + 1e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < 4e-4 and rel_l2(got, two) < 8e-4
 
 
 @pytest.mark.parametrize("dims,cin,cout,use_res", [((3, 4, 11, 13), 64, 256, True), ((2, 5, 7, 9), 128, 72, False),
