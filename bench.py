@@ -35,10 +35,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--arch", default="largei3d", choices=["largei3d", "i3d"])
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--batch", type=int, default=75, help="clips per forward")
+    ap.add_argument("--batch", type=int, default=225, help="clips per forward (225: the 256 x 256 ping-pong tiles of layer3/4 need >= 1 workgroup per CU)")
     ap.add_argument("--clip-times", type=int, default=225, help="clip times per GPU (7200 frames / 32)")
     ap.add_argument("--crops", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the clip batches alternate over (fills the tail of one forward with the next)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the clip batches alternate over (fills the tail of one forward with the next)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -363,7 +363,7 @@ class PackedConv:
         return out
 
     def dual_supported(self, other: "PackedConv", x: Act, x2: Act) -> bool:
-        return (self.k == (1, 1, 1) and other.k == (1, 1, 1) and self.stride == (1, 1, 1) and other.stride == (1, 1, 1) and
+        return (os.environ.get("TEDSPAD_DUAL_PW", "1") != "0" and self.k == (1, 1, 1) and other.k == (1, 1, 1) and self.stride == (1, 1, 1) and other.stride == (1, 1, 1) and
                 self.cin == 64 and other.cin == 64 and self.cout == other.cout and x.dims == x2.dims and self.dtype_code == other.dtype_code)
 
     def call_dual(self, x: Act, other: "PackedConv", x2: Act, relu=True) -> Act:
