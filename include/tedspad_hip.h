@@ -130,6 +130,20 @@ int32_t tedspad_conv_pw_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
                                  const float *shift, const void *x2, int32_t ldx2, const void *w2_packed,
                                  const float *scale2, const float *shift2, void *y, void *stream);
 
+/* Cin = 3 stem in temporal-unfolded form (csrc/conv_stem_tu.hip): Unit3D / conv1 of large_i3d.py:133-137 for inference.
+ * tedspad_clip_to_tu lays the fp32 (n,c<=3,t,h,w) clip out as X'[n][to][h][2][w/2][16] 16-bit (value dt*3 + ci of position
+ * (h, 2*wq + b) = x[n][ci][to*stride_t - pad_t + dt][h][2*wq + b], zero outside the clip; kt <= 5), tedspad_stem_tu_fwd then
+ * runs the stem as a 2-D stride-2 convolution with cin = 16: y[n][to][ho][wo][cout] = act(conv * scale + shift), weights
+ * packed [>= 64][tedspad_stem_tu_kpad(kh, kw)] with k = (dh*kw + dw)*16 + dt*3 + ci. K = kh*kw*16 (784 for 5x7x7) instead
+ * of the 1120 of the pixel-pair form. */
+int32_t tedspad_clip_to_tu(const float *x, void *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc,
+                           int64_t st, int64_t sh, int64_t sw, int32_t kt, int32_t stride_t, int32_t pad_t, int32_t to, int32_t dtype,
+                           void *stream);
+int32_t tedspad_stem_tu_kpad(int32_t kh, int32_t kw);
+int32_t tedspad_stem_tu_fwd(const void *x_tu, const void *w_packed, const float *scale, const float *shift, void *y, int32_t n, int32_t to,
+                            int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t kh, int32_t kw, int32_t ph, int32_t pw, int32_t cout,
+                            int32_t ldy, int32_t relu, int32_t dtype, void *stream);
+
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
  * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be
  * zeroed by the caller (hipMemsetAsync on the same stream); accumulation uses float atomics.

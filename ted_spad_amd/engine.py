@@ -24,6 +24,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # calls of a conv on a new geometry the tile configurations of the kernel take turns, timed in context with
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
+STEM_TU = os.environ.get("TEDSPAD_STEM_TU", "0") == "1"   # temporal-unfolded stem (StemTU): the kernel is 14 % faster, its layout pass costs that back -> off by default
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
 FORCE_TILE_CFG = None   # tests: run every conv with this tile configuration (error if it does not apply)
@@ -492,6 +493,62 @@ def clip_to_act(x: torch.Tensor, cpad: int, dtype: str = DEFAULT_DTYPE) -> Act:
     check(_lib.lib().tedspad_clip_to_channels_last(x.data_ptr(), buf.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw,
                                                    cpad, code, _stream_ptr()), "tedspad_clip_to_channels_last")
     return Act(buf, 8)
+
+
+class StemTU:
+    """The Cin = 3 stem (conv + folded BN + ReLU) in temporal-unfolded form (csrc/conv_stem_tu.hip), inference only:
+    the kt temporal taps x 3 channels become the 16 values of one 32-byte position, the conv a 2-D stride-2 one with
+    K = kh*kw*16 (784 for the 5x7x7 stem of large_i3d.py:133) instead of the 1120 of the pixel-pair form."""
+
+    def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(2, 2, 2), pads=(2, 3, 3),
+                 dtype: str = DEFAULT_DTYPE, device="cuda"):
+        co, ci, kt, kh, kw = weight.shape
+        assert self.supported(weight, stride), "StemTU: cin <= 3, kt <= 5, cout <= 64, spatial stride 2"
+        device = torch.device(device)
+        self.k, self.stride, self.pads, self.cout = (kt, kh, kw), tuple(stride), tuple(pads), (co + 7) // 8 * 8
+        self.torch_dtype, self.dtype_code = DTYPES[dtype]
+        self.kpad = _lib.lib().tedspad_stem_tu_kpad(kh, kw)
+        w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 3, 4, 2, 1).reshape(co, kh * kw, kt * ci)   # (co, tap, dt*ci + c)
+        if ci != 3:
+            w = torch.nn.functional.pad(weight.detach().to(device=device, dtype=torch.float32).permute(0, 3, 4, 2, 1), (0, 3 - ci)).reshape(co, kh * kw, kt * 3)
+        w = torch.nn.functional.pad(w, (0, 16 - w.shape[2])).reshape(co, kh * kw * 16)
+        self.w = torch.zeros((128, self.kpad), dtype=self.torch_dtype, device=device)
+        self.w[:co, :kh * kw * 16] = w.to(self.torch_dtype)
+        self.scale = _padded_vec(scale, co, 128, device, 1.0)
+        self.shift = _padded_vec(shift, co, 128, device, 0.0)
+
+    @staticmethod
+    def supported(weight: torch.Tensor, stride) -> bool:
+        co, ci, kt, kh, kw = weight.shape
+        return ci <= 3 and kt <= 5 and co <= 64 and kh <= 7 and kw <= 7 and tuple(stride[1:]) == (2, 2)
+
+    def layout(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 (n, c, t, h, w) clip batch (W contiguous, a multiple of 8) -> X'[n][to][h][2][w/2][16]."""
+        require_cuda(x, "StemTU")
+        if x.dtype != torch.float32:
+            x = x.float()
+        n, c, t, h, w = x.shape
+        to = conv_out(t, self.k[0], self.stride[0], self.pads[0], self.pads[0])
+        xtu = torch.empty((n, to, h, 2, w // 2, 16), dtype=self.torch_dtype, device=x.device)
+        sn, sc, st, sh, sw = x.stride()
+        check(_lib.lib().tedspad_clip_to_tu(x.data_ptr(), xtu.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw, self.k[0], self.stride[0], self.pads[0],
+                                            to, self.dtype_code, _stream_ptr()), "tedspad_clip_to_tu")
+        return xtu
+
+    def conv(self, xtu: torch.Tensor, relu=True) -> Act:
+        n, to, h, _, wq, _ = xtu.shape
+        w = 2 * wq
+        kt, kh, kw = self.k
+        ho, wo = conv_out(h, kh, 2, self.pads[1], self.pads[1]), conv_out(w, kw, 2, self.pads[2], self.pads[2])
+        out = Act.empty(n, to, ho, wo, self.cout, self.torch_dtype, xtu.device)
+        check(_lib.lib().tedspad_stem_tu_fwd(xtu.data_ptr(), self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, to, h, w,
+                                             ho, wo, kh, kw, self.pads[1], self.pads[2], self.cout, out.ld, int(relu), self.dtype_code, _stream_ptr()),
+              "tedspad_stem_tu_fwd")
+        return out
+
+    def __call__(self, x: torch.Tensor, relu=True) -> Act:
+        """x: fp32 (n, c, t, h, w) clip batch -> the stem's output Act (n, to, ho, wo, cout)."""
+        return self.conv(self.layout(x), relu)
 
 
 def act_to_nchw(x: Act, c: Optional[int] = None) -> torch.Tensor:

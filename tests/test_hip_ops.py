@@ -103,6 +103,34 @@ def test_stem_pixel_pair_rewrite(arch, k, pw):
     assert rel_l2(got, ref) < 4e-4
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 32, 32), (1, 3, 16, 120, 88), (3, 3, 5, 18, 72), (1, 2, 4, 66, 24)])
+def test_stem_temporal_unfolded(shape, dtype):
+    """The Cin = 3 stem as a 2-D stride-2 conv over temporally unfolded positions (engine.StemTU, K = 7*7*16): against
+    the oracle's Conv3d (ragged patches, odd frame counts, frames / rows / columns outside the clip) and against the
+    pixel-pair form it replaces."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, c, t, h, w = shape
+    clip = _round(synth_tensor(5, "tuclip%d" % h, shape), tdt)
+    wgt = _round(synth_tensor(5, "tuw", (64, c, 5, 7, 7), -0.1, 0.1), tdt)
+    scale, shift = synth_tensor(5, "tus", (64,), 0.5, 1.5), synth_tensor(5, "tub", (64,), -0.3, 0.3)
+    ref = conv_cl(clip.permute(0, 2, 3, 4, 1), wgt, scale, shift, (2, 2, 2), (2, 3, 3), (2, 3, 3))
+    tu = E.StemTU(wgt, scale, shift, stride=(2, 2, 2), pads=(2, 3, 3), dtype=dtype, device="cuda")
+    got = tu(clip.cuda()).buf.float().cpu()
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    err = (got - ref).abs()
+    assert bool((err <= ulp * ref.abs() + 2e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
+    if c == 3:
+        pc = E.PackedConv(wgt, scale, shift, stride=(2, 2, 2), dtype=dtype, device="cuda", pair_w=3)
+        old = pc(E.clip_to_act(clip.cuda(), cpad=4, dtype=dtype), pads=(2, 3, pc.pair_pw), pads_back=(2, 3, 1)).buf.float().cpu()
+        assert bool(((got - old).abs() <= ulp * old.abs() + 1e-3).all())
+
+
 POOLS = [
     ("res_maxpool1", (2, 8, 30, 30), 64, (2, 3, 3), (2, 2, 2), (0, 0, 0), (0, 0, 0), False),
     ("res_maxpool2", (2, 4, 9, 9), 256, (2, 1, 1), (2, 1, 1), (0, 0, 0), (0, 0, 0), False),
