@@ -56,6 +56,6 @@ int32_t launch_conv_halo(int dtype, const ConvKP &p, int N, int cin, int bn, hip
 int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t = false);
 
 // conv_p8.hip: ping-pong 256 x 256 kernel (two waves per SIMD one barrier apart) for cin % 64 == 0, cout % 256 == 0 (tile_cfg 25).
-int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s);
+int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s, int mf = 32);   // mf 16: tile_cfg 26 (16x16x32 MFMA)
 
 }  // namespace tedspad

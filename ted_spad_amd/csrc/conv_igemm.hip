@@ -638,7 +638,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
 //  25  256 x 256, PING-PONG (conv_p8.hip): 8 waves, the two waves of a SIMD one barrier apart, 4 phases per K tile, 1 WG/CU
-constexpr int NUM_CFGS = 25;
+//  26  the same on v_mfma_f32_16x16x32 (higher sustained clock; fp32 sums re-associated)
+constexpr int NUM_CFGS = 26;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -668,6 +669,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 18: return launch<T, 128, 128, 2, 2, 2, 0>(p, s);
         case 19: return launch_conv_pw(T::kDtype, p, s);
         case 25: return launch_conv_p8(T::kDtype, p, s);
+        case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
     return TEDSPAD_EINVAL;
