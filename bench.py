@@ -147,7 +147,7 @@ def main():
             traffic = tj["conv_traffic_bytes_per_forward"]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "kernel": "conv stack of one batch forward (conv_igemm_kernel launches + conv_stem_halo_kernel; pools/layout included in the time)",
+                "kernel": "conv stack of one batch forward (conv_p8_kernel + conv_igemm_kernel + conv_pw_kernel launches + conv_stem_halo_kernel; pools/layout included in the time)",
                 "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}
 
     if rank != 0:
