@@ -130,6 +130,14 @@ int32_t tedspad_conv_pw_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
                                  const float *shift, const void *x2, int32_t ldx2, const void *w2_packed,
                                  const float *scale2, const float *shift2, void *y, void *stream);
 
+/* First bottleneck of layer2/3/4 (large_i3d.py:77-84 with a STRIDED downsample branch) as one GEMM on the ping-pong kernel:
+ * y = act([W3*s3 | Wd*sd] . [x ; x2 sampled with stride (sh2, sw2)] + shift). `d` describes the first conv (1x1x1, stride 1,
+ * cin % 64 == 0, cout % 256 == 0); x2 is (n, t, h2, w2) with cin2 % 64 == 0 channels and pixel stride ldx2; w_packed is the
+ * [cout_pad][cin + cin2] matrix with the BatchNorm scales already folded into the rows (scale = ones, shift = b3 + bd). */
+int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, const void *x2, int32_t cin2, int32_t ldx2, int32_t h2, int32_t w2,
+                                 int32_t sh2, int32_t sw2, const void *w_packed, const float *scale, const float *shift, void *y,
+                                 void *stream);
+
 /* Cin = 3 stem in temporal-unfolded form (csrc/conv_stem_tu.hip): Unit3D / conv1 of large_i3d.py:133-137 for inference.
  * tedspad_clip_to_tu lays the fp32 (n,c<=3,t,h,w) clip out as X'[n][to][h][2][w/2][16] 16-bit (value dt*3 + ci of position
  * (h, 2*wq + b) = x[n][ci][to*stride_t - pad_t + dt][h][2*wq + b], zero outside the clip; kt <= 5), tedspad_stem_tu_fwd then

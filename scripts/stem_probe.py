@@ -7,7 +7,7 @@ from ted_spad_amd.synth import synth_state_dict, synth_clips
 with contextlib.redirect_stdout(io.StringIO()):
     ft = load_ft_model('largei3d', num_classes=102)
 ft.load_state_dict(synth_state_dict(ft.state_dict(), 0)); ft = ft.cuda().eval()
-for batch in (50, 75):
+for batch in (75, 225):
     a = E.clip_to_act(synth_clips(0, batch, (3, 16, 224, 224), device='cuda'), cpad=4)
     st = ft.i3d.packed()["stem"]
     call = lambda: st(a, pads=(2, 3, st.pair_pw), pads_back=(2, 3, 1))

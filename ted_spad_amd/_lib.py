@@ -71,6 +71,7 @@ SYMBOLS = {
     "tedspad_l2_normalize_rows": (_I32, [_P, _P, _I32, _I32, C.c_float, _P]),
     "tedspad_conv_pool_t2_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "tedspad_conv_pw_dual_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "tedspad_conv_p8_dual_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P] + [_I32] * 6 + [_P, _P, _P, _P, _P]),
     "tedspad_clip_to_tu": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 5 + [_P]),
     "tedspad_stem_tu_kpad": (_I32, [_I32, _I32]),
     "tedspad_stem_tu_fwd": (_I32, [_P] * 5 + [_I32] * 14 + [_P]),

@@ -32,6 +32,7 @@ struct ConvKP {
     const uint16_t *x2, *w2;
     const float *scale2, *shift2;
     int ldx2;
+    int nk1, Hi2, Wi2, sh2, sw2;     // conv_p8.hip DUAL: K tiles of the first source; grid and spatial stride of the second
 };
 
 constexpr int BK = 64;                  // K elements per LDS tile row (8 chunks of 16 bytes)

@@ -777,7 +777,15 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     p.inv_wo = 1.0f / (float)d->wo; p.inv_ho = 1.0f / (float)d->ho; p.inv_to = 1.0f / (float)d->to;
     p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
-    p.x2 = p.w2 = nullptr; p.scale2 = p.shift2 = nullptr; p.ldx2 = 0;
+    p.x2 = p.w2 = nullptr; p.scale2 = p.shift2 = nullptr; p.ldx2 = 0; p.nk1 = 0; p.Hi2 = p.Wi2 = 0; p.sh2 = p.sw2 = 1;
+    if (dual && dual->nk1 > 0) {      // K-concatenated pair on the ping-pong kernel (tedspad_conv_p8_dual_fwd)
+        TS_REQUIRE(p.pointwise && d->cin % BK == 0 && !residual && !ex && !sigmoid && !pool_t && d->cout % 256 == 0,
+                   "tedspad_conv_p8_dual_fwd: first conv 1x1x1 stride 1 with cin %% 64 == 0, cout %% 256 == 0");
+        p.x2 = dual->x2; p.ldx2 = dual->ldx2; p.nk1 = d->cin / BK; p.Hi2 = dual->Hi2; p.Wi2 = dual->Wi2; p.sh2 = dual->sh2; p.sw2 = dual->sw2;
+        p.Kpad = d->cin + dual->nk1 * BK; p.nk = p.Kpad / BK;      // dual->nk1 carries the K tiles of the SECOND source here
+        p.utap = 1;
+        return launch_conv_p8(d->dtype, p, (hipStream_t)stream);
+    }
     if (dual) {
         TS_REQUIRE(p.pointwise && d->cin == 64 && !residual && !ex && !sigmoid && !pool_t, "tedspad_conv_pw_dual_fwd: two 1x1x1 stride-1 convs with cin = 64");
         p.x2 = dual->x2; p.w2 = dual->w2; p.scale2 = dual->scale2; p.shift2 = dual->shift2; p.ldx2 = dual->ldx2;
@@ -834,6 +842,21 @@ extern "C" int32_t tedspad_conv_pw_dual_fwd(const tedspad_conv_desc *d, const vo
                "tedspad_conv_pw_dual_fwd: second source: null / misaligned pointer or bad ldx2");
     ConvKP dual;
     dual.x2 = (const uint16_t *)x2; dual.w2 = (const uint16_t *)w2_packed; dual.scale2 = scale2; dual.shift2 = shift2; dual.ldx2 = ldx2;
+    dual.nk1 = 0;
+    return conv_fwd_impl(d, x, w_packed, dummy_ktab, scale, shift, nullptr, y, 0, nullptr, stream, 0, &dual);
+}
+
+extern "C" int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, const void *x2, int32_t cin2, int32_t ldx2, int32_t h2, int32_t w2,
+                                            int32_t sh2, int32_t sw2, const void *w_packed, const float *scale, const float *shift, void *y,
+                                            void *stream) {
+    static const int32_t dummy_ktab[2] = {0, 0};
+    TS_REQUIRE(d && x2 && cin2 > 0 && cin2 % BK == 0 && ldx2 >= cin2 && ldx2 % 8 == 0 && (uintptr_t)x2 % 16 == 0 && sh2 > 0 && sw2 > 0 &&
+                   (d->ho - 1) * sh2 < h2 && (d->wo - 1) * sw2 < w2,
+               "tedspad_conv_p8_dual_fwd: second source: cin2 %% 64 == 0, strided grid must cover the output");
+    TS_REQUIRE((long)d->n * d->t * h2 * w2 * ldx2 < (1L << 31), "tedspad_conv_p8_dual_fwd: second source too large for 32-bit gather offsets; split the batch");
+    ConvKP dual;
+    dual.x2 = (const uint16_t *)x2; dual.ldx2 = ldx2; dual.nk1 = cin2 / BK; dual.Hi2 = h2; dual.Wi2 = w2; dual.sh2 = sh2; dual.sw2 = sw2;
+    dual.w2 = nullptr; dual.scale2 = dual.shift2 = nullptr;
     return conv_fwd_impl(d, x, w_packed, dummy_ktab, scale, shift, nullptr, y, 0, nullptr, stream, 0, &dual);
 }
 

@@ -63,7 +63,11 @@ __device__ __forceinline__ void keep4(const uint4 &v) { asm volatile("" ::"v"(v.
 // DMAC = 1 (experiment, not instantiated): the LDS-DMA instructions of a phase issued from the COMPUTE segment, between its MFMAs.
 // Measured 10-25 % SLOWER on every layer shape (and 5-10x slower on two of them): a DMA instruction holds the wave for its whole
 // queueing time at the CU's address unit, and the MFMAs behind it in program order wait with it. The load segment is where it belongs.
-template <typename T, int ABL, int MF = 32, int DMAC = 0>
+// DUAL: K-concatenated pair of pointwise convs with two sources (tedspad_conv_p8_dual_fwd): K tiles [0, nk1) gather from x (1x1x1,
+// stride 1), K tiles [nk1, nk) from x2 (1x1x1 with spatial stride (sh2, sw2) on an (Hi2, Wi2) grid) -- conv3 and the strided downsample
+// conv of the first bottleneck of layer2/3/4 (large_i3d.py:77-84) as ONE GEMM over [W3*s3 | Wd*sd]: the downsample tensor is never
+// written or re-read and its launch disappears.
+template <typename T, int ABL, int MF = 32, int DMAC = 0, bool DUAL = false>
 __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ROWB = BK * 2;                 // 128-byte rows
@@ -88,13 +92,19 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     // the block's two instructions per unit cover rows [wave*8 + lane/8] and [64 + ...] --------------------------------
     const int rsub = wave * 8 + (lane >> 3);
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);   // SOURCE chunk (swizzle (row >> 1) & 7 on the source)
-    int a_base[4];
+    int a_base[4], a_base2[DUAL ? 4 : 1];
     unsigned a_mask[4];   // bits 0..6 valid dt, 8..14 valid dh, 16..22 valid dw
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + i * 64 + rsub;       // i = 2*half + slot
         a_base[i] = 0;
         a_mask[i] = 0;
+        if (DUAL) a_base2[i] = 0;
+        if (DUAL && m < p.M) {
+            const int r1 = fdiv_p(m, p.Wo, p.inv_wo), wo = m - r1 * p.Wo;
+            const int r2 = fdiv_p(r1, p.Ho, p.inv_ho), ho = r1 - r2 * p.Ho;      // r2 = n * To + to (no temporal stride)
+            a_base2[i] = ((r2 * p.Hi2 + ho * p.sh2) * p.Wi2 + wo * p.sw2) * p.ldx2;
+        }
         if (m < p.M) {
             if (p.pointwise) {
                 a_base[i] = m * p.ldx;
@@ -127,8 +137,16 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
 
     // K tile -> tap: wave-uniform counters advancing with the staging order (cin % 64 == 0: a tile never straddles a tap)
     int u_dt = 0, u_dh = 0, u_dw = 0, u_c = 0;
+    int u_tile = 0;
     auto next_entry = [&]() -> int2 {
         int2 e;
+        if (DUAL) {      // both sources are pointwise: K tile -> channel offset inside its source; bit 30 of e.y marks the second source
+            const bool second = u_tile >= p.nk1;
+            e.x = (second ? u_tile - p.nk1 : u_tile) * BK + kc * 8;
+            e.y = (8 << 8) | (16 << 16) | (second ? (1 << 30) : 0);
+            ++u_tile;
+            return e;
+        }
         e.x = ((u_dt * p.Hi + u_dh) * p.Wi + u_dw) * p.ldx + u_c + kc * 8;
         e.y = u_dt | ((8 + u_dh) << 8) | ((16 + u_dw) << 16);
         u_c += BK;
@@ -138,12 +156,14 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     // unit slots: slot = (tile & 1) * 4 + {0: Xh0, 1: Wh0, 2: Wh1, 3: Xh1}
     auto stage_x = [&](int2 e, int half, int slot) {
         const unsigned dst = ldsw + slot * UNIT;
-        const unsigned s_t = e.y & 255, s_h = (e.y >> 8) & 255, s_w = (unsigned)e.y >> 16;
+        const unsigned s_t = e.y & 255, s_h = (e.y >> 8) & 255, s_w = ((unsigned)e.y >> 16) & 255;
+        const bool second = DUAL && (e.y & (1 << 30));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned mk = a_mask[half * 2 + i];
             const unsigned ok = (mk >> s_t) & (mk >> s_h) & (mk >> s_w) & 1u;
-            const uint16_t *src = (ABL & 8) ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + (e.x & 1023)) : ok ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + e.x) : zero;
+            const uint16_t *src = (ABL & 8) ? p.x + (ptrdiff_t)(a_base[half * 2 + i] + (e.x & 1023)) : !ok ? zero :
+                                  second ? p.x2 + (ptrdiff_t)(a_base2[DUAL ? half * 2 + i : 0] + e.x) : p.x + (ptrdiff_t)(a_base[half * 2 + i] + e.x);
             lds_dma16(src, dst + i * 64 * ROWB);
         }
     };
@@ -374,6 +394,10 @@ int32_t launch_p8(const ConvKP &p, hipStream_t s, int mf) {
     q.tiles_n = p.Cout / 256;
     const int tiles_m = (p.M + 255) / 256;
     const dim3 grid(tiles_m * q.tiles_n), block(512);
+    if (p.x2) {
+        hipLaunchKernelGGL((conv_p8_kernel<T, 0, 32, 0, true>), grid, block, 0, s, q);
+        return check_launch("tedspad_conv_p8_dual_fwd");
+    }
     if (mf == 16) {
         hipLaunchKernelGGL((conv_p8_kernel<T, 0, 16>), grid, block, 0, s, q);
         return check_launch("tedspad_conv_fwd(p8/16)");
@@ -407,6 +431,10 @@ extern "C" int32_t tedspad_debug_set_p8_ts(void *buf) {
 namespace tedspad {
 
 int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s, int mf) {
+    if (p.x2 && (!p.pointwise || p.res || p.nk1 < 1 || p.nk1 >= p.nk)) {
+        set_error("tedspad_conv_p8_dual_fwd: two 1x1x1 convs (the first with stride 1), no residual");
+        return TEDSPAD_EINVAL;
+    }
     if (!p.utap || p.nk < 2 || p.Cout % 256 != 0 || p.sigmoid || p.mask || p.stats || p.ostrided || p.y32 || !p.y) {
         set_error("tedspad_conv_fwd: ping-pong config needs cin %% 64 == 0, K >= 128, cout %% 256 == 0 and the plain epilogue");
         return TEDSPAD_EINVAL;

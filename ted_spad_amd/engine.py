@@ -384,6 +384,38 @@ class PackedConv:
                                                       os_.ptr, _stream_ptr()), "tedspad_conv_pw_dual_fwd")
         return out
 
+    @classmethod
+    def fused_pair(cls, w1: torch.Tensor, s1, b1, w2: torch.Tensor, s2, b2, dtype: str = DEFAULT_DTYPE, device="cuda") -> "PackedConv":
+        """[W1*s1 | W2*s2] as ONE 1x1x1 matrix over the concatenated input channels (shift = b1 + b2, scale = 1): the
+        K-concatenated form of `act(bn(conv1(x)) + bn(conv2(x2)))` that `call_dual_p8` runs as a single GEMM."""
+        assert tuple(w1.shape[2:]) == (1, 1, 1) and tuple(w2.shape[2:]) == (1, 1, 1) and w1.shape[0] == w2.shape[0]
+        dev = torch.device(device)
+        wc = torch.cat([w1.detach().to(dev, torch.float32) * s1.to(dev).view(-1, 1, 1, 1, 1),
+                        w2.detach().to(dev, torch.float32) * s2.to(dev).view(-1, 1, 1, 1, 1)], dim=1)
+        pc = cls(wc, torch.ones(w1.shape[0], device=dev), (b1.to(dev) + b2.to(dev)), dtype=dtype, device=dev)
+        pc.cin1, pc.cin2 = int(w1.shape[1]), int(w2.shape[1])
+        return pc
+
+    def dual_p8_supported(self, x: Act, x2: Act, stride2) -> bool:
+        n, t, h, w = x.dims
+        n2, t2, h2, w2 = x2.dims
+        return (os.environ.get("TEDSPAD_DUAL_P8", "1") != "0" and getattr(self, "cin1", 0) > 0 and self.cin1 % 64 == 0 and self.cin2 % 64 == 0 and
+                self.cout % 256 == 0 and x.c == self.cin1 and x2.c == self.cin2 and n2 == n and t2 == t and
+                (h - 1) * stride2[0] < h2 and (w - 1) * stride2[1] < w2 and n * t * h2 * w2 * x2.ld < MAX_ELEMS and n * t * h * w * max(x.ld, self.cout) < MAX_ELEMS)
+
+    def call_dual_p8(self, x: Act, x2: Act, stride2=(2, 2), relu=True) -> Act:
+        """act([W1*s1 | W2*s2] . [x ; x2 sampled with spatial stride stride2] + shift) on the ping-pong kernel
+        (tedspad_conv_p8_dual_fwd): conv3 + bn3 and the strided downsample branch of layer2.0 / 3.0 / 4.0 as one GEMM."""
+        assert self.dual_p8_supported(x, x2, stride2)
+        n, t, h, w = x.dims
+        out = Act.empty(n, t, h, w, self.cout, self.torch_dtype, x.buf.device)
+        d = self._desc(n, t, h, w, x.ld, (0, 0, 0), (t, h, w), out.ld, 0, relu)
+        d.cin = self.cin1
+        check(_lib.lib().tedspad_conv_p8_dual_fwd(C.byref(d), x.ptr, x2.ptr, self.cin2, x2.ld, x2.dims[2], x2.dims[3], stride2[0], stride2[1],
+                                                  self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, _stream_ptr()),
+              "tedspad_conv_p8_dual_fwd")
+        return out
+
     def _run(self, x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid):
         """One launch (through the tuner) on tensors small enough for the kernel's 32-bit offsets."""
         n, t, h, w = x.dims

@@ -84,6 +84,10 @@ class I3Res50(nn.Module):
                         s, b = self._bn_fold(blk.downsample[1])
                         P[p + "down"] = E.PackedConv(blk.downsample[0].weight, s, b, stride=(1, blk.stride, blk.stride),
                                                      dtype=self.compute_dtype, device=dev)
+                        if blk.stride == 2:     # conv3 + bn3 and the strided downsample branch as one K-concatenated GEMM
+                            s3, b3 = self._bn_fold(blk.bn3)
+                            P[p + "dual"] = E.PackedConv.fused_pair(blk.conv3.weight, s3, b3, blk.downsample[0].weight, s, b,
+                                                                    dtype=self.compute_dtype, device=dev)
             self._packed, self._packed_sig = P, sig
         return self._packed
 
@@ -121,6 +125,10 @@ class I3Res50(nn.Module):
                     # layer1.0: conv3 + bn3 and the downsample branch in one launch (the 256-channel downsample tensor
                     # is never written; both branches stay fp32 until the sum)
                     a = P[p + "conv3"].call_dual(h, P[p + "down"], a, relu=True)
+                    continue
+                if (p + "dual") in P and taps is None and P[p + "dual"].dual_p8_supported(h, a, (blk.stride, blk.stride)):
+                    # layer2.0 / 3.0 / 4.0: the same pair as ONE GEMM over [W3*s3 | Wd*sd] on the ping-pong kernel
+                    a = P[p + "dual"].call_dual_p8(h, a, (blk.stride, blk.stride), relu=True)
                     continue
                 res = P[p + "down"](a, relu=False) if blk.downsample is not None else a
                 if li == 1 and i == len(layer) - 1 and taps is None and P[p + "conv3"].pool_t2_supported(h):

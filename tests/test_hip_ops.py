@@ -334,6 +334,38 @@ def test_dual_pointwise_equals_two_convs(dims, cout, ld2):
     assert rel_l2(got, ref) < 4e-4 and rel_l2(got, two) < 8e-4
 
 
+@pytest.mark.parametrize("dims,c1,c2,cout,stride", [((3, 2, 14, 14), 128, 256, 512, 2), ((2, 2, 7, 9), 256, 512, 1024, 2), ((1, 3, 5, 5), 64, 64, 256, 1),
+                                                    ((2, 1, 28, 27), 128, 64, 256, 2)])
+def test_dual_p8_k_concatenated_pair(dims, c1, c2, cout, stride):
+    """tedspad_conv_p8_dual_fwd (conv3 + bn3 and the STRIDED downsample branch of layer2.0 / 3.0 / 4.0 as one GEMM over
+    [W3*s3 | Wd*sd]) against the oracle's two convolutions summed in fp32 and against the two launches it replaces."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    n, t, h, w = dims
+    h2, w2 = (h - 1) * stride + 1 + (stride - 1), (w - 1) * stride + 1      # odd / even source grids
+    tdt = torch.float16
+    x = synth_tensor(12, "px", (n, t, h, w, c1), -1, 1).to(tdt).float()
+    x2 = synth_tensor(12, "px2", (n, t, h2, w2, c2), -1, 1).to(tdt).float()
+    w1 = (synth_tensor(12, "pw1", (cout, c1, 1, 1, 1), -1, 1) * (2.0 / c1) ** 0.5).to(tdt).float()
+    w2_ = (synth_tensor(12, "pw2", (cout, c2, 1, 1, 1), -1, 1) * (2.0 / c2) ** 0.5).to(tdt).float()
+    s1, b1 = synth_tensor(12, "ps1", (cout,), 0.5, 1.5), synth_tensor(12, "pb1", (cout,), -0.3, 0.3)
+    s2, b2 = synth_tensor(12, "ps2", (cout,), 0.5, 1.5), synth_tensor(12, "pb2", (cout,), -0.3, 0.3)
+    z = (0, 0, 0)
+    a = conv_cl(x, w1, s1, b1, (1, 1, 1), z, z, None, relu=False)
+    b = conv_cl(x2, w2_, s2, b2, (1, stride, stride), z, z, None, relu=False)[:, :, :h, :w]
+    ref = torch.relu(a + b)
+    pc = E.PackedConv.fused_pair(w1, s1, b1, w2_, s2, b2, dtype="f16", device="cuda")
+    xa, x2a = E.Act(x.to(tdt).cuda(), c1), E.Act(x2.to(tdt).cuda(), c2)
+    assert pc.dual_p8_supported(xa, x2a, (stride, stride))
+    got = pc.call_dual_p8(xa, x2a, (stride, stride), relu=True).buf.float().cpu()
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    # the BatchNorm scales are folded into the 16-bit weights here (one more rounding per weight than the two-launch path)
+    err = (got - ref).abs()
+    assert bool((err <= 2.0 ** -9 * (a.abs() + b.abs()) + 2e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < 5e-4
+
+
 @pytest.mark.parametrize("dims,cin,cout,use_res", [((3, 4, 11, 13), 64, 256, True), ((2, 5, 7, 9), 128, 72, False),
                                                    ((2, 2, 16, 16), 64, 64, True), ((1, 8, 30, 30), 64, 256, True)])
 def test_conv_pool_t2_fused_equals_conv_then_pool(dims, cin, cout, use_res):
