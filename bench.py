@@ -113,6 +113,11 @@ def main():
             multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
             with torch.cuda.stream(streams[(i // args.batch) % len(streams) if multi and i else 0]):
                 fx(clips[:args.batch])
+        rem = n_local % args.batch              # a ragged last batch is its own conv geometry: tune it too
+        for i in range(96 if (rem and _E.AUTOTUNE) else 0):
+            multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
+            with torch.cuda.stream(streams[i % len(streams) if multi and i else 0]):
+                fx(clips[:rem])
         torch.cuda.synchronize()
         for _ in range(args.warmup):
             step(False)

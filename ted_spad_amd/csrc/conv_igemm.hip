@@ -423,11 +423,12 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
     __syncthreads();  // table complete (and its global loads retired) before any DMA is counted
     // ---- halo: one 16-byte DMA per position, lane-linear in LDS --------------------------------
     const int t0 = to * p.st - p.pt, h0 = ho0 * p.sh - p.ph, w0 = wo0 * p.sw - p.pw;
-    for (int i = 0; i < NH; ++i) {
+    const float inv_wh = 1.0f / (float)WH, inv_hh = 1.0f / (float)HH;   // fp32 reciprocal + exactness fix-up instead of integer division:
+    for (int i = 0; i < NH; ++i) {                                       // 2 divisions x up to 15 DMA slots per thread were ~4 k cycles of a 10 k prologue
         if (i * NT + wave * 64 >= Pr) break;             // wave-uniform: nothing of this instruction is inside the halo
         const int idx = i * NT + tid;
-        const int ww = idx % WH; const int r = idx / WH;
-        const int hh = r % HH; const int dt = r / HH;
+        const int r = fdiv(idx, WH, inv_wh); const int ww = idx - r * WH;
+        const int dt = fdiv(r, HH, inv_hh); const int hh = r - dt * HH;
         const int it = t0 + dt, ih = h0 + hh, iw = w0 + ww;
         const bool ok = idx < P && (unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
         const uint16_t *src = ok ? p.x + ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.ldx : zero;
