@@ -640,6 +640,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
 //  25  256 x 256, PING-PONG (conv_p8.hip): 8 waves, the two waves of a SIMD one barrier apart, 4 phases per K tile, 1 WG/CU
 //  26  the same on v_mfma_f32_16x16x32 (higher sustained clock; fp32 sums re-associated)
+// (256 x 64 with 4 waves of 64 px x 64 co, and 512 x 64 with 8 such waves, were measured on the 64-channel layers of layer1: 404 / 455 us
+//  against 390 us for tile 17 -- every tile shape lands on the same ~515 TFLOP/s there, time proportional to K: the L2 -> LDS stream)
 constexpr int NUM_CFGS = 26;
 
 template <typename T>
