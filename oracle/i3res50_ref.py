@@ -97,11 +97,12 @@ def extract_features(x, sd, q=_id, taps=None):
     return x.mean(dim=(2, 3, 4), keepdim=True)
 
 
-def forward(x, sd, train=False):
+def forward(x, sd, train=False, frozen_bn=False):
     """I3Res50.forward, large_i3d.py:228-246 -> (logits (B,nc), feat = avgpool.squeeze()).
+    frozen_bn: the trunk's BatchNorm3d layers replaced by FrozenBN (large_i3d.py:8-38, `freeze_bn` :30-38): running statistics.
     Dropout(0.5) before fc is stochastic in train mode; the oracle omits it (p -> 0),
     SURVEY.md Q13. `feat` is taken BEFORE dropout, so it is unaffected."""
-    x = trunk(x, sd, bn=_bn_train if train else _bn_eval)
+    x = trunk(x, sd, bn=_bn_train if (train and not frozen_bn) else _bn_eval)
     x = x.mean(dim=(2, 3, 4), keepdim=True)
     feat = x.squeeze()
     logits = F.linear(x.flatten(1), sd["fc.weight"], sd["fc.bias"])
@@ -116,8 +117,8 @@ def mlp(feat, sd, p="mlp.", train=False):
     return F.normalize(h, p=2, dim=1)
 
 
-def wrapper_forward(x, sd, train=False):
+def wrapper_forward(x, sd, train=False, frozen_bn=False):
     """wrapper_i3d.forward, model_loaders.py:265-268; sd keys prefixed `i3d.` / `mlp.`."""
     i3d = {k[4:]: v for k, v in sd.items() if k.startswith("i3d.")}
-    pred, feat = forward(x, i3d, train=train)
+    pred, feat = forward(x, i3d, train=train, frozen_bn=frozen_bn)
     return pred, mlp(feat, sd, "mlp.", train=train)

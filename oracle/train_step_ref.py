@@ -23,8 +23,8 @@ def _grad_sd(sd):
             for k, v in sd.items()}
 
 
-def _utility(ft_sd, clips, labels, train, tlw=0.1):
-    heads = [i3res50_ref.wrapper_forward(c, ft_sd, train=train) for c in clips]
+def _utility(ft_sd, clips, labels, train, tlw=0.1, frozen_bn=False):
+    heads = [i3res50_ref.wrapper_forward(c, ft_sd, train=train, frozen_bn=frozen_bn) for c in clips]
     ce = losses_ref.cross_entropy_torch(heads[0][0], labels)
     trip = losses_ref.triplet_torch(heads[0][1], heads[1][1], heads[2][1])
     return ce + tlw * trip, ce, trip
@@ -77,3 +77,21 @@ def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
     loss_ft.backward()
     grads = {k: p.grad for k, p in ft.items() if p.requires_grad and p.grad is not None}
     return dict(loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads
+
+
+def action_step(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
+    """One iteration of action_training/train_anonymized_action.py:43-94 (`--temporal_loss trip`, cross-entropy loss):
+    fa under no_grad (:52-57), ft with its trunk BatchNorm3d layers frozen (`freeze_bn`, :39-40; FrozenBN keeps gamma / beta
+    as BUFFERS, large_i3d.py:15-20, so they get no gradient: dropped from the returned dict), head in train mode.
+    Parity of this restatement is unpinned (no golden vector was captured through the reference for this script)."""
+    ft = _grad_sd(ft_sd)
+    v = video_b48.permute(0, 2, 1, 3, 4)
+    b, c, t, h, w = v.shape
+    with torch.no_grad():
+        anon = unet_ref.forward(v.reshape(-1, c, h, w), fa_sd, train=False).reshape(b, c, t, h, w)
+    clips = torch.split(anon, [num_frames] * 3, dim=2)
+    loss, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw, frozen_bn=True)
+    loss.backward()
+    frozen = {k for k in ft if k.startswith("i3d.") and (".bn" in k or k.startswith("i3d.bn") or ".downsample.1." in k)}
+    grads = {k: p.grad for k, p in ft.items() if p.requires_grad and p.grad is not None and k not in frozen}
+    return dict(loss=loss.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads

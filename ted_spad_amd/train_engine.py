@@ -282,6 +282,10 @@ class ConvLayer:
         g = self._dwp[:co, :pc.K].view(co, kt_, kh_, kw_, pc.cin).permute(0, 4, 1, 2, 3)
         g = E.stem_pair_grad(g, ci, kw, self.pair_w) if self.pair_w is not None else g[:, :ci]
         g = g.reshape(self.weight.shape)
+        rs = getattr(self, "_grad_row_scale", None)      # frozen-BN mode: d(conv output) = delta * folded BN scale per output channel
+        if rs is not None:
+            g = g * rs[:co].view([-1] + [1] * (g.dim() - 1))
+            self._grad_row_scale = None
         self.weight.grad = g.contiguous() if self.weight.grad is None else self.weight.grad + g
         if self.bias is not None and self._db is not None:
             db = self._db[:co]

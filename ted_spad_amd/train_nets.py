@@ -82,8 +82,10 @@ def _mul(a, b, scale):
 class BottleneckTrunk:
     """stem conv + BN + ReLU -> max-pool -> bottleneck blocks (optionally a max-pool in front of a block) -> global
     average pool, forward with tape and both backward flavours:
-       'train': batch-statistics BN, parameter gradients (+ nothing w.r.t. the input)
-       'eval' : BN folded, gradient w.r.t. the INPUT only (the network is frozen in that phase)."""
+       'train' : batch-statistics BN, parameter gradients (+ nothing w.r.t. the input)
+       'eval'  : BN folded, gradient w.r.t. the INPUT only (the network is frozen in that phase)
+       'frozen': BN folded (FrozenBN of large_i3d.py:8-38: running statistics, gamma / beta are buffers), gradients of the CONV
+                 WEIGHTS only -- `freeze_bn(ft_model)` of action_training/train_anonymized_action.py:39-40."""
 
     def __init__(self, stem, stem_bn, pool1, blocks):
         """pool1 = (kernel, stride, pads); blocks = dicts with c1,c2,c3,cd (ConvLayer | None), bn1,bn2,bn3,bnd,
@@ -111,9 +113,10 @@ class BottleneckTrunk:
             self._folds[id(bn)] = hit
         return hit[1], hit[2]
 
-    def forward(self, a: Act, train: bool):
+    def forward(self, a: Act, train: bool, frozen: bool = False):
         """a: the pixel-pair input Act. Returns (f (B,C) fp32 pooled feature, tape)."""
-        tape = dict(train=train, units=[], clip=a)
+        assert not (train and frozen)
+        tape = dict(train=train, frozen=frozen, units=[], clip=a)
 
         def unit(conv, bn, xin, relu=True, residual=None):
             if train:
@@ -167,12 +170,27 @@ class BottleneckTrunk:
             da = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], da, k1, s1, pads=p1)
             TE.conv_bn_act_train_bwd(tape["stem"], da, need_dx=False)
             return None
-        # eval mode: only d(input). delta = gradient w.r.t. a block output's PRE-activation (already ReLU-masked).
+        # eval / frozen mode. delta = gradient w.r.t. a block output's PRE-activation (already ReLU-masked).
+        # frozen: every conv also gets its weight gradient: d(conv output) = delta * scale per output channel, so the packed
+        # accumulator takes wgrad(x, delta) and the rows are multiplied by the folded BN scale when it is flushed.
+        frozen = tape.get("frozen", False)
+
+        def wg(unit, x, d):
+            if frozen:
+                conv, sc = unit
+                conv.wgrad(x, d)
+                conv._grad_row_scale = sc
+
         delta = TE.global_avgpool_bwd(df, last, mask=last)
         for rec in reversed(tape["units"]):
             (c3, s3), (c2, s2), (c1, sc1) = rec["u3"], rec["u2"], rec["u1"]
+            wg(rec["u3"], rec["h2"], delta)
             du2 = c3.dgrad(delta, rec["h2"].dims[1:], scale=s3, mask=rec["h2"])
+            wg(rec["u2"], rec["h1"], du2)
             du1 = c2.dgrad(du2, rec["h1"].dims[1:], scale=s2, mask=rec["h1"])
+            wg(rec["u1"], rec["a_in"], du1)
+            if "ud" in rec:
+                wg(rec["ud"], rec["a_in"], delta)
             t = rec["ud"][0].dgrad(delta, rec["a_in"].dims[1:], scale=rec["ud"][1]) if "ud" in rec else delta
             delta = c1.dgrad(du1, rec["a_in"].dims[1:], scale=sc1, residual=t, mask=None if rec["after_pool"] else rec["a_in"])
             if "pool_idx" in rec:
@@ -180,6 +198,9 @@ class BottleneckTrunk:
                 delta = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], delta, pk, ps, relu_mask=True)
         delta = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], delta, k1, s1, pads=p1, relu_mask=True)
         conv, s = tape["stem"]
+        if frozen:                                                           # the anonymizer in front is not trained: no d(input)
+            wg(tape["stem"], tape["clip"], delta)
+            return None
         return conv.dgrad(delta, tape["clip"].dims[1:], scale=s)             # (B,T,H,W/2,8) == (B,T,H,W,4)
 
 
@@ -230,13 +251,15 @@ class I3DTrainer:
     def forward(self, x: torch.Tensor, mode: str, drop_mask: Optional[torch.Tensor] = None):
         """x: (B,3,T,H,W) fp32 (any strides: a `torch.split` view is fine).
         Returns (pred (B,nc), feat (B,128), tape)."""
-        assert mode in ("eval", "train")
+        assert mode in ("eval", "train", "frozen")
         i3d, mlp = self.m.i3d, self.m.mlp
         E.require_cuda(x, "I3DTrainer")
         if x.shape[0] < 2:
             raise ValueError("wrapper_i3d.forward needs B >= 2 (BatchNorm1d; SURVEY.md Q3)")
-        train = mode == "train"
-        f, tape = self.trunk.forward(E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype), train)   # feat = x.squeeze() BEFORE dropout
+        # 'frozen' (train_anonymized_action.py:39-40): freeze_bn swaps only the BatchNorm3d modules of the trunk; dropout and the
+        # mlp head's BatchNorm1d keep following the module's train flag, i.e. behave as in 'train'
+        train = mode in ("train", "frozen")
+        f, tape = self.trunk.forward(E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype), mode == "train", frozen=mode == "frozen")   # feat = x.squeeze() BEFORE dropout
         tape["mode"], tape["x_shape"] = mode, tuple(x.shape)
         # ---- head: fc on dropout(f) ; mlp on f ---------------------------------------------------------------------
         fd = f
@@ -265,7 +288,7 @@ class I3DTrainer:
         """Accumulates parameter gradients (mode 'train') and/or writes d(loss)/d(clip) into `dx_out`
         ((B,3,T,H,W) fp32 view, any strides; mode 'eval')."""
         i3d, mlp = self.m.i3d, self.m.mlp
-        train = tape["mode"] == "train"
+        train = tape["mode"] in ("train", "frozen")
         f, h, g = tape["f"], tape["h"], tape["g"]
         df = torch.zeros_like(f)
         if dpred is not None:

@@ -206,6 +206,38 @@ class AnonymizerTrainStep:
         return dict(phase=2, loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
                     loss_fb=None if loss_fb is None else float(loss_fb.detach()), skipped=not ok)
 
+    def step_action(self, inputs_video, labels, drop_masks=None):
+        """One iteration of action_training/train_anonymized_action.py:43-94 (`--temporal_loss trip`, cross-entropy): the
+        anonymizer is frozen and run without gradients (:52-57), ft is trained on the anonymised clips with its trunk
+        BatchNorm3d layers frozen (`freeze_bn`, :39-40: running statistics, gamma / beta are buffers and get no gradient;
+        dropout and the mlp head follow the train flag), loss = CE(pred of clip 1) + w * triplet(feat1, feat2, feat3)
+        (:64-84), then the optimizer step on ft (:86-88; the GradScaler is the static `loss_scale` here)."""
+        p = self.params
+        self.fa.eval(); self.ft.train()
+        self.opt_ft.zero_grad(set_to_none=True)                       # :46
+        TE.ARENA.reset(inputs_video.device)
+        frames, shape = self._feed(inputs_video)                      # :47,54-55 (Q2)
+        with torch.no_grad():
+            anon = self.fa(frames).reshape(shape)                     # :56-57
+        clips = torch.split(anon, [p.num_frames] * 3, dim=2)          # :62
+        tapes, leaves = [], []
+        for k, c in enumerate(clips):
+            pred, feat, tape = self.ft_tr.forward(c, "frozen", drop_mask=None if drop_masks is None else drop_masks[k])
+            tapes.append(tape)
+            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
+        loss, loss_ce, loss_trip = self._utility_losses(leaves, labels)
+        loss.backward()
+        for tape, (pl, fl) in zip(tapes, leaves):
+            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad))
+        self.ft_tr.flush_grads()
+        ok = self._unscale(self.ft)
+        allreduce_mean_grads(list(self.ft.parameters()), self.group)
+        if ok:
+            self.opt_ft.step()                                        # :87
+        self.iteration += 1
+        return dict(phase="action", loss=float(loss.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
+                    skipped=not ok)
+
     def step(self, inputs_video, labels, inputs_vispr=None):
         """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft (and fb)."""
         if self.iteration % 2 == 0:

@@ -107,6 +107,36 @@ def test_phase2_update_ft_vs_oracle(loss_scale):
     assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())                     # fa frozen in phase 2
 
 
+def test_action_training_step_frozen_bn_vs_oracle():
+    """action_training/train_anonymized_action.py:43-94: fa frozen, ft trained with its trunk BatchNorm3d
+    layers frozen (freeze_bn): loss values, conv / fc / mlp gradients against the fp32 oracle, no gradient on the frozen
+    BatchNorm parameters, running statistics of the trunk untouched, the Adam step changes ft only."""
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
+    labels = torch.tensor([5, 77, 101, 1])
+    ref_l, ref_g = train_step_ref.action_step(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft)
+    fa_before = {k: v.detach().clone() for k, v in fa.state_dict().items()}
+    ft_before = {k: v.detach().clone() for k, v in ft.state_dict().items()}
+    out = step.step_action(video.cuda(), labels.cuda())
+    assert out["phase"] == "action"
+    assert abs(out["loss"] - ref_l["loss"]) < 5e-3 * abs(ref_l["loss"])
+    assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 2e-2 * abs(ref_l["loss_temporal"])
+    got = {k: p.grad for k, p in ft.named_parameters() if p.grad is not None}
+    frozen = [k for k, _ in ft.named_parameters() if k.startswith("i3d.") and (".bn" in k or ".downsample.1." in k)]
+    assert frozen and all(k not in got for k in frozen), "FrozenBN parameters are buffers in the reference: no gradient"
+    assert set(ref_g) <= set(got), sorted(set(ref_g) - set(got))[:5]
+    errs = _report("action step ft grads", got, ref_g, min_cos=0.9, med_cos=0.97)      # eval-mode BN chain: as tight as phase 1
+    assert float(np.median(list(errs.values()))) < 0.25
+    after = ft.state_dict()
+    assert all(torch.equal(after[k], ft_before[k]) for k in after if k.startswith("i3d.") and ("running_" in k or "num_batches" in k)), \
+        "frozen BatchNorm3d: running statistics untouched"
+    assert any(not torch.equal(after[k], ft_before[k]) for k in after if k.endswith("conv1.weight"))     # Adam moved the conv weights
+    assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())                          # fa is not trained here
+
+
 def _smooth(sd, beta=4.0):
     """Every BatchNorm bias = +4: almost no pre-activation is near 0, so the ReLUs are (nearly) the identity and
     the networks are smooth -- the end-to-end gradient error of the tests above (ReLU branch flips) disappears and
