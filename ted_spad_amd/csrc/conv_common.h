@@ -59,4 +59,7 @@ int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t = 
 // conv_p8.hip: ping-pong 256 x 256 kernel (two waves per SIMD one barrier apart) for cin % 64 == 0, cout % 256 == 0 (tile_cfg 25).
 int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s, int mf = 32);   // mf 16: tile_cfg 26 (16x16x32 MFMA)
 
+// conv_flat.hip: flat-halo kernel for stride-1 'same' 1 x kh x kw convs with cin = 64, cout <= 64 (tile_cfg 27).
+int32_t launch_conv_flat(int dtype, const ConvKP &p, int cin, hipStream_t s);
+
 }  // namespace tedspad

@@ -642,7 +642,9 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  26  the same on v_mfma_f32_16x16x32 (higher sustained clock; fp32 sums re-associated)
 // (256 x 64 with 4 waves of 64 px x 64 co, and 512 x 64 with 8 such waves, were measured on the 64-channel layers of layer1: 404 / 455 us
 //  against 390 us for tile 17 -- every tile shape lands on the same ~515 TFLOP/s there, time proportional to K: the L2 -> LDS stream)
-constexpr int NUM_CFGS = 26;
+//  27  256-pixel flat halo (conv_flat.hip): stride-1 'same' 1 x kh x kw convs with cin = 64, cout <= 64: the tile's input halo is one contiguous
+//      run of pixels fetched once, taps read from it; 4 waves, 2 WG/CU
+constexpr int NUM_CFGS = 27;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -672,6 +674,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 18: return launch<T, 128, 128, 2, 2, 2, 0>(p, s);
         case 19: return launch_conv_pw(T::kDtype, p, s);
         case 25: return launch_conv_p8(T::kDtype, p, s);
+        case 27: return launch_conv_flat(T::kDtype, p, cin, s);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);

@@ -252,6 +252,8 @@ AGREE = [
     ("a_1x1x1_c64_res", (7, 3, 13, 11), 64, 256, (1, 1, 1), (0, 0, 0), True),        # persistent pointwise (19): ragged M
     ("a_1x1x1_c128", (3, 2, 9, 10), 128, 72, (1, 1, 1), (0, 0, 0), False),            # ... cin 128, ragged N
     ("a_1x1x1_c64_big", (40, 2, 28, 28), 64, 64, (1, 1, 1), (0, 0, 0), True),         # ... many tiles per persistent workgroup
+    ("a_flat_3x3_c64_w55", (2, 3, 11, 55), 64, 64, (1, 3, 3), (0, 1, 1), False),     # flat-halo tile (27): tiles cross rows, frames and clips
+    ("a_flat_3x3_c64_cout40", (1, 2, 9, 7), 64, 40, (1, 3, 3), (0, 1, 1), True),     # ... frames smaller than a tile, ragged N, residual
     ("a_p8_1x3x3_c256", (3, 2, 14, 13), 256, 256, (1, 3, 3), (0, 1, 1), False),       # ping-pong tile (25): ragged M, 36 K tiles
     ("a_p8_3x1x1_c128_res", (2, 4, 9, 11), 128, 512, (3, 1, 1), (1, 0, 0), True),     # ... two channel tiles, residual, 6 K tiles
     ("a_p8_1x1x1_k128", (5, 2, 17, 9), 128, 256, (1, 1, 1), (0, 0, 0), True),         # ... the shortest K it takes (2 K tiles)
