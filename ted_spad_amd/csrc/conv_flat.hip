@@ -8,7 +8,7 @@
 // copy, no gather arithmetic -- fetched once (47 KB for W = 55 instead of 9 x 32 KB), and every MFMA pixel fragment is read from it at
 // `pixel + tap delta`. Taps that fall outside the frame (which, flattened, alias pixels of the neighbouring row / frame / clip) are
 // redirected per lane to a zero position by a 9-bit validity mask computed once per pixel. Only the [64 co][64 k] weight tile of
-// a tap streams (2-slot ring). One K tile = one tap (64 channels, four k16 sub-steps).
+// a tap streams (3-slot ring, one stage in flight across every barrier). One K tile = one tap (64 channels, four k16 sub-steps).
 //
 // LDS image: positions of 128 bytes; chunk c of position p is stored at chunk c ^ ((p >> 1) & 7) (applied to the DMA source
 // address and to the read address): 16 consecutive positions then cover all 64 banks in every 16-lane group of a ds_read_b128
@@ -31,7 +31,7 @@ struct FlatGeo {
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvKP p, const FlatGeo g) {
-    constexpr int NT = 256, WS = 2;
+    constexpr int NT = 256, WS = 3;      // weight ring: stage kt+2 is issued in step kt, one stage stays in flight across every barrier
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvKP p, const Fl
         lds_dma16(wsrc + kt * BK, dst);
         lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));
     };
-    issue_w(0, 0);
+    issue_w(0, 0);                                       // issue order w(0), halo, w(1): the counted waits below rely on it
     const int NH = (Sr + NT - 1) / NT;
     for (int i = 0; i < NH; ++i) {
         if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvKP p, const Fl
         const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
         lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
     }
+    if (g.ntaps > 1) issue_w(1, 1);
 
     // ---- MFMA roles: wave w owns pixels 64w .. 64w+63 (two 32-pixel fragments) x 64 channels -----------------------------------
     const int l31 = lane & 31, lh = lane >> 5;
@@ -93,9 +94,13 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvKP p, const Fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    if (g.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     int dh = 0, dw = 0;
     for (int kt = 0; kt < g.ntaps; ++kt) {
-        // this tap's pixel positions (do not depend on the weight stage: computed before the wait)
+        // this tap's pixel positions and its first pixel fragments: they depend on the resident halo only, not on the weight
+        // stage, so they are requested BEFORE the wait / barrier of the step
         const int delta = dh * g.W + dw;
         unsigned xoff[2], xswz[2];
 #pragma unroll
@@ -104,13 +109,23 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvKP p, const Fl
             xoff[b] = (unsigned)pos * 128u;
             xswz[b] = (unsigned)(pos >> 1) & 7u;
         }
-        wait_vmcnt<0>();                // weight stage kt (issued one step ago) and, on kt = 0, the halo
-        __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
+        const uint4 fa00 = *reinterpret_cast<const uint4 *>(dsm + xoff[0] + (((unsigned)lh ^ xswz[0]) << 4));
+        const uint4 fa01 = *reinterpret_cast<const uint4 *>(dsm + xoff[1] + (((unsigned)lh ^ xswz[1]) << 4));
+        if (kt + 1 < g.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
+        __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free (on kt = 0 this repeats the barrier above)
         asm volatile("" ::: "memory");
-        if (kt + 1 < g.ntaps) issue_w(kt + 1, (kt + 1) & 1);
-        const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt & 1) * FL_WSTAGE) + l31 * BK;
+        if (kt + 2 < g.ntaps) issue_w(kt + 2, (kt + 2) % WS);
+        const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * FL_WSTAGE) + l31 * BK;
+        {   // k16 sub-step 0 on the fragments requested before the barrier
+            const unsigned c = (unsigned)lh;
+            const uint4 fw0 = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 3)), fw1 = *reinterpret_cast<const uint4 *>(Wt + 32 * BK + ((c ^ swz) << 3));
+            acc[0][0] = T::mfma(fw0, fa00, acc[0][0]);
+            acc[0][1] = T::mfma(fw0, fa01, acc[0][1]);
+            acc[1][0] = T::mfma(fw1, fa00, acc[1][0]);
+            acc[1][1] = T::mfma(fw1, fa01, acc[1][1]);
+        }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 1; ks < 4; ++ks) {
             const unsigned c = (unsigned)((ks << 1) | lh);
             uint4 fa[2], fw[2];
 #pragma unroll
@@ -177,7 +192,7 @@ int32_t launch_flat_t(const ConvKP &p, hipStream_t s) {
     g.W = p.Wi; g.H = p.Hi; g.R = p.ph * p.Wi + p.pw; g.ntaps = p.kh * p.kw;
     g.NP = FL_BM + (p.kh - 1) * p.Wi + (p.kw - 1);
     const int S = (g.NP + 1) * 8;
-    const int main_bytes = (S + 63) / 64 * 64 * 16 + 2 * FL_WSTAGE;
+    const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * FL_WSTAGE;
     const int stage_bytes = FL_BM * (64 + 4) * 4;
     const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
     if (lds > 160 * 1024) {

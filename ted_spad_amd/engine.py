@@ -25,6 +25,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 STEM_TU = os.environ.get("TEDSPAD_STEM_TU", "0") == "1"   # temporal-unfolded stem (StemTU): the kernel is 14 % faster, its layout pass costs that back -> off by default
+SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
 FORCE_TILE_CFG = None   # tests: run every conv with this tile configuration (error if it does not apply)
@@ -296,7 +297,7 @@ class PackedConv:
             check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd")
             return
         if st is None:
-            st = {"cands": list(range(0, L.tedspad_conv_num_tile_cfgs() + 1)), "pos": 0, "rep": 0, "rec": {}}
+            st = {"cands": [c for c in range(0, L.tedspad_conv_num_tile_cfgs() + 1) if c not in SKIP_TILE_CFGS], "pos": 0, "rep": 0, "rec": {}}
             self._cfgs[key] = st
             _TUNING.add((id(self), key))
         while True:
