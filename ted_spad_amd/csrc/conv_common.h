@@ -61,5 +61,7 @@ int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s, int mf = 32); 
 
 // conv_flat.hip: flat-halo kernel for stride-1 'same' 1 x kh x kw convs with cin = 64, cout <= 64 (tile_cfg 27).
 int32_t launch_conv_flat(int dtype, const ConvKP &p, int cin, hipStream_t s);
+// ... and its temporal sibling for stride-1 'same' kt x 1 x 1 convs with cin % 64 == 0, cout <= 64, T <= 4 (tile_cfg 28).
+int32_t launch_conv_tflat(int dtype, const ConvKP &p, int N, int cin, hipStream_t s);
 
 }  // namespace tedspad

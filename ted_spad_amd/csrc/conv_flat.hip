@@ -213,6 +213,167 @@ int32_t launch_flat_t(const ConvKP &p, hipStream_t s) {
     return check_launch("tedspad_conv_fwd(flat halo)");
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Temporal flat-halo kernel (tile_cfg 28): stride-1 "same" kt x 1 x 1 convs (conv1 of the bottlenecks with a temporal kernel,
+// large_i3d.py:47) with cin % 64 == 0, cout <= 64 and T <= 4 frames. The generic tiles fetch every input pixel once per temporal
+// tap; here a workgroup owns 64 consecutive spatial positions of ALL T frames of a clip (wave f = output frame f: 64 px x 64 co), so
+// for each 64-channel chunk the T x 64 input positions (32 KB) are fetched once and serve every tap of every output frame: X bytes
+// per 256 outputs drop from kt x 4 x 32 KB to 4 x 32 KB for cin = 256. Whether a tap exists (frame f + dt - pt inside the clip) is
+// wave-uniform: missing taps are skipped, not multiplied by zeros. K is walked (chunk, tap) instead of (tap, chunk): fp32 sums are
+// re-associated with respect to the generic tiles (like the halo-direct tiles 15 / 16).
+// ------------------------------------------------------------------------------------------------------------------------------
+struct TFlatGeo {
+    int T, HW, tiles_s, nchunks, kt, pt;
+};
+
+template <typename T_>
+__global__ __launch_bounds__(256) void conv_tflat_kernel(const ConvKP p, const TFlatGeo g) {
+    constexpr int NT = 256;
+    constexpr int NP = 256;                              // positions: frame f (< 4) x 64 pixels; position NP is the zero position
+    constexpr int HALO = (NP + 8) * 128;                 // rounded to whole wave instructions (64 slots = 8 positions)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = tile / g.tiles_s, s0 = (tile - n * g.tiles_s) * 64;
+    unsigned char *wbuf = dsm + HALO;                    // [kt][64][64] 16-bit
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16f);
+
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w + (size_t)rsub * p.Kpad + kc * 8;
+    // halo slots of this thread: slot s = i*256 + tid -> position s >> 3 = frame (pos >> 6), pixel (pos & 63); chunk slot s & 7
+    int hsrc[9];                                          // element offset of the slot's source (without the channel chunk), or -1
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int s = i * NT + tid;
+        const int pos = s >> 3, cs = s & 7;
+        const int f = pos >> 6, px = pos & 63;
+        hsrc[i] = -1;
+        if (pos < NP && f < g.T && s0 + px < g.HW) hsrc[i] = (int)((((long)n * g.T + f) * g.HW + s0 + px) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int ch = 0; ch < g.nchunks; ++ch) {
+        if (ch) __builtin_amdgcn_s_barrier();            // every wave has read the previous chunk's halo and weights
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (i * NT + wave * 64 >= (NP + 8) * 8) break;     // wave-uniform
+            lds_dma16(hsrc[i] >= 0 ? p.x + hsrc[i] + ch * 64 : zero, lds0 + (i * NT + wave * 64) * 16);
+        }
+        for (int dt = 0; dt < g.kt; ++dt) {
+            const unsigned dst = lds0 + HALO + dt * FL_WSTAGE + wave * 8 * (BK * 2);
+            const uint16_t *src = wsrc + dt * p.cin + ch * 64;
+            lds_dma16(src, dst);
+            lds_dma16(src + (size_t)32 * p.Kpad, dst + 32 * (BK * 2));
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int dt = 0; dt < g.kt; ++dt) {
+            const int fin = wave + dt - g.pt;             // input frame of this tap for the wave's output frame: wave-uniform
+            if (wave >= g.T || fin < 0 || fin >= g.T) continue;
+            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wbuf + dt * FL_WSTAGE) + l31 * BK;
+            unsigned xoff[2], xswz[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int pos = fin * 64 + b * 32 + l31;
+                xoff[b] = (unsigned)pos * 128u;
+                xswz[b] = (unsigned)(pos >> 1) & 7u;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = T_::mfma(fw[a], fa[b], acc[a][b]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: staging row f*64 + px -> output pixel (n, f, s0 + px) ------------------------------------------------------------
+    constexpr int STG_LD = 64 + 4;
+    float *stg = reinterpret_cast<float *>(dsm);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ml = wave * 64 + b * 32 + l31;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                f32x4 v = {acc[a][b][4 * qd], acc[a][b][4 * qd + 1], acc[a][b][4 * qd + 2], acc[a][b][4 * qd + 3]};
+                *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + a * 32 + 8 * qd + 4 * lh) = v;
+            }
+        }
+    __syncthreads();
+    const int cc = tid & 7, r0 = tid >> 3;
+    const int nch = cc * 8;
+    if (nch >= p.Cout) return;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = r0 + it * 32;
+        const int f = r >> 6, px = r & 63;
+        if (f >= g.T || s0 + px >= g.HW) continue;
+        const size_t m = ((size_t)n * g.T + f) * g.HW + s0 + px;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch + 4);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+        if (p.res) {
+            float rr[8];
+            unpack8<T_>(*reinterpret_cast<const uint4 *>(p.res + m * p.ldres + nch), rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rr[i];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T_>(v);
+    }
+}
+
+template <typename T_>
+int32_t launch_tflat_t(const ConvKP &p, int N, int cin, hipStream_t s) {
+    TFlatGeo g;
+    g.T = p.Ti; g.HW = p.Hi * p.Wi; g.tiles_s = (g.HW + 63) / 64; g.nchunks = cin / 64; g.kt = p.kt; g.pt = p.pt;
+    const int main_bytes = (256 + 8) * 128 + p.kt * FL_WSTAGE;
+    const int stage_bytes = FL_BM * (64 + 4) * 4;
+    const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_tflat_kernel<T_>;
+    if (!attr_set[T_::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T_::kDtype] = 1;
+    }
+    hipLaunchKernelGGL(kfn, dim3(N * g.tiles_s), dim3(256), lds, s, p, g);
+    return check_launch("tedspad_conv_fwd(temporal flat halo)");
+}
+
 }  // namespace
 
 int32_t launch_conv_flat(int dtype, const ConvKP &p, int cin, hipStream_t s) {
@@ -223,6 +384,20 @@ int32_t launch_conv_flat(int dtype, const ConvKP &p, int cin, hipStream_t s) {
         return TEDSPAD_EINVAL;
     }
     return dtype == TEDSPAD_F16 ? launch_flat_t<F16>(p, s) : launch_flat_t<BF16>(p, s);
+}
+
+}  // namespace tedspad
+
+namespace tedspad {
+
+int32_t launch_conv_tflat(int dtype, const ConvKP &p, int N, int cin, hipStream_t s) {
+    const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.ph == 0 && p.pw == 0 && p.pt < p.kt;
+    if (cin % 64 != 0 || p.kh != 1 || p.kw != 1 || p.kt < 2 || p.kt > 3 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.Ti > 4 || p.Cout > 64 ||
+        p.Kpad != p.kt * cin || p.mask || p.stats || p.ostrided || p.y32 || p.sigmoid || !p.y) {
+        set_error("tedspad_conv_fwd: temporal flat-halo config needs a stride-1 'same' kt x 1 x 1 conv (kt 2..3) with cin %% 64 == 0, cout <= 64, T <= 4");
+        return TEDSPAD_EINVAL;
+    }
+    return dtype == TEDSPAD_F16 ? launch_tflat_t<F16>(p, N, cin, s) : launch_tflat_t<BF16>(p, N, cin, s);
 }
 
 }  // namespace tedspad

@@ -644,7 +644,9 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  against 390 us for tile 17 -- every tile shape lands on the same ~515 TFLOP/s there, time proportional to K: the L2 -> LDS stream)
 //  27  256-pixel flat halo (conv_flat.hip): stride-1 'same' 1 x kh x kw convs with cin = 64, cout <= 64: the tile's input halo is one contiguous
 //      run of pixels fetched once, taps read from it; 4 waves, 2 WG/CU
-constexpr int NUM_CFGS = 27;
+//  28  temporal flat halo (conv_flat.hip): stride-1 'same' kt x 1 x 1 convs with cin % 64 == 0, cout <= 64, T <= 4: a workgroup owns 64 spatial
+//      positions of all frames of a clip; each 64-channel chunk of the input is fetched once for all taps (K walked chunk-major)
+constexpr int NUM_CFGS = 28;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -675,6 +677,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 19: return launch_conv_pw(T::kDtype, p, s);
         case 25: return launch_conv_p8(T::kDtype, p, s);
         case 27: return launch_conv_flat(T::kDtype, p, cin, s);
+        case 28: return launch_conv_tflat(T::kDtype, p, N, cin, s);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
