@@ -12,7 +12,7 @@ for batch in (75, 225):
     st = ft.i3d.packed()["stem"]
     call = lambda: st(a, pads=(2, 3, st.pair_pw), pads_back=(2, 3, 1))
     outs = {}
-    for cfg in (9, 20, 21):
+    for cfg in (9, 20, 21, 29, 30):
         E.FORCE_TILE_CFG = cfg
         try:
             o = call()
@@ -26,5 +26,6 @@ for batch in (75, 225):
         outs[cfg] = o.buf.clone()
         print('batch', batch, 'cfg', cfg, '%.1f us' % (e0.elapsed_time(e1) / 10 * 1e3))
     if 20 in outs: print('20 == 9:', bool(torch.equal(outs[9], outs[20])))
+    if 29 in outs: print('29 == 9:', bool(torch.equal(outs[9], outs[29])), ' 30 == 21:', bool(torch.equal(outs[21], outs[30])) if 30 in outs else None)
     if 21 in outs: print('21 vs 9: max |diff| %.3e, differing %.4f %%' % (float((outs[21].float() - outs[9].float()).abs().max()), 100 * float((outs[21] != outs[9]).float().mean())))
     E.FORCE_TILE_CFG = None

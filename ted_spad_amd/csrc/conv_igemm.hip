@@ -374,7 +374,8 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
 // 4 waves, each 64 pixels (2 output rows) x 64 channels; <= 80 KB LDS so two workgroups share a CU
 // (one loads its halo while the other computes).
 // ------------------------------------------------------------------------------------------
-constexpr int ST_TH = 8, ST_TW = 32;          // output patch (rows x cols); ST_TW = one MFMA pixel group
+// output patch (rows x cols) = (256 / TW) x TW with TW = 32 (one MFMA pixel group per row) or 16 (a pixel group = two rows of 16: the
+// 112 x 112 stem outputs of a 224 x 224 clip tile exactly with 16 x 16 patches, while 8 x 32 patches waste 12.5 % of their columns)
 constexpr int ST_WSTAGE = 64 * BK * 2;        // 64 channels x 64 k x 2 B
 
 // FR = output frames per patch (1: 4 waves, 256 pixels; 2: 8 waves, 512 pixels on frames to, to+1). The kernel is bound
@@ -388,9 +389,10 @@ constexpr int ST_WSTAGE = 64 * BK * 2;        // 64 channels x 64 k x 2 B
 // partial sums added through the staging tile -- a single workgroup saturates the matrix cores, so the other workgroup's
 // prologue / epilogue no longer idles them. (fp32 partial sums are re-associated: results within one f16 rounding step
 // of KS = 1, like the halo-direct trunk kernels.)
-template <typename T, int FR, int KS>
+template <typename T, int FR, int KS, int TW = 32>
 __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const ConvKP p, const int HH, const int WH, const int tiles_h, const int tiles_w) {
     constexpr int NT = 256 * FR * KS;
+    constexpr int ST_TH = 256 / TW, ST_TW = TW;
     constexpr int WS = (FR == 1) ? 2 : 4;    // weight ring slots: FR = 2 has the LDS for four (its staging tile is larger anyway)
     constexpr int WL = NT == 256 ? 2 : 1;    // weight DMA instructions per thread and stage
     static_assert(FR * KS <= 2, "8 waves at most");
@@ -454,7 +456,10 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
     const int kh2 = KS == 2 ? wave >> 2 : 0;        // which half of the k16 sub-steps this wave multiplies
     int pixb[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) pixb[g] = ((wf * p.st * HH + (2 * wq + g) * p.sh) * WH + l31 * p.sw) * 16;
+    for (int g = 0; g < 2; ++g) {      // fragment g of wave wq = patch pixels (2*wq + g)*32 .. +31 in row-major order of the TH x TW patch
+        const int pr = ((2 * wq + g) * 32 + l31) / TW, pc = ((2 * wq + g) * 32 + l31) % TW;
+        pixb[g] = ((wf * p.st * HH + pr * p.sh) * WH + pc * p.sw) * 16;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
     for (int r = r0; r < 256 * FR; r += NT / 8) {
-        const int tf = to + (r >> 8), ho = ho0 + ((r & 255) >> 5), wo = wo0 + (r & 31);
+        const int tf = to + (r >> 8), ho = ho0 + (r & 255) / TW, wo = wo0 + (r & 255) % TW;
         if (tf >= p.To || ho >= p.Ho || wo >= p.Wo) continue;
         const size_t m = (((size_t)n * p.To + tf) * p.Ho + ho) * p.Wo + wo;
         const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch);
@@ -563,8 +568,9 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
     }
 }
 
-template <typename T, int FR, int KS>
+template <typename T, int FR, int KS, int TW = 32>
 int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
+    constexpr int ST_TH = 256 / TW, ST_TW = TW;
     if (p.ldx < 8 || p.Cout > 64 || p.Kpad > 8 * 256 * 8 || p.sw != 1 || p.sigmoid) {
         set_error("tedspad_conv_fwd: halo-direct config needs cin == 8, cout <= 64, sw == 1");
         return TEDSPAD_EINVAL;
@@ -581,7 +587,7 @@ int32_t launch_stem_halo(const ConvKP &p, int N, hipStream_t s) {
         return TEDSPAD_EINVAL;
     }
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_stem_halo_kernel<T, FR, KS>;
+    auto kfn = conv_stem_halo_kernel<T, FR, KS, TW>;
     if (attr_set[T::kDtype] < lds) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -646,7 +652,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //      run of pixels fetched once, taps read from it; 4 waves, 2 WG/CU
 //  28  temporal flat halo (conv_flat.hip): stride-1 'same' kt x 1 x 1 convs with cin % 64 == 0, cout <= 64, T <= 4: a workgroup owns 64 spatial
 //      positions of all frames of a clip; each 64-channel chunk of the input is fetched once for all taps (K walked chunk-major)
-constexpr int NUM_CFGS = 28;
+//  29  stem, 16 x 16 patch (otherwise tile 9);  30  stem, 16 x 16 patch with split-K over 8 waves (otherwise tile 21)
+constexpr int NUM_CFGS = 30;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -654,6 +661,8 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 9: return launch_stem_halo<T, 1, 1>(p, N, s);
         case 20: return launch_stem_halo<T, 2, 1>(p, N, s);
         case 21: return launch_stem_halo<T, 1, 2>(p, N, s);
+        case 29: return launch_stem_halo<T, 1, 1, 16>(p, N, s);
+        case 30: return launch_stem_halo<T, 1, 2, 16>(p, N, s);
         case 22: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES, 2>(p, s);
         case 23: return launch<T, 128, 128, 2, 2, 2, 0, 2>(p, s);
         case 24: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES, 2>(p, s);
@@ -823,7 +832,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         return launch_conv_pw(d->dtype, p, s, true);
     }
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
-    if (cfg == 9 || cfg == 20 || cfg == 21) {
+    if (cfg == 9 || cfg == 20 || cfg == 21 || cfg == 29 || cfg == 30) {
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
         TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
     }
