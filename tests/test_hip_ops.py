@@ -338,6 +338,50 @@ def test_dual_pointwise_equals_two_convs(dims, cout, ld2):
     assert rel_l2(got, ref) < 4e-4 and rel_l2(got, two) < 8e-4
 
 
+def test_flat_halo_kernels_on_awkward_geometries():
+    """The flat-halo tiles (27: 1 x kh x kw, 28: kt x 1 x 1) against a generic tile on seeded random small geometries: frames
+    narrower than the kernel, single rows / columns / frames, tiles that span several clips, ragged cout, asymmetric front pads,
+    residual on and off. 27 must agree bit for bit; 28 walks K chunk-major: within one f16 rounding step."""
+    from ted_spad_amd import _lib, engine as E
+    rng = np.random.RandomState(1234)
+    tdt = torch.float16
+    cases = []
+    for _ in range(10):
+        kh, kw = int(rng.choice([1, 2, 3])), int(rng.choice([2, 3]))
+        cases.append((27, (int(rng.randint(1, 5)), int(rng.randint(1, 4)), int(rng.randint(1, 12)), int(rng.randint(1, 20))), 64,
+                      int(rng.choice([8, 24, 40, 64])), (1, kh, kw), (0, int(rng.randint(0, kh)), int(rng.randint(0, kw))), bool(rng.randint(2))))
+    for _ in range(10):
+        kt = int(rng.choice([2, 3]))
+        cases.append((28, (int(rng.randint(1, 5)), int(rng.randint(1, 5)), int(rng.randint(1, 12)), int(rng.randint(1, 14))), int(rng.choice([64, 128, 256])),
+                      int(rng.choice([8, 32, 56, 64])), (kt, 1, 1), (int(rng.randint(0, kt)), 0, 0), bool(rng.randint(2))))
+    ran = {27: 0, 28: 0}
+    for i, (cfg, dims, cin, cout, k, pf, use_res) in enumerate(cases):
+        n, t, h, w = dims
+        pb = tuple(k[d] - 1 - pf[d] for d in range(3))                 # 'same' output extent with an asymmetric split of the padding
+        x = synth_tensor(21, "fz_x%d" % i, (n, t, h, w, cin), -1, 1).to(tdt)
+        wgt = (synth_tensor(21, "fz_w%d" % i, (cout, cin) + k, -1, 1) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5).to(tdt).float()
+        scale, shift = synth_tensor(21, "fz_s%d" % i, (cout,), 0.5, 1.5), synth_tensor(21, "fz_b%d" % i, (cout,), -0.3, 0.3)
+        pc = E.PackedConv(wgt, scale, shift, dtype="f16", device="cuda")
+        xa = E.Act(x.cuda(), cin)
+        ra = E.Act(synth_tensor(21, "fz_r%d" % i, (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout) if use_res else None
+        outs = {}
+        try:
+            for c in (cfg, 5):
+                E.FORCE_TILE_CFG = c
+                outs[c] = pc(xa, pads=pf, pads_back=pb, residual=ra, relu=True).buf.float().cpu()
+        except _lib.TedSpadHipError as e:
+            assert c == cfg, (c, str(e))        # the generic tile always applies; the flat tiles may decline (e.g. T > 4)
+            continue
+        finally:
+            E.FORCE_TILE_CFG = None
+        ran[cfg] += 1
+        if cfg == 27:
+            assert torch.equal(outs[27], outs[5]), (cfg, dims, cin, cout, k, pf)
+        else:
+            assert bool(((outs[28] - outs[5]).abs() <= 2.0 ** -10 * outs[5].abs() + 1e-4).all()), (cfg, dims, cin, cout, k, pf)
+    assert ran[27] >= 6 and ran[28] >= 5, ran
+
+
 @pytest.mark.parametrize("dims,c1,c2,cout,stride", [((3, 2, 14, 14), 128, 256, 512, 2), ((2, 2, 7, 9), 256, 512, 1024, 2), ((1, 3, 5, 5), 64, 64, 256, 1),
                                                     ((2, 1, 28, 27), 128, 64, 256, 2)])
 def test_dual_p8_k_concatenated_pair(dims, c1, c2, cout, stride):
