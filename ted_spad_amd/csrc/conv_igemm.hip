@@ -257,6 +257,18 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
 #endif
 
     // ---- epilogue: fp32 tile -> LDS -> coalesced 16-byte rows --------------------------
+    // The residual rows this thread will add are requested BEFORE the staging writes (forward layers with the plain output map):
+    // their L2 / HBM round trip runs under the staging traffic and the barriers instead of once per row inside the store loop.
+    // Named variables, not an array: hipcc puts a conditionally filled array of this size into scratch.
+    constexpr int NR = BM / RPP;          // output rows per thread
+    static_assert(BM % RPP == 0 && NR <= 8, "epilogue row passes");
+    const bool res_pre = p.res && !p.ostrided && active;
+    auto res_row = [&](int it) -> uint4 {
+        const int m = m0 + r0 + it * RPP;
+        return (res_pre && it < NR && m < p.M) ? *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n) : make_uint4(0, 0, 0, 0);
+    };
+    const uint4 rres0 = res_row(0), rres1 = res_row(1), rres2 = res_row(2), rres3 = res_row(3);
+    const uint4 rres4 = res_row(4), rres5 = res_row(5), rres6 = res_row(6), rres7 = res_row(7);
     float *stg = reinterpret_cast<float *>(smem);
     if (KS == 1 || kh2 == 1) {
 #pragma unroll
@@ -296,53 +308,63 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    if (active) {
-#pragma unroll 4
-        for (int r = r0; r < BM; r += RPP) {
-            const int m = m0 + r;
-            if (m >= p.M) break;
-            size_t op = (size_t)m;
-            if (p.ostrided) {
-                const int wo = m % p.Wo; const int q1 = m / p.Wo;
-                const int ho = q1 % p.Ho; const int q2 = q1 / p.Ho;
-                const int to = q2 % p.To; const int nb = q2 / p.To;
-                op = (((size_t)nb * p.TF + to * p.ost + p.oot) * p.HF + ho * p.osh + p.ooh) * p.WF + wo * p.osw + p.oow;
-            }
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
-            if (p.stats) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
-            }
-            if (p.res) {
-                float rr[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + op * p.ldres + n), rr);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += rr[i];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
-            }
-            if (p.sigmoid) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = 1.f / (1.f + __expf(-v[i]));
-            }
-            if (p.mask) {
-                float mk[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(p.mask + op * p.ldmask + n), mk);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
-            }
-            if (p.y) *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
-            if (p.y32) {
-                *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            }
+    auto out_row = [&](const int it, const uint4 rpre) {
+        const int r = r0 + it * RPP;
+        const int m = m0 + r;
+        if (m >= p.M) return;
+        size_t op = (size_t)m;
+        if (p.ostrided) {
+            const int wo = m % p.Wo; const int q1 = m / p.Wo;
+            const int ho = q1 % p.Ho; const int q2 = q1 / p.Ho;
+            const int to = q2 % p.To; const int nb = q2 / p.To;
+            op = (((size_t)nb * p.TF + to * p.ost + p.oot) * p.HF + ho * p.osh + p.ooh) * p.WF + wo * p.osw + p.oow;
         }
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+        if (p.stats) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+        }
+        if (p.res) {
+            float rr[8];
+            uint4 rv = rpre;
+            if (!res_pre) rv = *reinterpret_cast<const uint4 *>(p.res + op * p.ldres + n);
+            unpack8<T>(rv, rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rr[i];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        }
+        if (p.sigmoid) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 1.f / (1.f + __expf(-v[i]));
+        }
+        if (p.mask) {
+            float mk[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p.mask + op * p.ldmask + n), mk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
+        }
+        if (p.y) *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
+        if (p.y32) {
+            *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    };
+    if (active) {
+        out_row(0, rres0);
+        if constexpr (NR > 1) out_row(1, rres1);
+        if constexpr (NR > 2) out_row(2, rres2);
+        if constexpr (NR > 3) out_row(3, rres3);
+        if constexpr (NR > 4) out_row(4, rres4);
+        if constexpr (NR > 5) out_row(5, rres5);
+        if constexpr (NR > 6) out_row(6, rres6);
+        if constexpr (NR > 7) out_row(7, rres7);
     }
     if (p.stats) {   // block-level reduction of the batch statistics, then one atomic per channel
         __syncthreads();
