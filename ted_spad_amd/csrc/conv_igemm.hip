@@ -675,7 +675,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  28  temporal flat halo (conv_flat.hip): stride-1 'same' kt x 1 x 1 convs with cin % 64 == 0, cout <= 64, T <= 4: a workgroup owns 64 spatial
 //      positions of all frames of a clip; each 64-channel chunk of the input is fetched once for all taps (K walked chunk-major)
 //  29  stem, 16 x 16 patch (otherwise tile 9);  30  stem, 16 x 16 patch with split-K over 8 waves (otherwise tile 21)
-constexpr int NUM_CFGS = 30;
+//  31  stem, two output frames per workgroup (tile 20) on 16 x 16 patches
+constexpr int NUM_CFGS = 31;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -685,6 +686,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 21: return launch_stem_halo<T, 1, 2>(p, N, s);
         case 29: return launch_stem_halo<T, 1, 1, 16>(p, N, s);
         case 30: return launch_stem_halo<T, 1, 2, 16>(p, N, s);
+        case 31: return launch_stem_halo<T, 2, 1, 16>(p, N, s);
         case 22: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES, 2>(p, s);
         case 23: return launch<T, 128, 128, 2, 2, 2, 0, 2>(p, s);
         case 24: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES, 2>(p, s);
@@ -854,7 +856,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         return launch_conv_pw(d->dtype, p, s, true);
     }
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
-    if (cfg == 9 || cfg == 20 || cfg == 21 || cfg == 29 || cfg == 30) {
+    if (cfg == 9 || cfg == 20 || cfg == 21 || (cfg >= 29 && cfg <= 31)) {
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
         TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
     }

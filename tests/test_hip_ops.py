@@ -448,14 +448,14 @@ def test_two_frame_stem_equals_halo_stem(dims):
     a = E.clip_to_act(synth_tensor(13, "stx", (n, 3, t, h, w), device="cuda"), cpad=4)
     outs = {}
     try:
-        for cfg in (9, 20, 21, 29, 30, 2):
+        for cfg in (9, 20, 21, 29, 30, 31, 2):
             E.FORCE_TILE_CFG = cfg
             outs[cfg] = pc(a, pads=(2, 3, pc.pair_pw), pads_back=(2, 3, 1)).buf.clone()
     finally:
         E.FORCE_TILE_CFG = None
     assert torch.equal(outs[9], outs[2])
     assert torch.equal(outs[20], outs[9])
-    assert torch.equal(outs[29], outs[9]) and torch.equal(outs[30], outs[21])    # 16 x 16 patches: same sums, other pixel -> lane map
+    assert torch.equal(outs[29], outs[9]) and torch.equal(outs[30], outs[21]) and torch.equal(outs[31], outs[9])    # 16 x 16 patches: same sums, other pixel -> lane map
     # 21: split-K over 8 waves -- fp32 partial sums re-associated: within one f16 rounding step
     o21, o9 = outs[21].float(), outs[9].float()
     assert bool(((o21 - o9).abs() <= 2.0 ** -10 * o9.abs() + 1e-4).all())
