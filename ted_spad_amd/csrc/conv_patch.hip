@@ -1,0 +1,224 @@
+// Patch-halo convolution for gfx950 (tile_cfg 32): stride-1 'same' 1 x kh x kw convs with cin % 64 == 0 and cout <= 128 on WIDE frames --
+// the DoubleConv layers of the UNet's outer levels (unet_parts.py:8-25: 64 / 128 channels at 224 x 224 and 112 x 112), where the
+// flat-halo tile (conv_flat.hip) needs a halo of 256 + 2 W + 2 pixels and loses its second workgroup per CU.
+//
+// A workgroup owns a 16 x 16 output patch of one frame x all (<= 128) output channels and walks K chunk-major: for every 64-channel
+// chunk of the input the (16 + kh - 1) x (16 + kw - 1) halo (18 x 18 positions x 128 B = 41 KB) is fetched ONCE -- positions
+// outside the frame come from the zero page, so the taps need no masks -- and serves all kh x kw taps; the [BN][64] weight tile of
+// a (chunk, tap) streams through a ring. Same LDS image as conv_flat.hip (128-byte positions, chunk XOR ((position >> 1) & 7) on
+// the DMA source and on the read side), same 4-wave / two-workgroups-per-CU structure; a wave owns four rows of the patch (two
+// MFMA pixel groups of two rows) x BN channels. cin = 64 walks K like the generic tiles (bit-identical); cin > 64 walks (chunk, tap):
+// fp32 sums re-associated, like tiles 15 / 16 / 28.
+#include "conv_common.h"
+
+namespace tedspad {
+namespace {
+
+__device__ uint4 g_zero16q;
+
+constexpr int PT_S = 16;                 // patch side
+
+struct PatchGeo {
+    int HH, WH, NP, ntaps, nchunks, tiles_h, tiles_w;
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const PatchGeo g) {
+    constexpr int NT = 256;
+    constexpr int WS = BN == 64 ? 3 : 2;                  // weight ring slots ([BN][64] 16-bit each)
+    constexpr int WSTAGE = BN * BK * 2;
+    constexpr int WL = BN / 32;                           // weight DMA instructions per thread and stage
+    constexpr int NA = BN / 32;                           // 32-channel fragments per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = b % g.tiles_w; b /= g.tiles_w;
+    const int th = b % g.tiles_h; b /= g.tiles_h;          // b = n * T + t
+    const int ho0 = th * PT_S, wo0 = tw * PT_S;
+    const int S = g.NP * 8;
+    const int Sr = (S + 63) / 64 * 64;
+    const int halo_bytes = Sr * 16;
+    unsigned char *wring = dsm + halo_bytes;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16q);
+
+    // ---- halo slots of this thread: slot s -> position s >> 3 = (row, col) of the halo, stored chunk s & 7 -----------------------
+    constexpr int NHMAX = 12;                              // 12 x 256 slots = 384 positions (e.g. 19 x 19 for a 4 x 4 kernel)
+    int hsrc[NHMAX];                                       // element offset of the slot's source (without the channel chunk), or -1
+    const int NH = (Sr + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < NHMAX; ++i) {
+        const int s = i * NT + tid;
+        const int pos = s >> 3, cs = s & 7;
+        const int hr = pos / g.WH, hc = pos - hr * g.WH;
+        const int ih = ho0 - p.ph + hr, iw = wo0 - p.pw + hc;
+        hsrc[i] = -1;
+        if (i < NH && pos < g.NP && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+            hsrc[i] = (int)((((long)b * p.Hi + ih) * p.Wi + iw) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+    }
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w + (size_t)rsub * p.Kpad + kc * 8;
+    auto issue_w = [&](int ch, int tap, int slot) {
+        const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
+        const uint16_t *src = wsrc + tap * p.cin + ch * 64;
+#pragma unroll
+        for (int j = 0; j < WL; ++j) lds_dma16(src + (size_t)(j * 32) * p.Kpad, dst + j * 32 * (BK * 2));
+    };
+
+    // ---- MFMA roles: wave w owns patch rows 4w .. 4w+3; pixel group b = rows 4w+2b, 4w+2b+1 (lane l31: row l31 >> 4, col l31 & 15) ----
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    int pbase[2];
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) pbase[bq] = (4 * wave + 2 * bq + (l31 >> 4)) * g.WH + (l31 & 15);
+    f32x16 acc[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][bq][r] = 0.f;
+
+    for (int ch = 0; ch < g.nchunks; ++ch) {
+        if (ch) __builtin_amdgcn_s_barrier();              // every wave has read the previous chunk's halo and weight slots
+        asm volatile("" ::: "memory");
+        issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
+#pragma unroll
+        for (int i = 0; i < NHMAX; ++i) {
+            if (i * NT + wave * 64 >= Sr) break;           // wave-uniform
+            lds_dma16(hsrc[i] >= 0 ? p.x + hsrc[i] + ch * 64 : zero, lds0 + (i * NT + wave * 64) * 16);
+        }
+        if (g.ntaps > 1) issue_w(ch, 1, 1);
+        int dh = 0, dw = 0;
+        for (int kt = 0; kt < g.ntaps; ++kt) {
+            const int delta = dh * g.WH + dw;
+            unsigned xoff[2], xswz[2];
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                const int pos = pbase[bq] + delta;
+                xoff[bq] = (unsigned)pos * 128u;
+                xswz[bq] = (unsigned)(pos >> 1) & 7u;
+            }
+            if (kt + 1 < g.ntaps) wait_vmcnt<WL>(); else wait_vmcnt<0>();   // stage kt (and, on kt = 0, the halo) landed; stage kt+1 may stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (WS == 3 && kt + 2 < g.ntaps) issue_w(ch, kt + 2, (kt + 2) % WS);
+            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * WSTAGE) + l31 * BK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[NA];
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) fa[bq] = *reinterpret_cast<const uint4 *>(dsm + xoff[bq] + ((c ^ xswz[bq]) << 4));
+#pragma unroll
+                for (int a = 0; a < NA; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int bq = 0; bq < 2; ++bq) acc[a][bq] = T::mfma(fw[a], fa[bq], acc[a][bq]);
+            }
+            if (WS == 2 && kt + 1 < g.ntaps) {             // two slots: stage kt+1 can only be issued once every wave has read stage kt-1 ... and kt
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < g.ntaps) issue_w(ch, kt + 2, kt & 1);
+            }
+            if (++dw == p.kw) { dw = 0; ++dh; }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: BN / 64 passes of [256 px][64 co] fp32 through LDS -> coalesced 16-byte rows -----------------------------------
+    constexpr int STG_LD = 64 + 4;
+    float *stg = reinterpret_cast<float *>(dsm);
+    const int cc = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int pass = 0; pass < BN / 64; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                const int ml = wave * 64 + bq * 32 + l31;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x16 &A = acc[pass * 2 + a2][bq];
+                    f32x4 v = {A[4 * qd], A[4 * qd + 1], A[4 * qd + 2], A[4 * qd + 3]};
+                    *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + a2 * 32 + 8 * qd + 4 * lh) = v;
+                }
+            }
+        __syncthreads();
+        const int nch = pass * 64 + cc * 8;
+        if (nch < p.Cout) {
+            float sc[8], sf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = r0 + it * 32;                 // staging row = wave*64 + bq*32 + l31  ->  patch row r >> 4, col r & 15
+                const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
+                if (ho >= p.Ho || wo >= p.Wo) continue;
+                const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+                if (p.res) {
+                    float rr[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + m * p.ldres + nch), rr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += rr[i];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+                }
+                *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int BN>
+int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
+    PatchGeo g;
+    g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
+    g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S;
+    const int S = g.NP * 8, Sr = (S + 63) / 64 * 64;
+    if ((Sr + 255) / 256 > 12) {
+        set_error("tedspad_conv_fwd: patch-halo config: kernel too large for the 16 x 16 patch halo");
+        return TEDSPAD_EINVAL;
+    }
+    const int main_bytes = Sr * 16 + (BN == 64 ? 3 : 2) * BN * BK * 2;
+    const int stage_bytes = 256 * (64 + 4) * 4;
+    const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_patch_kernel<T, BN>;
+    if (!attr_set[T::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 1;
+    }
+    hipLaunchKernelGGL(kfn, dim3(NTf * g.tiles_h * g.tiles_w), dim3(256), lds, s, p, g);
+    return check_launch("tedspad_conv_fwd(patch halo)");
+}
+
+}  // namespace
+
+int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s) {
+    const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt == 0 && p.ph < p.kh && p.pw < p.kw;
+    if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 128 ||
+        p.Kpad != p.kh * p.kw * cin || p.mask || p.stats || p.ostrided || p.y32 || p.sigmoid || !p.y) {
+        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' 1 x kh x kw conv with cin %% 64 == 0, cout <= 128 and the plain epilogue");
+        return TEDSPAD_EINVAL;
+    }
+    const int frames = N * p.Ti;
+    if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64>(p, frames, cin, s) : launch_patch_t<BF16, 64>(p, frames, cin, s);
+    return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128>(p, frames, cin, s) : launch_patch_t<BF16, 128>(p, frames, cin, s);
+}
+
+}  // namespace tedspad

@@ -256,6 +256,9 @@ AGREE = [
     ("a_flat_3x3_c64_cout40", (1, 2, 9, 7), 64, 40, (1, 3, 3), (0, 1, 1), True),     # ... frames smaller than a tile, ragged N, residual
     ("a_tflat_3x1x1_c256", (3, 4, 9, 11), 256, 64, (3, 1, 1), (1, 0, 0), False),      # temporal flat-halo tile (28): T = 4, ragged spatial tile
     ("a_tflat_3x1x1_t3_c64", (2, 3, 5, 13), 64, 48, (3, 1, 1), (1, 0, 0), True),      # ... T = 3 (an idle wave), one chunk, ragged N, residual
+    ("a_patch_3x3_c64", (2, 1, 20, 37), 64, 64, (1, 3, 3), (0, 1, 1), True),          # patch-halo tile (32): ragged 16 x 16 patches, residual
+    ("a_patch_3x3_c128_n128", (1, 2, 17, 16), 128, 128, (1, 3, 3), (0, 1, 1), False),  # ... two channel chunks, 128 output channels (2-slot ring)
+    ("a_patch_3x3_c192_n72", (1, 1, 9, 33), 192, 72, (1, 3, 3), (0, 1, 1), False),     # ... three chunks, ragged N in the second staging pass
     ("a_p8_1x3x3_c256", (3, 2, 14, 13), 256, 256, (1, 3, 3), (0, 1, 1), False),       # ping-pong tile (25): ragged M, 36 K tiles
     ("a_p8_3x1x1_c128_res", (2, 4, 9, 11), 128, 512, (3, 1, 1), (1, 0, 0), True),     # ... two channel tiles, residual, 6 K tiles
     ("a_p8_1x1x1_k128", (5, 2, 17, 9), 128, 256, (1, 1, 1), (0, 0, 0), True),         # ... the shortest K it takes (2 K tiles)
@@ -293,7 +296,7 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
                 continue                                   # configuration not applicable to this geometry
     finally:
         E.FORCE_TILE_CFG = None
-    REASSOC = (15, 16, 22, 23, 24, 26, 28)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
+    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
     generic = {c: o for c, o in outs.items() if c not in REASSOC}
     assert len(generic) >= 4, sorted(outs)
     first = next(iter(generic.values()))
