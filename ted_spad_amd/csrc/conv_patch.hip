@@ -8,7 +8,8 @@
 // a (chunk, tap) streams through a ring. Same LDS image as conv_flat.hip (128-byte positions, chunk XOR ((position >> 1) & 7) on
 // the DMA source and on the read side), same 4-wave / two-workgroups-per-CU structure; a wave owns four rows of the patch (two
 // MFMA pixel groups of two rows) x BN channels. cin = 64 walks K like the generic tiles (bit-identical); cin > 64 walks (chunk, tap):
-// fp32 sums re-associated, like tiles 15 / 16 / 28.
+// fp32 sums re-associated, like tiles 15 / 16 / 28. The epilogue also carries the training extras (batch statistics, fp32 output, ReLU-backward
+// mask): the UNet's train-mode forward and its data gradients run on it too.
 #include "conv_common.h"
 
 namespace tedspad {
@@ -150,6 +151,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             }
         __syncthreads();
         const int nch = pass * 64 + cc * 8;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
         if (nch < p.Cout) {
             float sc[8], sf[8];
 #pragma unroll
@@ -165,6 +169,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+                if (p.stats) {          // batch statistics of the pre-activation (train-mode BatchNorm), as the generic epilogue
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                }
                 if (p.res) {
                     float rr[8];
                     unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + m * p.ldres + nch), rr);
@@ -175,7 +183,33 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
                 }
-                *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+                if (p.mask) {           // ReLU backward fused into the data gradient that produces d(input)
+                    float mk[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(p.mask + m * p.ldmask + nch), mk);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
+                }
+                if (p.y) *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+                if (p.y32) {
+                    *reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        }
+        if (p.stats) {   // block-level reduction over the 32 row groups, then one atomic per channel
+            __syncthreads();
+            float *red = stg;   // [2][32][64]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[r0 * 64 + cc * 8 + i] = s1[i];
+                red[(32 + r0) * 64 + cc * 8 + i] = s2[i];
+            }
+            __syncthreads();
+            if (tid < 64 && pass * 64 + tid < p.Cout) {
+                float sa = 0.f, sb = 0.f;
+                for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
+                atomicAdd(p.stats + pass * 64 + tid, sa);
+                atomicAdd(p.stats + p.stats_ld + pass * 64 + tid, sb);
             }
         }
     }
@@ -212,8 +246,8 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
 int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s) {
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt == 0 && p.ph < p.kh && p.pw < p.kw;
     if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 128 ||
-        p.Kpad != p.kh * p.kw * cin || p.mask || p.stats || p.ostrided || p.y32 || p.sigmoid || !p.y) {
-        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' 1 x kh x kw conv with cin %% 64 == 0, cout <= 128 and the plain epilogue");
+        p.Kpad != p.kh * p.kw * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
+        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' 1 x kh x kw conv with cin %% 64 == 0, cout <= 128 (mask / stats / fp32 output allowed, no strided output map)");
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;

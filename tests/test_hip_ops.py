@@ -341,6 +341,41 @@ def test_dual_pointwise_equals_two_convs(dims, cout, ld2):
     assert rel_l2(got, ref) < 4e-4 and rel_l2(got, two) < 8e-4
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (128, 40)])
+def test_patch_halo_training_epilogues(cin, cout):
+    """tile_cfg 32 with the training extras of the conv epilogue -- ReLU-backward mask (+ residual), batch statistics, fp32 output --
+    against a generic tile on the same launch arguments (the extras' own arithmetic is checked in test_hip_train_ops.py)."""
+    from ted_spad_amd import engine as E
+    tdt = torch.float16
+    n, t, h, w = 2, 1, 37, 21
+    x = E.Act(synth_tensor(31, "pe_x%d" % cin, (n, t, h, w, cin), -1, 1).to(tdt).cuda(), cin)
+    wgt = (synth_tensor(31, "pe_w%d%d" % (cin, cout), (cout, cin, 1, 3, 3), -1, 1) * (2.0 / (9 * cin)) ** 0.5).to(tdt).float()
+    pc = E.PackedConv(wgt, synth_tensor(31, "pe_s", (cout,), 0.5, 1.5), synth_tensor(31, "pe_b", (cout,), -0.3, 0.3), dtype="f16", device="cuda")
+    res = E.Act(synth_tensor(31, "pe_r", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
+    mask = E.Act(synth_tensor(31, "pe_m", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
+    got = {}
+    try:
+        for cfg in (32, 5):
+            E.FORCE_TILE_CFG = cfg
+            st1 = torch.zeros((2, pc.cpad), device="cuda"); st2 = torch.zeros((2, pc.cpad), device="cuda")
+            a = pc(x, pads=(0, 1, 1), residual=res, mask=mask, relu=False).buf.float().cpu()
+            bq = pc(x, pads=(0, 1, 1), relu=True, stats=st1).buf.float().cpu()
+            c32 = pc(x, pads=(0, 1, 1), relu=False, stats=st2, y32=True).cpu()
+            got[cfg] = (a, bq, c32, st1.cpu(), st2.cpu())
+    finally:
+        E.FORCE_TILE_CFG = None
+    ulp = 2.0 ** -10
+    for i in range(3):      # cin = 64 walks K like the generic tile (bit-identical), cin = 128 chunk-major (one rounding step; fp32 output: 1e-5)
+        g, r = got[32][i], got[5][i]
+        assert g.shape == r.shape
+        if cin == 64:
+            assert torch.equal(g, r), i
+        else:
+            assert bool(((g - r).abs() <= (ulp if i < 2 else 2e-5) * r.abs() + 1e-4).all()), i
+    for i in (3, 4):        # batch statistics: float atomics in a different order
+        assert rel_l2(got[32][i], got[5][i]) < 1e-5, i
+
+
 def test_flat_halo_kernels_on_awkward_geometries():
     """The flat-halo tiles (27: 1 x kh x kw, 28: kt x 1 x 1) against a generic tile on seeded random small geometries: frames
     narrower than the kernel, single rows / columns / frames, tiles that span several clips, ragged cout, asymmetric front pads,
