@@ -21,9 +21,13 @@ constexpr int PT_S = 16;                 // patch side
 
 struct PatchGeo {
     int HH, WH, NP, ntaps, nchunks, tiles_h, tiles_w;
+    int R;                   // FLAT: halo positions in front of the tile (ph * W + pw)
 };
 
-template <typename T, int BN>
+// FLAT: the tile is 256 CONSECUTIVE output pixels (flattened (n,t,h,w) index) instead of a 16 x 16 patch, its halo the contiguous run of
+// 256 + (kh-1) W + (kw-1) pixels of conv_flat.hip, taps outside the frame redirected per lane to a zero position (tile_cfg 33): no tile
+// quantisation on small frames (28 x 28, 14 x 14), for frames narrow enough that the run fits (W <= 60 for a 3 x 3 kernel).
+template <typename T, int BN, bool FLAT = false>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const PatchGeo g) {
     constexpr int NT = 256;
     constexpr int WS = BN == 64 ? 3 : 2;                  // weight ring slots ([BN][64] 16-bit each)
@@ -37,7 +41,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int tw = b % g.tiles_w; b /= g.tiles_w;
     const int th = b % g.tiles_h; b /= g.tiles_h;          // b = n * T + t
     const int ho0 = th * PT_S, wo0 = tw * PT_S;
-    const int S = g.NP * 8;
+    const int q0 = (int)xcd_remap(blockIdx.x, gridDim.x) * 256;      // FLAT: first output pixel of the tile
+    const int S = (g.NP + (FLAT ? 1 : 0)) * 8;                         // FLAT: one more (zero) position
     const int Sr = (S + 63) / 64 * 64;
     const int halo_bytes = Sr * 16;
     unsigned char *wring = dsm + halo_bytes;
@@ -55,7 +60,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         const int hr = pos / g.WH, hc = pos - hr * g.WH;
         const int ih = ho0 - p.ph + hr, iw = wo0 - p.pw + hc;
         hsrc[i] = -1;
-        if (i < NH && pos < g.NP && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+        if (FLAT) {
+            const int q = q0 - g.R + pos;
+            if (i < NH && pos < g.NP && (unsigned)q < (unsigned)p.M) hsrc[i] = (int)((long)q * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+        } else if (i < NH && pos < g.NP && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
             hsrc[i] = (int)((((long)b * p.Hi + ih) * p.Wi + iw) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
     }
     const int rsub = wave * 8 + (lane >> 3);
@@ -73,7 +81,21 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int swz = (l31 >> 1) & 7;
     int pbase[2];
 #pragma unroll
-    for (int bq = 0; bq < 2; ++bq) pbase[bq] = (4 * wave + 2 * bq + (l31 >> 4)) * g.WH + (l31 & 15);
+    for (int bq = 0; bq < 2; ++bq) pbase[bq] = FLAT ? wave * 64 + bq * 32 + l31 : (4 * wave + 2 * bq + (l31 >> 4)) * g.WH + (l31 & 15);
+    unsigned vmask[2] = {0u, 0u};      // FLAT: bit (dh*kw + dw): the tap lies inside the frame
+    if (FLAT) {
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq) {
+            const int q = q0 + pbase[bq];
+            if (q < p.M) {
+                const int r1 = q / p.Wi, w = q - r1 * p.Wi;
+                const int h = r1 % p.Hi;
+                for (int dh = 0; dh < p.kh; ++dh)
+                    for (int dw = 0; dw < p.kw; ++dw)
+                        if ((unsigned)(h + dh - p.ph) < (unsigned)p.Hi && (unsigned)(w + dw - p.pw) < (unsigned)p.Wi) vmask[bq] |= 1u << (dh * p.kw + dw);
+            }
+        }
+    }
     f32x16 acc[NA][2];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -94,11 +116,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         if (g.ntaps > 1) issue_w(ch, 1, 1);
         int dh = 0, dw = 0;
         for (int kt = 0; kt < g.ntaps; ++kt) {
-            const int delta = dh * g.WH + dw;
+            const int delta = dh * g.WH + dw;                 // FLAT: g.WH = W
             unsigned xoff[2], xswz[2];
 #pragma unroll
             for (int bq = 0; bq < 2; ++bq) {
-                const int pos = pbase[bq] + delta;
+                const int pos = (!FLAT || ((vmask[bq] >> kt) & 1u)) ? pbase[bq] + delta : g.NP;
                 xoff[bq] = (unsigned)pos * 128u;
                 xswz[bq] = (unsigned)(pos >> 1) & 7u;
             }
@@ -162,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             for (int it = 0; it < 8; ++it) {
                 const int r = r0 + it * 32;                 // staging row = wave*64 + bq*32 + l31  ->  patch row r >> 4, col r & 15
                 const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
-                if (ho >= p.Ho || wo >= p.Wo) continue;
-                const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+                if (FLAT ? q0 + r >= p.M : (ho >= p.Ho || wo >= p.Wo)) continue;
+                const size_t m = FLAT ? (size_t)q0 + r : ((size_t)b * p.Ho + ho) * p.Wo + wo;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
                 float v[8];
@@ -215,21 +237,22 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool FLAT = false>
 int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
     PatchGeo g;
     g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
-    g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S;
-    const int S = g.NP * 8, Sr = (S + 63) / 64 * 64;
+    g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.R = 0;
+    if (FLAT) { g.WH = p.Wi; g.NP = 256 + (p.kh - 1) * p.Wi + (p.kw - 1); g.R = p.ph * p.Wi + p.pw; g.tiles_h = 1; g.tiles_w = 1; }
+    const int S = (g.NP + (FLAT ? 1 : 0)) * 8, Sr = (S + 63) / 64 * 64;
     if ((Sr + 255) / 256 > 12) {
-        set_error("tedspad_conv_fwd: patch-halo config: kernel too large for the 16 x 16 patch halo");
+        set_error("tedspad_conv_fwd: patch / flat halo config: halo larger than 384 positions (kernel too large, or frame too wide for the flat form)");
         return TEDSPAD_EINVAL;
     }
     const int main_bytes = Sr * 16 + (BN == 64 ? 3 : 2) * BN * BK * 2;
     const int stage_bytes = 256 * (64 + 4) * 4;
     const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_patch_kernel<T, BN>;
+    auto kfn = conv_patch_kernel<T, BN, FLAT>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -237,13 +260,13 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
         }
         attr_set[T::kDtype] = 1;
     }
-    hipLaunchKernelGGL(kfn, dim3(NTf * g.tiles_h * g.tiles_w), dim3(256), lds, s, p, g);
+    hipLaunchKernelGGL(kfn, dim3(FLAT ? (p.M + 255) / 256 : NTf * g.tiles_h * g.tiles_w), dim3(256), lds, s, p, g);
     return check_launch("tedspad_conv_fwd(patch halo)");
 }
 
 }  // namespace
 
-int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s) {
+int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, bool flat) {
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt == 0 && p.ph < p.kh && p.pw < p.kw;
     if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 128 ||
         p.Kpad != p.kh * p.kw * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
@@ -251,6 +274,10 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;
+    if (flat) {
+        if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64, true>(p, frames, cin, s) : launch_patch_t<BF16, 64, true>(p, frames, cin, s);
+        return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128, true>(p, frames, cin, s) : launch_patch_t<BF16, 128, true>(p, frames, cin, s);
+    }
     if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64>(p, frames, cin, s) : launch_patch_t<BF16, 64>(p, frames, cin, s);
     return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128>(p, frames, cin, s) : launch_patch_t<BF16, 128>(p, frames, cin, s);
 }

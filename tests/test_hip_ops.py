@@ -256,6 +256,7 @@ AGREE = [
     ("a_flat_3x3_c64_cout40", (1, 2, 9, 7), 64, 40, (1, 3, 3), (0, 1, 1), True),     # ... frames smaller than a tile, ragged N, residual
     ("a_tflat_3x1x1_c256", (3, 4, 9, 11), 256, 64, (3, 1, 1), (1, 0, 0), False),      # temporal flat-halo tile (28): T = 4, ragged spatial tile
     ("a_tflat_3x1x1_t3_c64", (2, 3, 5, 13), 64, 48, (3, 1, 1), (1, 0, 0), True),      # ... T = 3 (an idle wave), one chunk, ragged N, residual
+    ("a_cflat_3x3_c128_n128", (3, 2, 13, 28), 128, 128, (1, 3, 3), (0, 1, 1), True),   # flat chunk-major tile (33): tiles cross rows / frames / clips
     ("a_patch_3x3_c64", (2, 1, 20, 37), 64, 64, (1, 3, 3), (0, 1, 1), True),          # patch-halo tile (32): ragged 16 x 16 patches, residual
     ("a_patch_3x3_c128_n128", (1, 2, 17, 16), 128, 128, (1, 3, 3), (0, 1, 1), False),  # ... two channel chunks, 128 output channels (2-slot ring)
     ("a_patch_3x3_c192_n72", (1, 1, 9, 33), 192, 72, (1, 3, 3), (0, 1, 1), False),     # ... three chunks, ragged N in the second staging pass
@@ -296,7 +297,7 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
                 continue                                   # configuration not applicable to this geometry
     finally:
         E.FORCE_TILE_CFG = None
-    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
+    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
     generic = {c: o for c, o in outs.items() if c not in REASSOC}
     assert len(generic) >= 4, sorted(outs)
     first = next(iter(generic.values()))
@@ -355,7 +356,7 @@ def test_patch_halo_training_epilogues(cin, cout):
     mask = E.Act(synth_tensor(31, "pe_m", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
     got = {}
     try:
-        for cfg in (32, 5):
+        for cfg in (32, 33, 5):
             E.FORCE_TILE_CFG = cfg
             st1 = torch.zeros((2, pc.cpad), device="cuda"); st2 = torch.zeros((2, pc.cpad), device="cuda")
             a = pc(x, pads=(0, 1, 1), residual=res, mask=mask, relu=False).buf.float().cpu()
@@ -365,15 +366,16 @@ def test_patch_halo_training_epilogues(cin, cout):
     finally:
         E.FORCE_TILE_CFG = None
     ulp = 2.0 ** -10
-    for i in range(3):      # cin = 64 walks K like the generic tile (bit-identical), cin = 128 chunk-major (one rounding step; fp32 output: 1e-5)
-        g, r = got[32][i], got[5][i]
-        assert g.shape == r.shape
-        if cin == 64:
-            assert torch.equal(g, r), i
-        else:
-            assert bool(((g - r).abs() <= (ulp if i < 2 else 2e-5) * r.abs() + 1e-4).all()), i
-    for i in (3, 4):        # batch statistics: float atomics in a different order
-        assert rel_l2(got[32][i], got[5][i]) < 1e-5, i
+    for c in (32, 33):
+        for i in range(3):      # cin = 64 walks K like the generic tile (bit-identical), cin = 128 chunk-major (one rounding step; fp32 output: 1e-5)
+            g, r = got[c][i], got[5][i]
+            assert g.shape == r.shape
+            if cin == 64:
+                assert torch.equal(g, r), (c, i)
+            else:
+                assert bool(((g - r).abs() <= (ulp if i < 2 else 2e-5) * r.abs() + 1e-4).all()), (c, i)
+        for i in (3, 4):        # batch statistics: float atomics in a different order
+            assert rel_l2(got[c][i], got[5][i]) < 1e-5, (c, i)
 
 
 def test_flat_halo_kernels_on_awkward_geometries():
