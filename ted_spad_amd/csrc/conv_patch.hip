@@ -20,7 +20,7 @@ __device__ uint4 g_zero16q;
 constexpr int PT_S = 16;                 // patch side
 
 struct PatchGeo {
-    int HH, WH, NP, ntaps, nchunks, tiles_h, tiles_w;
+    int HH, WH, NP, ntaps, nchunks, tiles_h, tiles_w, tiles_n;
     int R;                   // FLAT: halo positions in front of the tile (ph * W + pw)
 };
 
@@ -38,10 +38,13 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (b % g.tiles_n) * BN;                  // channel tile (fastest: consecutive workgroups share one halo through L2)
+    b /= g.tiles_n;
+    const int tile_lin = b;
     const int tw = b % g.tiles_w; b /= g.tiles_w;
     const int th = b % g.tiles_h; b /= g.tiles_h;          // b = n * T + t
     const int ho0 = th * PT_S, wo0 = tw * PT_S;
-    const int q0 = (int)xcd_remap(blockIdx.x, gridDim.x) * 256;      // FLAT: first output pixel of the tile
+    const int q0 = tile_lin * 256;                         // FLAT: first output pixel of the tile
     const int S = (g.NP + (FLAT ? 1 : 0)) * 8;                         // FLAT: one more (zero) position
     const int Sr = (S + 63) / 64 * 64;
     const int halo_bytes = Sr * 16;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     }
     const int rsub = wave * 8 + (lane >> 3);
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-    const uint16_t *wsrc = p.w + (size_t)rsub * p.Kpad + kc * 8;
+    const uint16_t *wsrc = p.w + (size_t)(n0 + rsub) * p.Kpad + kc * 8;
     auto issue_w = [&](int ch, int tap, int slot) {
         const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
         const uint16_t *src = wsrc + tap * p.cin + ch * 64;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 }
             }
         __syncthreads();
-        const int nch = pass * 64 + cc * 8;
+        const int nch = n0 + pass * 64 + cc * 8;
         float s1[8], s2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -227,11 +230,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 red[(32 + r0) * 64 + cc * 8 + i] = s2[i];
             }
             __syncthreads();
-            if (tid < 64 && pass * 64 + tid < p.Cout) {
+            if (tid < 64 && n0 + pass * 64 + tid < p.Cout) {
                 float sa = 0.f, sb = 0.f;
                 for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
-                atomicAdd(p.stats + pass * 64 + tid, sa);
-                atomicAdd(p.stats + p.stats_ld + pass * 64 + tid, sb);
+                atomicAdd(p.stats + n0 + pass * 64 + tid, sa);
+                atomicAdd(p.stats + p.stats_ld + n0 + pass * 64 + tid, sb);
             }
         }
     }
@@ -241,7 +244,7 @@ template <typename T, int BN, bool FLAT = false>
 int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
     PatchGeo g;
     g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
-    g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.R = 0;
+    g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.R = 0; g.tiles_n = (p.Cout + BN - 1) / BN;
     if (FLAT) { g.WH = p.Wi; g.NP = 256 + (p.kh - 1) * p.Wi + (p.kw - 1); g.R = p.ph * p.Wi + p.pw; g.tiles_h = 1; g.tiles_w = 1; }
     const int S = (g.NP + (FLAT ? 1 : 0)) * 8, Sr = (S + 63) / 64 * 64;
     if ((Sr + 255) / 256 > 12) {
@@ -260,7 +263,7 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
         }
         attr_set[T::kDtype] = 1;
     }
-    hipLaunchKernelGGL(kfn, dim3(FLAT ? (p.M + 255) / 256 : NTf * g.tiles_h * g.tiles_w), dim3(256), lds, s, p, g);
+    hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 255) / 256 : NTf * g.tiles_h * g.tiles_w) * g.tiles_n), dim3(256), lds, s, p, g);
     return check_launch("tedspad_conv_fwd(patch halo)");
 }
 
@@ -268,9 +271,9 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
 
 int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, bool flat) {
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt == 0 && p.ph < p.kh && p.pw < p.kw;
-    if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 128 ||
+    if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 512 ||
         p.Kpad != p.kh * p.kw * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
-        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' 1 x kh x kw conv with cin %% 64 == 0, cout <= 128 (mask / stats / fp32 output allowed, no strided output map)");
+        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' 1 x kh x kw conv with cin %% 64 == 0, cout <= 512 (mask / stats / fp32 output allowed, no strided output map)");
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;

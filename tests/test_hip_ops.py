@@ -257,6 +257,7 @@ AGREE = [
     ("a_tflat_3x1x1_c256", (3, 4, 9, 11), 256, 64, (3, 1, 1), (1, 0, 0), False),      # temporal flat-halo tile (28): T = 4, ragged spatial tile
     ("a_tflat_3x1x1_t3_c64", (2, 3, 5, 13), 64, 48, (3, 1, 1), (1, 0, 0), True),      # ... T = 3 (an idle wave), one chunk, ragged N, residual
     ("a_cflat_3x3_c128_n128", (3, 2, 13, 28), 128, 128, (1, 3, 3), (0, 1, 1), True),   # flat chunk-major tile (33): tiles cross rows / frames / clips
+    ("a_patch_3x3_c128_n320", (2, 2, 14, 14), 128, 320, (1, 3, 3), (0, 1, 1), True),   # patch / flat chunk-major tiles with three channel tiles (N-tiling)
     ("a_patch_3x3_c64", (2, 1, 20, 37), 64, 64, (1, 3, 3), (0, 1, 1), True),          # patch-halo tile (32): ragged 16 x 16 patches, residual
     ("a_patch_3x3_c128_n128", (1, 2, 17, 16), 128, 128, (1, 3, 3), (0, 1, 1), False),  # ... two channel chunks, 128 output channels (2-slot ring)
     ("a_patch_3x3_c192_n72", (1, 1, 9, 33), 192, 72, (1, 3, 3), (0, 1, 1), False),     # ... three chunks, ragged N in the second staging pass
