@@ -65,6 +65,6 @@ int32_t launch_conv_flat(int dtype, const ConvKP &p, int cin, hipStream_t s);
 int32_t launch_conv_tflat(int dtype, const ConvKP &p, int N, int cin, hipStream_t s);
 
 // conv_patch.hip: 16 x 16 patch-halo kernel for stride-1 'same' 1 x kh x kw convs with cin % 64 == 0, cout <= 128 on wide frames (tile_cfg 32).
-int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, bool flat = false);   // flat: tile_cfg 33 (256 consecutive pixels)
+int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode = 0);   // mode 1: tile_cfg 33 (256 consecutive pixels), 2: tile_cfg 34 (temporal)
 
 }  // namespace tedspad

@@ -678,7 +678,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  31  stem, two output frames per workgroup (tile 20) on 16 x 16 patches
 //  32  16 x 16 patch halo (conv_patch.hip): stride-1 'same' 1 x kh x kw convs with cin % 64 == 0, cout <= 128 (the UNet's wide outer levels)
 //  33  the same with flat tiles (256 consecutive output pixels, halo = one contiguous run as tile 27): cin % 64 == 0, cout <= 128, narrow frames
-constexpr int NUM_CFGS = 33;
+//  34  the same for kt x 1 x 1 'same' convs: a tile is all T <= 4 frames of 256 / T spatial positions, taps outside the clip skipped (cout <= 512)
+constexpr int NUM_CFGS = 34;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -714,7 +715,8 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 27: return launch_conv_flat(T::kDtype, p, cin, s);
         case 28: return launch_conv_tflat(T::kDtype, p, N, cin, s);
         case 32: return launch_conv_patch(T::kDtype, p, N, cin, s);
-        case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, true);
+        case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, 1);
+        case 34: return launch_conv_patch(T::kDtype, p, N, cin, s, 2);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);

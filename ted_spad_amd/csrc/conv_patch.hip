@@ -22,13 +22,18 @@ constexpr int PT_S = 16;                 // patch side
 struct PatchGeo {
     int HH, WH, NP, ntaps, nchunks, tiles_h, tiles_w, tiles_n;
     int R;                   // FLAT: halo positions in front of the tile (ph * W + pw)
+    int T, HW, PXF;          // TEMPORAL: frames of a clip, pixels of a frame, pixels per frame in a tile (256 / T rounded to a power of two)
 };
 
 // FLAT: the tile is 256 CONSECUTIVE output pixels (flattened (n,t,h,w) index) instead of a 16 x 16 patch, its halo the contiguous run of
 // 256 + (kh-1) W + (kw-1) pixels of conv_flat.hip, taps outside the frame redirected per lane to a zero position (tile_cfg 33): no tile
 // quantisation on small frames (28 x 28, 14 x 14), for frames narrow enough that the run fits (W <= 60 for a 3 x 3 kernel).
-template <typename T, int BN, bool FLAT = false>
+// MODE 2 (TEMPORAL, tile_cfg 34): kt x 1 x 1 'same' convs, the generalisation of conv_tflat_kernel to cout <= 512: a tile is PXF spatial positions of
+// ALL T <= 4 frames of a clip (position = frame * PXF + pixel), the chunk's T x PXF input positions are the halo, a tap moves a whole
+// frame (delta = +-PXF positions) and taps that leave the clip are skipped wave-uniformly (T = 2: a third of a 3 x 1 x 1 conv's taps).
+template <typename T, int BN, int MODE = 0>
 __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const PatchGeo g) {
+    constexpr bool FLAT = MODE == 1, TEMP = MODE == 2;
     constexpr int NT = 256;
     constexpr int WS = BN == 64 ? 3 : 2;                  // weight ring slots ([BN][64] 16-bit each)
     constexpr int WSTAGE = BN * BK * 2;
@@ -63,7 +68,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         const int hr = pos / g.WH, hc = pos - hr * g.WH;
         const int ih = ho0 - p.ph + hr, iw = wo0 - p.pw + hc;
         hsrc[i] = -1;
-        if (FLAT) {
+        if (TEMP) {
+            const int f = pos / g.PXF, px = pos - f * g.PXF;
+            const int nclip = tile_lin / g.tiles_w, s0 = (tile_lin - nclip * g.tiles_w) * g.PXF;
+            if (i < NH && pos < g.NP && s0 + px < g.HW) hsrc[i] = (int)((((long)nclip * g.T + f) * g.HW + s0 + px) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+        } else if (FLAT) {
             const int q = q0 - g.R + pos;
             if (i < NH && pos < g.NP && (unsigned)q < (unsigned)p.M) hsrc[i] = (int)((long)q * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
         } else if (i < NH && pos < g.NP && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int swz = (l31 >> 1) & 7;
     int pbase[2];
 #pragma unroll
-    for (int bq = 0; bq < 2; ++bq) pbase[bq] = FLAT ? wave * 64 + bq * 32 + l31 : (4 * wave + 2 * bq + (l31 >> 4)) * g.WH + (l31 & 15);
+    for (int bq = 0; bq < 2; ++bq) pbase[bq] = (FLAT || TEMP) ? wave * 64 + bq * 32 + l31 : (4 * wave + 2 * bq + (l31 >> 4)) * g.WH + (l31 & 15);
     unsigned vmask[2] = {0u, 0u};      // FLAT: bit (dh*kw + dw): the tap lies inside the frame
     if (FLAT) {
 #pragma unroll
@@ -118,8 +127,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         }
         if (g.ntaps > 1) issue_w(ch, 1, 1);
         int dh = 0, dw = 0;
+        const int f_out = TEMP ? (wave * 64) / g.PXF : 0;   // TEMPORAL: the wave's output frame (PXF >= 64: one frame per wave)
         for (int kt = 0; kt < g.ntaps; ++kt) {
-            const int delta = dh * g.WH + dw;                 // FLAT: g.WH = W
+            const int fin = f_out + kt - p.pt;                 // TEMPORAL: input frame of this tap
+            const bool tap_on = !TEMP || (wave * 64 < g.NP && fin >= 0 && fin < g.T);
+            const int delta = TEMP ? (kt - p.pt) * g.PXF : dh * g.WH + dw;                 // FLAT: g.WH = W
             unsigned xoff[2], xswz[2];
 #pragma unroll
             for (int bq = 0; bq < 2; ++bq) {
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             asm volatile("" ::: "memory");
             if (WS == 3 && kt + 2 < g.ntaps) issue_w(ch, kt + 2, (kt + 2) % WS);
             const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * WSTAGE) + l31 * BK;
+            if (tap_on) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const unsigned c = (unsigned)((ks << 1) | lh);
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 for (int a = 0; a < NA; ++a)
 #pragma unroll
                     for (int bq = 0; bq < 2; ++bq) acc[a][bq] = T::mfma(fw[a], fa[bq], acc[a][bq]);
+            }
             }
             if (WS == 2 && kt + 1 < g.ntaps) {             // two slots: stage kt+1 can only be issued once every wave has read stage kt-1 ... and kt
                 __builtin_amdgcn_s_barrier();
@@ -187,8 +201,16 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             for (int it = 0; it < 8; ++it) {
                 const int r = r0 + it * 32;                 // staging row = wave*64 + bq*32 + l31  ->  patch row r >> 4, col r & 15
                 const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
-                if (FLAT ? q0 + r >= p.M : (ho >= p.Ho || wo >= p.Wo)) continue;
-                const size_t m = FLAT ? (size_t)q0 + r : ((size_t)b * p.Ho + ho) * p.Wo + wo;
+                size_t m;
+                if (TEMP) {
+                    const int f = r / g.PXF, px = r - f * g.PXF;
+                    const int nclip = tile_lin / g.tiles_w, s0 = (tile_lin - nclip * g.tiles_w) * g.PXF;
+                    if (r >= g.NP || s0 + px >= g.HW) continue;
+                    m = ((size_t)nclip * g.T + f) * g.HW + s0 + px;
+                } else {
+                    if (FLAT ? q0 + r >= p.M : (ho >= p.Ho || wo >= p.Wo)) continue;
+                    m = FLAT ? (size_t)q0 + r : ((size_t)b * p.Ho + ho) * p.Wo + wo;
+                }
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
                 float v[8];
@@ -240,12 +262,15 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     }
 }
 
-template <typename T, int BN, bool FLAT = false>
+template <typename T, int BN, int MODE = 0>
 int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
+    constexpr bool FLAT = MODE == 1, TEMP = MODE == 2;
     PatchGeo g;
     g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
     g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.R = 0; g.tiles_n = (p.Cout + BN - 1) / BN;
     if (FLAT) { g.WH = p.Wi; g.NP = 256 + (p.kh - 1) * p.Wi + (p.kw - 1); g.R = p.ph * p.Wi + p.pw; g.tiles_h = 1; g.tiles_w = 1; }
+    g.T = p.Ti; g.HW = p.Hi * p.Wi; g.PXF = p.Ti <= 1 ? 256 : p.Ti == 2 ? 128 : 64;
+    if (TEMP) { g.ntaps = p.kt; g.NP = g.T * g.PXF; g.tiles_h = 1; g.tiles_w = (g.HW + g.PXF - 1) / g.PXF; }
     const int S = (g.NP + (FLAT ? 1 : 0)) * 8, Sr = (S + 63) / 64 * 64;
     if ((Sr + 255) / 256 > 12) {
         set_error("tedspad_conv_fwd: patch / flat halo config: halo larger than 384 positions (kernel too large, or frame too wide for the flat form)");
@@ -255,7 +280,7 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
     const int stage_bytes = 256 * (64 + 4) * 4;
     const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_patch_kernel<T, BN, FLAT>;
+    auto kfn = conv_patch_kernel<T, BN, MODE>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -263,13 +288,25 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
         }
         attr_set[T::kDtype] = 1;
     }
-    hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 255) / 256 : NTf * g.tiles_h * g.tiles_w) * g.tiles_n), dim3(256), lds, s, p, g);
+    hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 255) / 256 : TEMP ? (NTf / p.Ti) * g.tiles_w : NTf * g.tiles_h * g.tiles_w) * g.tiles_n), dim3(256), lds, s, p, g);
     return check_launch("tedspad_conv_fwd(patch halo)");
 }
 
 }  // namespace
 
-int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, bool flat) {
+int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode) {
+    const bool flat = mode == 1;
+    if (mode == 2) {
+        const bool same_t = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.ph == 0 && p.pw == 0 && p.pt < p.kt;
+        if (cin % 64 != 0 || p.kh != 1 || p.kw != 1 || p.kt < 2 || p.kt > 3 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same_t || p.Ti > 4 || p.Cout > 512 ||
+            p.Kpad != p.kt * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
+            set_error("tedspad_conv_fwd: temporal halo config needs a stride-1 'same' kt x 1 x 1 conv (kt 2..3) with cin %% 64 == 0, cout <= 512, T <= 4");
+            return TEDSPAD_EINVAL;
+        }
+        const int frames = N * p.Ti;
+        if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64, 2>(p, frames, cin, s) : launch_patch_t<BF16, 64, 2>(p, frames, cin, s);
+        return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128, 2>(p, frames, cin, s) : launch_patch_t<BF16, 128, 2>(p, frames, cin, s);
+    }
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt == 0 && p.ph < p.kh && p.pw < p.kw;
     if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 512 ||
         p.Kpad != p.kh * p.kw * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
@@ -278,8 +315,8 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
     }
     const int frames = N * p.Ti;
     if (flat) {
-        if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64, true>(p, frames, cin, s) : launch_patch_t<BF16, 64, true>(p, frames, cin, s);
-        return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128, true>(p, frames, cin, s) : launch_patch_t<BF16, 128, true>(p, frames, cin, s);
+        if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64, 1>(p, frames, cin, s) : launch_patch_t<BF16, 64, 1>(p, frames, cin, s);
+        return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128, 1>(p, frames, cin, s) : launch_patch_t<BF16, 128, 1>(p, frames, cin, s);
     }
     if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64>(p, frames, cin, s) : launch_patch_t<BF16, 64>(p, frames, cin, s);
     return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128>(p, frames, cin, s) : launch_patch_t<BF16, 128>(p, frames, cin, s);
