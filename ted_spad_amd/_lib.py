@@ -75,6 +75,9 @@ SYMBOLS = {
     "tedspad_clip_to_tu": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 5 + [_P]),
     "tedspad_stem_tu_kpad": (_I32, [_I32, _I32]),
     "tedspad_stem_tu_fwd": (_I32, [_P] * 5 + [_I32] * 14 + [_P]),
+    "tedspad_clip_to_tc": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 2 + [_P]),
+    "tedspad_stem_pt_wimg_bytes": (_I32, []),
+    "tedspad_stem_pt_fwd": (_I32, [_P] * 5 + [_I32] * 12 + [_P]),
     "tedspad_bn_fold": (_I32, [_P, _P, _P, _P, _P, C.c_double, _I32, _P, _P, _P]),
     "tedspad_resize_aa_taps": (_I32, [_I32, _I32]),
     "tedspad_resize_aa_table": (_I32, [_I32, _I32, _P]),

@@ -584,6 +584,75 @@ class StemTU:
         return self.conv(self.layout(x), relu)
 
 
+class StemPT:
+    """conv1 5x7x7 / 2 / pad (2,3,3) + bn1 + ReLU of I3Res50 (large_i3d.py:133-137,229-231) on the persistent stem kernel
+    (csrc/conv_stem_pt.hip), inference only, with the TEMPORAL half of maxpool1 (large_i3d.py:138,232) fused: the result is
+    max(frame 2k, frame 2k+1) of the stem output, (n, To // 2, ho, wo, 64); `engine.maxpool(., (1,3,3), (1,2,2))` finishes the pool.
+    K = 7*7*16 = 784 (temporal taps x channels folded into one 32-byte position), all weights resident in LDS."""
+    VARIANT = int(os.environ.get("TEDSPAD_STEM_PT_VARIANT", "1"))
+
+    def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(2, 2, 2), pads=(2, 3, 3),
+                 dtype: str = DEFAULT_DTYPE, device="cuda"):
+        co, ci, kt, kh, kw = weight.shape
+        assert self.supported(weight, stride, pads), "StemPT: 64 x (<=3) x (<=5) x 7 x 7 weights, spatial stride 2 / pad 3, even temporal stride"
+        device = torch.device(device)
+        self.kt, self.stride_t, self.pad_t = kt, int(stride[0]), int(pads[0])
+        self.torch_dtype, self.dtype_code = DTYPES[dtype]
+        w = weight.detach().to(device=device, dtype=torch.float32)
+        if ci < 3:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 3 - ci))
+        w = w.permute(3, 4, 0, 2, 1).reshape(49, 64, kt * 3)                      # [tap = dh*7 + dw][co][dt*3 + ci]
+        w = torch.nn.functional.pad(w, (0, 16 - kt * 3)).reshape(49, 64, 2, 8)
+        swap = ((torch.arange(64, device=device) >> 4) & 1).bool().view(1, 64, 1, 1)
+        self.wimg = torch.where(swap, w.flip(2), w).to(self.torch_dtype).contiguous()   # halves of a row swapped when (co >> 4) & 1
+        assert self.wimg.numel() * 2 == _lib.lib().tedspad_stem_pt_wimg_bytes()
+        self.scale = _padded_vec(scale, co, 64, device, 1.0)
+        self.shift = _padded_vec(shift, co, 64, device, 0.0)
+        self.nwg = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
+
+    @staticmethod
+    def supported(weight: torch.Tensor, stride, pads) -> bool:
+        co, ci, kt, kh, kw = weight.shape
+        return (co == 64 and ci <= 3 and kt <= 5 and (kh, kw) == (7, 7) and tuple(stride[1:]) == (2, 2) and tuple(pads[1:]) == (3, 3) and
+                stride[0] % 2 == 0)
+
+    def frame_pairs(self, t: int) -> int:
+        return conv_out(t, self.kt, self.stride_t, self.pad_t, self.pad_t) // 2
+
+    def applies(self, x: torch.Tensor) -> bool:
+        """The record of a pixel holds (t + pad_t) * 3 <= 64 values and every output frame's 16 values lie inside it."""
+        n, c, t, h, w = x.shape
+        tp = self.frame_pairs(t)
+        return (x.is_cuda and c <= 3 and x.stride(4) == 1 and (t + self.pad_t) * 3 <= 64 and tp >= 1 and
+                (2 * tp - 1) * self.stride_t * 3 + 16 <= 64 and h * w * 128 < (1 << 31))
+
+    def layout(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 (n, c, t, h, w) clip batch -> time-channels-last records X[n][h][w][64]."""
+        require_cuda(x, "StemPT")
+        if x.dtype != torch.float32:
+            x = x.float()
+        n, c, t, h, w = x.shape
+        xtc = torch.empty((n, h, w, 64), dtype=self.torch_dtype, device=x.device)
+        sn, sc, st, sh, sw = x.stride()
+        check(_lib.lib().tedspad_clip_to_tc(x.data_ptr(), xtc.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw, self.pad_t, self.dtype_code,
+                                            _stream_ptr()), "tedspad_clip_to_tc")
+        return xtc
+
+    def conv(self, xtc: torch.Tensor, t: int, relu=True, variant=None) -> Act:
+        n, h, w, _ = xtc.shape
+        tp = self.frame_pairs(t)
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+        out = Act.empty(n, tp, ho, wo, 64, self.torch_dtype, xtc.device)
+        check(_lib.lib().tedspad_stem_pt_fwd(xtc.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, tp, h, w,
+                                             ho, wo, self.stride_t, out.ld, int(relu), self.nwg, self.VARIANT if variant is None else variant,
+                                             self.dtype_code, _stream_ptr()), "tedspad_stem_pt_fwd")
+        return out
+
+    def __call__(self, x: torch.Tensor, relu=True) -> Act:
+        """x: fp32 (n, c, t, h, w) -> max over output-frame pairs of act(bn(conv(x))): Act (n, To // 2, ho, wo, 64)."""
+        return self.conv(self.layout(x), x.shape[2], relu)
+
+
 def act_to_nchw(x: Act, c: Optional[int] = None) -> torch.Tensor:
     n, t, h, w = x.dims
     c = x.c if c is None else c

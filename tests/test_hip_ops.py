@@ -131,6 +131,56 @@ def test_stem_temporal_unfolded(shape, dtype):
         assert bool(((got - old).abs() <= ulp * old.abs() + 1e-3).all())
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (1, 3, 16, 120, 88), (3, 3, 5, 18, 72), (1, 2, 8, 66, 24), (1, 3, 16, 224, 224), (40, 3, 16, 40, 40)])
+def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
+    """engine.StemPT (csrc/conv_stem_pt.hip): conv1 5x7x7/2 + bn1 + ReLU of large_i3d.py:133-137 with the temporal half of
+    maxpool1 (large_i3d.py:138) fused, against the oracle's Conv3d followed by a max over output-frame pairs: ragged patches,
+    rows / columns / frames outside the clip, odd frame counts (the unpaired last frame is dropped like MaxPool3d does), more
+    patches than workgroups (persistent loop), and -- with the spatial half of the pool -- the pixel-pair stem + max-pool it replaces."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, c, t, h, w = shape
+    clip = _round(synth_tensor(5, "ptclip%d" % h, shape), tdt)
+    wgt = _round(synth_tensor(5, "tuw", (64, c, 5, 7, 7), -0.1, 0.1), tdt)
+    scale, shift = synth_tensor(5, "tus", (64,), 0.5, 1.5), synth_tensor(5, "tub", (64,), -0.3, 0.3)
+    full = conv_cl(clip.permute(0, 2, 3, 4, 1), wgt, scale, shift, (2, 2, 2), (2, 3, 3), (2, 3, 3))     # (n, To, ho, wo, 64), ReLU applied
+    tp = full.shape[1] // 2
+    ref = torch.maximum(full[:, 0:2 * tp:2], full[:, 1:2 * tp:2])
+    st = E.StemPT(wgt, scale, shift, stride=(2, 2, 2), pads=(2, 3, 3), dtype=dtype, device="cuda")
+    assert st.applies(clip.cuda())
+    got_a = st.conv(st.layout(clip.cuda()), t, variant=variant)
+    got = got_a.buf.float().cpu()
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    err = (got - ref).abs()
+    assert bool((err <= ulp * ref.abs() + 2e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
+    if c == 3 and full.shape[2] >= 3 and full.shape[3] >= 3:
+        pc = E.PackedConv(wgt, scale, shift, stride=(2, 2, 2), dtype=dtype, device="cuda", pair_w=3)
+        old = pc(E.clip_to_act(clip.cuda(), cpad=4, dtype=dtype), pads=(2, 3, pc.pair_pw), pads_back=(2, 3, 1))
+        old = E.maxpool(old, (2, 3, 3), (2, 2, 2)).buf.float().cpu()
+        new = E.maxpool(got_a, (1, 3, 3), (1, 2, 2)).buf.float().cpu()
+        assert new.shape == old.shape
+        assert bool(((new - old).abs() <= ulp * old.abs() + 1e-3).all())
+
+
+def test_clip_to_time_channels_last_layout():
+    """tedspad_clip_to_tc: value (t + pad_t)*3 + c of pixel (h, w) = x[n][c][t][h][w], zeros elsewhere; strided (Q15) input views."""
+    from ted_spad_amd import engine as E
+    big = synth_tensor(6, "tcbig", (2, 3, 48, 10, 70))
+    x = big[:, :, 16:32]                                          # a torch.split-style view: not contiguous
+    wgt = torch.zeros(64, 3, 5, 7, 7)
+    st = E.StemPT(wgt, None, None, dtype="f16", device="cuda")
+    got = st.layout(x.cuda()).float().cpu()
+    ref = torch.zeros(2, 10, 70, 64)
+    ref[..., 6:6 + 48] = x.permute(0, 3, 4, 2, 1).reshape(2, 10, 70, 48).half().float()
+    assert torch.equal(got, ref)
+
+
 POOLS = [
     ("res_maxpool1", (2, 8, 30, 30), 64, (2, 3, 3), (2, 2, 2), (0, 0, 0), (0, 0, 0), False),
     ("res_maxpool2", (2, 4, 9, 9), 256, (2, 1, 1), (2, 1, 1), (0, 0, 0), (0, 0, 0), False),
