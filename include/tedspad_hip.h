@@ -138,36 +138,23 @@ int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
                                  int32_t sh2, int32_t sw2, const void *w_packed, const float *scale, const float *shift, void *y,
                                  void *stream);
 
-/* Cin = 3 stem in temporal-unfolded form (csrc/conv_stem_tu.hip): Unit3D / conv1 of large_i3d.py:133-137 for inference.
- * tedspad_clip_to_tu lays the fp32 (n,c<=3,t,h,w) clip out as X'[n][to][h][2][w/2][16] 16-bit (value dt*3 + ci of position
- * (h, 2*wq + b) = x[n][ci][to*stride_t - pad_t + dt][h][2*wq + b], zero outside the clip; kt <= 5), tedspad_stem_tu_fwd then
- * runs the stem as a 2-D stride-2 convolution with cin = 16: y[n][to][ho][wo][cout] = act(conv * scale + shift), weights
- * packed [>= 64][tedspad_stem_tu_kpad(kh, kw)] with k = (dh*kw + dw)*16 + dt*3 + ci. K = kh*kw*16 (784 for 5x7x7) instead
- * of the 1120 of the pixel-pair form. */
-int32_t tedspad_clip_to_tu(const float *x, void *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc,
-                           int64_t st, int64_t sh, int64_t sw, int32_t kt, int32_t stride_t, int32_t pad_t, int32_t to, int32_t dtype,
-                           void *stream);
-int32_t tedspad_stem_tu_kpad(int32_t kh, int32_t kw);
-int32_t tedspad_stem_tu_fwd(const void *x_tu, const void *w_packed, const float *scale, const float *shift, void *y, int32_t n, int32_t to,
-                            int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t kh, int32_t kw, int32_t ph, int32_t pw, int32_t cout,
-                            int32_t ldy, int32_t relu, int32_t dtype, void *stream);
-
 /* Persistent Cin = 3 stem (csrc/conv_stem_pt.hip): conv1 5x7x7 / stride 2 / pad (2,3,3) + bn1 + ReLU of large_i3d.py:133-137,229-231
  * with the temporal half of maxpool1 (MaxPool3d((2,3,3), 2), large_i3d.py:138,232) fused: y[n][to/2][ho][wo][64] =
  * max over the output frame pair (to, to+1) of act(conv * scale + shift); the spatial 3x3 / 2 half of the pool is a
  * tedspad_maxpool_fwd with kt = 1 on y.
- * tedspad_clip_to_tc lays the fp32 (n, c <= 3, t, h, w) clip out as x_tc[n][h][w][64] 16-bit: value (ti + pad_t)*3 + ci of pixel
- * (h, w) = x[n][ci][ti][h][w], zeros elsewhere ((t + pad_t)*3 <= 64). Output frame `to` of the conv reads the 16 values starting at
- * value stride_t*3*to of each record (stride_t even: a 4-byte aligned offset).
+ * tedspad_clip_to_tp lays the fp32 (n, c <= 3, t, h, w) clip (W even) out as x_tp[n][tp][h][b][w/2][24] 16-bit: the 48-byte record of
+ * pixel (h, 2*wq + b) for output-frame pair tp holds value dt*3 + ci = x[n][ci][4*tp - pad_t + dt][h][2*wq + b], dt = 0..7, zeros
+ * outside the clip (stride_t = 2). Output frame 2*tp reads the 32 bytes at offset 0 of a record, frame 2*tp + 1 those at offset 12.
  * w_img (tedspad_stem_pt_wimg_bytes() bytes): [tap = dh*7 + dw][co 0..63][half][8] 16-bit, value v = dt*3 + ci (zero for v >= kt*3)
  * of half v / 8, the two halves of a row stored swapped when (co >> 4) & 1 (the kernel's conflict-free LDS image, copied linearly).
- * t_pairs = output frame pairs (floor(To / 2)); ho = ceil(h / 2), wo = ceil(w / 2); nwg = persistent workgroups (0: 256);
- * variant bit 0: fragment prefetch one tap ahead (same results). */
-int32_t tedspad_clip_to_tc(const float *x, void *x_tc, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc,
-                           int64_t st, int64_t sh, int64_t sw, int32_t pad_t, int32_t dtype, void *stream);
+ * t_pairs = output frame pairs (floor(To / 2)); ho = ceil(h / 2), wo = w / 2; nwg = persistent workgroups (0: 256);
+ * variant bit 1: 8 waves per workgroup, the output channels split between the two waves of a SIMD (same results); bits 8-10:
+ * timing ablations (wrong results, see the kernel). */
+int32_t tedspad_clip_to_tp(const float *x, void *x_tp, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc,
+                           int64_t st, int64_t sh, int64_t sw, int32_t pad_t, int32_t stride_t, int32_t t_pairs, int32_t dtype, void *stream);
 int32_t tedspad_stem_pt_wimg_bytes(void);
-int32_t tedspad_stem_pt_fwd(const void *x_tc, const void *w_img, const float *scale, const float *shift, void *y, int32_t n, int32_t t_pairs,
-                            int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t stride_t, int32_t ldy, int32_t relu, int32_t nwg,
+int32_t tedspad_stem_pt_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, int32_t n, int32_t t_pairs,
+                            int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t ldy, int32_t relu, int32_t nwg,
                             int32_t variant, int32_t dtype, void *stream);
 
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the

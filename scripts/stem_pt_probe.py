@@ -34,13 +34,15 @@ print("old: layout %.0f us, stem %.0f us, pool %.0f us" % (
     timed(lambda: E.maxpool(y_old, (2, 3, 3), (2, 2, 2)))))
 del y_old
 xtc = st.layout(x)
-for v in (0, 1):
-    y = st.conv(xtc, 16, variant=v)
+for v in (0, 2):
+    y = st.conv(xtc, variant=v)
     p_new = E.maxpool(y, (1, 3, 3), (1, 2, 2))
     d = (p_new.buf.float() - p_old.buf.float()).abs()
     print("variant %d: layout %.0f us, stem %.0f us, pool %.0f us; vs old pooled: max abs diff %.3g, mismatching %.4f %%" % (
-        v, timed(lambda: st.layout(x)), timed(lambda: st.conv(xtc, 16, variant=v)), timed(lambda: E.maxpool(y, (1, 3, 3), (1, 2, 2))),
+        v, timed(lambda: st.layout(x)), timed(lambda: st.conv(xtc, variant=v)), timed(lambda: E.maxpool(y, (1, 3, 3), (1, 2, 2))),
         float(d.max()), 100.0 * float((d > 0).float().mean())))
-for nwg in (128, 256, 512):
+for nwg in (256, 512):
     st.nwg = nwg
-    print("nwg %d: stem %.0f us" % (nwg, timed(lambda: st.conv(xtc, 16, variant=1))))
+    print("nwg %d: stem %.0f us (4 waves), %.0f us (8 waves)" % (nwg, timed(lambda: st.conv(xtc, variant=0)), timed(lambda: st.conv(xtc, variant=2))))
+for dbg, what in ((1, "no halo DMA"), (2, "no stores"), (3, "no DMA, no stores"), (4, "no MFMA"), (7, "loop skeleton only")):
+    print("ablation %s: %.0f us (4 waves), %.0f us (8 waves)" % (what, timed(lambda: st.conv(xtc, variant=0 | (dbg << 8))), timed(lambda: st.conv(xtc, variant=2 | (dbg << 8)))))

@@ -1,4 +1,4 @@
-// Shared between the conv kernels (conv_igemm.hip, conv_halo.hip): kernel parameter block, constants.
+// Shared between the conv kernels: kernel parameter block, constants.
 #pragma once
 #include "common.h"
 
@@ -49,9 +49,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-
-// conv_halo.hip: halo-direct kernel for stride-1 multi-tap convolutions with cin % 64 == 0 (tile_cfg 15 / 16).
-int32_t launch_conv_halo(int dtype, const ConvKP &p, int N, int cin, int bn, hipStream_t s);
 
 // conv_pw.hip: persistent pointwise kernel for 1x1x1 stride-1 convolutions with cin = 64 / 128 (tile_cfg 19).
 int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t = false);

@@ -664,8 +664,7 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  24  256 x 128, split-K over 16 waves, ring 3, 1 WG/CU
 //  21  1x8x32 patch, halo-direct stem with split-K over 8 waves (a single workgroup saturates the MFMA pipe), 2 WG/CU
 //  19  128 x 64, PERSISTENT pointwise (conv_pw.hip): 1x1x1 convs with cin = 64 / 128, next tile prefetched under the stores
-//  15  <=256 px patch x 128, halo-direct (conv_halo.hip): stride-1 multi-tap convs with cin % 64 == 0
-//  16  <=256 px patch x  64, halo-direct (N <= 64 layers)
+//  15, 16  retired (the round-1 8-wave halo-direct kernel: superseded by 32-34)
 //  25  256 x 256, PING-PONG (conv_p8.hip): 8 waves, the two waves of a SIMD one barrier apart, 4 phases per K tile, 1 WG/CU
 //  26  the same on v_mfma_f32_16x16x32 (higher sustained clock; fp32 sums re-associated)
 // (256 x 64 with 4 waves of 64 px x 64 co, and 512 x 64 with 8 such waves, were measured on the 64-channel layers of layer1: 404 / 455 us
@@ -693,8 +692,10 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 22: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES, 2>(p, s);
         case 23: return launch<T, 128, 128, 2, 2, 2, 0, 2>(p, s);
         case 24: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES, 2>(p, s);
-        case 15: return launch_conv_halo(T::kDtype, p, N, cin, 128, s);
-        case 16: return launch_conv_halo(T::kDtype, p, N, cin, 64, s);
+        case 15:
+        case 16:   // the 8-wave halo-direct kernel (round 1) never won the tuner once the chunk-major tiles 32-34 existed: retired, ids kept
+            set_error("tedspad_conv_fwd: tile_cfg 15 / 16 are retired");
+            return TEDSPAD_EINVAL;
         case 1: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 2: return launch<T, 256, 64, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 3: return launch<T, 128, 128, 2, 2, 3, KTAB_MAX_BYTES>(p, s);

@@ -21,7 +21,7 @@ constexpr int PW_BM = 128, PW_BN = 64, PW_STG_LD = PW_BN + 4;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: a store of > 64 bits reads its data registers late; hipcc pads nothing after an asm statement and may overwrite them
 }
 
 // POOLT: the conv output additionally goes through MaxPool3d((2,1,1), stride (2,1,1)) before it is written: the sequence

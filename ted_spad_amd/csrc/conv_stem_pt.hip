@@ -6,21 +6,26 @@
 // prologue and a 7 k-cycle epilogue around a 19 k-cycle loop; 2.89 GB written per 225 clips that the max-pool shrinks 8x.
 // Here:
 //   * temporal-unfolded K (one k16 MFMA step per (dh, dw) tap: 16 values = 5 frames x 3 channels + 1 zero) -> K = 784;
-//   * the clip is laid out ONCE as X[n][h][w][64] 16-bit ("time-channels-last", tedspad_clip_to_tc): value (t + pt)*3 + c of a
-//     pixel's 128-byte record is x[n][c][t][h][w]; the 16 values output frame `to` needs at that pixel are the 32 bytes
-//     starting at value st*3*to (byte 12*to for the stride-2 stem): no temporal duplication (6.4 MB per clip, what the
-//     pixel-pair layout took), the halo DMA simply reads at a 4-byte-aligned offset inside the record;
-//   * ALL weights (49 taps x [64 co][16] = 98 KB) stay resident in LDS: the K loop has no barrier and no weight stream, its
-//     fragment addresses are a per-lane base + compile-time immediates (fully unrolled, no address arithmetic);
-//   * a workgroup is persistent (one per CU, 4 waves) and walks patches of 8 x 16 output pixels x 2 output frames; the
-//     input halo of a patch (2 frames x 21 rows x 38 columns x 32 B = 50 KB) lives in two regions by ROW PARITY: the taps
-//     with even dh read only even halo rows, the odd ones only odd rows, so while the 28 even-dh taps of patch i are
-//     multiplied the odd rows of patch i are landing, and while its 21 odd-dh taps run the even rows of patch i+1 land:
-//     one halo buffer, two barriers per patch, the DMA always a phase ahead;
-//   * a wave owns output rows (r, r+4) x 16 columns of BOTH frames (64 px x 64 co, four 32x32x16 MFMAs per tap); the two
-//     frames are the temporal pooling window, so relu(bn(.)) of both are max-ed in registers and only the pooled tensor
-//     Y[n][to/2][ho][wo][64] is written (half the bytes), straight from the accumulators: v_permlane32_swap gives lane l the even and
-//     lane l + 32 the odd 8-channel group of its pixel -> 16-byte stores, no LDS staging, no barrier.
+//   * the clip is laid out ONCE per output-frame PAIR (tedspad_clip_to_tp): X[n][tp][h][b][w/2][24] 16-bit, a 48-byte record per
+//     pixel (column 2*wq + b, the two column parities in separate planes) holding the 8 input frames 4*tp - 2 .. 4*tp + 5 x 3
+//     channels that output frames 2*tp and 2*tp + 1 read: frame 2*tp takes the 32 bytes at offset 0, frame 2*tp + 1 the 32 bytes
+//     at offset 12 (a 4-byte aligned LDS-DMA source). 9.6 MB per clip. (First version: one 128-byte record per pixel with all 16
+//     frames, 6.4 MB per clip -- but then every 16-byte DMA piece comes from a different 128-byte line, 32 lines per 1 KB
+//     wave-instruction, and the halo stream alone took 1180 us per 225 clips, the cache's line rate, not bytes; here consecutive
+//     positions of a plane are consecutive records: 12 lines per instruction.)
+//   * ALL weights (49 taps x [64 co][16] = 98 KB) stay resident in LDS: the K loop has no weight stream, its fragment
+//     addresses are per-lane bases + compile-time immediates (fully unrolled, no address arithmetic);
+//   * a workgroup is persistent (one per CU) and walks patches of 8 x 16 output pixels x 2 output frames; the input halo of a
+//     patch (2 frames x 21 rows x 38 columns x 32 B = 50 KB) lives in two LDS regions by ROW PARITY: the taps with even dh read
+//     only even halo rows, the odd ones only odd rows, so while the 28 even-dh taps of patch i are multiplied the odd rows of patch
+//     i are landing, and while its 21 odd-dh taps run the even rows of patch i+1 land: one halo buffer, two barriers per patch.
+//     (Four regions by (row, column) parity -- a DMA distance of 2/3 of a patch instead of 1/2 -- were measured: 10 % slower, the
+//     two extra barriers and pipeline restarts per patch cost more than the distance buys; the halo stream is throughput-, not
+//     latency-bound.)
+//   * a wave owns output rows (r, r+4) x 16 columns of BOTH frames (64 px); the two frames are the temporal pooling window, so
+//     relu(bn(.)) of both are max-ed in registers and only the pooled tensor Y[n][to/2][ho][wo][64] is written (half the bytes),
+//     straight from the accumulators: v_permlane32_swap gives lane l the even and lane l + 32 the odd 8-channel group of its
+//     pixel -> 16-byte stores, no LDS staging; the barrier after them waits with a counted vmcnt that leaves them in flight.
 // LDS images are bank-conflict free for ds_read_b128: positions are 32 B (two 16-byte halves = the two k8 halves of the MFMA
 // B operand); the halves of position p are stored swapped when (p >> 3) & 1, and the second pixel row of a fragment is 4
 // output rows away (4 x 1216 B = 0 mod 256 B); weight rows (32 B per co) swap halves when (co >> 4) & 1.
@@ -35,77 +40,76 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PT_TH = 8, PT_TW = 16;                  // output patch (rows x columns), x 2 output frames
 constexpr int PT_PP = PT_TW + 3;                      // positions per parity-plane row (a = -2 .. +1 around 16 columns)
-constexpr int PT_RE = PT_TH + 3, PT_RO = PT_TH + 2;   // even / odd halo rows under the patch (halo rows 0 .. 20)
 constexpr int PT_ROWB = 2 * PT_PP * 32;               // bytes per halo row: 2 column-parity planes
-constexpr int PT_FE = PT_RE * PT_ROWB, PT_FO = PT_RO * PT_ROWB;   // bytes per frame and region
 constexpr int PT_NTAP = 49;
 constexpr int PT_W_BYTES = PT_NTAP * 64 * 32;         // 100352
-constexpr int PT_E_SLOTS = 2 * PT_FE / 16, PT_O_SLOTS = 2 * PT_FO / 16;
-constexpr int PT_E_JOBS = (PT_E_SLOTS + 63) / 64, PT_O_JOBS = (PT_O_SLOTS + 63) / 64;   // 1 KB wave-instructions per region
-constexpr int PT_E_OFF = PT_W_BYTES, PT_O_OFF = PT_E_OFF + PT_E_JOBS * 1024;
-constexpr int PT_LDS = PT_O_OFF + PT_O_JOBS * 1024;
-constexpr int PT_E_ROUNDS = (PT_E_JOBS + 3) / 4, PT_O_ROUNDS = (PT_O_JOBS + 3) / 4;
+constexpr int PT_REC = 48;                            // bytes per pixel record of the clip layout
+__host__ __device__ constexpr int pt_rows(int par) { return par == 0 ? PT_TH + 3 : PT_TH + 2; }   // even halo rows 0..20: 11, odd: 10
+__host__ __device__ constexpr int pt_frame(int par) { return pt_rows(par) * PT_ROWB; }            // bytes per frame of a region
+__host__ __device__ constexpr int pt_jobs(int par) { return (2 * pt_frame(par) + 1023) / 1024; }  // 1 KB wave-instructions (27 / 24)
+// the halo regions come first (their fragment addresses then are one per-lane base + a 16-bit immediate), the weights after them
+__host__ __device__ constexpr int pt_off(int par) { return par == 0 ? 0 : pt_jobs(0) * 1024; }
+constexpr int PT_W_OFF = pt_off(1) + pt_jobs(1) * 1024;
+constexpr int PT_LDS = PT_W_OFF + PT_W_BYTES;
 static_assert(PT_LDS <= 160 * 1024, "weights + halo must fit the CU's LDS");
 static_assert(PT_W_BYTES % 1024 == 0 && (4 * PT_ROWB) % 256 == 0, "LDS image alignment");
 
 struct StemPT {
-    const unsigned char *x;       // time-channels-last clip
+    const unsigned char *x;       // X[n][tp][h][b][wq][24] 16-bit (tedspad_clip_to_tp)
     const unsigned char *wimg;    // [49][64][2][8] 16-bit, halves swizzled (tedspad_stem_pt_fwd)
     const float *scale, *shift;
     uint16_t *y;
-    long sN;                      // bytes per clip
-    int sTo, sH, sW;              // bytes per output frame / row / pixel of x
-    int N, Tp, H, W, Ho, Wo, ldy, relu;
+    long sTp;                     // bytes per frame pair of x
+    int sH, sP;                   // bytes per row (both planes) / plane row
+    int N, Tp, H, Wq, Ho, Wo, ldy, relu;
     int tiles_h, tiles_w, total, chunk;
+    int dbg;                      // timing ablations (wrong results): 1 = no halo DMA after the first patch, 2 = no stores, 4 = no MFMA phases
 };
 
 __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: a store of > 64 bits reads its data registers late; hipcc pads nothing after an asm statement and may overwrite them
 }
 
-// The taps of one phase, fully unrolled. SCHED 0: the order hipcc picks (it requests the fragments of a tap only after the previous tap's
-// MFMAs are issued); SCHED 1: the fragments of tap i+1 are requested BEFORE the MFMAs of tap i (two register sets), pinned with
-// sched_group_barrier, so one wave per SIMD keeps its matrix pipe fed across the LDS latency.
-template <typename T, int PAR, int SCHED>
-__device__ __forceinline__ void stem_pt_phase(const unsigned char *dsm, const int (&pa)[4], const int (&wa)[2], f32x16 (&acc)[2][2]) {
-    constexpr int FR = PAR == 0 ? PT_FE : PT_FO;
+// The taps of one row parity, fully unrolled: the fragments of tap i+1 are requested BEFORE the MFMAs of tap i (two register sets),
+// pinned with sched_group_barrier, so the matrix pipe stays fed across the LDS latency (hipcc's own order requests a tap's fragments
+// only after the previous tap's MFMAs are issued: 2580 vs 2300 us per 225 clips).
+template <typename T, int PAR, int NA>
+__device__ __forceinline__ void stem_pt_phase(const unsigned char *dsm, const int (&pa)[4], const int (&wa)[NA], f32x16 (&acc)[NA][2]) {
     constexpr int NT = (PAR == 0 ? 4 : 3) * 7;
-    uint4 fa[2][2], fw[2][2];
-    auto load = [&](int i, uint4 (&xa)[2], uint4 (&xw)[2]) {
+    constexpr int FR = pt_frame(PAR);
+    uint4 fa[2][2], fw[2][NA];
+    auto load = [&](int i, uint4 (&xa)[2], uint4 (&xw)[NA]) {
         const int dhh = i / 7, dw = i % 7;
         const int b = (dw + 1) & 1;                   // column 2*wo + dw - 3 = 2*(wo + a) + b
         const int ta = (dw - 3 - b) / 2 + 2;          // a + 2 (dw - 3 - b is even)
         const int tau = (2 * dhh + PAR) * 7 + dw;
-        const int imm = dhh * PT_ROWB + b * PT_PP * 32;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) xa[g] = *reinterpret_cast<const uint4 *>(dsm + pa[ta] + g * FR + imm);
+        for (int g = 0; g < 2; ++g) xa[g] = *reinterpret_cast<const uint4 *>(dsm + pa[ta] + (pt_off(PAR) + g * FR + dhh * PT_ROWB + b * PT_PP * 32));
 #pragma unroll
-        for (int a = 0; a < 2; ++a) xw[a] = *reinterpret_cast<const uint4 *>(dsm + wa[a] + tau * 2048);
+        for (int a = 0; a < NA; ++a) xw[a] = *reinterpret_cast<const uint4 *>(dsm + wa[a] + tau * 2048);
     };
-    if (SCHED == 1) {
-        load(0, fa[0], fw[0]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the first tap's reads open the pipeline
-    }
+    load(0, fa[0], fw[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NA, 0);      // the first tap's reads open the pipeline
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        if (SCHED == 1) {
-            if (i + 1 < NT) load(i + 1, fa[(i + 1) & 1], fw[(i + 1) & 1]);
-        } else {
-            load(i, fa[i & 1], fw[i & 1]);
-        }
+        if (i + 1 < NT) load(i + 1, fa[(i + 1) & 1], fw[(i + 1) & 1]);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int g = 0; g < 2; ++g) acc[a][g] = T::mfma(fw[i & 1][a], fa[i & 1][g], acc[a][g]);
-        if (SCHED == 1) {
-            if (i + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 LDS reads (tap i+1)
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                   // 4 MFMAs (tap i)
-        }
+        if (i + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NA, 0);   // the LDS reads of tap i+1
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NA, 0);                   // the MFMAs of tap i
     }
 }
 
-template <typename T, int SCHED>
-__global__ __launch_bounds__(256) void conv_stem_pt_kernel(const StemPT p) {
+// NW = 4: one wave per SIMD, every wave multiplies all 64 output channels of its 64 pixels (4 fragment reads per 4 MFMAs).
+// NW = 8: two waves per SIMD; waves w and w + 4 own the same pixels and the output channels [0,32) / [32,64) (3 reads per 2
+// MFMAs: 192 B/clk of the CU's 256 B/clk LDS at full MFMA rate): one wave's epilogue, DMA issue and patch arithmetic run
+// under its partner's MFMAs.
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
+    constexpr int NA = NW == 8 ? 1 : 2;
+    constexpr int ROUNDS = (pt_jobs(0) + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,88 +125,92 @@ __global__ __launch_bounds__(256) void conv_stem_pt_kernel(const StemPT p) {
     if (k >= lim) return;                                   // workgroup-uniform, before any barrier
 
     // ---- resident weights: a linear 98 KB copy --------------------------------------------------------------------------------
-    for (int j = wave; j < PT_W_BYTES / 1024; j += 4) lds_dma16(p.wimg + j * 1024 + lane * 16, lds0 + j * 1024);
+    for (int j = wave; j < PT_W_BYTES / 1024; j += NW) lds_dma16(p.wimg + j * 1024 + lane * 16, lds0 + PT_W_OFF + j * 1024);
 
     // ---- halo DMA slots of this lane (patch-invariant): LDS slot s of a region = (frame, row, plane, position, half) --------------
-    int offE[PT_E_ROUNDS], rcE[PT_E_ROUNDS], offO[PT_O_ROUNDS], rcO[PT_O_ROUNDS];
-    auto decode = [&](int s, int rows, int par, int &off, int &rc) {
-        const int hs = s & 1;
-        int q = s >> 1;
-        const int pos = q % PT_PP; q /= PT_PP;
-        const int b = q & 1; q >>= 1;
-        const int row = q % rows, f = q / rows;
-        const int hr = 2 * row + par, col = 2 * (pos - 2) + b;     // halo row 0..20 (input row ih0 + hr), column relative to 2*wo0
-        const int hf = hs ^ ((pos >> 3) & 1);
-        const bool ok = f < 2;
-        off = ok ? f * p.sTo + hr * p.sH + col * p.sW + hf * 16 : 0;
-        rc = ok ? (hr << 8) | (col + 4) : (1 << 28);                // a row far outside any clip: the slot reads the zero page
-    };
+    int off[2][ROUNDS], rc[2][ROUNDS];
 #pragma unroll
-    for (int i = 0; i < PT_E_ROUNDS; ++i) decode((i * 4 + wave) * 64 + lane, PT_RE, 0, offE[i], rcE[i]);
+    for (int par = 0; par < 2; ++par)
 #pragma unroll
-    for (int i = 0; i < PT_O_ROUNDS; ++i) decode((i * 4 + wave) * 64 + lane, PT_RO, 1, offO[i], rcO[i]);
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int s = (i * NW + wave) * 64 + lane;
+            const int hs = s & 1;
+            int q = s >> 1;
+            const int pos = q % PT_PP; q /= PT_PP;
+            const int b = q & 1; q >>= 1;
+            const int row = q % pt_rows(par), f = q / pt_rows(par);
+            const int hr = 2 * row + par;                               // halo row 0..20 (input row ih0 + hr); plane column wo0 - 2 + pos
+            const int hf = hs ^ ((pos >> 3) & 1);
+            const bool ok = f < 2;
+            off[par][i] = ok ? f * 12 + hf * 16 + hr * p.sH + b * p.sP + (pos - 2) * PT_REC : 0;
+            rc[par][i] = ok ? (hr << 8) | pos : (1 << 28);              // a row far outside any clip: the slot reads the zero page
+        }
 
-    struct Patch { const unsigned char *pb; int ih0, iwm4, n, tp, ho0, wo0; };
-    auto patch_of = [&](int kk) {
-        Patch q;
-        int r = base + kk;
-        const int tw = r % p.tiles_w; r /= p.tiles_w;
-        const int th = r % p.tiles_h; r /= p.tiles_h;
-        q.tp = r % p.Tp; q.n = r / p.Tp;
-        q.ho0 = th * PT_TH; q.wo0 = tw * PT_TW;
-        q.ih0 = 2 * q.ho0 - 3; q.iwm4 = 2 * q.wo0 - 4;
-        q.pb = p.x + (long)q.n * p.sN + (long)(2 * q.tp) * p.sTo + (long)q.ih0 * p.sH + (long)(2 * q.wo0) * p.sW;
+    // patch coordinates advance by a constant step (nx patches): mixed-radix addition with carries instead of three integer
+    // divisions per patch
+    struct Patch { const unsigned char *pb; int ih0, wqm2, n, tp, th, tw, ho0, wo0; };
+    auto split = [&](int r, int &n_, int &tp_, int &th_, int &tw_) {
+        tw_ = r % p.tiles_w; r /= p.tiles_w;
+        th_ = r % p.tiles_h; r /= p.tiles_h;
+        tp_ = r % p.Tp; n_ = r / p.Tp;
+    };
+    auto locate = [&](Patch &q) {
+        q.ho0 = q.th * PT_TH; q.wo0 = q.tw * PT_TW;
+        q.ih0 = 2 * q.ho0 - 3; q.wqm2 = q.wo0 - 2;
+        q.pb = p.x + ((long)q.n * p.Tp + q.tp) * p.sTp + (long)q.ih0 * p.sH + (long)q.wo0 * PT_REC;
+    };
+    int dn, dtp, dth, dtw;
+    split(nx, dn, dtp, dth, dtw);
+    auto advance = [&](const Patch &c) {
+        Patch q = c;
+        q.tw += dtw; if (q.tw >= p.tiles_w) { q.tw -= p.tiles_w; ++q.th; }
+        q.th += dth; if (q.th >= p.tiles_h) { q.th -= p.tiles_h; ++q.tp; }
+        q.tp += dtp; if (q.tp >= p.Tp) { q.tp -= p.Tp; ++q.n; }
+        q.n += dn;
+        locate(q);
         return q;
     };
-    auto issue_E = [&](const Patch &q) {
+    auto issue = [&](int par, const Patch &q) {              // par is a literal at every call site
 #pragma unroll
-        for (int i = 0; i < PT_E_ROUNDS; ++i) {
-            const int j = i * 4 + wave;
-            if (j >= PT_E_JOBS) break;                      // wave-uniform
-            const bool ok = (unsigned)(q.ih0 + (rcE[i] >> 8)) < (unsigned)p.H && (unsigned)(q.iwm4 + (rcE[i] & 255)) < (unsigned)p.W;
-            lds_dma16(ok ? q.pb + offE[i] : zero, lds0 + PT_E_OFF + j * 1024);
-        }
-    };
-    auto issue_O = [&](const Patch &q) {
-#pragma unroll
-        for (int i = 0; i < PT_O_ROUNDS; ++i) {
-            const int j = i * 4 + wave;
-            if (j >= PT_O_JOBS) break;
-            const bool ok = (unsigned)(q.ih0 + (rcO[i] >> 8)) < (unsigned)p.H && (unsigned)(q.iwm4 + (rcO[i] & 255)) < (unsigned)p.W;
-            lds_dma16(ok ? q.pb + offO[i] : zero, lds0 + PT_O_OFF + j * 1024);
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int j = i * NW + wave;
+            if (j >= pt_jobs(par)) break;                    // wave-uniform
+            const bool ok = (unsigned)(q.ih0 + (rc[par][i] >> 8)) < (unsigned)p.H && (unsigned)(q.wqm2 + (rc[par][i] & 255)) < (unsigned)p.Wq;
+            lds_dma16(ok ? q.pb + off[par][i] : zero, lds0 + pt_off(par) + j * 1024);
         }
     };
 
-    Patch cur = patch_of(k);
-    issue_E(cur);
-    issue_O(cur);
+    Patch cur;
+    split(base + k, cur.n, cur.tp, cur.th, cur.tw);
+    locate(cur);
+    issue(0, cur);
+    issue(1, cur);
 
     // ---- fragment bases ---------------------------------------------------------------------------------------------------------
     const int l15 = lane & 15, rsel = (lane >> 4) & 1, lh = lane >> 5, l31 = lane & 31;
-    const int prow = wave + 4 * rsel;                       // output row of this lane's pixel inside the patch
-    int paE[4], paO[4], wa[2];
+    const int prow = (wave & 3) + 4 * rsel;                 // output row of this lane's pixel inside the patch
+    const int a0 = NW == 8 ? wave >> 2 : 0;                 // first 32-channel group of this wave
+    int pa[4], wa[NA];
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta) {
         const int pos = l15 + ta;
-        const int o = prow * PT_ROWB + pos * 32 + 16 * (lh ^ ((pos >> 3) & 1));
-        paE[ta] = PT_E_OFF + o;
-        paO[ta] = PT_O_OFF + o;
+        pa[ta] = prow * PT_ROWB + pos * 32 + 16 * (lh ^ ((pos >> 3) & 1));
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a) wa[a] = (a * 32 + l31) * 32 + 16 * (lh ^ (((a * 32 + l31) >> 4) & 1));
+    for (int a = 0; a < NA; ++a) wa[a] = PT_W_OFF + ((a0 + a) * 32 + l31) * 32 + 16 * (lh ^ ((((a0 + a) * 32 + l31) >> 4) & 1));
 
-    // BatchNorm scale / shift of this lane's 32 output channels: co = a*32 + (r & 3) + 8*(r >> 2) + 4*lh
-    float sc[2][16], sf[2][16];
+    // BatchNorm scale / shift of this lane's output channels: co = a*32 + (r & 3) + 8*(r >> 2) + 4*lh
+    float sc[NA][16], sf[NA][16];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = (a0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             sc[a][r] = p.scale[co];
             sf[a][r] = p.shift[co];
         }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(sc[a][r]), "+v"(sf[a][r]));   // hipcc's wait for these loads happens here, not in the loop
 
@@ -210,34 +218,37 @@ __global__ __launch_bounds__(256) void conv_stem_pt_kernel(const StemPT p) {
     __builtin_amdgcn_s_barrier();      // weights + both halo regions of the first patch visible
     asm volatile("" ::: "memory");
 
+    const bool dma = !(p.dbg & 1);
     while (true) {
         const int kn = k + nx;
         const bool more = kn < lim;                         // workgroup-uniform
         Patch nxt = cur;
-        if (more) nxt = patch_of(kn);
+        if (more) nxt = advance(cur);
 
-        f32x16 acc[2][2];
+        f32x16 acc[NA][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][g][r] = 0.f;
 
-        stem_pt_phase<T, 0, SCHED>(dsm, paE, wa, acc);             // taps dh = 0, 2, 4, 6 on the even halo rows
-        wait_vmcnt<0>();                                    // odd rows of this patch (issued a phase ago) landed
+        if (!(p.dbg & 4)) stem_pt_phase<T, 0, NA>(dsm, pa, wa, acc);             // taps dh = 0, 2, 4, 6 on the even halo rows
+        wait_vmcnt<0>();                                    // odd rows of this patch (the youngest operation of this wave) landed
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the even rows
         asm volatile("" ::: "memory");
-        if (more) issue_E(nxt);                             // even rows of the NEXT patch land under the odd taps + epilogue
-        stem_pt_phase<T, 1, SCHED>(dsm, paO, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
+        if (more && dma) issue(0, nxt);                     // even rows of the NEXT patch land under the odd taps + epilogue
+        if (!(p.dbg & 4)) stem_pt_phase<T, 1, NA>(dsm, pa, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
 
         // ---- epilogue: relu(bn(.)) of both frames, max over the two frames (the temporal window of maxpool1), 16-byte stores --------
+        bool stored;
         {
             const int ho = cur.ho0 + prow, wo = cur.wo0 + l15;
-            const bool inb = ho < p.Ho && wo < p.Wo;
+            const bool inb = ho < p.Ho && wo < p.Wo && !(p.dbg & 2);
+            stored = __builtin_amdgcn_ballot_w64(inb) != 0;  // the store instructions below are issued iff any lane is in bounds
             uint16_t *dst = p.y + ((((size_t)cur.n * p.Tp + cur.tp) * p.Ho + ho) * p.Wo + wo) * p.ldy + 8 * lh;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < NA; ++a) {
                 unsigned d[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -264,52 +275,70 @@ __global__ __launch_bounds__(256) void conv_stem_pt_kernel(const StemPT p) {
                         d[q + 1][h] = sw[1];
                     }
                 if (inb) {
-                    gstore16(dst + a * 32, u32x4{d[0][0], d[0][1], d[1][0], d[1][1]});
-                    gstore16(dst + a * 32 + 16, u32x4{d[2][0], d[2][1], d[3][0], d[3][1]});
+                    gstore16(dst + (a0 + a) * 32, u32x4{d[0][0], d[0][1], d[1][0], d[1][1]});
+                    gstore16(dst + (a0 + a) * 32 + 16, u32x4{d[2][0], d[2][1], d[3][0], d[3][1]});
                 }
             }
         }
         if (!more) break;
-        wait_vmcnt<0>();                                    // even rows of the next patch landed (and this patch's stores retired)
+        // even rows of the next patch landed; this patch's stores (issued after them; vector-memory operations retire in issue
+        // order on gfx9) stay in flight
+        if (stored) wait_vmcnt<2 * NA>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the odd rows
         asm volatile("" ::: "memory");
-        issue_O(nxt);                                       // odd rows of the next patch land under its even taps
+        if (dma) issue(1, nxt);                             // odd rows of the next patch land under its even taps
         cur = nxt;
         k = kn;
     }
 }
 
-// fp32 NCTHW clip (any strides, W contiguous) -> X[n][h][w][64] 16-bit: value (t + pt)*3 + c of pixel (h, w) = x[n][c][t][h][w], zero
-// elsewhere (the temporal zero padding of the conv lives in the record). A thread owns 16 values of one pixel: 16 coalesced row
-// loads (a wave covers 64 consecutive pixels of one (c, t) row), two 16-byte LDS writes, then the 64-pixel tile leaves as one
-// contiguous 8 KB run.
+// fp32 NCTHW clip (any strides, W contiguous) -> X[n][tp][h][b][w/2][24] 16-bit: the record of pixel (h, 2*wq + b) for output-frame
+// pair tp holds value dt*3 + c = x[n][c][2*st*tp - pt + dt][h][2*wq + b], dt = 0..7, zero outside the clip. A workgroup owns 64
+// consecutive pixels of one row; wave g builds the records of pair g (g + 4, ...): 24 coalesced row loads per thread (the four
+// frames two neighbouring pairs share are re-read through L1), three 16-byte LDS writes, then every (pair, plane) leaves as one
+// contiguous 1.5 KB run.
 template <typename T>
-__global__ __launch_bounds__(256) void clip_to_tc_kernel(const float *x, uint16_t *y, int c, int t, int h, int w, long sn, long sc, long st, long sh,
-                                                         int pt, int wtiles) {
-    __shared__ __attribute__((aligned(16))) uint4 tile[64 * 8];
-    const int tid = threadIdx.x, px = tid & 63, vq = tid >> 6;
+__global__ __launch_bounds__(256) void clip_to_tp_kernel(const float *x, uint16_t *y, int c, int t, int h, int w, long sn, long sc, long st, long sh,
+                                                         int pt, int stt, int tp_n, int wtiles) {
+    __shared__ __attribute__((aligned(16))) uint4 tile[4 * 2 * 32 * 3];     // [wave = pair][plane][32 records][3 x 16 B]
+    const int tid = threadIdx.x, px = tid & 63, grp = tid >> 6;
     int b = blockIdx.x;
     const int wt = b % wtiles; b /= wtiles;
     const int ih = b % h;
     const long n = b / h;
     const int iw = wt * 64 + px;
-    float v[16];
+    const int wq_n = w >> 1;
+    const int nrec = min(64, w - wt * 64) >> 1;                             // records per plane in this tile
+    for (int tp0 = 0; tp0 < tp_n; tp0 += 4) {
+        const int tp = tp0 + grp;
+        if (tp < tp_n) {
+            float v[24];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int val = vq * 16 + e;
-        const int tt = val / 3 - pt, ch = val % 3;
-        v[e] = 0.f;
-        if (iw < w && tt >= 0 && tt < t && ch < c) v[e] = x[n * sn + ch * sc + tt * st + ih * sh + iw];
+            for (int e = 0; e < 24; ++e) {
+                const int tt = 2 * stt * tp - pt + e / 3, ch = e % 3;
+                v[e] = 0.f;
+                if (iw < w && tt >= 0 && tt < t && ch < c) v[e] = x[n * sn + ch * sc + tt * st + ih * sh + iw];
+            }
+            uint4 *rec = tile + ((grp * 2 + (px & 1)) * 32 + (px >> 1)) * 3;
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                float f8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f8[e] = v[k3 * 8 + e];
+                rec[k3] = pack8<T>(f8);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * 96; i += 256) {
+            const int run = i / 96, j = i - run * 96;                       // run = (wave, plane); j-th 16-byte piece of its 32 records
+            const int g = run >> 1, bb = run & 1;
+            if (tp0 + g < tp_n && j < nrec * 3) {
+                uint4 *dst = reinterpret_cast<uint4 *>(y) + ((((n * tp_n + tp0 + g) * h + ih) * 2 + bb) * (long)wq_n + wt * 32) * 3;
+                dst[j] = tile[run * 96 + j];
+            }
+        }
+        __syncthreads();
     }
-    float lo[8], hi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[8 + e]; }
-    tile[px * 8 + vq * 2] = pack8<T>(lo);
-    tile[px * 8 + vq * 2 + 1] = pack8<T>(hi);
-    __syncthreads();
-    const int npx = min(64, w - wt * 64);
-    uint4 *dst = reinterpret_cast<uint4 *>(y + ((n * h + ih) * (long)w + wt * 64) * 64);
-    for (int i = tid; i < npx * 8; i += 256) dst[i] = tile[i];
 }
 
 }  // namespace
@@ -317,37 +346,35 @@ __global__ __launch_bounds__(256) void clip_to_tc_kernel(const float *x, uint16_
 
 using namespace tedspad;
 
-extern "C" int32_t tedspad_clip_to_tc(const float *x, void *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc,
-                                      int64_t st, int64_t sh, int64_t sw, int32_t pad_t, int32_t dtype, void *stream) {
-    TS_REQUIRE(x && y && n > 0 && c > 0 && c <= 3 && t > 0 && h > 0 && w > 0 && pad_t >= 0, "tedspad_clip_to_tc: bad arguments");
-    TS_REQUIRE((t + pad_t) * 3 <= 64, "tedspad_clip_to_tc: (t + pad_t) * 3 values must fit the 64-value pixel record");
-    TS_REQUIRE(sw == 1 && (uintptr_t)y % 16 == 0, "tedspad_clip_to_tc: rows must be contiguous, y 16-byte aligned");
-    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_clip_to_tc: bad dtype");
-    TS_REQUIRE((long)n * h * ((w + 63) / 64) < (1L << 31), "tedspad_clip_to_tc: too many tiles");
+extern "C" int32_t tedspad_clip_to_tp(const float *x, void *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc,
+                                      int64_t st, int64_t sh, int64_t sw, int32_t pad_t, int32_t stride_t, int32_t t_pairs, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && c <= 3 && t > 0 && h > 0 && w > 0 && pad_t >= 0 && t_pairs > 0, "tedspad_clip_to_tp: bad arguments");
+    TS_REQUIRE(stride_t == 2, "tedspad_clip_to_tp: temporal stride 2 (the second frame of a pair starts 12 bytes into the 48-byte record)");
+    TS_REQUIRE(sw == 1 && w % 2 == 0 && (uintptr_t)y % 16 == 0, "tedspad_clip_to_tp: rows must be contiguous, W even, y 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_clip_to_tp: bad dtype");
+    TS_REQUIRE((long)n * h * ((w + 63) / 64) < (1L << 31), "tedspad_clip_to_tp: too many tiles");
     const int wtiles = (w + 63) / 64;
     const dim3 g((unsigned)((long)n * h * wtiles));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(clip_to_tc_kernel<F16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, wtiles);
-    else hipLaunchKernelGGL(clip_to_tc_kernel<BF16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, wtiles);
-    return check_launch("tedspad_clip_to_tc");
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(clip_to_tp_kernel<F16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, stride_t, t_pairs, wtiles);
+    else hipLaunchKernelGGL(clip_to_tp_kernel<BF16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, stride_t, t_pairs, wtiles);
+    return check_launch("tedspad_clip_to_tp");
 }
 
 extern "C" int32_t tedspad_stem_pt_wimg_bytes(void) { return PT_W_BYTES; }
 
-extern "C" int32_t tedspad_stem_pt_fwd(const void *x_tc, const void *w_img, const float *scale, const float *shift, void *y, int32_t n, int32_t t_pairs,
-                                       int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t stride_t, int32_t ldy, int32_t relu, int32_t nwg,
+extern "C" int32_t tedspad_stem_pt_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, int32_t n, int32_t t_pairs,
+                                       int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t ldy, int32_t relu, int32_t nwg,
                                        int32_t variant, int32_t dtype, void *stream) {
-    TS_REQUIRE(x_tc && w_img && scale && shift && y && n > 0 && t_pairs > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "tedspad_stem_pt_fwd: bad arguments");
-    TS_REQUIRE(stride_t > 0 && (stride_t * 6) % 4 == 0 && (2 * t_pairs - 1) * stride_t * 3 + 16 <= 64,
-               "tedspad_stem_pt_fwd: the 16 values of every output frame must lie inside the 64-value record at a 4-byte offset");
-    TS_REQUIRE(ho == (h + 1) / 2 && wo == (w + 1) / 2, "tedspad_stem_pt_fwd: 7x7 stride-2 pad-3 geometry (ho = ceil(h / 2))");
-    TS_REQUIRE(ldy >= 64 && ldy % 8 == 0 && ((uintptr_t)x_tc | (uintptr_t)w_img | (uintptr_t)y) % 16 == 0, "tedspad_stem_pt_fwd: 64 output channels, 16-byte aligned pointers");
+    TS_REQUIRE(x_tp && w_img && scale && shift && y && n > 0 && t_pairs > 0 && h > 0 && w > 0 && w % 2 == 0 && ho > 0 && wo > 0, "tedspad_stem_pt_fwd: bad arguments");
+    TS_REQUIRE(ho == (h + 1) / 2 && wo == w / 2, "tedspad_stem_pt_fwd: 7x7 stride-2 pad-3 geometry (ho = ceil(h / 2))");
+    TS_REQUIRE(ldy >= 64 && ldy % 8 == 0 && ((uintptr_t)x_tp | (uintptr_t)w_img | (uintptr_t)y) % 16 == 0, "tedspad_stem_pt_fwd: 64 output channels, 16-byte aligned pointers");
     TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_stem_pt_fwd: bad dtype");
-    TS_REQUIRE((long)h * w * 128 < (1L << 31), "tedspad_stem_pt_fwd: frame too large for 32-bit halo offsets");
+    TS_REQUIRE((long)h * w * PT_REC < (1L << 31), "tedspad_stem_pt_fwd: frame too large for 32-bit halo offsets");
     StemPT p;
-    p.x = (const unsigned char *)x_tc; p.wimg = (const unsigned char *)w_img; p.scale = scale; p.shift = shift; p.y = (uint16_t *)y;
-    p.sW = 128; p.sH = w * 128; p.sN = (long)h * w * 128; p.sTo = stride_t * 6;
-    p.N = n; p.Tp = t_pairs; p.H = h; p.W = w; p.Ho = ho; p.Wo = wo; p.ldy = ldy; p.relu = relu;
+    p.x = (const unsigned char *)x_tp; p.wimg = (const unsigned char *)w_img; p.scale = scale; p.shift = shift; p.y = (uint16_t *)y;
+    p.Wq = w / 2; p.sP = p.Wq * PT_REC; p.sH = 2 * p.sP; p.sTp = (long)h * p.sH;
+    p.N = n; p.Tp = t_pairs; p.H = h; p.Ho = ho; p.Wo = wo; p.ldy = ldy; p.relu = relu;
     p.tiles_h = (ho + PT_TH - 1) / PT_TH; p.tiles_w = (wo + PT_TW - 1) / PT_TW;
     const long total = (long)n * t_pairs * p.tiles_h * p.tiles_w;
     TS_REQUIRE(total < (1L << 30), "tedspad_stem_pt_fwd: too many patches");
@@ -358,10 +385,11 @@ extern "C" int32_t tedspad_stem_pt_fwd(const void *x_tc, const void *w_img, cons
     if ((long)grid > total + 7) grid = (int)((total + 7) / 8 * 8);
     hipStream_t s = (hipStream_t)stream;
     static thread_local int attr_set[4] = {0, 0, 0, 0};
-    const int sched = variant & 1;
-    const int di = (dtype == TEDSPAD_F16 ? 0 : 1) * 2 + sched;
-    const void *fns[4] = {(const void *)conv_stem_pt_kernel<F16, 0>, (const void *)conv_stem_pt_kernel<F16, 1>,
-                          (const void *)conv_stem_pt_kernel<BF16, 0>, (const void *)conv_stem_pt_kernel<BF16, 1>};
+    const int w8 = (variant >> 1) & 1;
+    p.dbg = (variant >> 8) & 7;
+    const int di = (dtype == TEDSPAD_F16 ? 0 : 1) * 2 + w8;
+    const void *fns[4] = {(const void *)conv_stem_pt_kernel<F16, 4>, (const void *)conv_stem_pt_kernel<F16, 8>,
+                          (const void *)conv_stem_pt_kernel<BF16, 4>, (const void *)conv_stem_pt_kernel<BF16, 8>};
     if (!attr_set[di]) {
         if (hipFuncSetAttribute(fns[di], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_stem_pt_fwd: cannot raise the dynamic LDS limit");
@@ -369,11 +397,12 @@ extern "C" int32_t tedspad_stem_pt_fwd(const void *x_tc, const void *w_img, cons
         }
         attr_set[di] = 1;
     }
+    const dim3 g(grid), b(w8 ? 512 : 256);
     switch (di) {
-        case 0: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 0>), dim3(grid), dim3(256), PT_LDS, s, p); break;
-        case 1: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 1>), dim3(grid), dim3(256), PT_LDS, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 0>), dim3(grid), dim3(256), PT_LDS, s, p); break;
-        default: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 1>), dim3(grid), dim3(256), PT_LDS, s, p); break;
+        case 0: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 4>), g, b, PT_LDS, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8>), g, b, PT_LDS, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 4>), g, b, PT_LDS, s, p); break;
+        default: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8>), g, b, PT_LDS, s, p); break;
     }
     return check_launch("tedspad_stem_pt_fwd");
 }

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -24,7 +25,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # calls of a conv on a new geometry the tile configurations of the kernel take turns, timed in context with
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
-STEM_TU = os.environ.get("TEDSPAD_STEM_TU", "0") == "1"   # temporal-unfolded stem (StemTU): the kernel is 14 % faster, its layout pass costs that back -> off by default
+STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
 PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
@@ -43,13 +44,25 @@ def batch_chunk(n: int, per_sample_sizes, limit: int) -> int:
     return max(1, min(n, limit // worst))
 
 
-_TUNING = set()         # (id(PackedConv), geometry key) of the convs whose configurations are still taking turns
+class _Cfgs(dict):
+    """geometry key -> chosen tile configuration (int) or the tuner's in-progress state (dict). One instance per convolution,
+    SHARED by the PackedConv objects that succeed each other when the weights are re-packed after an optimizer step
+    (train_engine.ConvLayer.fwd_conv), so it -- not the PackedConv -- is the identity of a tuning job."""
+    __slots__ = ("__weakref__",)
+
+
+_TUNING = {}            # (id(_Cfgs), geometry key) -> weakref to the _Cfgs whose configurations are still taking turns
 
 
 def tuning_pending() -> bool:
     """True while any conv geometry seen so far is still being tuned. Callers that overlap forwards on several
     streams stay on ONE stream until this is False: a candidate timed while other streams' kernels share the CUs
-    is measured with their interference and can lose to a slower configuration."""
+    is measured with their interference and can lose to a slower configuration. Jobs whose convolution was dropped
+    (a model re-packed from scratch) or already decided are pruned here."""
+    for k, ref in list(_TUNING.items()):
+        cfgs = ref()
+        if cfgs is None or not isinstance(cfgs.get(k[1]), dict):
+            del _TUNING[k]
     return bool(_TUNING)
 
 
@@ -213,7 +226,7 @@ class PackedConv:
         self.shift = _padded_vec(shift, cout, self.cpad, device, 0.0)
         self.device = device
         self._ktabs = {}
-        self._cfgs = {}
+        self._cfgs = _Cfgs()
 
     @classmethod
     def dgrad_sub(cls, w5: torch.Tensor, wscale, geo, pair_w, dtype):
@@ -246,7 +259,7 @@ class PackedConv:
         self.scale = _padded_vec(None, cin_k, self.cpad, dev, 1.0)
         self.shift = _padded_vec(None, cin_k, self.cpad, dev, 0.0)
         self.device = dev
-        self._ktabs, self._cfgs = {}, {}
+        self._ktabs, self._cfgs = {}, _Cfgs()
         return self
 
     def _desc(self, n, t, h, w, ldx, pads, out, ldy, ldres, relu):
@@ -299,7 +312,7 @@ class PackedConv:
         if st is None:
             st = {"cands": [c for c in range(0, L.tedspad_conv_num_tile_cfgs() + 1) if c not in SKIP_TILE_CFGS], "pos": 0, "rep": 0, "rec": {}}
             self._cfgs[key] = st
-            _TUNING.add((id(self), key))
+            _TUNING[(id(self._cfgs), key)] = weakref.ref(self._cfgs)
         while True:
             cfg = st["cands"][st["pos"]]
             d.tile_cfg = cfg
@@ -341,7 +354,7 @@ class PackedConv:
                 if med[cfg] < best_ms * 0.98:
                     best, best_ms = cfg, med[cfg]
             self._cfgs[key] = best
-            _TUNING.discard((id(self), key))
+            _TUNING.pop((id(self._cfgs), key), None)
 
     def pool_t2_supported(self, x: Act) -> bool:
         return self.k == (1, 1, 1) and self.stride == (1, 1, 1) and self.cin in (64, 128) and x.dims[1] >= 2
@@ -528,68 +541,12 @@ def clip_to_act(x: torch.Tensor, cpad: int, dtype: str = DEFAULT_DTYPE) -> Act:
     return Act(buf, 8)
 
 
-class StemTU:
-    """The Cin = 3 stem (conv + folded BN + ReLU) in temporal-unfolded form (csrc/conv_stem_tu.hip), inference only:
-    the kt temporal taps x 3 channels become the 16 values of one 32-byte position, the conv a 2-D stride-2 one with
-    K = kh*kw*16 (784 for the 5x7x7 stem of large_i3d.py:133) instead of the 1120 of the pixel-pair form."""
-
-    def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(2, 2, 2), pads=(2, 3, 3),
-                 dtype: str = DEFAULT_DTYPE, device="cuda"):
-        co, ci, kt, kh, kw = weight.shape
-        assert self.supported(weight, stride), "StemTU: cin <= 3, kt <= 5, cout <= 64, spatial stride 2"
-        device = torch.device(device)
-        self.k, self.stride, self.pads, self.cout = (kt, kh, kw), tuple(stride), tuple(pads), (co + 7) // 8 * 8
-        self.torch_dtype, self.dtype_code = DTYPES[dtype]
-        self.kpad = _lib.lib().tedspad_stem_tu_kpad(kh, kw)
-        w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 3, 4, 2, 1).reshape(co, kh * kw, kt * ci)   # (co, tap, dt*ci + c)
-        if ci != 3:
-            w = torch.nn.functional.pad(weight.detach().to(device=device, dtype=torch.float32).permute(0, 3, 4, 2, 1), (0, 3 - ci)).reshape(co, kh * kw, kt * 3)
-        w = torch.nn.functional.pad(w, (0, 16 - w.shape[2])).reshape(co, kh * kw * 16)
-        self.w = torch.zeros((128, self.kpad), dtype=self.torch_dtype, device=device)
-        self.w[:co, :kh * kw * 16] = w.to(self.torch_dtype)
-        self.scale = _padded_vec(scale, co, 128, device, 1.0)
-        self.shift = _padded_vec(shift, co, 128, device, 0.0)
-
-    @staticmethod
-    def supported(weight: torch.Tensor, stride) -> bool:
-        co, ci, kt, kh, kw = weight.shape
-        return ci <= 3 and kt <= 5 and co <= 64 and kh <= 7 and kw <= 7 and tuple(stride[1:]) == (2, 2)
-
-    def layout(self, x: torch.Tensor) -> torch.Tensor:
-        """fp32 (n, c, t, h, w) clip batch (W contiguous, a multiple of 8) -> X'[n][to][h][2][w/2][16]."""
-        require_cuda(x, "StemTU")
-        if x.dtype != torch.float32:
-            x = x.float()
-        n, c, t, h, w = x.shape
-        to = conv_out(t, self.k[0], self.stride[0], self.pads[0], self.pads[0])
-        xtu = torch.empty((n, to, h, 2, w // 2, 16), dtype=self.torch_dtype, device=x.device)
-        sn, sc, st, sh, sw = x.stride()
-        check(_lib.lib().tedspad_clip_to_tu(x.data_ptr(), xtu.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw, self.k[0], self.stride[0], self.pads[0],
-                                            to, self.dtype_code, _stream_ptr()), "tedspad_clip_to_tu")
-        return xtu
-
-    def conv(self, xtu: torch.Tensor, relu=True) -> Act:
-        n, to, h, _, wq, _ = xtu.shape
-        w = 2 * wq
-        kt, kh, kw = self.k
-        ho, wo = conv_out(h, kh, 2, self.pads[1], self.pads[1]), conv_out(w, kw, 2, self.pads[2], self.pads[2])
-        out = Act.empty(n, to, ho, wo, self.cout, self.torch_dtype, xtu.device)
-        check(_lib.lib().tedspad_stem_tu_fwd(xtu.data_ptr(), self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, to, h, w,
-                                             ho, wo, kh, kw, self.pads[1], self.pads[2], self.cout, out.ld, int(relu), self.dtype_code, _stream_ptr()),
-              "tedspad_stem_tu_fwd")
-        return out
-
-    def __call__(self, x: torch.Tensor, relu=True) -> Act:
-        """x: fp32 (n, c, t, h, w) clip batch -> the stem's output Act (n, to, ho, wo, cout)."""
-        return self.conv(self.layout(x), relu)
-
-
 class StemPT:
     """conv1 5x7x7 / 2 / pad (2,3,3) + bn1 + ReLU of I3Res50 (large_i3d.py:133-137,229-231) on the persistent stem kernel
     (csrc/conv_stem_pt.hip), inference only, with the TEMPORAL half of maxpool1 (large_i3d.py:138,232) fused: the result is
     max(frame 2k, frame 2k+1) of the stem output, (n, To // 2, ho, wo, 64); `engine.maxpool(., (1,3,3), (1,2,2))` finishes the pool.
     K = 7*7*16 = 784 (temporal taps x channels folded into one 32-byte position), all weights resident in LDS."""
-    VARIANT = int(os.environ.get("TEDSPAD_STEM_PT_VARIANT", "1"))
+    VARIANT = int(os.environ.get("TEDSPAD_STEM_PT_VARIANT", "2"))      # bit 1: 8 waves per workgroup
 
     def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(2, 2, 2), pads=(2, 3, 3),
                  dtype: str = DEFAULT_DTYPE, device="cuda"):
@@ -620,37 +577,36 @@ class StemPT:
         return conv_out(t, self.kt, self.stride_t, self.pad_t, self.pad_t) // 2
 
     def applies(self, x: torch.Tensor) -> bool:
-        """The record of a pixel holds (t + pad_t) * 3 <= 64 values and every output frame's 16 values lie inside it."""
         n, c, t, h, w = x.shape
-        tp = self.frame_pairs(t)
-        return (x.is_cuda and c <= 3 and x.stride(4) == 1 and (t + self.pad_t) * 3 <= 64 and tp >= 1 and
-                (2 * tp - 1) * self.stride_t * 3 + 16 <= 64 and h * w * 128 < (1 << 31))
+        return (x.is_cuda and c <= 3 and x.stride(4) == 1 and w % 2 == 0 and self.stride_t == 2 and self.frame_pairs(t) >= 1 and
+                h * w * 48 < (1 << 31))
 
     def layout(self, x: torch.Tensor) -> torch.Tensor:
-        """fp32 (n, c, t, h, w) clip batch -> time-channels-last records X[n][h][w][64]."""
+        """fp32 (n, c, t, h, w) clip batch -> X[n][tp][h][b][w/2][24]: per output-frame pair one 48-byte record per pixel."""
         require_cuda(x, "StemPT")
         if x.dtype != torch.float32:
             x = x.float()
         n, c, t, h, w = x.shape
-        xtc = torch.empty((n, h, w, 64), dtype=self.torch_dtype, device=x.device)
-        sn, sc, st, sh, sw = x.stride()
-        check(_lib.lib().tedspad_clip_to_tc(x.data_ptr(), xtc.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw, self.pad_t, self.dtype_code,
-                                            _stream_ptr()), "tedspad_clip_to_tc")
-        return xtc
-
-    def conv(self, xtc: torch.Tensor, t: int, relu=True, variant=None) -> Act:
-        n, h, w, _ = xtc.shape
         tp = self.frame_pairs(t)
-        ho, wo = (h + 1) // 2, (w + 1) // 2
-        out = Act.empty(n, tp, ho, wo, 64, self.torch_dtype, xtc.device)
-        check(_lib.lib().tedspad_stem_pt_fwd(xtc.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, tp, h, w,
-                                             ho, wo, self.stride_t, out.ld, int(relu), self.nwg, self.VARIANT if variant is None else variant,
+        xtp = torch.empty((n, tp, h, 2, w // 2, 24), dtype=self.torch_dtype, device=x.device)
+        sn, sc, st, sh, sw = x.stride()
+        check(_lib.lib().tedspad_clip_to_tp(x.data_ptr(), xtp.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw, self.pad_t, self.stride_t, tp,
+                                            self.dtype_code, _stream_ptr()), "tedspad_clip_to_tp")
+        return xtp
+
+    def conv(self, xtp: torch.Tensor, relu=True, variant=None) -> Act:
+        n, tp, h, _, wq, _ = xtp.shape
+        w = 2 * wq
+        ho, wo = (h + 1) // 2, wq
+        out = Act.empty(n, tp, ho, wo, 64, self.torch_dtype, xtp.device)
+        check(_lib.lib().tedspad_stem_pt_fwd(xtp.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, tp, h, w,
+                                             ho, wo, out.ld, int(relu), self.nwg, self.VARIANT if variant is None else variant,
                                              self.dtype_code, _stream_ptr()), "tedspad_stem_pt_fwd")
         return out
 
     def __call__(self, x: torch.Tensor, relu=True) -> Act:
         """x: fp32 (n, c, t, h, w) -> max over output-frame pairs of act(bn(conv(x))): Act (n, To // 2, ho, wo, 64)."""
-        return self.conv(self.layout(x), x.shape[2], relu)
+        return self.conv(self.layout(x), relu)
 
 
 def act_to_nchw(x: Act, c: Optional[int] = None) -> torch.Tensor:

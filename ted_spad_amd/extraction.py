@@ -24,6 +24,16 @@ def _extract_fn(ft_model):
     return ft_model.extract_features if hasattr(ft_model, "extract_features") else ft_model.i3d.extract_features
 
 
+def feature_width(ft_model) -> int:
+    """F of the (n, F) rows `extract_features` returns: 2048 for I3Res50 / wrapper_i3d (large_i3d.py:262), 1024 for InceptionI3d
+    (i3d.py:336-340). Taken from the model, not from a probe forward: an empty shard must not launch anything."""
+    for m in (ft_model, getattr(ft_model, "i3d", None)):
+        f = getattr(m, "feature_dim", None) if m is not None else None
+        if f is not None:
+            return int(f)
+    raise AttributeError("extraction: the feature extractor must expose `feature_dim` (I3Res50 2048, InceptionI3d 1024)")
+
+
 def feed(clips: torch.Tensor, fa_model=None, layout: str = "reference") -> torch.Tensor:
     """clips: (B, 16, 3, H, W) fp32 in [0,1] as the loaders deliver them -> ft input (B, 3, 16, H, W).
 
@@ -53,9 +63,15 @@ def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 75, o
     fx = _extract_fn(ft_model)
     n = clips_cthw.shape[0]
     if out is None:
-        f0 = fx(clips_cthw[:1]) if n else None
-        out = torch.empty((n, f0.flatten(1).shape[1]), dtype=torch.float32, device=clips_cthw.device)
+        out = torch.empty((n, feature_width(ft_model)), dtype=torch.float32, device=clips_cthw.device)
+    if n == 0:                # an empty shard (T < world, sharding.shard_range): nothing to launch, the collective still runs
+        return out
     dev = clips_cthw.device
+    if dev.type != "cuda":    # host-logic tests drive the sharding with a stub extractor on CPU tensors: no streams there
+        for i in range(0, n, batch):
+            f = fx(clips_cthw[i:i + batch]).flatten(1)
+            out[i:i + f.shape[0]] = f
+        return out
     pool = _STREAMS.setdefault((dev, streams), [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))])
     main = torch.cuda.current_stream(dev)
     for st in pool:

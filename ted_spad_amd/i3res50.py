@@ -38,6 +38,8 @@ class Bottleneck(nn.Module):
 
 
 class I3Res50(nn.Module):
+    feature_dim = 2048       # width of the clip feature (large_i3d.py:262)
+
     def __init__(self, num_classes=400, use_nl=False, dtype=E.DEFAULT_DTYPE):
         super().__init__()
         if use_nl:
@@ -69,7 +71,7 @@ class I3Res50(nn.Module):
             P = {}
             s, b = self._bn_fold(self.bn1)
             P["stem"] = E.PackedConv(self.conv1.weight, s, b, stride=(2, 2, 2), dtype=self.compute_dtype, device=dev, pair_w=3)
-            P["stem_tu"] = E.StemTU(self.conv1.weight, s, b, stride=(2, 2, 2), pads=(2, 3, 3), dtype=self.compute_dtype, device=dev)
+            P["stem_pt"] = E.StemPT(self.conv1.weight, s, b, stride=(2, 2, 2), pads=(2, 3, 3), dtype=self.compute_dtype, device=dev)
             for li in range(1, 5):
                 for i, blk in enumerate(getattr(self, "layer%d" % li)):
                     p = "layer%d.%d." % (li, i)
@@ -102,14 +104,17 @@ class I3Res50(nn.Module):
         if x.shape[4] % 2:
             raise ValueError("W must be even")
         P = self.packed()
-        if E.STEM_TU and x.shape[4] % 8 == 0 and x.stride(4) == 1 and all(s % 4 == 0 for s in x.stride()[:4]) and x.data_ptr() % 16 == 0:
-            a = P["stem_tu"](x)                                          # 5x7x7 s2 p(2,3,3) + BN + ReLU, K = 7*7*16
+        if E.STEM_PT and taps is None and P["stem_pt"].applies(x):
+            # conv1 + bn1 + ReLU on the persistent stem kernel with the temporal half of maxpool1 fused (large_i3d.py:229-232):
+            # the 112 x 112 x 8-frame stem tensor is never written, only its frame-pair maximum
+            a = P["stem_pt"](x)
+            a = E.maxpool(a, (1, 3, 3), (1, 2, 2))                       # the spatial half of MaxPool3d((2,3,3), 2)
         else:
             a = E.clip_to_act(x, cpad=4, dtype=self.compute_dtype)       # (B,T,H,W/2, 2px x 4ch)
-            a = P["stem"](a, pads=(2, 3, P["stem"].pair_pw), pads_back=(2, 3, 1))   # the same in pixel-pair form, K = 5*7*4*8
-        if taps is not None:
-            taps["stem"] = a
-        a = E.maxpool(a, (2, 3, 3), (2, 2, 2))                           # large_i3d.py:138
+            a = P["stem"](a, pads=(2, 3, P["stem"].pair_pw), pads_back=(2, 3, 1))   # the same conv in pixel-pair form, K = 5*7*4*8
+            if taps is not None:
+                taps["stem"] = a
+            a = E.maxpool(a, (2, 3, 3), (2, 2, 2))                       # large_i3d.py:138
         if taps is not None:
             taps["maxpool1"] = a
         pooled = False

@@ -286,7 +286,13 @@ class ConvLayer:
         if rs is not None:
             g = g * rs[:co].view([-1] + [1] * (g.dim() - 1))
             self._grad_row_scale = None
-        self.weight.grad = g.contiguous() if self.weight.grad is None else self.weight.grad + g
+        if self.weight.grad is None:
+            g = g.contiguous()
+            if g.untyped_storage().data_ptr() == self._dwp.untyped_storage().data_ptr():
+                g = g.clone()        # 1x1x1 convs: the view IS the arena slice, which the next step's reset zeroes
+            self.weight.grad = g
+        else:
+            self.weight.grad = self.weight.grad + g
         if self.bias is not None and self._db is not None:
             db = self._db[:co]
             self.bias.grad = db.clone() if self.bias.grad is None else self.bias.grad + db

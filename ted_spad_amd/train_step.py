@@ -92,7 +92,9 @@ class AnonymizerTrainStep:
         return g if (g is None or self.loss_scale == 1.0) else g * self.loss_scale
 
     def _unscale(self, module) -> bool:
-        """Divide the loss scale out of `module`'s gradients; False if they are not finite (the step is skipped)."""
+        """Divide the loss scale out of `module`'s gradients; False if they are not finite (the step is skipped).
+        Called on the ALL-REDUCED gradients: an overflow on any rank makes the sum non-finite on every rank, so all
+        ranks take the same step / skip decision (replicas and Adam step counts stay in lock-step)."""
         if self.loss_scale == 1.0:
             return True
         grads = [p.grad for p in module.parameters() if p.grad is not None]
@@ -149,8 +151,8 @@ class AnonymizerTrainStep:
             self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad), dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
         self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape))
         self.fa_tr.flush_grads()
-        ok = self._unscale(self.fa)
         allreduce_mean_grads(list(self.fa.parameters()), self.group)
+        ok = self._unscale(self.fa)
         if ok:
             self.opt_fa.step()                                        # :123
         self.iteration += 1
@@ -183,8 +185,8 @@ class AnonymizerTrainStep:
             for tape_b, z in ctx:
                 self.fb_tr.backward(tape_b, self._scaled(z.grad))
             self.fb_tr.flush_grads()
-            ok_fb = self._unscale(self.fb)
             allreduce_mean_grads(list(self.fb.parameters()), self.group)
+            ok_fb = self._unscale(self.fb)
             if ok_fb:
                 self.opt_fb.step()
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)
@@ -198,8 +200,8 @@ class AnonymizerTrainStep:
         for tape, (pl, fl) in zip(tapes, leaves):
             self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad))
         self.ft_tr.flush_grads()
-        ok = self._unscale(self.ft)
         allreduce_mean_grads(list(self.ft.parameters()), self.group)
+        ok = self._unscale(self.ft)
         if ok:
             self.opt_ft.step()                                        # :193
         self.iteration += 1
@@ -230,8 +232,8 @@ class AnonymizerTrainStep:
         for tape, (pl, fl) in zip(tapes, leaves):
             self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad))
         self.ft_tr.flush_grads()
-        ok = self._unscale(self.ft)
         allreduce_mean_grads(list(self.ft.parameters()), self.group)
+        ok = self._unscale(self.ft)
         if ok:
             self.opt_ft.step()                                        # :87
         self.iteration += 1
