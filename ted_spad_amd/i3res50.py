@@ -97,7 +97,8 @@ class I3Res50(nn.Module):
     def _trunk(self, x: torch.Tensor, taps=None) -> E.Act:
         """conv1 .. layer4 (large_i3d.py:229-238 == :251-260) on a (B,3,T,H,W) fp32 clip batch."""
         if self.training:
-            raise NotImplementedError("train-mode (batch-statistics BN + backward) is not built yet; call .eval()")
+            raise NotImplementedError("a bare I3Res50 in train() mode has no caller in the reference: training goes through wrapper_i3d "
+                                      "(load_ft_model('largei3d'); ted_spad_amd/autograd.py) or train_step.AnonymizerTrainStep")
         E.require_cuda(x, "I3Res50")
         if x.dim() != 5 or x.shape[1] != 3:
             raise ValueError("expected (B,3,T,H,W), got %s" % (tuple(x.shape),))

@@ -41,7 +41,8 @@ class mlp(nn.Module):
 
     def forward(self, x):
         if self.training:
-            raise NotImplementedError("train-mode mlp (batch-statistics BN1d + backward) is not built yet; call .eval()")
+            raise NotImplementedError("train-mode mlp runs inside wrapper_i3d.forward (one autograd node for trunk + head, "
+                                      "ted_spad_amd/autograd.py) or AnonymizerTrainStep; a stand-alone train-mode call has no caller in the reference")
         if x.dim() != 2:
             # the reference's BatchNorm1d raises here too when I3Res50.forward squeezed B=1 away
             raise ValueError("mlp expects (B, 2048) with B >= 2, got %s" % (tuple(x.shape),))
@@ -59,6 +60,11 @@ class wrapper_i3d(nn.Module):
         self.mlp = mlp()
 
     def forward(self, x):
+        if self.training or (x.requires_grad and torch.is_grad_enabled()):
+            # train(): batch-statistics BN, dropout, parameter gradients (train_anonymizer.py:139,166-179); eval() with an input
+            # that requires grad: the frozen ft of phase 1, gradient w.r.t. the clip only (:74,99-112,122)
+            from . import autograd
+            return autograd.wrapper_forward(self, x)
         pred, feature = self.i3d(x)
         feature = self.mlp(feature)
         return pred, feature

@@ -88,7 +88,8 @@ class ResNet50(nn.Module):
     def features(self, x: torch.Tensor) -> torch.Tensor:
         """(N,3,H,W) fp32 -> (N,2048) fp32: conv1 .. avgpool + flatten (eval-mode BN folded)."""
         if self.training:
-            raise NotImplementedError("train-mode fb runs through AnonymizerTrainStep (train_nets.FBTrainer); call .eval() here")
+            raise NotImplementedError("a bare ResNet50 in train() mode: training goes through the Sequential(ResNet50, MLP) that "
+                                      "load_fb_model(ssl=True) returns (ted_spad_amd/autograd.py) or train_step.AnonymizerTrainStep")
         E.require_cuda(x, "ResNet50")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[3] % 2:
             raise ValueError("expected (N,3,H,W) with even W, got %s" % (tuple(x.shape),))
@@ -127,9 +128,21 @@ class PrivacyMLP(nn.Module):
         return head.l2_normalize(head.linear(h, self.fc2.weight, self.fc2.bias))
 
 
+class PrivacySSL(nn.Sequential):
+    """nn.Sequential(resnet50 with fc = Identity, MLP) of model_loaders.py:124-153 (keys `0.*`, `1.fc{1,2}.*`). In train() mode, or in
+    eval() mode with an input that requires grad (phase 1: the NT-Xent gradient flows through the frozen fb into fa,
+    train_anonymizer.py:75-84), the pair runs as ONE autograd node (ted_spad_amd/autograd.py)."""
+
+    def forward(self, x):
+        if self.training or (x.requires_grad and torch.is_grad_enabled()):
+            from . import autograd
+            return autograd.fb_forward(self, x)
+        return super().forward(x)
+
+
 def load_privacy_ssl(dtype=E.DEFAULT_DTYPE):
     """model_loaders.py:124-153: nn.Sequential(resnet50 with fc = Identity, MLP); keys `0.*`, `1.fc{1,2}.*`."""
-    return nn.Sequential(ResNet50(num_classes=0, dtype=dtype), PrivacyMLP())
+    return PrivacySSL(ResNet50(num_classes=0, dtype=dtype), PrivacyMLP())
 
 
 def build_resnet_predictor(num_classes=7, pretrained=True, dtype=E.DEFAULT_DTYPE):

@@ -253,7 +253,7 @@ class ConvLayer:
         pc = self.fwd_conv()
         n, t, h, w = x.dims
         pk, _ = self._pads_k(pc)
-        if getattr(self, "_dwp_gen", -1) != ARENA.gen:
+        if getattr(self, "_dwp_gen", -1) != ARENA.gen or self._dwp is None:     # new step, or flushed since (one flush per backward pass in the autograd path)
             self._dwp = ARENA.take((pc.cpad, pc.kpad), x.buf.device)
             self._dwp_gen = ARENA.gen
             self._db = None

@@ -93,8 +93,11 @@ class UNet(nn.Module):
         return self._packed
 
     def forward(self, x: torch.Tensor, taps=None) -> torch.Tensor:
-        if self.training:
-            raise NotImplementedError("train-mode UNet (batch-statistics BN2d + backward) is not built yet; call .eval()")
+        if self.training:      # batch-statistics BatchNorm2d + a tape for loss.backward() (train_anonymizer.py:73,80,92)
+            from . import autograd
+            return autograd.unet_forward(self, x)
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("UNet in eval() mode with a gradient w.r.t. its input: not built (no caller in the reference)")
         E.require_cuda(x, "UNet")
         if x.dim() != 4 or x.shape[1] != self.n_channels:
             raise ValueError("expected (N,%d,H,W), got %s" % (self.n_channels, tuple(x.shape)))

@@ -480,7 +480,7 @@ def test_two_frame_stem_equals_halo_stem(dims):
 
 
 def test_hand_counted_waits_are_race_free_over_many_launches():
-    """The persistent pointwise kernel (19, incl. the fused temporal pool), the halo-direct kernels (15) and the split-K
+    """The persistent pointwise kernel (19, incl. the fused temporal pool), the chunk-major flat tiles (33) and the split-K
     stem (21) order their LDS reads behind LDS-DMA with hand-counted `s_waitcnt vmcnt(N)`; a wrong count shows up as a
     rare stale tile that comes and goes with timing. 60 launches each on large shapes, interleaved with a kernel that
     thrashes L2, must reproduce the first result bit for bit."""
@@ -508,9 +508,15 @@ def test_hand_counted_waits_are_race_free_over_many_launches():
         E.FORCE_TILE_CFG = 19
         repeat(lambda: pc(x, residual=r, relu=True).buf)
         repeat(lambda: pc.call_pool_t2(x, residual=r, relu=True).buf)
-        E.FORCE_TILE_CFG = 15
+        E.FORCE_TILE_CFG = 33
         repeat(lambda: pc3(x3, pads=(0, 1, 1)).buf)
         E.FORCE_TILE_CFG = 21
         repeat(lambda: st(clip, pads=(2, 3, st.pair_pw), pads_back=(2, 3, 1)).buf, n=30)
     finally:
         E.FORCE_TILE_CFG = None
+    # the persistent stem (csrc/conv_stem_pt.hip): halo regions re-filled a phase ahead, the epilogue's stores left in flight
+    # across the barrier by a counted wait; more patches than workgroups so that every workgroup walks several
+    spt = E.StemPT(synth_tensor(17, "rws", (64, 3, 5, 7, 7), -0.1, 0.1), torch.ones(64), torch.zeros(64), dtype="f16", device="cuda")
+    xtp = spt.layout(synth_tensor(17, "rc", (6, 3, 16, 224, 224), device="cuda"))
+    for variant in (0, 2):
+        repeat(lambda: spt.conv(xtp, variant=variant).buf, n=30)
