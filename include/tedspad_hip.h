@@ -259,6 +259,15 @@ int32_t tedspad_maxpool_bwd(const tedspad_pool_desc *d, const void *x, const uin
 int32_t tedspad_global_avgpool_bwd(const float *dfeat, const void *mask, int32_t ldmask, void *dx, int32_t n,
                                    int32_t spatial, int32_t c, int32_t lddx, int32_t dtype, void *stream);
 
+/* F.interpolate(scale_factor=2, mode="nearest") of the UNet++ decoder blocks (segmentation_models_pytorch 0.3.3,
+ * decoders/unetplusplus/decoder.py, DecoderBlock.forward; the anonymizer of model_loaders.py:17-30), written straight into its channel
+ * slice of the block's concat buffer: y[n][2h+a][2w+b][0..c) = x[n][h][w][0..c), 16-bit elements, pixel strides ldx / ldy.
+ * tedspad_copy_channels copies a channel slice (npix pixels x c channels) between two channels-last buffers: the dense skip pathway
+ * concatenates some tensors into two different blocks' inputs (torch.cat in UnetPlusPlusDecoder.forward). */
+int32_t tedspad_upsample_nearest2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t ldy,
+                                       void *stream);
+int32_t tedspad_copy_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, void *stream);
+
 /* Backward of tedspad_upsample_bilinear2x_fwd: dy is the (n,ho,wo,c) slice the forward wrote, dx is (n,h,w,c). */
 int32_t tedspad_upsample_bilinear2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c,
                                         int32_t lddy, int32_t lddx, int32_t ho, int32_t wo, int32_t pad_top,

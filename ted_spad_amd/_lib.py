@@ -75,6 +75,8 @@ SYMBOLS = {
     "tedspad_clip_to_tp": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 4 + [_P]),
     "tedspad_stem_pt_wimg_bytes": (_I32, []),
     "tedspad_stem_pt_fwd": (_I32, [_P] * 5 + [_I32] * 11 + [_P]),
+    "tedspad_upsample_nearest2x_fwd": (_I32, [_P, _P] + [_I32] * 6 + [_P]),
+    "tedspad_copy_channels": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _P]),
     "tedspad_bn_fold": (_I32, [_P, _P, _P, _P, _P, C.c_double, _I32, _P, _P, _P]),
     "tedspad_resize_aa_taps": (_I32, [_I32, _I32]),
     "tedspad_resize_aa_table": (_I32, [_I32, _I32, _P]),

@@ -322,6 +322,29 @@ inline int grid_for(long work_items) {
     return g < 1 ? 1 : (int)g;
 }
 
+// F.interpolate(scale_factor=2, mode="nearest") of smp's DecoderBlock (segmentation_models_pytorch 0.3.3, decoders/unetplusplus/decoder.py:
+// DecoderBlock.forward), written into its channel slice of the block's concat buffer; also the plain channel-slice copy that places a
+// tensor the UNet++ dense skip pathway concatenates twice. 16 bytes (8 channels) per thread, dtype-agnostic.
+__global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const uint4 *x, uint4 *y, int h, int w, int C8, int ldx8, int ldy8, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int wo = (int)(r % (2 * w)); r /= 2 * w;
+        const int ho = (int)(r % (2 * h));
+        const long n = r / (2 * h);
+        y[((n * 2 * h + ho) * 2 * w + wo) * ldy8 + c8] = x[((n * h + (ho >> 1)) * w + (wo >> 1)) * ldx8 + c8];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const uint4 *x, uint4 *y, int C8, int ldx8, int ldy8, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long px = idx / C8;
+        const int c8 = (int)(idx - px * C8);
+        y[px * ldy8 + c8] = x[px * ldx8 + c8];
+    }
+}
+
+
 }  // namespace
 }  // namespace tedspad
 
@@ -443,4 +466,23 @@ extern "C" int32_t tedspad_upsample_bilinear2x_fwd(const void *x, void *y, int32
     if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, (uint16_t *)y, h, w, c / 8, ldx, ldy, ho, wo, pad_top, pad_left, total);
     else hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, (uint16_t *)y, h, w, c / 8, ldx, ldy, ho, wo, pad_top, pad_left, total);
     return check_launch("tedspad_upsample_bilinear2x_fwd");
+}
+
+extern "C" int32_t tedspad_upsample_nearest2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t ldy,
+                                                  void *stream) {
+    TS_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c,
+               "tedspad_upsample_nearest2x_fwd: bad arguments");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_upsample_nearest2x_fwd: pointers must be 16-byte aligned");
+    const long total = (long)n * 2 * h * 2 * w * (c / 8);
+    hipLaunchKernelGGL(upsample_nearest2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y, h, w, c / 8,
+                       ldx / 8, ldy / 8, total);
+    return check_launch("tedspad_upsample_nearest2x_fwd");
+}
+
+extern "C" int32_t tedspad_copy_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, void *stream) {
+    TS_REQUIRE(x && y && npix > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "tedspad_copy_channels: bad arguments");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_copy_channels: pointers must be 16-byte aligned");
+    const long total = (long)npix * (c / 8);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
+    return check_launch("tedspad_copy_channels");
 }

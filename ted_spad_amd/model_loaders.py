@@ -7,10 +7,10 @@ the networks running on MI355X HIP kernels (libtedspad_hip.so).
                   kin_pretrained=False)                                       model_loaders.py:56-90
     mlp, wrapper_i3d                                                          model_loaders.py:235-268
 
-In scope: arch 'largei3d' and 'i3d' for ft, 'unet' for fa (the architectures whose source
-is part of the reference) and 'r50' for fb (torchvision's ResNet-50, restated: resnet50.py). 'unet++', 'r3d_18'
-and 'mvitv2' are third-party models (segmentation_models_pytorch / torchvision) that are out of scope
-(SURVEY.md §2 row 5): they raise NotImplementedError rather than silently falling back.
+In scope: arch 'largei3d' and 'i3d' for ft, 'unet' for fa (the architectures whose source is part of the reference), 'unet++' for
+fa (segmentation_models_pytorch's UnetPlusPlus, the reference's default, restated: unetpp.py; inference) and 'r50' for fb
+(torchvision's ResNet-50, restated: resnet50.py). 'r3d_18' and 'mvitv2' are third-party torchvision video models that are out of
+scope: they raise NotImplementedError rather than silently falling back.
 """
 from __future__ import annotations
 
@@ -107,8 +107,10 @@ def _strip_module(sd):
 
 def load_fa_model(saved_model_file=None, arch="unet++"):
     if arch == "unet++":
-        raise NotImplementedError("arch 'unet++' is segmentation_models_pytorch's UnetPlusPlus (third-party, not part of "
-                                  "the reference repo): out of scope. Use arch='unet'.")
+        # smp's UnetPlusPlus(resnet18, depth 4, (256,128,64,32), batch-norm decoder, 3 classes, no activation) restated from its
+        # published source (unetpp.py); `encoder_weights="imagenet"` is a download there -- offline the encoder is randomly initialised
+        from .unetpp import UnetPlusPlus
+        fa_model = UnetPlusPlus()
     elif arch == "unet":
         from .unet import UNet
         fa_model = UNet(n_channels=3, n_classes=3)

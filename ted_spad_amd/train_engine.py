@@ -292,10 +292,13 @@ class ConvLayer:
                 g = g.clone()        # 1x1x1 convs: the view IS the arena slice, which the next step's reset zeroes
             self.weight.grad = g
         else:
-            self.weight.grad = self.weight.grad + g
+            self.weight.grad.add_(g)                 # in place: .grad may be a view into a gradient bucket (grad_reduce.py)
         if self.bias is not None and self._db is not None:
             db = self._db[:co]
-            self.bias.grad = db.clone() if self.bias.grad is None else self.bias.grad + db
+            if self.bias.grad is None:
+                self.bias.grad = db.clone()
+            else:
+                self.bias.grad.add_(db)
         self._dwp = None
 
 

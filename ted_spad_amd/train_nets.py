@@ -23,7 +23,10 @@ from .engine import Act, _stream_ptr
 
 
 def _acc_grad(p, g):
-    p.grad = g.clone() if p.grad is None else p.grad + g
+    if p.grad is None:
+        p.grad = g.clone()
+    else:
+        p.grad.add_(g)          # in place: p.grad may be a view into a gradient bucket (grad_reduce.GradBucketReducer)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -152,11 +155,33 @@ class BottleneckTrunk:
             TE.flush_counters()
         return f, tape
 
-    def backward(self, tape, df: torch.Tensor):
+    def stage_params(self):
+        """Parameter groups in the order their gradients become final in `backward`: [layer4, layer3, layer2, layer1, stem]."""
+        groups = {}
+        for d in self.blocks:
+            g = groups.setdefault(d["li"], [])
+            for c, bn in ((d["c1"], d["bn1"]), (d["c2"], d["bn2"]), (d["c3"], d["bn3"]), (d["cd"], d["bnd"])):
+                if c is not None:
+                    g += [c.weight] + ([c.bias] if c.bias is not None else []) + [bn.weight, bn.bias]
+        out = [groups[li] for li in sorted(groups, reverse=True)]
+        out.append([self.stem.weight] + ([self.stem.bias] if self.stem.bias is not None else []) + [self.stem_bn.weight, self.stem_bn.bias])
+        return out
+
+    def _flush_stage(self, li):
+        for d in self.blocks:
+            if d["li"] == li:
+                for k in ("c1", "c2", "c3", "cd"):
+                    if d[k] is not None:
+                        d[k].flush_grad()
+
+    def backward(self, tape, df: torch.Tensor, on_stage_done=None):
         """df: (B,C) fp32 gradient w.r.t. the pooled feature. 'train' tape: accumulates the parameter gradients,
-        returns None. 'eval' tape: returns d(input) as the stem's pixel-pair Act."""
+        returns None. 'eval' tape: returns d(input) as the stem's pixel-pair Act.
+        on_stage_done(k): called (train / frozen tapes) right after the k-th parameter group of `stage_params()` received its last
+        contribution of this pass and was flushed into `.grad` -- the hook the bucketed gradient all-reduce hangs on."""
         last = tape["units"][-1]["out"]
         k1, s1, p1 = self.pool1
+        stages = sorted({d["li"] for d in self.blocks}, reverse=True)
         if tape["train"]:
             da = TE.global_avgpool_bwd(df, last)
             for rec in reversed(tape["units"]):
@@ -167,8 +192,14 @@ class BottleneckTrunk:
                 if "pool_idx" in rec:
                     pk, ps = rec["d"]["pre_pool"]
                     da = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], da, pk, ps)
+                if on_stage_done is not None and rec["d"]["bi"] == 0:       # first block of a stage = the last one backward reaches
+                    self._flush_stage(rec["d"]["li"])
+                    on_stage_done(stages.index(rec["d"]["li"]))
             da = TE.maxpool_bwd(tape["stem_y"], tape["idx1"], da, k1, s1, pads=p1)
             TE.conv_bn_act_train_bwd(tape["stem"], da, need_dx=False)
+            if on_stage_done is not None:
+                self.stem.flush_grad()
+                on_stage_done(len(stages))
             return None
         # eval / frozen mode. delta = gradient w.r.t. a block output's PRE-activation (already ReLU-masked).
         # frozen: every conv also gets its weight gradient: d(conv output) = delta * scale per output channel, so the packed
@@ -200,6 +231,10 @@ class BottleneckTrunk:
         conv, s = tape["stem"]
         if frozen:                                                           # the anonymizer in front is not trained: no d(input)
             wg(tape["stem"], tape["clip"], delta)
+            if on_stage_done is not None:
+                self.flush_grads()
+                for k in range(len(stages) + 1):
+                    on_stage_done(k)
             return None
         return conv.dgrad(delta, tape["clip"].dims[1:], scale=s)             # (B,T,H,W/2,8) == (B,T,H,W,4)
 
@@ -284,9 +319,17 @@ class I3DTrainer:
         return pred, feat, tape
 
     # ---- backward --------------------------------------------------------------------------------------------------
-    def backward(self, tape, dpred: Optional[torch.Tensor], dfeat: Optional[torch.Tensor], dx_out: Optional[torch.Tensor] = None):
+    def grad_buckets(self):
+        """Parameters grouped in the order `backward` finishes them: [head (fc + mlp), layer4, layer3, layer2, layer1, stem]."""
+        i3d, mlp = self.m.i3d, self.m.mlp
+        head = [i3d.fc.weight, i3d.fc.bias] + list(mlp.parameters())
+        return [head] + self.trunk.stage_params()
+
+    def backward(self, tape, dpred: Optional[torch.Tensor], dfeat: Optional[torch.Tensor], dx_out: Optional[torch.Tensor] = None,
+                 on_bucket_done=None):
         """Accumulates parameter gradients (mode 'train') and/or writes d(loss)/d(clip) into `dx_out`
-        ((B,3,T,H,W) fp32 view, any strides; mode 'eval')."""
+        ((B,3,T,H,W) fp32 view, any strides; mode 'eval'). on_bucket_done(k): the k-th group of `grad_buckets()` is final
+        (pass it on the LAST backward pass of a step only: earlier passes still add to every group)."""
         i3d, mlp = self.m.i3d, self.m.mlp
         train = tape["mode"] in ("train", "frozen")
         f, h, g = tape["f"], tape["h"], tape["g"]
@@ -319,7 +362,9 @@ class I3DTrainer:
                 dz1 = _mul(dh, (h > 0).float(), 1.0) * s1
                 dfm = head.linear(dz1, mlp.fc1.weight.detach().t().contiguous())
             df = df + dfm
-        dclip = self.trunk.backward(tape, df)
+        if train and on_bucket_done is not None:
+            on_bucket_done(0)                                   # fc + mlp gradients are complete
+        dclip = self.trunk.backward(tape, df, on_stage_done=None if on_bucket_done is None else (lambda k: on_bucket_done(k + 1)))
         if train:
             return None
         B, _, T, Hh, Ww = tape["x_shape"]
@@ -365,7 +410,10 @@ class FBTrainer:
         tape["h"], tape["g"] = h, g
         return head.l2_normalize(g), tape
 
-    def backward(self, tape, demb: torch.Tensor, dx_out: Optional[torch.Tensor] = None):
+    def grad_buckets(self):
+        return [list(self.m[1].parameters())] + self.trunk.stage_params()
+
+    def backward(self, tape, demb: torch.Tensor, dx_out: Optional[torch.Tensor] = None, on_bucket_done=None):
         mlp = self.m[1]
         train = tape["mode"] == "train"
         f, h, g = tape["f"], tape["h"], tape["g"]
@@ -376,7 +424,9 @@ class FBTrainer:
         if train:
             _acc_grad(mlp.fc2.weight, dw2); _acc_grad(mlp.fc2.bias, db2)
             _acc_grad(mlp.fc1.weight, dw1); _acc_grad(mlp.fc1.bias, db1)
-        dimg = self.trunk.backward(tape, df)
+        if train and on_bucket_done is not None:
+            on_bucket_done(0)
+        dimg = self.trunk.backward(tape, df, on_stage_done=None if on_bucket_done is None else (lambda k: on_bucket_done(k + 1)))
         if train:
             return None
         N, _, Hh, Ww = tape["x_shape"]
@@ -462,27 +512,54 @@ class UNetTrainer:
         TE.flush_counters()
         return y, tape
 
-    def backward(self, tape, dy: torch.Tensor):
-        """dy: (N,3,H,W) fp32 gradient w.r.t. the UNet output; accumulates every parameter's .grad."""
+    @staticmethod
+    def _unit_params(units):
+        out = []
+        for c, bn in units:
+            out += [c.weight] + ([c.bias] if c.bias is not None else []) + [bn.weight, bn.bias]
+        return out
+
+    def grad_buckets(self):
+        """Parameters in the order `backward` finishes them: [outc + up4, up3, up2, up1, down4, down3, down2, down1, inc]."""
+        b = [[self.outc.weight, self.outc.bias] + self._unit_params(self.up[3])]
+        b += [self._unit_params(self.up[i]) for i in (2, 1, 0)]
+        b += [self._unit_params(self.down[i]) for i in (3, 2, 1, 0)]
+        b.append(self._unit_params(self.inc))
+        return b
+
+    def backward(self, tape, dy: torch.Tensor, on_bucket_done=None):
+        """dy: (N,3,H,W) fp32 gradient w.r.t. the UNet output; accumulates every parameter's .grad.
+        on_bucket_done(k): the k-th group of `grad_buckets()` is final and flushed (last backward pass of a step only)."""
+        def done(k, units, extra=()):
+            if on_bucket_done is not None:
+                for c, _ in units:
+                    c.flush_grad()
+                for c in extra:
+                    c.flush_grad()
+                on_bucket_done(k)
+
         n, H, W = tape["n"], tape["H"], tape["W"]
         dlogit = TE.nchw_grad_to_act(dy, tape["y"], (1, H, W), dtype=self.m.compute_dtype)     # sigmoid backward fused
         self.outc.wgrad(tape["u4"], dlogit)
         d = self.outc.dgrad(dlogit, tape["u4"].dims[1:])
         dskip = {}
-        for rec in reversed(tape["dec"]):
+        for j, rec in enumerate(reversed(tape["dec"])):           # up4, up3, up2, up1
             lvl = rec["lvl"]
             dmid, _ = TE.conv_bn_act_train_bwd(rec["u2"], d)
             dcat, _ = TE.conv_bn_act_train_bwd(rec["u1"], dmid)
             c = self.ENC[lvl]
             dskip[lvl] = dcat.slice(0, c)
             d = TE.upsample2x_bwd(dcat.slice(c, c), rec["in_hw"][0], rec["in_hw"][1], rec["pad"][0], rec["pad"][1])
+            done(j, self.up[3 - j], extra=(self.outc,) if j == 0 else ())
         rec = tape["bottom"]
         dmid, _ = TE.conv_bn_act_train_bwd(rec["u2"], d)
         d, _ = TE.conv_bn_act_train_bwd(rec["u1"], dmid)
         d = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], d, (1, 2, 2), (1, 2, 2), add=dskip[3])
+        done(4, self.down[3])
         for lvl in (3, 2, 1, 0):
             rec = tape["enc"][lvl]
             dmid, _ = TE.conv_bn_act_train_bwd(rec["u2"], d)
             d, _ = TE.conv_bn_act_train_bwd(rec["u1"], dmid, need_dx=lvl > 0)
             if lvl > 0:
                 d = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], d, (1, 2, 2), (1, 2, 2), add=dskip[lvl - 1])
+            done(8 - lvl, self.inc if lvl == 0 else self.down[lvl - 1])

@@ -22,7 +22,9 @@ entering the networks and is divided out of every parameter gradient before the 
 are not finite is skipped and reported (`skipped: True`), like `GradScaler.step`.
 
 Data parallel: one process per GPU, per-rank BatchNorm statistics (what nn.DataParallel does in the
-reference), gradients of the network being updated averaged with ONE flat RCCL all-reduce.
+reference). The gradients of the network being updated live in flat buckets (grad_reduce.GradBucketReducer): on
+the LAST backward pass of a step every bucket is all-reduced (RCCL) as soon as the backward sequence has finished its stage,
+overlapped with the backward of the earlier stages; the optimizer then reads the averaged buckets in place.
 """
 from __future__ import annotations
 
@@ -31,6 +33,7 @@ from types import SimpleNamespace
 import torch
 import torch.distributed as dist
 
+from .grad_reduce import GradBucketReducer
 from .losses import CrossEntropyLoss, NTXentLoss, TripletMarginLoss
 from . import train_engine as TE
 from .train_nets import FBTrainer, I3DTrainer, UNetTrainer
@@ -42,7 +45,8 @@ DEFAULT_PARAMS = SimpleNamespace(num_frames=16, learning_rate=1e-5, learning_rat
 
 
 def allreduce_mean_grads(params, group=None):
-    """Average .grad over the ranks with one flat all-reduce (RCCL over xGMI; gloo in the CPU tests)."""
+    """Average .grad over the ranks with one flat all-reduce after the whole backward (the round-1 exchange; kept as the reference
+    the bucketed reducer is tested against, and for callers that own their gradients)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     grads = [p.grad for p in params if p.grad is not None]
@@ -72,6 +76,13 @@ class AnonymizerTrainStep:
         self.ce = CrossEntropyLoss()
         self.trip = TripletMarginLoss(margin=params.triplet_loss_margin)
         self.iteration = 0
+        # gradient buckets in the order each backward sequence finishes them (train_nets.*.grad_buckets)
+        self.red_fa = GradBucketReducer(self.fa_tr.grad_buckets(), group, all_params=list(fa_model.parameters()))
+        self.red_ft = GradBucketReducer(self.ft_tr.grad_buckets(), group, all_params=list(ft_model.parameters()))
+        self.red_fb = GradBucketReducer(self.fb_tr.grad_buckets(), group, all_params=list(fb_model.parameters())) if self.fb_tr is not None else None
+        # freeze_bn (train_anonymized_action.py:39-40): gamma / beta of the trunk's BatchNorm3d layers are buffers there -> no gradient
+        self._frozen_bn_params = [p for n_, p in ft_model.named_parameters()
+                                  if n_.startswith("i3d.") and (".bn" in n_ or n_.startswith("i3d.bn") or ".downsample.1." in n_)]
 
     # ---- shared pieces -------------------------------------------------------------------------------------------
     @staticmethod
@@ -123,6 +134,7 @@ class AnonymizerTrainStep:
         for opt in self._opts():
             opt.zero_grad(set_to_none=True)
         TE.ARENA.reset(inputs_video.device)
+        self.red_fa.prepare()                                         # fa's gradients: zeroed views into the buckets
         fb_ctx, loss_fb = [], None
         if views is not None:                                         # :80-84: fa (train mode) on each view, frozen fb
             for v in views:
@@ -149,9 +161,9 @@ class AnonymizerTrainStep:
         danon = torch.zeros(shape, dtype=torch.float32, device=anon.device)
         for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
             self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad), dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
-        self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape))
+        self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape), on_bucket_done=self.red_fa.bucket_ready)   # fa's last backward pass of the step
         self.fa_tr.flush_grads()
-        allreduce_mean_grads(list(self.fa.parameters()), self.group)
+        self.red_fa.finish()
         ok = self._unscale(self.fa)
         if ok:
             self.opt_fa.step()                                        # :123
@@ -170,6 +182,9 @@ class AnonymizerTrainStep:
         for opt in self._opts():
             opt.zero_grad(set_to_none=True)
         TE.ARENA.reset(inputs_video.device)
+        self.red_ft.prepare()
+        if self.red_fb is not None:
+            self.red_fb.prepare()
         frames, shape = self._feed(inputs_video)
         with torch.no_grad():
             anon_views = [self.fa(v) for v in views] if views is not None else []      # :147
@@ -182,10 +197,10 @@ class AnonymizerTrainStep:
                 ctx.append((tape_b, emb.detach().requires_grad_()))
             loss_fb = NTXentLoss(inputs_video.device, ctx[0][1].shape[0], 0.1, False)(ctx[0][1], ctx[1][1])
             loss_fb.backward()
-            for tape_b, z in ctx:
-                self.fb_tr.backward(tape_b, self._scaled(z.grad))
+            for j, (tape_b, z) in enumerate(ctx):
+                self.fb_tr.backward(tape_b, self._scaled(z.grad), on_bucket_done=self.red_fb.bucket_ready if j == len(ctx) - 1 else None)
             self.fb_tr.flush_grads()
-            allreduce_mean_grads(list(self.fb.parameters()), self.group)
+            self.red_fb.finish()
             ok_fb = self._unscale(self.fb)
             if ok_fb:
                 self.opt_fb.step()
@@ -197,10 +212,11 @@ class AnonymizerTrainStep:
             leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
         loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
         loss_ft.backward()                                            # :191
-        for tape, (pl, fl) in zip(tapes, leaves):
-            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad))
+        for j, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):     # the third clip's pass finishes every bucket -> all-reduce under it
+            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad),
+                                on_bucket_done=self.red_ft.bucket_ready if j == len(tapes) - 1 else None)
         self.ft_tr.flush_grads()
-        allreduce_mean_grads(list(self.ft.parameters()), self.group)
+        self.red_ft.finish()
         ok = self._unscale(self.ft)
         if ok:
             self.opt_ft.step()                                        # :193
@@ -218,6 +234,7 @@ class AnonymizerTrainStep:
         self.fa.eval(); self.ft.train()
         self.opt_ft.zero_grad(set_to_none=True)                       # :46
         TE.ARENA.reset(inputs_video.device)
+        self.red_ft.prepare(exclude=self._frozen_bn_params)
         frames, shape = self._feed(inputs_video)                      # :47,54-55 (Q2)
         with torch.no_grad():
             anon = self.fa(frames).reshape(shape)                     # :56-57
@@ -229,10 +246,11 @@ class AnonymizerTrainStep:
             leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
         loss, loss_ce, loss_trip = self._utility_losses(leaves, labels)
         loss.backward()
-        for tape, (pl, fl) in zip(tapes, leaves):
-            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad))
+        for j, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
+            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad),
+                                on_bucket_done=self.red_ft.bucket_ready if j == len(tapes) - 1 else None)
         self.ft_tr.flush_grads()
-        allreduce_mean_grads(list(self.ft.parameters()), self.group)
+        self.red_ft.finish()
         ok = self._unscale(self.ft)
         if ok:
             self.opt_ft.step()                                        # :87

@@ -76,6 +76,38 @@ def test_unet_eval(unet, golden, golden_meta):
     assert float(y.min()) > 0 and float(y.max()) < 1
 
 
+@pytest.fixture(scope="module")
+def unetpp():
+    from ted_spad_amd.model_loaders import load_fa_model
+    return _load(load_fa_model())                              # the reference's default: arch='unet++'
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 112, 112), (1, 3, 48, 80)])
+def test_unetpp_eval_vs_oracle(unetpp, shape):
+    """The default anonymizer (smp UnetPlusPlus, resnet18 encoder; model_loaders.py:17-30) against oracle/unetpp_ref.py (restated from
+    the published smp / torchvision sources: parity unpinned, see its header): output and every dense-pathway tensor."""
+    from oracle import unetpp_ref
+    from ted_spad_amd import engine as E
+    frames = synth_tensor(0, "upp_frames%d" % shape[2], shape)
+    sd = {k: v.cpu() for k, v in unetpp.state_dict().items()}
+    rt, gt = {}, {}
+    with torch.no_grad():
+        ref = unetpp_ref.forward(frames, sd, taps=rt)
+    y = unetpp(frames.cuda(), taps=gt)
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    for k in ("f1", "f2", "f3", "f4", "x00", "x11", "x22", "x01", "x12", "x02", "x03"):
+        got = E.act_to_nchw(gt[k]).squeeze(2).cpu()
+        r = rt[k if k.startswith("f") else "x_%s_%s" % (k[1], k[2])]
+        assert rel_l2(got, r) < TOL, (k, rel_l2(got, r))
+    assert rel_l2(y.cpu(), ref) < TOL
+    with pytest.raises(RuntimeError):
+        unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
+    unetpp.train()
+    with pytest.raises(NotImplementedError):
+        unetpp(frames.cuda())
+    unetpp.eval()
+
+
 def test_unet_odd_size_vs_oracle(unet):
     """Up's pad-to-skip path (unet_parts.py:56-62): 100x92 -> 6x5 at the bottom, skips are odd."""
     from oracle import unet_ref

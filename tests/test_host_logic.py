@@ -85,8 +85,22 @@ def test_loader_signatures_and_checkpoint_fallbacks(tmp_path, capsys):
     assert ml.load_ft_model() is None                      # default arch 'r3d' matches no branch (model_loaders.py:65-67)
     assert "invalid for ft_model" in capsys.readouterr().out
     assert ml.load_fa_model(arch="nope") is None
-    with pytest.raises(NotImplementedError):
-        ml.load_fa_model()                                 # default 'unet++' is third-party
+    upp = ml.load_fa_model()                               # default arch 'unet++' (model_loaders.py:17): smp's UnetPlusPlus, restated
+    assert "freshly initialized" in capsys.readouterr().out
+    keys = list(upp.state_dict())
+    assert len(keys) == 206 and sum(p.numel() for p in upp.parameters()) == 13898787
+    for k, shape in (("encoder.conv1.weight", (64, 3, 7, 7)), ("encoder.layer2.0.downsample.0.weight", (128, 64, 1, 1)),
+                     ("encoder.layer4.1.bn2.running_var", (512,)),                      # ResNetEncoder keeps layer4 at depth 4
+                     ("decoder.blocks.x_0_0.conv1.0.weight", (256, 384, 3, 3)), ("decoder.blocks.x_1_1.conv1.0.weight", (64, 192, 3, 3)),
+                     ("decoder.blocks.x_2_2.conv2.1.num_batches_tracked", ()), ("decoder.blocks.x_0_1.conv1.0.weight", (128, 384, 3, 3)),
+                     ("decoder.blocks.x_1_2.conv1.0.weight", (64, 192, 3, 3)), ("decoder.blocks.x_0_2.conv1.0.weight", (64, 320, 3, 3)),
+                     ("decoder.blocks.x_0_3.conv1.0.weight", (32, 64, 3, 3)), ("segmentation_head.0.weight", (3, 32, 3, 3)),
+                     ("segmentation_head.0.bias", (3,))):
+        assert tuple(upp.state_dict()[k].shape) == shape, k
+    assert not any(k.startswith("encoder.fc") or "attention" in k for k in keys)
+    pu = str(tmp_path / "upp.pth")                         # DataParallel-style 'module.' checkpoint (model_loaders.py:38-46)
+    torch.save({"fa_model_state_dict": {"module." + k: v for k, v in upp.state_dict().items()}}, pu)
+    assert ml.load_fa_model(saved_model_file=pu) is not None and "loaded from" in capsys.readouterr().out
     ft = ml.load_ft_model("largei3d", num_classes=102)
     sd = synth_state_dict(ft.state_dict(), 5)
     # (1) plain checkpoint dict, as train_anonymizer.py:519-550 writes it
