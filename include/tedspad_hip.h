@@ -176,6 +176,11 @@ int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const void *x, void 
 int32_t tedspad_global_avgpool_fwd(const void *x, float *y, int32_t n, int32_t spatial, int32_t c,
                                    int32_t ldx, int32_t dtype, void *stream);
 
+/* nn.AvgPool3d(kernel_size=[kt,kh,kw], stride=(1,1,1)) of InceptionI3d.extract_features (aux_code/models/i3d.py:293-295,336-340) on a
+ * Mixed_5c map larger than the kernel: x (n,t,h,w,c) 16-bit channels-last, pixel stride ldx -> y fp32 (n,c,t-kt+1,h-kh+1,w-kw+1). */
+int32_t tedspad_avgpool3d_s1_fwd(const void *x, float *y, int32_t n, int32_t t, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t kt,
+                                 int32_t kh, int32_t kw, int32_t dtype, void *stream);
+
 /* fp32 NCTHW clip (as ft.extract_features takes it: large_i3d.py:249) -> 16-bit NTHWC with the
  * channel dim zero-padded to cpad (4: stem pixel-pair form; 8: UNet).  x strides in elements. */
 int32_t tedspad_clip_to_channels_last(const float *x, void *y, int32_t n, int32_t c, int32_t t,
@@ -330,6 +335,15 @@ int32_t tedspad_frames_crop_resize(const void *frames, int32_t in_is_float, int3
                                    int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t oh, int32_t ow,
                                    const int32_t *ytab, const int32_t *xtab, float divisor, int32_t flip, float *out,
                                    int64_t so_t, int64_t so_c, int64_t so_h, int64_t so_w, void *stream);
+
+/* `shanghai_frames_dataset.augmentation` (feature_extraction/shanghai_dl.py:27-40): uint8 frames (T,H,W,C) -> crop box -> Pillow's
+ * two-pass BILINEAR resize with its 8-bit intermediate image (what torchvision's resize does for a PIL image) -> to_tensor (/255)
+ * -> fp32 out[t*so_t + c*so_c + y*so_h + x*so_w]. ytab / xtab: device tables of (2 + taps) int32 per output index
+ * {first input index, count, coefficients with 22 fractional bits}, built by the host as libImaging/Resample.c does
+ * (ted_spad_amd/preprocess.pil_table). Bit-exact with Pillow (tests/test_hip_feed.py). */
+int32_t tedspad_frames_crop_resize_pil(const void *frames, int32_t T, int32_t H, int32_t W, int32_t C, int32_t y0, int32_t x0, int32_t ch,
+                                       int32_t cw, int32_t oh, int32_t ow, const int32_t *ytab, int32_t ytaps, const int32_t *xtab,
+                                       int32_t xtaps, float *out, int64_t so_t, int64_t so_c, int64_t so_h, int64_t so_w, void *stream);
 
 /* MGFN feature feed (anomaly_detection_mgfn/datasets/dataset.py:65-100): feat (T, ncrops, F) fp32.
  * length > 0 (train): out (ncrops, length, F+1) = process_feat (utils/utils.py:34-42: means over the

@@ -40,3 +40,22 @@ def resize_matrix(in_size, out_size):
     # N=1, C=in (one channel per basis vector), H=in, W=2 (a width-1 image takes a degenerate path in torch 2.10)
     eye = torch.eye(in_size).view(1, in_size, in_size, 1).expand(1, in_size, in_size, 2).contiguous()
     return F.interpolate(eye, size=(out_size, 2), mode="bilinear", align_corners=False, antialias=True)[0, :, :, 0].t()
+
+
+def shanghai_augmentation(image, cropping_factor=0.8, no_ar_distortion=False, reso_h=224, reso_w=224):
+    """`shanghai_frames_dataset.augmentation` (feature_extraction/shanghai_dl.py:27-40) for one (H,W,3) uint8 numpy frame ->
+    (3,reso_h,reso_w) fp32. torchvision's PIL branch restated (to_pil_image = Image.fromarray; center_crop = the box rule above +
+    Image.crop; resize = Image.resize(size[::-1], BILINEAR); to_tensor = uint8 HWC -> CHW float / 255); the resampling itself is
+    PILLOW'S OWN (installed in this image): pinned. The crop arithmetic follows the reference lines literally, including
+    `min(image.shape)` (minimum over H, W and the channel count) and the square crop of side int(H * factor)."""
+    import numpy as np
+    from PIL import Image
+    ori_h, ori_w = image.shape[0], image.shape[1]
+    min_size = min(image.shape)
+    pil = Image.fromarray(image)
+    side = int(min_size * cropping_factor) if no_ar_distortion else int(ori_h * cropping_factor)
+    top, left = int(round((ori_h - side) / 2.0)), int(round((ori_w - side) / 2.0))
+    pil = pil.crop((left, top, left + side, top + side))
+    pil = pil.resize((reso_w, reso_h), Image.BILINEAR)
+    arr = np.array(pil, copy=True)
+    return torch.from_numpy(arr).permute(2, 0, 1).contiguous().to(torch.float32).div(255)

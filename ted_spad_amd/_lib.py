@@ -47,6 +47,7 @@ SYMBOLS = {
     "tedspad_maxpool_fwd": (_I32, [C.POINTER(PoolDesc), _P, _P, _P]),
     "tedspad_maxpool_fwd_idx": (_I32, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "tedspad_global_avgpool_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "tedspad_avgpool3d_s1_fwd": (_I32, [_P, _P] + [_I32] * 10 + [_P]),
     "tedspad_clip_to_channels_last": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _P]),
     "tedspad_channels_last_to_nchw": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_upsample_bilinear2x_fwd": (_I32, [_P, _P] + [_I32] * 11 + [_P]),
@@ -81,6 +82,7 @@ SYMBOLS = {
     "tedspad_resize_aa_taps": (_I32, [_I32, _I32]),
     "tedspad_resize_aa_table": (_I32, [_I32, _I32, _P]),
     "tedspad_frames_crop_resize": (_I32, [_P] + [_I32] * 11 + [_P, _P, C.c_float, _I32, _P] + [_I64] * 4 + [_P]),
+    "tedspad_frames_crop_resize_pil": (_I32, [_P] + [_I32] * 10 + [_P, _I32, _P, _I32, _P] + [_I64] * 4 + [_P]),
     "tedspad_segment_pool_mag": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P]),
 }
 

@@ -102,6 +102,49 @@ __global__ __launch_bounds__(256) void crop_resize_aa_kernel(const ResizeKP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// uint8 frames -> crop box -> Pillow's two-pass BILINEAR resize (8-bit intermediate image) -> /255 -> fp32:
+// `shanghai_frames_dataset.augmentation` (feature_extraction/shanghai_dl.py:27-40: to_pil_image, center_crop, resize(antialias),
+// to_tensor). Pillow (libImaging/Resample.c, 8 bits per channel) resamples HORIZONTALLY first, rounds that image to uint8, then
+// vertically, with fixed-point coefficients of 22 fractional bits: out = clip8((2^21 + sum px * kk) >> 22). The integer tables
+// {first index, count, kk[0..taps)} are built on the host exactly as precompute_coeffs / normalize_coeffs_8bpc do (preprocess.py).
+// One workgroup per (frame, output row): a thread owns output pixels (x, c) and runs the horizontal pass of the <= ytaps
+// temporary rows it needs itself (every input row feeds ~2 output rows: 2x redundant integer MACs on a memory-bound op).
+// ------------------------------------------------------------------------------------------------------------
+struct ResizeU8KP {
+    const uint8_t *in;
+    float *out;
+    const int32_t *ytab, *xtab;
+    int T, H, W, C, y0, x0, oh, ow, ytaps, xtaps;
+    long so_t, so_c, so_h, so_w;
+};
+
+__device__ __forceinline__ int clip8_fixed(int v) {
+    v >>= 22;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void crop_resize_pil_kernel(const ResizeU8KP p) {
+    const int t = blockIdx.x / p.oh, oy = blockIdx.x % p.oh;
+    const int32_t *ye = p.ytab + (size_t)oy * (2 + p.ytaps);
+    const int ymin = ye[0], yn = ye[1];
+    const uint8_t *base = p.in + (((long)t * p.H + p.y0 + ymin) * p.W + p.x0) * p.C;
+    const long rstride = (long)p.W * p.C;
+    for (int e = threadIdx.x; e < p.ow * p.C; e += 256) {
+        const int ox = e / p.C, c = e - ox * p.C;
+        const int32_t *xe = p.xtab + (size_t)ox * (2 + p.xtaps);
+        const int xmin = xe[0], xn = xe[1];
+        int acc = 1 << 21;
+        for (int j = 0; j < yn; j++) {
+            const uint8_t *r = base + j * rstride + (long)xmin * p.C + c;
+            int hs = 1 << 21;
+            for (int i = 0; i < xn; i++) hs += (int)r[(long)i * p.C] * xe[2 + i];
+            acc += clip8_fixed(hs) * ye[2 + j];                  // the horizontal pass's uint8 pixel of temporary row ymin + j
+        }
+        p.out[t * p.so_t + c * p.so_c + oy * p.so_h + ox * p.so_w] = (float)clip8_fixed(acc) / 255.f;   // to_tensor: uint8 -> float / 255
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // process_feat + magnitude. One workgroup per (crop, segment); lanes stride over F (consecutive floats).
 // length > 0 : out (ncrops, length, F+1): row s = mean of feature rows r[s]..r[s+1]-1 (or row r[s] if empty),
 //              r = linspace(0, T, length+1) truncated to int exactly as numpy does it in float64.
@@ -187,4 +230,19 @@ extern "C" int32_t tedspad_segment_pool_mag(const float *feat, int32_t T, int32_
     const dim3 g((unsigned)(length > 0 ? length : T), (unsigned)ncrops);
     hipLaunchKernelGGL(segment_pool_mag_kernel, g, dim3(256), 0, (hipStream_t)stream, feat, out, T, ncrops, F, length);
     return check_launch("tedspad_segment_pool_mag");
+}
+
+extern "C" int32_t tedspad_frames_crop_resize_pil(const void *frames, int32_t t, int32_t h, int32_t w, int32_t c, int32_t y0, int32_t x0, int32_t ch,
+                                                  int32_t cw, int32_t oh, int32_t ow, const int32_t *ytab, int32_t ytaps, const int32_t *xtab,
+                                                  int32_t xtaps, float *out, int64_t so_t, int64_t so_c, int64_t so_h, int64_t so_w, void *stream) {
+    TS_REQUIRE(frames && ytab && xtab && out && t > 0 && h > 0 && w > 0 && c > 0 && c <= 4 && oh > 0 && ow > 0 && ytaps > 0 && xtaps > 0,
+               "tedspad_frames_crop_resize_pil: bad arguments");
+    TS_REQUIRE(y0 >= 0 && x0 >= 0 && ch > 0 && cw > 0 && y0 + ch <= h && x0 + cw <= w, "tedspad_frames_crop_resize_pil: crop box outside the frame");
+    TS_REQUIRE((long)t * oh < (1L << 31), "tedspad_frames_crop_resize_pil: too many rows");
+    ResizeU8KP p;
+    p.in = (const uint8_t *)frames; p.out = out; p.ytab = ytab; p.xtab = xtab;
+    p.T = t; p.H = h; p.W = w; p.C = c; p.y0 = y0; p.x0 = x0; p.oh = oh; p.ow = ow; p.ytaps = ytaps; p.xtaps = xtaps;
+    p.so_t = so_t; p.so_c = so_c; p.so_h = so_h; p.so_w = so_w;
+    hipLaunchKernelGGL(crop_resize_pil_kernel, dim3((unsigned)((long)t * oh)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("tedspad_frames_crop_resize_pil");
 }

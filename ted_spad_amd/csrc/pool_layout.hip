@@ -210,6 +210,36 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const uint16_t *x, float *
     for (int j = 0; j < 8; ++j) py[j] = s[j] * inv;
 }
 
+// nn.AvgPool3d(kernel (kt,kh,kw), stride 1, no padding) of InceptionI3d.extract_features on maps larger than the kernel
+// (aux_code/models/i3d.py:293-295,336-340): x (n,t,h,w,c) 16-bit channels-last -> y fp32 (n,c,to,ho,wo) contiguous (the NCTHW tensor
+// the reference returns). One thread per (output position, 8-channel chunk), fp32 accumulate.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3d_s1_kernel(const uint16_t *x, float *y, int t, int h, int w, int c8n, int ldx, int kt, int kh, int kw,
+                                                           int to, int ho, int wo, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int c8 = (int)(r % c8n); r /= c8n;
+        const int ow = (int)(r % wo); r /= wo;
+        const int oh = (int)(r % ho); r /= ho;
+        const int ot = (int)(r % to);
+        const long n = r / to;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < kt; ++a)
+            for (int b = 0; b < kh; ++b)
+                for (int d = 0; d < kw; ++d) {
+                    float v[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(x + ((((n * t + ot + a) * h + oh + b) * w + ow + d) * (long)ldx + c8 * 8)), v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += v[j];
+                }
+        const float inv = 1.f / (float)(kt * kh * kw);
+        const long plane = (long)to * ho * wo;
+        float *py = y + ((n * c8n * 8 + c8 * 8) * plane + ((long)ot * ho + oh) * wo + ow);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) py[j * plane] = s[j] * inv;
+    }
+}
+
 // fp32 (n,c,t,h,w) with arbitrary element strides -> 16-bit (n,t,h,w,cpad).
 // One thread per 8 output channels-last elements: cpad=4 -> two pixels, cpad=8 -> one.
 template <typename T>
@@ -485,4 +515,18 @@ extern "C" int32_t tedspad_copy_channels(const void *x, void *y, int64_t npix, i
     const long total = (long)npix * (c / 8);
     hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
     return check_launch("tedspad_copy_channels");
+}
+
+extern "C" int32_t tedspad_avgpool3d_s1_fwd(const void *x, float *y, int32_t n, int32_t t, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t kt,
+                                            int32_t kh, int32_t kw, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldx >= c && kt > 0 && kh > 0 && kw > 0 && t >= kt && h >= kh && w >= kw,
+               "tedspad_avgpool3d_s1_fwd: bad arguments (the map must be at least as large as the kernel)");
+    TS_REQUIRE(((uintptr_t)x) % 16 == 0, "tedspad_avgpool3d_s1_fwd: x must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_avgpool3d_s1_fwd: bad dtype");
+    const int to = t - kt + 1, ho = h - kh + 1, wo = w - kw + 1;
+    const long total = (long)n * to * ho * wo * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(avgpool3d_s1_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, t, h, w, c / 8, ldx, kt, kh, kw, to, ho, wo, total);
+    else hipLaunchKernelGGL(avgpool3d_s1_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, t, h, w, c / 8, ldx, kt, kh, kw, to, ho, wo, total);
+    return check_launch("tedspad_avgpool3d_s1_fwd");
 }

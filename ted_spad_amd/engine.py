@@ -525,6 +525,16 @@ def global_avgpool(x: Act) -> torch.Tensor:
     return y
 
 
+def avgpool3d_stride1(x: Act, k) -> torch.Tensor:
+    """nn.AvgPool3d(k, stride 1): (n,t,h,w,c) -> fp32 (n, c, t-kt+1, h-kh+1, w-kw+1)."""
+    n, t, h, w = x.dims
+    y = torch.empty((n, x.c, t - k[0] + 1, h - k[1] + 1, w - k[2] + 1), dtype=torch.float32, device=x.buf.device)
+    code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
+    check(_lib.lib().tedspad_avgpool3d_s1_fwd(x.ptr, y.data_ptr(), n, t, h, w, x.c, x.ld, k[0], k[1], k[2], code, _stream_ptr()),
+          "tedspad_avgpool3d_s1_fwd")
+    return y
+
+
 def clip_to_act(x: torch.Tensor, cpad: int, dtype: str = DEFAULT_DTYPE) -> Act:
     """fp32 (n,c,t,h,w) (any strides) -> channels-last 16-bit Act. cpad=4 returns the
     pixel-pair view (n,t,h,w/2,8) the stems consume; cpad=8 returns (n,t,h,w,8)."""

@@ -61,6 +61,7 @@ class InceptionModule(nn.Module):
 
 
 class InceptionI3d(nn.Module):
+    feature_dim = 1024       # width of the clip feature (i3d.py:336-340)
     VALID_ENDPOINTS = tuple(n for n, _, _ in PLAN) + ("Logits", "Predictions")
 
     def __init__(self, num_classes=400, spatial_squeeze=True, final_endpoint="Logits", name="inception_i3d",
@@ -157,15 +158,15 @@ class InceptionI3d(nn.Module):
         return a
 
     def extract_features(self, x: torch.Tensor) -> torch.Tensor:
-        """i3d.py:336-340: AvgPool3d([2,7,7], stride 1) of Mixed_5c. A 16x224x224 clip gives a
-        (2,7,7) map -> (B,1024,1,1,1). Smaller maps raise like the reference."""
+        """i3d.py:293-295,336-340: AvgPool3d([2,7,7], stride 1) of Mixed_5c. A 16x224x224 clip gives a (2,7,7) map ->
+        (B,1024,1,1,1); larger clips give (B,1024,t-1,h-6,w-6) like the reference; smaller maps raise like it."""
         a = self._trunk(x)
         _, t, h, w = a.dims
         if t < 2 or h < 7 or w < 7:
             raise RuntimeError("AvgPool3d kernel (2,7,7) is larger than the Mixed_5c map (%d,%d,%d)" % (t, h, w))
-        if (t, h, w) != (2, 7, 7):
-            raise NotImplementedError("extract_features is built for 16x224x224 clips (Mixed_5c map (2,7,7))")
-        return E.global_avgpool(a).view(x.shape[0], -1, 1, 1, 1)
+        if (t, h, w) == (2, 7, 7):
+            return E.global_avgpool(a).view(x.shape[0], -1, 1, 1, 1)
+        return E.avgpool3d_stride1(a, (2, 7, 7))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """i3d.py:324-333 (eval): adaptive avg-pool -> 1x1x1 logits conv with bias -> (B, num_classes)."""

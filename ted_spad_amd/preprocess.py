@@ -10,8 +10,10 @@ restated from its published source (parity unpinned for that integer rounding ru
 `torch.nn.functional.interpolate(mode='bilinear', antialias=True)` call torchvision makes for float tensors, which IS
 importable and pins oracle/preprocess_ref.py.
 
-`shanghai_frames_dataset.augmentation` (shanghai_dl.py:27-40) goes through PIL images (uint8 intermediate rounding
-inside PIL's resize); that variant is not built.
+`shanghai_frames_dataset.augmentation` (shanghai_dl.py:27-40) goes through PIL images: torchvision's `resize` of a PIL image is
+Pillow's `Image.resize(BILINEAR)`, a two-pass fixed-point resample with a uint8 intermediate image. `shanghai_augmentation` below
+reproduces it bit for bit on the GPU (tedspad_frames_crop_resize_pil); Pillow IS installed in this image, so oracle/preprocess_ref.py
+calls it directly (pinned), only torchvision's `center_crop` box rule stays restated.
 """
 from __future__ import annotations
 
@@ -101,3 +103,104 @@ def val_augmentations(video: torch.Tensor, cropping_factor: float = 0.8, no_ar_d
         ch, cw = int(h * cropping_factor), int(w * cropping_factor)
     box = center_crop_box(h, w, ch, cw)
     return crop_resize(video[0].contiguous(), box, (reso_h, reso_w)).unsqueeze(0)
+
+
+# ---- shanghai_frames_dataset.augmentation (shanghai_dl.py:27-40): the PIL path ----------------------------------------------------
+
+_PIL_TABLES = {}
+PIL_PRECISION_BITS = 32 - 8 - 2          # libImaging/Resample.c
+
+
+def pil_table(in_size: int, out_size: int):
+    """Pillow's BILINEAR resample coefficients for in_size -> out_size (no box offset), as libImaging/Resample.c computes them:
+    precompute_coeffs (float64: support = max(scale, 1), triangle filter, normalised) then normalize_coeffs_8bpc
+    (kk = trunc(+-0.5 + k * 2^22)). Returns (int32 (out_size, 2 + ksize) array {xmin, count, kk...}, ksize)."""
+    scale = float(in_size) / float(out_size)
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    tab = np.zeros((out_size, 2 + ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = np.zeros(xmax, dtype=np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            if a < 0.0:
+                a = -a
+            w = 1.0 - a if a < 1.0 else 0.0
+            k[x] = w
+            ww += w
+        if ww != 0.0:
+            for x in range(xmax):
+                k[x] /= ww
+        tab[xx, 0], tab[xx, 1] = xmin, xmax
+        for x in range(xmax):
+            v = k[x] * (1 << PIL_PRECISION_BITS)
+            tab[xx, 2 + x] = int(-0.5 + v) if k[x] < 0 else int(0.5 + v)
+    return tab, ksize
+
+
+def _pil_table(in_size, out_size, device):
+    key = (int(in_size), int(out_size), str(device))
+    t = _PIL_TABLES.get(key)
+    if t is None:
+        tab, ks = pil_table(in_size, out_size)
+        t = (torch.from_numpy(tab).to(device), ks)
+        _PIL_TABLES[key] = t
+    return t
+
+
+def crop_resize_pil(frames: torch.Tensor, box, out_hw, out: torch.Tensor = None, layout: str = "tchw") -> torch.Tensor:
+    """frames: (T,H,W,C) uint8 on the GPU -> fp32 (T,C,oh,ow) ('tchw') or (C,T,oh,ow) ('cthw'): crop + Pillow BILINEAR resize + /255."""
+    require_cuda(frames, "crop_resize_pil")
+    if frames.dim() != 4 or frames.dtype != torch.uint8 or not frames.is_contiguous():
+        raise ValueError("crop_resize_pil: frames must be a contiguous (T,H,W,C) uint8 tensor (PIL images are 8-bit)")
+    t, h, w, c = frames.shape
+    y0, x0, ch, cw = [int(v) for v in box]
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    shape = (t, c, oh, ow) if layout == "tchw" else (c, t, oh, ow)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=frames.device)
+    if tuple(out.shape) != shape or out.dtype != torch.float32:
+        raise ValueError("crop_resize_pil: out must be fp32 %s" % (shape,))
+    s = out.stride()
+    so = (s[0], s[1]) if layout == "tchw" else (s[1], s[0])
+    (ytab, ky), (xtab, kx) = _pil_table(ch, oh, frames.device), _pil_table(cw, ow, frames.device)
+    check(_lib.lib().tedspad_frames_crop_resize_pil(frames.data_ptr(), t, h, w, c, y0, x0, ch, cw, oh, ow, ytab.data_ptr(), ky, xtab.data_ptr(), kx,
+                                                    out.data_ptr(), so[0], so[1], s[2], s[3], _stream_ptr()), "tedspad_frames_crop_resize_pil")
+    return out
+
+
+def shanghai_crop_size(h: int, w: int, c: int, cropping_factor: float = 0.8, no_ar_distortion: bool = False):
+    """The crop `shanghai_frames_dataset.augmentation` takes from an (h, w, c) frame (shanghai_dl.py:28-35), quirks included:
+    with no_ar_distortion the reference uses min(image.shape) -- the minimum over (H, W, C), i.e. the channel count 3 -- and
+    otherwise a SQUARE of side int(H * factor) (both sides from the height). Reproduced as written."""
+    if no_ar_distortion:
+        side = int(min(h, w, c) * cropping_factor)
+    else:
+        side = int(h * cropping_factor)
+    return side, side
+
+
+def shanghai_augmentation(frames: torch.Tensor, cropping_factor: float = 0.8, no_ar_distortion: bool = False, reso_h: int = 224,
+                          reso_w: int = 224, out: torch.Tensor = None, layout: str = "tchw") -> torch.Tensor:
+    """shanghai_dl.py:27-40 for a stack of decoded frames: (T,H,W,3) uint8 (or one (H,W,3) frame) -> fp32 (T,3,reso_h,reso_w) in [0,1]
+    (one frame: (3,reso_h,reso_w)), bit-identical to to_pil_image -> center_crop -> resize(antialias=True) -> to_tensor."""
+    single = frames.dim() == 3
+    if single:
+        frames = frames.unsqueeze(0)
+    t, h, w, c = frames.shape
+    ch, cw = shanghai_crop_size(h, w, c, cropping_factor, no_ar_distortion)
+    if ch < 1 or cw < 1:
+        raise ValueError("shanghai_augmentation: empty crop %dx%d" % (ch, cw))
+    y = crop_resize_pil(frames.contiguous(), center_crop_box(h, w, ch, cw), (reso_h, reso_w), out=out, layout=layout)
+    return y[0] if single and layout == "tchw" else y

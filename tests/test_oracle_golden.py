@@ -207,3 +207,29 @@ def test_train_step_oracle_vs_reference_modules(golden_meta, sd_largei3d, sd_une
     bad = [k for k, ref in g["phase2"]["grad_l2"].items() if abs(float(grads2[k].norm()) - ref) > 2e-2 * ref + 1e-6]
     assert len(bad) <= 3, bad   # a handful of tiny-norm BN gradients differ in fp32 summation order
     assert g["phase2"]["num_batches_tracked"] == 3   # Q14: three train-mode forwards per step
+
+
+@pytest.mark.parametrize("hw", [(480, 856), (97, 131), (224, 224)])
+def test_pil_resample_tables_reproduce_pillow(hw):
+    """Host logic of the shanghai pre-processing path: `preprocess.pil_table` (libImaging/Resample.c restated) driving the two-pass
+    integer resample in numpy must equal Pillow's own Image.resize(BILINEAR) -- through the oracle, which calls Pillow."""
+    import numpy as np
+    from oracle import preprocess_ref
+    from ted_spad_amd.preprocess import pil_table
+    h, w = hw
+    img = np.random.default_rng(h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = preprocess_ref.shanghai_augmentation(img).numpy()
+    side = int(h * 0.8)
+    top, left = int(round((h - side) / 2.0)), int(round((w - side) / 2.0))
+    crop = img[top:top + side, left:left + side].astype(np.int64)
+    tab, _ = pil_table(side, 224)
+    tmp = np.zeros((side, 224, 3), np.int64)
+    for ox in range(224):
+        x0, n = tab[ox, 0], tab[ox, 1]
+        tmp[:, ox] = np.clip(((1 << 21) + (crop[:, x0:x0 + n] * tab[ox, 2:2 + n].astype(np.int64)[None, :, None]).sum(1)) >> 22, 0, 255)
+    out = np.zeros((224, 224, 3), np.int64)
+    for oy in range(224):
+        y0, n = tab[oy, 0], tab[oy, 1]
+        out[oy] = np.clip(((1 << 21) + (tmp[y0:y0 + n] * tab[oy, 2:2 + n].astype(np.int64)[:, None, None]).sum(0)) >> 22, 0, 255)
+    got = (out.astype(np.float32) / np.float32(255)).transpose(2, 0, 1)
+    assert np.array_equal(got, ref)
