@@ -195,3 +195,4 @@ def test_batch_chunking_matches_single_launch(monkeypatch):
     assert torch.allclose(one[1], many[1], rtol=1e-5, atol=1e-5) and torch.allclose(one[3], many[3], rtol=1e-5, atol=1e-5)
     with pytest.raises(Exception):
         E.batch_chunk(2, [1 << 31], E.MAX_ELEMS)          # a single sample that does not fit fails loudly
+
