@@ -22,10 +22,11 @@ def short(n):
     return n[:90]
 
 rows = [r for r in csv.DictReader(open(a.trace)) if 'tedspad' in r['Kernel_Name']]
-starts = [i for i, r in enumerate(rows) if 'to_channels_last' in r['Kernel_Name']]
+FIRST = ('to_channels_last', 'clip_to_tp')      # the first kernel of a forward (layout pass)
+starts = [i for i, r in enumerate(rows) if any(f in r['Kernel_Name'] for f in FIRST)]
 first = starts[-a.forwards] if len(starts) >= a.forwards else starts[0]
 sel = rows[first:]
-nf = len([1 for r in sel if 'to_channels_last' in r['Kernel_Name']])
+nf = len([1 for r in sel if any(f in r['Kernel_Name'] for f in FIRST)])
 agg = collections.OrderedDict()
 for r in sel:
     k = short(r['Kernel_Name'])
@@ -56,7 +57,7 @@ def counter(path, name):
     """per-kernel sums over the LAST forward of the pass (earlier launches include the tile autotuner)."""
     rows = [r for r in csv.DictReader(open(path)) if r.get('Counter_Name') == name and 'tedspad' in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    st = [i for i, r in enumerate(rows) if 'to_channels_last' in r['Kernel_Name']]
+    st = [i for i, r in enumerate(rows) if any(f in r['Kernel_Name'] for f in FIRST)]
     rows = rows[st[-1]:]
     per = collections.OrderedDict(); n = collections.OrderedDict()
     for r in rows:

@@ -23,7 +23,7 @@ for r in rows:
     d = disp.setdefault(int(r['Dispatch_Id']), {'name': short(r['Kernel_Name']), 'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
     d[r['Counter_Name']] = float(r['Counter_Value'])
 ids = sorted(disp)
-starts = [i for i in ids if 'to_channels_last' in disp[i]['name']]
+starts = [i for i in ids if 'to_channels_last' in disp[i]['name'] or 'clip_to_tp' in disp[i]['name']]
 sel = [disp[i] for i in ids if i >= starts[-1]]
 agg = collections.OrderedDict()
 for d in sel:
