@@ -32,7 +32,7 @@ for d in sel:
     for k, v in d.items():
         if k != 'name':
             g[k] += v
-lines = ['# r01: MFMA utilisation and wave states per kernel, last forward of %d clips (bench.py cfg2 under rocprofv3 --pmc)' % a.batch, '',
+lines = ['# MFMA utilisation and wave states per kernel, last forward of %d clips (bench.py cfg2 under rocprofv3 --pmc)' % a.batch, '',
          'Counters: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY (one pass;',
          'kernels are serialised under counter collection). MFMA utilisation = MFMA busy cycles / (GPU-active cycles x 1024 SIMDs),',
          'GPU-active cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs).', '',
