@@ -138,6 +138,19 @@ int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
                                  int32_t sh2, int32_t sw2, const void *w_packed, const float *scale, const float *shift, void *y,
                                  void *stream);
 
+/* Tail of a layer1 bottleneck in one launch (csrc/conv_bneck.hip; aux_code/models/large_i3d.py:49-54,69-84):
+ *     y = act( bn3(conv3(relu(bn2(conv2(x))))) + residual )                         (plain block)
+ *     y = act( bn3(conv3(relu(bn2(conv2(x))))) + bn_d(conv_d(x2)) )                 (first block: downsample branch, stride 1)
+ * conv2 = `d2`: a stride-1 'same' 1 x kh x kw convolution with 64 input and 64 output channels (weights `w2_packed` in the
+ * tedspad_conv_fwd layout, BatchNorm folded to scale2 / shift2); conv3 / conv_d are 1x1x1 with 64 input channels and cout3 (a multiple of
+ * 64, <= 512) output channels. `w3p` is [cout3][KB * 64] 16-bit (KB = 2 with the second source): columns
+ * ((a*2 + s)*2 + h)*8 + j = conv3 weight of input channel 32 a + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the k order in which an MFMA
+ * accumulator tile is consumed as the next MFMA's operand), columns 64 + c = conv_d weight of input channel c. scale3 / scale_d are the two
+ * BatchNorm scales, shift3 the sum of the shifts. The 64-channel tensor between conv2 and conv3 is never written. */
+int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,
+                               const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual, int32_t ldres,
+                               const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu, void *stream);
+
 /* Persistent Cin = 3 stem (csrc/conv_stem_pt.hip): conv1 5x7x7 / stride 2 / pad (2,3,3) + bn1 + ReLU of large_i3d.py:133-137,229-231
  * with the temporal half of maxpool1 (MaxPool3d((2,3,3), 2), large_i3d.py:138,232) fused: y[n][to/2][ho][wo][64] =
  * max over the output frame pair (to, to+1) of act(conv * scale + shift); the spatial 3x3 / 2 half of the pool is a

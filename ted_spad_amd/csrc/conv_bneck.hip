@@ -1,0 +1,335 @@
+// Bottleneck tail for gfx950: conv2 (1 x 3 x 3, stride 1, 64 -> 64) + bn2 + ReLU -> conv3 (1 x 1 x 1, 64 -> 256) + bn3 (+ residual | +
+// the downsample branch) + ReLU of a layer1 bottleneck (aux_code/models/large_i3d.py:49-54,69-84) in ONE launch. The 64-channel tensor
+// between the two convolutions never leaves the registers.
+//
+// Why: layer1 is 31 % of an I3Res50 forward and HBM-bound (profiles/r02_bench_cfg2_kernels_1stream.md: the 64 -> 256 pointwise convs
+// run at 5.4 TB/s of their minimum bytes, conv2 at 32 % MFMA utilisation beside them). Separately the pair moves 1408 B per pixel
+// (conv2 reads 128 + writes 128, conv3 reads 128 + 512 residual + writes 512); fused it moves 1152, and -- with two workgroups per CU --
+// one workgroup's MFMA-bound conv2 loop runs under the other's memory-bound conv3 epilogue.
+//
+// Stage A = conv_flat_kernel (conv_flat.hip): a tile of 256 consecutive output pixels, its input halo one contiguous run in LDS, the
+// [64][64] weight tile of a tap streaming through a 3-slot ring; a wave ends with D[co][px] (64 co x 64 px) in 64 accumulator registers.
+// Stage B: `D = W2 . X` has its output channel on the accumulator ROWS, so the next product `Y3 = W3 . relu(bn2(D))` sums over rows and
+// takes the tile as its MFMA B operand WITHOUT any lane movement (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's
+// operand"): registers 8s .. 8s+7 of a 32 x 32 tile, packed to 16 bits, are the fragment of k-step s, in the k order
+//     element j of lane half h  <->  row 16 s + 8 (j >> 2) + 4 h + (j & 3)
+// which the host bakes into the column order of the conv3 weight image (`w3p`, tedspad_bneck_tail_fwd). The 256 x 64 (x 2 with the
+// downsample branch) weight image is copied once into the LDS that stage A has finished with; a wave then walks the 256 output
+// channels in 8 groups of 32: 8 MFMAs (16 with the second source, whose pixel fragments come straight from global memory), bn3 scale /
+// shift, the residual rows (loaded in the store layout and brought into the accumulator layout by v_permlane32_swap, which is its own
+// inverse), ReLU, and 16-byte stores straight from the registers (the same swap).
+#include "conv_common.h"
+
+namespace tedspad {
+namespace {
+
+__device__ uint4 g_zero16b;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BT_BM = 256;
+constexpr int BT_WSTAGE = 64 * BK * 2;
+
+struct BneckKP {
+    const uint16_t *x;          // conv2 input (n,t,h,w,64+) 16-bit, pixel stride ldx
+    const uint16_t *w2;         // conv2 weights, packed [>=64][Kpad] (K = (dh, dw, ci))
+    const float *scale2, *shift2;
+    const uint16_t *w3p;        // [cout3][KB*64]: columns 0..63 = conv3 weights in accumulator k order, 64..127 = downsample weights (natural order)
+    const float *scale3, *shift3, *scaled;    // shift3 already holds b3 (+ bd)
+    const uint16_t *res;        // residual (n,t,h,w,cout3) or NULL
+    const uint16_t *x2;         // second source of the downsample branch (same pixel grid, 64 channels) or NULL
+    uint16_t *y;
+    int M, Kpad, W, H, kh, kw, ph, pw, ldx, ldres, ldx2, ldy, cout3, relu;
+    int R, NP, ntaps;           // flat-halo geometry (conv_flat.hip)
+};
+
+template <typename T, bool DUAL>
+__global__ __launch_bounds__(256) void conv_bneck_tail_kernel(const BneckKP p) {
+    constexpr int NT = 256, WS = 3, KB = DUAL ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int q0 = tile * BT_BM;
+    const int S = (p.NP + 1) * 8;                       // 16-byte slots: the halo + one zero position
+    const int Sr = (S + 63) / 64 * 64;
+    const int halo_bytes = Sr * 16;
+    unsigned char *wring = dsm + halo_bytes;            // [WS][64][64] 16-bit
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16b);
+
+    // ================================ stage A: conv2 on the flat halo (conv_flat_kernel) ================================
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w2 + (size_t)rsub * p.Kpad + kc * 8;
+    auto issue_w = [&](int kt, int slot) {
+        const unsigned dst = lds0 + halo_bytes + slot * BT_WSTAGE + wave * 8 * (BK * 2);
+        lds_dma16(wsrc + kt * BK, dst);
+        lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));
+    };
+    issue_w(0, 0);                                       // issue order w(0), halo, w(1): the counted waits below rely on it
+    const int NH = (Sr + NT - 1) / NT;
+    for (int i = 0; i < NH; ++i) {
+        if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
+        const int s = i * NT + tid;
+        const int pos = s >> 3, cs = s & 7;
+        const int q = q0 - p.R + pos;
+        const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
+        const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
+        lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
+    }
+    if (p.ntaps > 1) issue_w(1, 1);
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    int pj[2];
+    unsigned vmask[2];        // bit (dh*kw + dw): the tap lies inside the frame
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = wave * 64 + b * 32 + l31;
+        pj[b] = j;
+        const int q = q0 + j;
+        unsigned mk = 0;
+        if (q < p.M) {
+            const int r1 = q / p.W, w = q - r1 * p.W;
+            const int h = r1 % p.H;
+            for (int dh = 0; dh < p.kh; ++dh)
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+        }
+        vmask[b] = mk;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int dh = 0, dw = 0;
+    for (int kt = 0; kt < p.ntaps; ++kt) {
+        const int delta = dh * p.W + dw;
+        unsigned xoff[2], xswz[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+            xoff[b] = (unsigned)pos * 128u;
+            xswz[b] = (unsigned)(pos >> 1) & 7u;
+        }
+        if (kt + 1 < p.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
+        __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
+        asm volatile("" ::: "memory");
+        if (kt + 2 < p.ntaps) issue_w(kt + 2, (kt + 2) % WS);
+        const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * BT_WSTAGE) + l31 * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned c = (unsigned)((ks << 1) | lh);
+            uint4 fa[2], fw[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+        }
+        if (++dw == p.kw) { dw = 0; ++dh; }
+    }
+    __syncthreads();          // every wave is done with the halo and the weight ring: their LDS now takes the conv3 weight image
+
+    // ================================ stage B: conv3 (+ downsample branch) on the register tile ================================
+    // ---- conv3 weight image: [KB][cout3 / 64] tiles of [64 co'][64 k], the swizzled image of every weight tile above ------------------
+    const int n3 = p.cout3 / 64;                           // 64-channel tiles of the output
+    for (int i = wave; i < KB * n3 * 8; i += 4) {          // 8 wave-instructions (8 rows x 128 B) per tile
+        const int tl = i >> 3, sub = i & 7;                // tile = kb * n3 + t64
+        const int kb = tl / n3, t64 = tl - kb * n3;
+        const int row = sub * 8 + (lane >> 3);             // row of the tile
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        lds_dma16(p.w3p + (size_t)(t64 * 64 + row) * (KB * 64) + kb * 64 + ch * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
+    }
+    float *bnv = reinterpret_cast<float *>(dsm + KB * n3 * BT_WSTAGE);     // [3][cout3]: scale3, shift3, scale of the second branch
+    for (int i = tid; i < p.cout3; i += NT) {
+        bnv[i] = p.scale3[i];
+        bnv[p.cout3 + i] = p.shift3[i];
+        bnv[2 * p.cout3 + i] = DUAL ? p.scaled[i] : 0.f;
+    }
+    // ---- this wave's pixels; the second source's pixel fragments (natural k order) straight from global memory --------------------------
+    size_t mpx[2];
+    bool inb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int q = q0 + wave * 64 + b * 32 + l31;
+        inb[b] = q < p.M;
+        mpx[b] = (size_t)(inb[b] ? q : 0);
+    }
+    uint4 xin[4][2];
+    if (DUAL) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xin[ks][b] = *reinterpret_cast<const uint4 *>(p.x2 + mpx[b] * p.ldx2 + (ks * 2 + lh) * 8);
+    }
+    // ---- relu(bn2(.)) of the conv2 tile, packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel half a ---------------
+    uint4 y2[4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        float sc[16], sf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sc[r] = p.scale2[c];
+            sf[r] = p.shift2[c];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s + j] * sc[8 * s + j] + sf[8 * s + j], 0.f);
+                y2[a * 2 + s][b] = pack8<T>(v);
+            }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();           // weight image + BN vectors visible
+
+    const int nt = p.cout3 / 32;
+    for (int t = 0; t < nt; ++t) {
+        const unsigned char *Wt = dsm + (t >> 1) * BT_WSTAGE + ((t & 1) * 32 + l31) * (BK * 2);
+        f32x16 a3[2], ad[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a3[b][r] = 0.f; ad[b][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned c = (unsigned)((ks << 1) | lh);
+            const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 4));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[ks][b], a3[b]);
+            if (DUAL) {
+                const uint4 fd = *reinterpret_cast<const uint4 *>(Wt + n3 * BT_WSTAGE + ((c ^ swz) << 4));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) ad[b] = T::mfma(fd, xin[ks][b], ad[b]);
+            }
+        }
+        // ---- epilogue of output channels 32 t .. 32 t + 31: lane (l31, lh) holds channels 32 t + 8 q + 4 lh + {0..3}, q = 0..3 -------------
+        f32x4 s3[4], b3[4], sd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 32 * t + 8 * q + 4 * lh;
+            s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
+            b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
+            if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+            if (!DUAL && p.res) {
+                // residual rows in the STORE layout (lane: channels 16 qq + 8 lh .. + 7), swapped back into the accumulator layout
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    uint4 L = make_uint4(0u, 0u, 0u, 0u);
+                    if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                    rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
+                    rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                }
+            }
+            unsigned d[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float v[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 4 * q + 2 * h + e;
+                        float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
+                        if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
+                        if (!DUAL && p.res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
+                        v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                    }
+                    d[q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(d[q][h], d[q + 1][h], false, false);
+                    d[q][h] = sw[0];
+                    d[q + 1][h] = sw[1];
+                }
+            if (inb[b]) {
+                uint16_t *dst = p.y + mpx[b] * p.ldy + 32 * t + 8 * lh;
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(d[0][0], d[0][1], d[1][0], d[1][1]);
+                *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(d[2][0], d[2][1], d[3][0], d[3][1]);
+            }
+        }
+    }
+}
+
+template <typename T, bool DUAL>
+int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
+    const int S = (p.NP + 1) * 8;
+    const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * BT_WSTAGE;
+    const int tail_bytes = (DUAL ? 2 : 1) * (p.cout3 / 64) * BT_WSTAGE + 3 * p.cout3 * 4;
+    const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
+    if (lds > 160 * 1024) {
+        set_error("tedspad_bneck_tail_fwd: halo / conv3 weight image does not fit LDS (%d bytes)", lds);
+        return TEDSPAD_EINVAL;
+    }
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_bneck_tail_kernel<T, DUAL>;
+    if (!attr_set[T::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 1;
+    }
+    hipLaunchKernelGGL(kfn, dim3((p.M + BT_BM - 1) / BT_BM), dim3(256), lds, s, p);
+    return check_launch("tedspad_bneck_tail_fwd");
+}
+
+}  // namespace
+}  // namespace tedspad
+
+using namespace tedspad;
+
+extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,
+                                          const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual,
+                                          int32_t ldres, const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu,
+                                          void *stream) {
+    TS_REQUIRE(d2 && x && w2_packed && scale2 && shift2 && w3p && scale3 && shift3 && y, "tedspad_bneck_tail_fwd: null pointer");
+    const bool same = d2->to == d2->t && d2->ho == d2->h && d2->wo == d2->w && d2->pt == 0 && d2->ph < d2->kh && d2->pw < d2->kw;
+    TS_REQUIRE(d2->cin == 64 && d2->cout == 64 && d2->kt == 1 && d2->st == 1 && d2->sh == 1 && d2->sw == 1 && same && d2->kh * d2->kw >= 2 &&
+                   d2->kh * d2->kw <= 32 && d2->ldx >= 64 && d2->ldx % 8 == 0,
+               "tedspad_bneck_tail_fwd: conv2 must be a stride-1 'same' 1 x kh x kw conv with 64 input and 64 output channels");
+    TS_REQUIRE(cout3 > 0 && cout3 % 64 == 0 && cout3 <= 512 && ldy >= cout3 && ldy % 8 == 0, "tedspad_bneck_tail_fwd: cout3 a multiple of 64 (<= 512), ldy >= cout3");
+    TS_REQUIRE(!(residual && x2), "tedspad_bneck_tail_fwd: either a residual tensor or the second (downsample) source, not both");
+    TS_REQUIRE(!residual || (ldres >= cout3 && ldres % 8 == 0), "tedspad_bneck_tail_fwd: bad ldres");
+    TS_REQUIRE(!x2 || (scale_d && ldx2 >= 64 && ldx2 % 8 == 0), "tedspad_bneck_tail_fwd: second source needs its BatchNorm scale and ldx2 >= 64");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)w2_packed | (uintptr_t)w3p | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)x2 | (uintptr_t)scale3 | (uintptr_t)shift3) % 16 == 0,
+               "tedspad_bneck_tail_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(d2->dtype == TEDSPAD_F16 || d2->dtype == TEDSPAD_BF16, "tedspad_bneck_tail_fwd: bad dtype");
+    const long M = (long)d2->n * d2->t * d2->h * d2->w;
+    TS_REQUIRE(M * (d2->ldx > ldy ? d2->ldx : ldy) < (1L << 31) && (!residual || M * ldres < (1L << 31)), "tedspad_bneck_tail_fwd: tensor too large for 32-bit offsets; split the batch");
+    BneckKP p;
+    p.x = (const uint16_t *)x; p.w2 = (const uint16_t *)w2_packed; p.scale2 = scale2; p.shift2 = shift2;
+    p.w3p = (const uint16_t *)w3p; p.scale3 = scale3; p.shift3 = shift3; p.scaled = scale_d;
+    p.res = (const uint16_t *)residual; p.x2 = (const uint16_t *)x2; p.y = (uint16_t *)y;
+    p.M = (int)M; p.Kpad = tedspad_conv_kpad(d2); p.W = d2->w; p.H = d2->h; p.kh = d2->kh; p.kw = d2->kw; p.ph = d2->ph; p.pw = d2->pw;
+    p.ldx = d2->ldx; p.ldres = ldres; p.ldx2 = ldx2; p.ldy = ldy; p.cout3 = cout3; p.relu = relu;
+    p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
+    TS_REQUIRE(p.Kpad == p.ntaps * 64, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
+    hipStream_t s = (hipStream_t)stream;
+    if (x2) return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, true>(p, s) : launch_bneck<BF16, true>(p, s);
+    return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, false>(p, s) : launch_bneck<BF16, false>(p, s);
+}

@@ -25,6 +25,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # calls of a conv on a new geometry the tile configurations of the kernel take turns, timed in context with
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
+BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
@@ -498,6 +499,65 @@ class PackedConv:
                 self._run(sub(x, n0, n1), pads, o, sub(out, n0, n1), sub(residual, n0, n1), sub(mask, n0, n1), stats, out_map,
                           None if z32 is None else z32[n0:n1], relu, sigmoid)
         return z32 if y32 else out
+
+
+class BneckTail:
+    """conv2 (1x3x3, 64 -> 64) + bn2 + ReLU -> conv3 (1x1x1, 64 -> cout3) + bn3 (+ residual | + downsample branch) + ReLU of a layer1
+    bottleneck (large_i3d.py:49-54,69-84) as ONE launch (csrc/conv_bneck.hip): the 64-channel tensor between the two convolutions stays in
+    registers (an MFMA accumulator tile is the next MFMA's operand; the conv3 weight columns are stored in that k order)."""
+
+    # column kk = ((a*2 + s)*2 + h)*8 + j of the conv3 weight image <- input channel 32 a + 16 s + 8 (j >> 2) + 4 h + (j & 3)
+    PERM = [32 * a + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for a in range(2) for s in range(2) for h in range(2) for j in range(8)]
+
+    def __init__(self, conv2: "PackedConv", w3: torch.Tensor, scale3, shift3, wd: Optional[torch.Tensor] = None, scale_d=None, shift_d=None):
+        assert self.supported(conv2, w3, wd)
+        dev = conv2.device
+        self.conv2 = conv2
+        self.cout3 = int(w3.shape[0])
+        w3m = w3.detach().to(dev, torch.float32).reshape(self.cout3, 64)[:, torch.tensor(self.PERM, device=dev)]
+        self.dual = wd is not None
+        if self.dual:
+            w3m = torch.cat([w3m, wd.detach().to(dev, torch.float32).reshape(self.cout3, 64)], dim=1)
+        self.w3p = w3m.to(conv2.torch_dtype).contiguous()
+        self.scale3 = scale3.detach().to(dev, torch.float32).contiguous()
+        sh = shift3.detach().to(dev, torch.float32)
+        self.shift3 = (sh + shift_d.detach().to(dev, torch.float32)).contiguous() if self.dual else sh.contiguous()
+        self.scale_d = scale_d.detach().to(dev, torch.float32).contiguous() if self.dual else None
+
+    @staticmethod
+    def supported(conv2: "PackedConv", w3: torch.Tensor, wd=None) -> bool:
+        kt, kh, kw = conv2.k
+        return (conv2.cin == 64 and conv2.cout == 64 and kt == 1 and 2 <= kh * kw <= 32 and conv2.stride == (1, 1, 1) and not conv2.pair and
+                tuple(w3.shape[1:]) == (64, 1, 1, 1) and w3.shape[0] % 64 == 0 and w3.shape[0] <= 512 and
+                (wd is None or tuple(wd.shape) == tuple(w3.shape)))
+
+    def applies(self, x: Act, pads) -> bool:
+        n, t, h, w = x.dims
+        kt, kh, kw = self.conv2.k
+        flat_halo = (256 + (kh - 1) * w + (kw - 1) + 1) * 128 + 3 * 8192
+        return (x.c == 64 and pads[0] == 0 and pads[1] < kh and pads[2] < kw and 2 * pads[1] == kh - 1 and 2 * pads[2] == kw - 1 and
+                flat_halo <= 80 * 1024 and n * t * h * w * max(x.ld, self.cout3) < MAX_ELEMS)
+
+    def __call__(self, x: Act, pads=(0, 1, 1), residual: Optional[Act] = None, x2: Optional[Act] = None, relu=True) -> Act:
+        n, t, h, w = x.dims
+        assert self.applies(x, pads) and (x2 is not None) == self.dual and not (self.dual and residual is not None)
+        out = Act.empty(n, t, h, w, self.cout3, self.conv2.torch_dtype, x.buf.device)
+        for o in (residual, x2):
+            if o is not None:
+                assert o.dims == x.dims
+        if residual is not None:
+            assert residual.c == self.cout3
+        if x2 is not None:
+            assert x2.c == 64
+        c2 = self.conv2
+        d = c2._desc(n, t, h, w, x.ld, pads, (t, h, w), 64, 0, True)
+        check(_lib.lib().tedspad_bneck_tail_fwd(C.byref(d), x.ptr, c2.w.data_ptr(), c2.scale.data_ptr(), c2.shift.data_ptr(), self.w3p.data_ptr(),
+                                                self.scale3.data_ptr(), self.shift3.data_ptr(), self.cout3,
+                                                residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
+                                                x2.ptr if x2 is not None else None, x2.ld if x2 is not None else 0,
+                                                self.scale_d.data_ptr() if self.dual else None, out.ptr, out.ld, int(relu), _stream_ptr()),
+              "tedspad_bneck_tail_fwd")
+        return out
 
 
 def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: Optional[Act] = None, return_idx=False):

@@ -86,6 +86,14 @@ class I3Res50(nn.Module):
                         s, b = self._bn_fold(blk.downsample[1])
                         P[p + "down"] = E.PackedConv(blk.downsample[0].weight, s, b, stride=(1, blk.stride, blk.stride),
                                                      dtype=self.compute_dtype, device=dev)
+                    if li == 1 and E.BneckTail.supported(P[p + "conv2"], blk.conv3.weight, blk.downsample[0].weight if blk.downsample is not None else None):
+                        s3, b3 = self._bn_fold(blk.bn3)
+                        if blk.downsample is not None and blk.stride == 1:
+                            sd_, bd_ = self._bn_fold(blk.downsample[1])
+                            P[p + "tail"] = E.BneckTail(P[p + "conv2"], blk.conv3.weight, s3, b3, blk.downsample[0].weight, sd_, bd_)
+                        elif blk.downsample is None:
+                            P[p + "tail"] = E.BneckTail(P[p + "conv2"], blk.conv3.weight, s3, b3)
+                    if blk.downsample is not None:
                         if blk.stride == 2:     # conv3 + bn3 and the strided downsample branch as one K-concatenated GEMM
                             s3, b3 = self._bn_fold(blk.bn3)
                             P[p + "dual"] = E.PackedConv.fused_pair(blk.conv3.weight, s3, b3, blk.downsample[0].weight, s, b,
@@ -126,6 +134,13 @@ class I3Res50(nn.Module):
             for i, blk in enumerate(layer):
                 p = "layer%d.%d." % (li, i)
                 h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
+                tail = P.get(p + "tail") if (E.BNECK_TAIL and taps is None) else None
+                fuse_pool = li == 1 and i == len(layer) - 1          # the last layer1 block fuses maxpool2 into its conv3 instead (below)
+                if tail is not None and not fuse_pool and tail.applies(h, (0, 1, 1)):
+                    # conv2 + bn2 + ReLU + conv3 + bn3 + (residual | downsample branch) + ReLU in one launch: the 64-channel tensor between
+                    # the two convolutions is never written (large_i3d.py:69-84)
+                    a = tail(h, pads=(0, 1, 1), x2=a) if tail.dual else tail(h, pads=(0, 1, 1), residual=a)
+                    continue
                 h = P[p + "conv2"](h, pads=(0, 1, 1))
                 if blk.downsample is not None and taps is None and P[p + "conv3"].dual_supported(P[p + "down"], h, a):
                     # layer1.0: conv3 + bn3 and the downsample branch in one launch (the 256-channel downsample tensor

@@ -155,6 +155,61 @@ def test_clip_to_frame_pair_layout():
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("dims", [(3, 4, 55, 55), (2, 3, 7, 9), (1, 1, 16, 16), (5, 2, 28, 30)])
+def test_bottleneck_tail_fused_vs_oracle_and_unfused(dims, dual, dtype):
+    """engine.BneckTail (csrc/conv_bneck.hip): conv2 1x3x3 (64 -> 64) + bn2 + ReLU -> conv3 1x1x1 (64 -> 256) + bn3 + (residual | downsample
+    branch) + ReLU of a layer1 bottleneck (large_i3d.py:69-84) in one launch, against the oracle (the 64-channel tensor rounded to the
+    storage type where the unfused path stores it) and against the two unfused launches it replaces. Tiles crossing rows, frames and
+    clips, a ragged last tile, frames smaller than a tile."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, t, h, w = dims
+    name = "bt%d%d" % (h, int(dual))
+    x = _round(synth_tensor(8, name + "x", (n, t, h, w, 64), -1, 1), tdt)
+    w2 = _round(synth_tensor(8, name + "w2", (64, 64, 1, 3, 3), -1, 1) * (2.0 / 576) ** 0.5, tdt)
+    w3 = _round(synth_tensor(8, name + "w3", (256, 64, 1, 1, 1), -1, 1) * (2.0 / 64) ** 0.5, tdt)
+    wd = _round(synth_tensor(8, name + "wd", (256, 64, 1, 1, 1), -1, 1) * (2.0 / 64) ** 0.5, tdt)
+    s2, b2 = synth_tensor(8, name + "s2", (64,), 0.5, 1.5), synth_tensor(8, name + "b2", (64,), -0.3, 0.3)
+    s3, b3 = synth_tensor(8, name + "s3", (256,), 0.5, 1.5), synth_tensor(8, name + "b3", (256,), -0.3, 0.3)
+    sd, bd = synth_tensor(8, name + "sd", (256,), 0.5, 1.5), synth_tensor(8, name + "bd", (256,), -0.3, 0.3)
+    res = _round(synth_tensor(8, name + "r", (n, t, h, w, 256), -1, 1), tdt)
+    x2 = _round(synth_tensor(8, name + "x2", (n, t, h, w, 64), -1, 1), tdt)
+    mid = _round(conv_cl(x, w2, s2, b2, (1, 1, 1), (0, 1, 1), (0, 1, 1), None, relu=True), tdt)
+    if dual:
+        ref = torch.relu(conv_cl(mid, w3, s3, b3, relu=False) + conv_cl(x2, wd, sd, bd, relu=False))
+    else:
+        ref = conv_cl(mid, w3, s3, b3, (1, 1, 1), (0, 0, 0), (0, 0, 0), res, relu=True)
+    c2 = E.PackedConv(w2, s2, b2, dtype=dtype, device="cuda")
+    tail = E.BneckTail(c2, w3, s3, b3, wd if dual else None, sd if dual else None, bd if dual else None)
+    xa = E.Act(x.to(tdt).cuda(), 64)
+    assert tail.applies(xa, (0, 1, 1))
+    if dual:
+        got = tail(xa, x2=E.Act(x2.to(tdt).cuda(), 64))
+    else:
+        got = tail(xa, residual=E.Act(res.to(tdt).cuda(), 256))
+    torch.cuda.synchronize()
+    got = got.buf.float().cpu()
+    assert got.shape == ref.shape
+    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    err = (got - ref).abs()
+    assert bool((err <= ulp * ref.abs() + 2e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
+    # the unfused launches: identical 64-channel intermediate, conv3 sums its 64 products in another order (fp32): one rounding step apart at most
+    E.FORCE_TILE_CFG = None
+    h2 = c2(xa, pads=(0, 1, 1))
+    c3 = E.PackedConv(w3, s3, b3, dtype=dtype, device="cuda")
+    if dual:
+        cd = E.PackedConv(wd, sd, bd, dtype=dtype, device="cuda")
+        old = c3.call_dual(h2, cd, E.Act(x2.to(tdt).cuda(), 64), relu=True)
+    else:
+        old = c3(h2, residual=E.Act(res.to(tdt).cuda(), 256), relu=True)
+    old = old.buf.float().cpu()
+    assert bool(((got - old).abs() <= ulp * old.abs() + 1e-3).all())
+
+
 POOLS = [
     ("res_maxpool1", (2, 8, 30, 30), 64, (2, 3, 3), (2, 2, 2), (0, 0, 0), (0, 0, 0), False),
     ("res_maxpool2", (2, 4, 9, 9), 256, (2, 1, 1), (2, 1, 1), (0, 0, 0), (0, 0, 0), False),
