@@ -146,10 +146,12 @@ int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
  * 64, <= 512) output channels. `w3p` is [cout3][KB * 64] 16-bit (KB = 2 with the second source): columns
  * ((a*2 + s)*2 + h)*8 + j = conv3 weight of input channel 32 a + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the k order in which an MFMA
  * accumulator tile is consumed as the next MFMA's operand), columns 64 + c = conv_d weight of input channel c. scale3 / scale_d are the two
- * BatchNorm scales, shift3 the sum of the shifts. The 64-channel tensor between conv2 and conv3 is never written. */
+ * BatchNorm scales, shift3 the sum of the shifts. The 64-channel tensor between conv2 and conv3 is never written.
+ * variant bit 0 (plain block) / bit 1 (second source): residual and result rows go through wave-private LDS images so that every global
+ * access moves whole 128-byte lines; 0: 16-byte accesses straight in the accumulator layout (same results). */
 int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,
                                const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual, int32_t ldres,
-                               const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu, void *stream);
+                               const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu, int32_t variant, void *stream);
 
 /* Persistent Cin = 3 stem (csrc/conv_stem_pt.hip): conv1 5x7x7 / stride 2 / pad (2,3,3) + bn1 + ReLU of large_i3d.py:133-137,229-231
  * with the temporal half of maxpool1 (MaxPool3d((2,3,3), 2), large_i3d.py:138,232) fused: y[n][to/2][ho][wo][64] =

@@ -14,21 +14,26 @@
 // operand"): registers 8s .. 8s+7 of a 32 x 32 tile, packed to 16 bits, are the fragment of k-step s, in the k order
 //     element j of lane half h  <->  row 16 s + 8 (j >> 2) + 4 h + (j & 3)
 // which the host bakes into the column order of the conv3 weight image (`w3p`, tedspad_bneck_tail_fwd). The 256 x 64 (x 2 with the
-// downsample branch) weight image is copied once into the LDS that stage A has finished with; a wave then walks the 256 output
-// channels in 8 groups of 32: 8 MFMAs (16 with the second source, whose pixel fragments come straight from global memory), bn3 scale /
-// shift, the residual rows (loaded in the store layout and brought into the accumulator layout by v_permlane32_swap, which is its own
-// inverse), ReLU, and 16-byte stores straight from the registers (the same swap).
+// downsample branch) weight image is copied into the LDS that stage A has finished with; a wave then walks the 256 output channels
+// in 4 steps of 64: 16 MFMAs (32 with the second source, whose pixel fragments come straight from global memory), bn3 scale / shift,
+// the residual (whole rows by LDS-DMA into a wave-private image, read in the store layout and brought into the accumulator layout by
+// v_permlane32_swap, which is its own inverse), ReLU, and the results leave through the same image as whole 128-byte rows.
 #include "conv_common.h"
 
 namespace tedspad {
 namespace {
 
 __device__ uint4 g_zero16b;
+__device__ uint4 g_sink16b[64];      // where the output rows past M go (never read)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BT_BM = 256;
 constexpr int BT_WSTAGE = 64 * BK * 2;
+
+__device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: the store reads its data registers late, hipcc pads nothing after an asm statement
+}
 
 struct BneckKP {
     const uint16_t *x;          // conv2 input (n,t,h,w,64+) 16-bit, pixel stride ldx
@@ -43,8 +48,10 @@ struct BneckKP {
     int R, NP, ntaps;           // flat-halo geometry (conv_flat.hip)
 };
 
-template <typename T, bool DUAL>
-__global__ __launch_bounds__(256) void conv_bneck_tail_kernel(const BneckKP p) {
+// STAGED: residual rows in / result rows out through wave-private LDS images (whole 128-byte lines per access); otherwise 16-byte
+// loads / stores straight in the accumulator layout (32-byte pieces per pixel) and the whole weight image resident.
+template <typename T, bool DUAL, bool STAGED>
+__global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p) {
     constexpr int NT = 256, WS = 3, KB = DUAL ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -143,16 +150,23 @@ __global__ __launch_bounds__(256) void conv_bneck_tail_kernel(const BneckKP p) {
     __syncthreads();          // every wave is done with the halo and the weight ring: their LDS now takes the conv3 weight image
 
     // ================================ stage B: conv3 (+ downsample branch) on the register tile ================================
-    // ---- conv3 weight image: [KB][cout3 / 64] tiles of [64 co'][64 k], the swizzled image of every weight tile above ------------------
-    const int n3 = p.cout3 / 64;                           // 64-channel tiles of the output
-    for (int i = wave; i < KB * n3 * 8; i += 4) {          // 8 wave-instructions (8 rows x 128 B) per tile
-        const int tl = i >> 3, sub = i & 7;                // tile = kb * n3 + t64
-        const int kb = tl / n3, t64 = tl - kb * n3;
-        const int row = sub * 8 + (lane >> 3);             // row of the tile
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
-        lds_dma16(p.w3p + (size_t)(t64 * 64 + row) * (KB * 64) + kb * 64 + ch * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
-    }
-    float *bnv = reinterpret_cast<float *>(dsm + KB * n3 * BT_WSTAGE);     // [3][cout3]: scale3, shift3, scale of the second branch
+    // ---- conv3 weight image: tiles of [64 co'][64 k] (the swizzled image of every weight tile above), HG output-channel groups of 64
+    // resident at a time: all of them for the plain block (32 KB), two at a time with the second source (2 x 2 x 8 KB), so that weight image
+    // + BatchNorm vectors + the waves' row images stay below the 80 KB that let two workgroups share a CU -------------------------------
+    const int n3 = p.cout3 / 64;                           // 64-channel groups of the output
+    const int HG = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    auto load_w3 = [&](int g0) {                           // groups g0 .. g0 + HG - 1: slot kb * HG + (g - g0)
+        for (int i = wave; i < KB * HG * 8; i += 4) {      // 8 wave-instructions (8 rows x 128 B) per tile
+            const int tl = i >> 3, sub = i & 7;
+            const int kb = tl / HG, g = g0 + tl - kb * HG;
+            if (g >= n3) continue;
+            const int row = sub * 8 + (lane >> 3);         // row of the tile
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            lds_dma16(p.w3p + (size_t)(g * 64 + row) * (KB * 64) + kb * 64 + ch * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
+        }
+    };
+    load_w3(0);
+    float *bnv = reinterpret_cast<float *>(dsm + KB * HG * BT_WSTAGE);     // [3][cout3]: scale3, shift3, scale of the second branch
     for (int i = tid; i < p.cout3; i += NT) {
         bnv[i] = p.scale3[i];
         bnv[p.cout3 + i] = p.shift3[i];
@@ -198,95 +212,162 @@ __global__ __launch_bounds__(256) void conv_bneck_tail_kernel(const BneckKP p) {
     wait_vmcnt<0>();
     __syncthreads();           // weight image + BN vectors visible
 
-    const int nt = p.cout3 / 32;
-    for (int t = 0; t < nt; ++t) {
-        const unsigned char *Wt = dsm + (t >> 1) * BT_WSTAGE + ((t & 1) * 32 + l31) * (BK * 2);
-        f32x16 a3[2], ad[2];
+    // ---- 64 output channels per step. Every global access of the step moves whole 128-byte lines: the residual rows arrive by LDS-DMA
+    // into a wave-private [64 px][64 ch] image (8 lanes per pixel row; the chunk swizzle of every other image here), the results leave
+    // through the same image and are stored 8 lanes per row. (First version: 16-byte loads / stores straight from the accumulator layout,
+    // one 32-byte piece per pixel and instruction -- 32 lines touched per instruction: 935 us for the plain block against 860 us unfused.)
+    unsigned char *wbuf = dsm + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
+    const unsigned wbuf_lds = lds0 + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
+    const bool has_res = !DUAL && p.res != nullptr;
+    // row-layout role of this lane in instruction k: pixel row k*8 + (lane >> 3) of the wave, physical chunk lane & 7
+    const int rrow = lane >> 3, rch = lane & 7;
+    auto issue_res = [&](int g) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 8; ++k) {
+            const int row = k * 8 + rrow;
+            const int q = q0 + wave * 64 + row;
+            const uint16_t *src = q < p.M ? p.res + (size_t)q * p.ldres + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3) : zero;
+            lds_dma16(src, wbuf_lds + k * 1024);
+        }
+    };
+    if (STAGED && has_res) issue_res(0);
+    const int ng = p.cout3 / 64;
+    for (int g = 0; g < ng; ++g) {
+        if (g && g % HG == 0) {                  // the next HG groups of the weight image (second-source variant only)
+            __syncthreads();
+            load_w3(g);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        unsigned d[2][2][4][2];                  // [tile of the pair][pixel group][q][h]: packed results in the accumulator layout
+        if (STAGED && has_res) {
+            if (g == 0) wait_vmcnt<0>(); else wait_vmcnt<8>();      // the residual rows of this step landed; the previous step's 8 stores stay in flight
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a3[b][r] = 0.f; ad[b][r] = 0.f; }
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * g + tt;
+            const unsigned char *Wt = dsm + (g % HG) * BT_WSTAGE + (tt * 32 + l31) * (BK * 2);
+            f32x16 a3[2], ad[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const unsigned c = (unsigned)((ks << 1) | lh);
-            const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 4));
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[ks][b], a3[b]);
-            if (DUAL) {
-                const uint4 fd = *reinterpret_cast<const uint4 *>(Wt + n3 * BT_WSTAGE + ((c ^ swz) << 4));
+                for (int r = 0; r < 16; ++r) { a3[b][r] = 0.f; ad[b][r] = 0.f; }
 #pragma unroll
-                for (int b = 0; b < 2; ++b) ad[b] = T::mfma(fd, xin[ks][b], ad[b]);
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 4));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[ks][b], a3[b]);
+                if (DUAL) {
+                    const uint4 fd = *reinterpret_cast<const uint4 *>(Wt + HG * BT_WSTAGE + ((c ^ swz) << 4));
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) ad[b] = T::mfma(fd, xin[ks][b], ad[b]);
+                }
+            }
+            // lane (l31, lh) holds channels 32 t + 8 q + 4 lh + {0..3}, q = 0..3
+            f32x4 s3[4], b3[4], sd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * t + 8 * q + 4 * lh;
+                s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
+                b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
+                if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                if (has_res) {
+                    // residual chunks in the STORE layout (lane: channels 16 qq + 8 lh .. + 7 of the tile), swapped back into the accumulator layout
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                        uint4 L = make_uint4(0u, 0u, 0u, 0u);
+                        if (STAGED) L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
+                        else if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
+                        auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                        rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
+                        rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 4 * q + 2 * h + e;
+                            float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
+                            if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
+                            if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
+                            v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                        }
+                        d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(d[tt][b][q][h], d[tt][b][q + 1][h], false, false);
+                        d[tt][b][q][h] = sw[0];
+                        d[tt][b][q + 1][h] = sw[1];
+                    }
             }
         }
-        // ---- epilogue of output channels 32 t .. 32 t + 31: lane (l31, lh) holds channels 32 t + 8 q + 4 lh + {0..3}, q = 0..3 -------------
-        f32x4 s3[4], b3[4], sd[4];
+        if (!STAGED) {                            // 16-byte stores straight from the registers (lane: channels 16 qq + 8 lh .. + 7 of tile tt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = 32 * t + 8 * q + 4 * lh;
-            s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
-            b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
-            if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (inb[b]) {
+                        uint16_t *dst = p.y + mpx[b] * p.ldy + 64 * g + 32 * tt + 8 * lh;
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(d[tt][b][0][0], d[tt][b][0][1], d[tt][b][1][0], d[tt][b][1][1]);
+                        *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(d[tt][b][2][0], d[tt][b][2][1], d[tt][b][3][0], d[tt][b][3][1]);
+                    }
+            continue;
         }
+        // ---- results -> the wave's image (every residual read above is complete: its data was consumed) -> whole rows -> global ------------
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-            if (!DUAL && p.res) {
-                // residual rows in the STORE layout (lane: channels 16 qq + 8 lh .. + 7), swapped back into the accumulator layout
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
-                    uint4 L = make_uint4(0u, 0u, 0u, 0u);
-                    if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
-                    auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
-                    rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
-                    rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                    const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                    *reinterpret_cast<uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4)) =
+                        make_uint4(d[tt][b][2 * qq][0], d[tt][b][2 * qq][1], d[tt][b][2 * qq + 1][0], d[tt][b][2 * qq + 1][1]);
                 }
-            }
-            unsigned d[4][2];
+        uint4 rowv[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 8; ++k) rowv[k] = *reinterpret_cast<const uint4 *>(wbuf + k * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the image is read back: the next step's residual rows may overwrite it
+        if (has_res && g + 1 < ng) issue_res(g + 1);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float v[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int r = 4 * q + 2 * h + e;
-                        float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
-                        if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
-                        if (!DUAL && p.res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
-                        v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
-                    }
-                    d[q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
-                }
-#pragma unroll
-            for (int q = 0; q < 4; q += 2)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    auto sw = __builtin_amdgcn_permlane32_swap(d[q][h], d[q + 1][h], false, false);
-                    d[q][h] = sw[0];
-                    d[q + 1][h] = sw[1];
-                }
-            if (inb[b]) {
-                uint16_t *dst = p.y + mpx[b] * p.ldy + 32 * t + 8 * lh;
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(d[0][0], d[0][1], d[1][0], d[1][1]);
-                *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(d[2][0], d[2][1], d[3][0], d[3][1]);
-            }
+        for (int k = 0; k < 8; ++k) {
+            const int row = k * 8 + rrow;
+            const int q = q0 + wave * 64 + row;
+            uint16_t *dst = q < p.M ? p.y + (size_t)q * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
+                                    : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;      // rows past M: a scratch line, so that every wave issues 8 stores
+            gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
         }
     }
 }
 
-template <typename T, bool DUAL>
+template <typename T, bool DUAL, bool STAGED>
 int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
     const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * BT_WSTAGE;
-    const int tail_bytes = (DUAL ? 2 : 1) * (p.cout3 / 64) * BT_WSTAGE + 3 * p.cout3 * 4;
+    const int n3 = p.cout3 / 64, hg = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * p.cout3 * 4 + (STAGED ? 4 * 8192 : 0);     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)
     const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
     if (lds > 160 * 1024) {
         set_error("tedspad_bneck_tail_fwd: halo / conv3 weight image does not fit LDS (%d bytes)", lds);
         return TEDSPAD_EINVAL;
     }
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_bneck_tail_kernel<T, DUAL>;
+    auto kfn = conv_bneck_tail_kernel<T, DUAL, STAGED>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
@@ -306,7 +387,7 @@ using namespace tedspad;
 extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,
                                           const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual,
                                           int32_t ldres, const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu,
-                                          void *stream) {
+                                          int32_t variant, void *stream) {
     TS_REQUIRE(d2 && x && w2_packed && scale2 && shift2 && w3p && scale3 && shift3 && y, "tedspad_bneck_tail_fwd: null pointer");
     const bool same = d2->to == d2->t && d2->ho == d2->h && d2->wo == d2->w && d2->pt == 0 && d2->ph < d2->kh && d2->pw < d2->kw;
     TS_REQUIRE(d2->cin == 64 && d2->cout == 64 && d2->kt == 1 && d2->st == 1 && d2->sh == 1 && d2->sw == 1 && same && d2->kh * d2->kw >= 2 &&
@@ -330,6 +411,12 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
     TS_REQUIRE(p.Kpad == p.ntaps * 64, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
     hipStream_t s = (hipStream_t)stream;
-    if (x2) return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, true>(p, s) : launch_bneck<BF16, true>(p, s);
-    return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, false>(p, s) : launch_bneck<BF16, false>(p, s);
+    const bool staged = x2 ? (variant & 2) != 0 : (variant & 1) != 0;
+    const bool f16 = d2->dtype == TEDSPAD_F16;
+    if (x2) {
+        if (staged) return f16 ? launch_bneck<F16, true, true>(p, s) : launch_bneck<BF16, true, true>(p, s);
+        return f16 ? launch_bneck<F16, true, false>(p, s) : launch_bneck<BF16, true, false>(p, s);
+    }
+    if (staged) return f16 ? launch_bneck<F16, false, true>(p, s) : launch_bneck<BF16, false, true>(p, s);
+    return f16 ? launch_bneck<F16, false, false>(p, s) : launch_bneck<BF16, false, false>(p, s);
 }
