@@ -123,7 +123,7 @@ def test_phase1_at_cfg3_resolution_vs_oracle():
     step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
     out = step.step_fa(video.cuda(), labels.cuda())
     assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * abs(ref_l["loss_fa"])
-    errs = _report("cfg3-resolution phase 1: fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g, min_cos=0.85, med_cos=0.95, abs_tol=0.1)   # conv biases in front of a train-mode BN: analytically zero, 96 x 112^2 pixels of rounding noise summed
+    errs = _report("cfg3-resolution phase 1: fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g, min_cos=0.85, med_cos=0.95, tiny=1e-2, abs_tol=0.1)   # conv biases in front of a train-mode BN: analytically zero, 96 x 112^2 pixels of rounding noise summed
     med, worst = float(np.median(list(errs.values()))), max(errs.values())
     print("cfg3-resolution phase 1: median rel-L2 %.3f, worst %.3f" % (med, worst))
     assert med < 0.3 and worst < 0.5
