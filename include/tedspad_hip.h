@@ -245,6 +245,15 @@ int32_t tedspad_cross_entropy_fwd_bwd(const float *logits, const int64_t *labels
  * Reference: autograd of the torch.nn modules of aux_code/models/{large_i3d,unet_parts}.py under
  * fa_model.train() / ft_model.train() (anonymization_training/train_anonymizer.py:73-75,137-139). */
 
+/* tedspad_bn_finalize + tedspad_scale_shift_act as ONE launch: y = act((z - mean) * gamma * invstd + beta (+ res)) with mean / invstd from the
+ * batch sums `stats` ([2][stats_ld]: sum, sum of squares over `count` values per channel); writes mean / invstd (C floats each, kept for the
+ * backward pass) and updates running_mean / running_var in place (momentum, unbiased variance; NULL: not tracked). z: fp32 (pixels, Cz)
+ * with Cz >= C channels per pixel (channels >= C come out as 0). nn.BatchNorm{2,3}d in train() mode. */
+int32_t tedspad_bn_train_apply(const float *z, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+                               float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
+                               const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
+                               int32_t dtype, void *stream);
+
 /* From the per-channel sum / sum-of-squares the conv epilogue accumulated (tedspad_conv_extras.stats) over
  * `count` pixels: batch mean / biased variance -> scale = gamma*invstd, shift = beta - mean*scale; updates
  * running_mean / running_var in place (momentum, unbiased variance) when they are not NULL. */

@@ -55,6 +55,7 @@ SYMBOLS = {
     "tedspad_triplet_fwd_bwd": (_I32, [_P] * 8 + [_I32, _I32, C.c_float, C.c_float, _P]),
     "tedspad_cross_entropy_fwd_bwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "tedspad_bn_finalize": (_I32, [_P, _I32, _I64, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "tedspad_bn_train_apply": (_I32, [_P, _P, _I32, _I64, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _I32, _P, _P, _I64] + [_I32] * 6 + [_P]),
     "tedspad_scale_shift_act": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_bn_bwd_reduce": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_bn_bwd_apply": (_I32, [_P] * 7 + [_I32, _P, _P, _I64] + [_I32] * 8 + [_P]),

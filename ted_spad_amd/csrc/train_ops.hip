@@ -70,6 +70,75 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *z, const flo
     }
 }
 
+// bn_finalize + bn_apply in ONE launch (train-mode BatchNorm forward after the conv that accumulated the statistics): every thread
+// derives scale / shift of its 8 channels from the batch sums itself (2 divisions and an rsqrt per channel: nothing beside the 32 + 16
+// bytes it moves per channel), so the separate per-layer finalize launch (159 per phase-2 iteration of cfg3) disappears; workgroup 0
+// also writes mean / invstd for the backward pass and updates the running statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, const float *stats, int stats_ld, float count, const float *gamma,
+                                                              const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                                              float *mean_out, float *invstd_out, int C, const uint16_t *res, uint16_t *y, long pixels,
+                                                              int C8, int ldz, int ldres, int ldy, int relu) {
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float mean = stats[c] / count;
+            float var = stats[stats_ld + c] / count - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            mean_out[c] = mean;
+            invstd_out[c] = rsqrtf(var + eps);
+            if (running_mean) {
+                const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+            }
+        }
+    }
+    const long total = pixels * C8;
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration
+    float sc[8], sf[8];
+    int have = -1;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const int c8 = (int)(idx % C8);
+        const long px = idx / C8;
+        if (!fixed || have != c8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c8 * 8 + i;
+                float s = 0.f, b = 0.f;
+                if (c < C) {
+                    const float mean = stats[c] / count;
+                    float var = stats[stats_ld + c] / count - mean * mean;
+                    var = var < 0.f ? 0.f : var;
+                    s = gamma[c] * rsqrtf(var + eps);
+                    b = beta[c] - mean * s;
+                }
+                sc[i] = s; sf[i] = b;
+            }
+            have = c8;
+        }
+        float v[8];
+        {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), b = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sf[i];
+        if (res) {
+            float r[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(res + px * ldres + c8 * 8), r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += r[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8<T>(v);
+    }
+}
+
 // per-channel sums over pixels:  out[0][c] += sum g,  out[1][c] += sum g * xhat
 //   g = dy * (y > 0 if relu),  xhat = (z - mean) * invstd  (xhat term skipped when z == nullptr)
 // block = 256 threads = (256 / C8L) pixel lanes x C8L channel chunks, C8L = min(C8, 32)
@@ -445,4 +514,17 @@ extern "C" int32_t tedspad_channels_last_to_nchw_strided(const void *x, float *y
     hipStream_t s = (hipStream_t)stream;
     LAUNCH_T(dtype, cl_to_nchw_strided_kernel, dim3(grid_for(total)), (const uint16_t *)x, y, c, t, h, w, ldx, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, total);
     return check_launch("tedspad_channels_last_to_nchw_strided");
+}
+
+extern "C" int32_t tedspad_bn_train_apply(const float *z, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+                                          float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
+                                          const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
+                                          int32_t dtype, void *stream) {
+    TS_REQUIRE(z && stats && gamma && beta && mean && invstd && y && count > 0 && pixels > 0 && C > 0 && Cz >= C && Cz % 8 == 0 && stats_ld >= C && ldz % 4 == 0 &&
+                   ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0,
+               "tedspad_bn_train_apply: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8))), z, stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
+             running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
+    return check_launch("tedspad_bn_train_apply");
 }

@@ -328,17 +328,16 @@ def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional
     z = conv.forward(x, stats=stats, y32=True)                       # (n,t,h,w,cout) fp32
     n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
-    scale, shift, mean, invstd = ARENA.take((4, cz), x.buf.device).unbind(0)
-    check(_lib.lib().tedspad_bn_finalize(stats.data_ptr(), pc.cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                         C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                         scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), c, _stream_ptr()),
-          "tedspad_bn_finalize")
+    mean, invstd = ARENA.take((2, cz), x.buf.device).unbind(0)
     bump_counter(bn.num_batches_tracked)
     tdt = E.DTYPES[conv.dtype][0]
     y = out if out is not None else Act.empty(n, t, h, w, cz, tdt, z.device)
-    check(_lib.lib().tedspad_scale_shift_act(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), residual.ptr if residual is not None else None,
-                                             y.ptr, n * t * h * w, cz, cz, residual.ld if residual is not None else 0, y.ld,
-                                             int(relu), _code(y.buf), _stream_ptr()), "tedspad_scale_shift_act")
+    # batch mean / variance -> scale / shift, the running-statistics update and the normalisation itself in ONE launch
+    check(_lib.lib().tedspad_bn_train_apply(z.data_ptr(), stats.data_ptr(), pc.cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                            C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), c, residual.ptr if residual is not None else None, y.ptr,
+                                            n * t * h * w, cz, cz, residual.ld if residual is not None else 0, y.ld, int(relu), _code(y.buf),
+                                            _stream_ptr()), "tedspad_bn_train_apply")
     ctx = BNTrainCtx()
     ctx.x, ctx.z, ctx.y, ctx.mean, ctx.invstd, ctx.bn, ctx.conv, ctx.relu, ctx.has_res = x, z, y, mean, invstd, bn, conv, relu, residual is not None
     return y, ctx
