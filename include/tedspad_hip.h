@@ -171,6 +171,15 @@ int32_t tedspad_stem_pt_wimg_bytes(void);
 int32_t tedspad_stem_pt_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, int32_t n, int32_t t_pairs,
                             int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t ldy, int32_t relu, int32_t nwg,
                             int32_t variant, int32_t dtype, void *stream);
+/* The same stem with the WHOLE maxpool1 fused (MaxPool3d((2,3,3), stride 2, no padding), large_i3d.py:138,232): ReLU always;
+ * y[n][t_pairs][hp][wp][ldy], hp = (ceil(h/2) - 3) / 2 + 1, wp = (w/2 - 3) / 2 + 1. Workgroups walk column strips of 8 x 16 patches top
+ * to bottom, pool each patch over columns in registers and over rows through LDS (the rows a window shares with the patch above are
+ * carried); the pooled column a patch shares with its right neighbour is joined by a second small launch from `side`
+ * (tedspad_stem_pt_side_bytes() bytes of scratch, 16-byte aligned). The 112 x 112 stem tensor never reaches HBM. */
+int64_t tedspad_stem_pt_side_bytes(int32_t n, int32_t t_pairs, int32_t h, int32_t w);
+int32_t tedspad_stem_pt_pool_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
+                                 int32_t t_pairs, int32_t h, int32_t w, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,
+                                 int32_t dtype, void *stream);
 
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
  * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be

@@ -41,8 +41,14 @@ for v in (0, 2):
     print("variant %d: layout %.0f us, stem %.0f us, pool %.0f us; vs old pooled: max abs diff %.3g, mismatching %.4f %%" % (
         v, timed(lambda: st.layout(x)), timed(lambda: st.conv(xtc, variant=v)), timed(lambda: E.maxpool(y, (1, 3, 3), (1, 2, 2))),
         float(d.max()), 100.0 * float((d > 0).float().mean())))
+    f = st.conv_pool(xtc, variant=v)
+    print("variant %d, pool fused: stem + pool %.0f us; identical to the separate pool: %s" % (
+        v, timed(lambda: st.conv_pool(xtc, variant=v)), bool(torch.equal(f.buf, p_new.buf))))
+    del f
 for nwg in (256, 512):
     st.nwg = nwg
     print("nwg %d: stem %.0f us (4 waves), %.0f us (8 waves)" % (nwg, timed(lambda: st.conv(xtc, variant=0)), timed(lambda: st.conv(xtc, variant=2))))
 for dbg, what in ((1, "no halo DMA"), (2, "no stores"), (3, "no DMA, no stores"), (4, "no MFMA"), (7, "loop skeleton only")):
-    print("ablation %s: %.0f us (4 waves), %.0f us (8 waves)" % (what, timed(lambda: st.conv(xtc, variant=0 | (dbg << 8))), timed(lambda: st.conv(xtc, variant=2 | (dbg << 8)))))
+    print("ablation %s: %.0f us (4 waves), %.0f us (8 waves); pool fused %.0f us (8 waves)" % (
+        what, timed(lambda: st.conv(xtc, variant=0 | (dbg << 8))), timed(lambda: st.conv(xtc, variant=2 | (dbg << 8))),
+        timed(lambda: st.conv_pool(xtc, variant=2 | (dbg << 8)))))

@@ -47,6 +47,10 @@ struct F16 {
         f = __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);  // saturate instead of inf
         return __builtin_bit_cast(uint16_t, (_Float16)f);
     }
+    static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {   // element-wise max of two packed pairs
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)));
+    }
 };
 
 struct BF16 {
@@ -59,6 +63,11 @@ struct BF16 {
     }
     static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
     static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+    static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+        const float lo = __builtin_fmaxf(__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, b << 16));
+        const float hi = __builtin_fmaxf(__builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b & 0xffff0000u));
+        return (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xffff0000u);
+    }
 };
 
 template <typename T>
@@ -77,6 +86,11 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f32(f[2 * i]) | ((uint32_t)T::from_f32(f[2 * i + 1]) << 16);
     return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pk_max8(uint4 a, uint4 b) {
+    return make_uint4(T::pk_max(a.x, b.x), T::pk_max(a.y, b.y), T::pk_max(a.z, b.z), T::pk_max(a.w, b.w));
 }
 
 typedef const __attribute__((address_space(1))) void *gptr_t;

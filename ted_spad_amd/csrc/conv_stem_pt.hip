@@ -51,7 +51,12 @@ __host__ __device__ constexpr int pt_jobs(int par) { return (2 * pt_frame(par) +
 __host__ __device__ constexpr int pt_off(int par) { return par == 0 ? 0 : pt_jobs(0) * 1024; }
 constexpr int PT_W_OFF = pt_off(1) + pt_jobs(1) * 1024;
 constexpr int PT_LDS = PT_W_OFF + PT_W_BYTES;
-static_assert(PT_LDS <= 160 * 1024, "weights + halo must fit the CU's LDS");
+// POOL: the patch's column-pooled rows [8 rows][9 slots][64 channels] 16-bit (slots 0..6: complete 3-column windows, 7: columns
+// 14, 15 of the window the next patch to the right completes, 8: column 0 alone, that patch's contribution to its left neighbour)
+constexpr int PT_XB_OFF = PT_LDS, PT_XB_ROW = 9 * 128, PT_XB_BYTES = PT_TH * PT_XB_ROW;
+constexpr int PT_LDS_POOL = PT_LDS + PT_XB_BYTES;
+constexpr int PT_POOL_PIECES = 4 * 9 * 8;            // 16-byte pieces a patch hands to the pooled tensor (4 pooled rows x 9 slots x 8)
+static_assert(PT_LDS_POOL <= 160 * 1024, "weights + halo (+ pooled rows) must fit the CU's LDS");
 static_assert(PT_W_BYTES % 1024 == 0 && (4 * PT_ROWB) % 256 == 0, "LDS image alignment");
 
 struct StemPT {
@@ -62,7 +67,9 @@ struct StemPT {
     long sTp;                     // bytes per frame pair of x
     int sH, sP;                   // bytes per row (both planes) / plane row
     int N, Tp, H, Wq, Ho, Wo, ldy, relu;
-    int tiles_h, tiles_w, total, chunk;
+    int tiles_h, tiles_w, total, chunk;     // POOL: total / chunk count column STRIPS (tiles_h patches each)
+    uint16_t *side;               // POOL: S[n][tp][hp][tiles_w][64], column 0 of every patch pooled over rows
+    int Hp, Wp;                   // POOL: pooled rows / columns
     int dbg;                      // timing ablations (wrong results): 1 = no halo DMA after the first patch, 2 = no stores, 4 = no MFMA phases
 };
 
@@ -106,9 +113,17 @@ __device__ __forceinline__ void stem_pt_phase(const unsigned char *dsm, const in
 // NW = 8: two waves per SIMD; waves w and w + 4 own the same pixels and the output channels [0,32) / [32,64) (3 reads per 2
 // MFMAs: 192 B/clk of the CU's 256 B/clk LDS at full MFMA rate): one wave's epilogue, DMA issue and patch arithmetic run
 // under its partner's MFMAs.
-template <typename T, int NW>
+//
+// POOL: the SPATIAL half of maxpool1 (3 x 3, stride 2, no padding) as well. A workgroup walks column strips top to bottom. In the
+// epilogue every wave pools its pixels over columns inside its 16-lane rows (DPP row shifts: lane = column) and leaves the patch's 8
+// column-pooled rows in LDS; after the next barrier (the one every patch has anyway) 288 threads pool them over rows and store 16
+// bytes each: pooled rows 4*th .. 4*th + 2 from this patch, row 4*th - 1 from rows 6, 7 of the patch above (carried in registers)
+// and row 0 of this one. The window a patch shares with its right neighbour is written as two partial maxima (slot 7 into the
+// pooled tensor, slot 8 into the side buffer) that stem_pool_fix_kernel joins. 1.44 GB per 225 clips no longer leave the chip.
+template <typename T, int NW, bool POOL>
 __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     constexpr int NA = NW == 8 ? 1 : 2;
+    constexpr int PIT = (PT_POOL_PIECES + 64 * NW - 1) / (64 * NW);
     constexpr int ROUNDS = (pt_jobs(0) + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,7 +166,8 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     struct Patch { const unsigned char *pb; int ih0, wqm2, n, tp, th, tw, ho0, wo0; };
     auto split = [&](int r, int &n_, int &tp_, int &th_, int &tw_) {
         tw_ = r % p.tiles_w; r /= p.tiles_w;
-        th_ = r % p.tiles_h; r /= p.tiles_h;
+        if (POOL) th_ = 0;                                  // r counts strips
+        else { th_ = r % p.tiles_h; r /= p.tiles_h; }
         tp_ = r % p.Tp; n_ = r / p.Tp;
     };
     auto locate = [&](Patch &q) {
@@ -163,8 +179,14 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     split(nx, dn, dtp, dth, dtw);
     auto advance = [&](const Patch &c) {
         Patch q = c;
-        q.tw += dtw; if (q.tw >= p.tiles_w) { q.tw -= p.tiles_w; ++q.th; }
-        q.th += dth; if (q.th >= p.tiles_h) { q.th -= p.tiles_h; ++q.tp; }
+        if (POOL && c.th + 1 < p.tiles_h) {                 // down the strip
+            ++q.th;
+            locate(q);
+            return q;
+        }
+        if (POOL) q.th = 0;
+        q.tw += dtw; if (q.tw >= p.tiles_w) { q.tw -= p.tiles_w; if (POOL) ++q.tp; else ++q.th; }
+        if (!POOL) { q.th += dth; if (q.th >= p.tiles_h) { q.th -= p.tiles_h; ++q.tp; } }
         q.tp += dtp; if (q.tp >= p.Tp) { q.tp -= p.Tp; ++q.n; }
         q.n += dn;
         locate(q);
@@ -218,12 +240,51 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     __builtin_amdgcn_s_barrier();      // weights + both halo regions of the first patch visible
     asm volatile("" ::: "memory");
 
+    // ---- POOL: this thread's pieces of the row pooling: u -> (pooled row i of the patch, slot, 8-channel group) --------------------
+    int pxo[PIT], pi[PIT], psl[PIT];
+    uint4 carry[PIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        const int u = tid + it * 64 * NW;
+        psl[it] = (u >> 3) % 9;
+        pi[it] = u < PT_POOL_PIECES ? (u >> 3) / 9 : -1;
+        pxo[it] = PT_XB_OFF + psl[it] * 128 + (u & 7) * 16;
+        carry[it] = make_uint4(0, 0, 0, 0);
+    }
+    auto pool_rows = [&](const Patch &q) {
+        const size_t fr = (size_t)q.n * p.Tp + q.tp;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            if (pi[it] < 0) continue;
+            const unsigned char *xb = dsm + pxo[it];
+            uint4 m;
+            int pr;
+            if (pi[it] < 3) {
+                const unsigned char *r = xb + 2 * pi[it] * PT_XB_ROW;
+                m = pk_max8<T>(pk_max8<T>(*reinterpret_cast<const uint4 *>(r), *reinterpret_cast<const uint4 *>(r + PT_XB_ROW)),
+                               *reinterpret_cast<const uint4 *>(r + 2 * PT_XB_ROW));
+                pr = 4 * q.th + pi[it];
+            } else {                                        // rows 6, 7 of the patch above + row 0 of this one
+                m = pk_max8<T>(carry[it], *reinterpret_cast<const uint4 *>(xb));
+                carry[it] = pk_max8<T>(*reinterpret_cast<const uint4 *>(xb + 6 * PT_XB_ROW), *reinterpret_cast<const uint4 *>(xb + 7 * PT_XB_ROW));
+                pr = q.th > 0 ? 4 * q.th - 1 : p.Hp;
+            }
+            const int pc = 8 * q.tw + psl[it];
+            uint16_t *dst = psl[it] < 8 ? p.y + ((fr * p.Hp + pr) * p.Wp + pc) * p.ldy : p.side + ((fr * p.Hp + pr) * p.tiles_w + q.tw) * 64;
+            if (pr < p.Hp && (psl[it] == 8 || pc < p.Wp) && !(p.dbg & 2)) gstore16(dst + (pxo[it] & 127) / 2, __builtin_bit_cast(u32x4, m));
+        }
+    };
+
     const bool dma = !(p.dbg & 1);
+    bool pending = false;                                   // POOL: the column-pooled rows of `prev` wait in LDS
+    Patch prev = cur;
     while (true) {
-        const int kn = k + nx;
+        const bool wrap = !POOL || cur.th + 1 == p.tiles_h;
+        const int kn = wrap ? k + nx : k;
         const bool more = kn < lim;                         // workgroup-uniform
         Patch nxt = cur;
         if (more) nxt = advance(cur);
+        if (POOL && pending) pool_rows(prev);               // before this patch's mid barrier; the epilogue after it rewrites the rows
 
         f32x16 acc[NA][2];
 #pragma unroll
@@ -241,8 +302,54 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         if (!(p.dbg & 4)) stem_pt_phase<T, 1, NA>(dsm, pa, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
 
         // ---- epilogue: relu(bn(.)) of both frames, max over the two frames (the temporal window of maxpool1), 16-byte stores --------
-        bool stored;
-        {
+        bool stored = false;
+        if (POOL) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                unsigned d[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 4 * q + 2 * h + e;
+                            const float v0 = acc[a][0][r] * sc[a][r] + sf[a][r], v1 = acc[a][1][r] * sc[a][r] + sf[a][r];
+                            v[e] = __builtin_fmaxf(__builtin_fmaxf(v0, v1), 0.f);      // ReLU always: the pooling below pads with 0
+                        }
+                        d[q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(d[q][h], d[q + 1][h], false, false);
+                        d[q][h] = sw[0];
+                        d[q + 1][h] = sw[1];
+                    }
+                // columns: lane = column inside a 16-lane DPP row; row_shl:n reads lane + n, lanes past the row read 0
+                unsigned m[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned s1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d[q][h], 0x101, 0xf, 0xf, true);
+                        const unsigned s2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d[q][h], 0x102, 0xf, 0xf, true);
+                        m[q][h] = T::pk_max(T::pk_max(d[q][h], s1), s2);
+                    }
+                unsigned char *xb = dsm + PT_XB_OFF + prow * PT_XB_ROW + ((a0 + a) * 32 + 8 * lh) * 2;
+                if (!(l15 & 1)) {
+                    *reinterpret_cast<uint4 *>(xb + (l15 >> 1) * 128) = make_uint4(m[0][0], m[0][1], m[1][0], m[1][1]);
+                    *reinterpret_cast<uint4 *>(xb + (l15 >> 1) * 128 + 32) = make_uint4(m[2][0], m[2][1], m[3][0], m[3][1]);
+                }
+                if (l15 == 0) {
+                    *reinterpret_cast<uint4 *>(xb + 8 * 128) = make_uint4(d[0][0], d[0][1], d[1][0], d[1][1]);
+                    *reinterpret_cast<uint4 *>(xb + 8 * 128 + 32) = make_uint4(d[2][0], d[2][1], d[3][0], d[3][1]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are in LDS before this wave reaches the next barrier
+        } else {
             const int ho = cur.ho0 + prow, wo = cur.wo0 + l15;
             const bool inb = ho < p.Ho && wo < p.Wo && !(p.dbg & 2);
             stored = __builtin_amdgcn_ballot_w64(inb) != 0;  // the store instructions below are issued iff any lane is in bounds
@@ -287,9 +394,30 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the odd rows
         asm volatile("" ::: "memory");
         if (dma) issue(1, nxt);                             // odd rows of the next patch land under its even taps
+        prev = cur;
+        pending = POOL;
         cur = nxt;
         k = kn;
     }
+    if (POOL) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        pool_rows(cur);
+    }
+}
+
+// joins the two halves of the pooled columns 8*tw - 1 (columns 14, 15 of patch tw - 1 | column 0 of patch tw)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_fix_kernel(uint16_t *y, const uint16_t *side, long rows, int wp, int tiles_w, int ldy) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(idx & 7);
+    const long r = idx >> 3;
+    const int tw = 1 + (int)(r % (tiles_w - 1));
+    const long row = r / (tiles_w - 1);
+    const int pc = 8 * tw - 1;
+    if (row >= rows || pc >= wp) return;
+    uint4 *d = reinterpret_cast<uint4 *>(y + (row * wp + pc) * ldy + c8 * 8);
+    *d = pk_max8<T>(*d, *reinterpret_cast<const uint4 *>(side + (row * tiles_w + tw) * 64 + c8 * 8));
 }
 
 // fp32 NCTHW clip (any strides, W contiguous) -> X[n][tp][h][b][w/2][24] 16-bit: the record of pixel (h, 2*wq + b) for output-frame
@@ -363,6 +491,63 @@ extern "C" int32_t tedspad_clip_to_tp(const float *x, void *y, int32_t n, int32_
 
 extern "C" int32_t tedspad_stem_pt_wimg_bytes(void) { return PT_W_BYTES; }
 
+// shared launcher: pool = the spatial 3x3 / 2 max-pool fused as well (y is the pooled tensor then, side its scratch)
+static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
+                              int32_t t_pairs, int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t hp, int32_t wp, int32_t ldy, int32_t relu, int32_t nwg,
+                              int32_t variant, int32_t dtype, bool pool, hipStream_t s) {
+    StemPT p;
+    p.x = (const unsigned char *)x_tp; p.wimg = (const unsigned char *)w_img; p.scale = scale; p.shift = shift; p.y = (uint16_t *)y;
+    p.side = (uint16_t *)side; p.Hp = hp; p.Wp = wp;
+    p.Wq = w / 2; p.sP = p.Wq * PT_REC; p.sH = 2 * p.sP; p.sTp = (long)h * p.sH;
+    p.N = n; p.Tp = t_pairs; p.H = h; p.Ho = ho; p.Wo = wo; p.ldy = ldy; p.relu = relu;
+    p.tiles_h = (ho + PT_TH - 1) / PT_TH; p.tiles_w = (wo + PT_TW - 1) / PT_TW;
+    const long total = (long)n * t_pairs * p.tiles_w * (pool ? 1 : p.tiles_h);      // pool: column strips
+    if (total >= (1L << 30) || (long)n * t_pairs * p.tiles_h * p.tiles_w >= (1L << 30)) {
+        set_error("%s: too many patches", who);
+        return TEDSPAD_EINVAL;
+    }
+    p.total = (int)total;
+    p.chunk = (int)((total + 7) / 8);
+    int grid = nwg > 0 ? nwg : 256;
+    grid = (grid + 7) / 8 * 8;
+    if ((long)grid > total + 7) grid = (int)((total + 7) / 8 * 8);
+    static thread_local int attr_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int w8 = (variant >> 1) & 1;
+    p.dbg = (variant >> 8) & 7;
+    const int di = ((dtype == TEDSPAD_F16 ? 0 : 1) * 2 + w8) * 2 + (pool ? 1 : 0);
+    const void *fns[8] = {(const void *)conv_stem_pt_kernel<F16, 4, false>, (const void *)conv_stem_pt_kernel<F16, 4, true>,
+                          (const void *)conv_stem_pt_kernel<F16, 8, false>, (const void *)conv_stem_pt_kernel<F16, 8, true>,
+                          (const void *)conv_stem_pt_kernel<BF16, 4, false>, (const void *)conv_stem_pt_kernel<BF16, 4, true>,
+                          (const void *)conv_stem_pt_kernel<BF16, 8, false>, (const void *)conv_stem_pt_kernel<BF16, 8, true>};
+    if (!attr_set[di]) {
+        if (hipFuncSetAttribute(fns[di], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("%s: cannot raise the dynamic LDS limit", who);
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[di] = 1;
+    }
+    const dim3 g(grid), b(w8 ? 512 : 256);
+    const int lds = pool ? PT_LDS_POOL : PT_LDS;
+    switch (di) {
+        case 0: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 4, false>), g, b, lds, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 4, true>), g, b, lds, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, false>), g, b, lds, s, p); break;
+        case 3: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true>), g, b, lds, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 4, false>), g, b, lds, s, p); break;
+        case 5: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 4, true>), g, b, lds, s, p); break;
+        case 6: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, false>), g, b, lds, s, p); break;
+        default: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true>), g, b, lds, s, p); break;
+    }
+    int32_t rc = check_launch(who);
+    if (rc != TEDSPAD_OK || !pool || p.tiles_w < 2) return rc;
+    const long rows = (long)n * t_pairs * hp;
+    const long pieces = rows * (p.tiles_w - 1) * 8;
+    const dim3 fg((unsigned)((pieces + 255) / 256));
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(stem_pool_fix_kernel<F16>, fg, dim3(256), 0, s, (uint16_t *)y, (const uint16_t *)side, rows, wp, p.tiles_w, ldy);
+    else hipLaunchKernelGGL(stem_pool_fix_kernel<BF16>, fg, dim3(256), 0, s, (uint16_t *)y, (const uint16_t *)side, rows, wp, p.tiles_w, ldy);
+    return check_launch(who);
+}
+
 extern "C" int32_t tedspad_stem_pt_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, int32_t n, int32_t t_pairs,
                                        int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t ldy, int32_t relu, int32_t nwg,
                                        int32_t variant, int32_t dtype, void *stream) {
@@ -371,38 +556,27 @@ extern "C" int32_t tedspad_stem_pt_fwd(const void *x_tp, const void *w_img, cons
     TS_REQUIRE(ldy >= 64 && ldy % 8 == 0 && ((uintptr_t)x_tp | (uintptr_t)w_img | (uintptr_t)y) % 16 == 0, "tedspad_stem_pt_fwd: 64 output channels, 16-byte aligned pointers");
     TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_stem_pt_fwd: bad dtype");
     TS_REQUIRE((long)h * w * PT_REC < (1L << 31), "tedspad_stem_pt_fwd: frame too large for 32-bit halo offsets");
-    StemPT p;
-    p.x = (const unsigned char *)x_tp; p.wimg = (const unsigned char *)w_img; p.scale = scale; p.shift = shift; p.y = (uint16_t *)y;
-    p.Wq = w / 2; p.sP = p.Wq * PT_REC; p.sH = 2 * p.sP; p.sTp = (long)h * p.sH;
-    p.N = n; p.Tp = t_pairs; p.H = h; p.Ho = ho; p.Wo = wo; p.ldy = ldy; p.relu = relu;
-    p.tiles_h = (ho + PT_TH - 1) / PT_TH; p.tiles_w = (wo + PT_TW - 1) / PT_TW;
-    const long total = (long)n * t_pairs * p.tiles_h * p.tiles_w;
-    TS_REQUIRE(total < (1L << 30), "tedspad_stem_pt_fwd: too many patches");
-    p.total = (int)total;
-    p.chunk = (int)((total + 7) / 8);
-    int grid = nwg > 0 ? nwg : 256;
-    grid = (grid + 7) / 8 * 8;
-    if ((long)grid > total + 7) grid = (int)((total + 7) / 8 * 8);
-    hipStream_t s = (hipStream_t)stream;
-    static thread_local int attr_set[4] = {0, 0, 0, 0};
-    const int w8 = (variant >> 1) & 1;
-    p.dbg = (variant >> 8) & 7;
-    const int di = (dtype == TEDSPAD_F16 ? 0 : 1) * 2 + w8;
-    const void *fns[4] = {(const void *)conv_stem_pt_kernel<F16, 4>, (const void *)conv_stem_pt_kernel<F16, 8>,
-                          (const void *)conv_stem_pt_kernel<BF16, 4>, (const void *)conv_stem_pt_kernel<BF16, 8>};
-    if (!attr_set[di]) {
-        if (hipFuncSetAttribute(fns[di], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            set_error("tedspad_stem_pt_fwd: cannot raise the dynamic LDS limit");
-            return TEDSPAD_ELAUNCH;
-        }
-        attr_set[di] = 1;
-    }
-    const dim3 g(grid), b(w8 ? 512 : 256);
-    switch (di) {
-        case 0: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 4>), g, b, PT_LDS, s, p); break;
-        case 1: hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8>), g, b, PT_LDS, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 4>), g, b, PT_LDS, s, p); break;
-        default: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8>), g, b, PT_LDS, s, p); break;
-    }
-    return check_launch("tedspad_stem_pt_fwd");
+    return stem_pt_launch("tedspad_stem_pt_fwd", x_tp, w_img, scale, shift, y, nullptr, n, t_pairs, h, w, ho, wo, 0, 0, ldy, relu, nwg, variant, dtype, false,
+                          (hipStream_t)stream);
+}
+
+extern "C" int64_t tedspad_stem_pt_side_bytes(int32_t n, int32_t t_pairs, int32_t h, int32_t w) {
+    const int ho = (h + 1) / 2, wo = w / 2;
+    if (n <= 0 || t_pairs <= 0 || ho < 3 || wo < 3) return 0;
+    return (int64_t)n * t_pairs * ((ho - 3) / 2 + 1) * ((wo + PT_TW - 1) / PT_TW) * 64 * 2;
+}
+
+// conv1 + bn1 + ReLU + the WHOLE maxpool1 (2 x 3 x 3 window, stride 2, no padding; large_i3d.py:133-138,229-232):
+// y[n][t_pairs][hp][wp][ldy], hp = (ho - 3) / 2 + 1, wp = (wo - 3) / 2 + 1; side: tedspad_stem_pt_side_bytes() of scratch.
+extern "C" int32_t tedspad_stem_pt_pool_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
+                                            int32_t t_pairs, int32_t h, int32_t w, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,
+                                            int32_t dtype, void *stream) {
+    TS_REQUIRE(x_tp && w_img && scale && shift && y && side && n > 0 && t_pairs > 0 && h > 0 && w > 0 && w % 2 == 0, "tedspad_stem_pt_pool_fwd: bad arguments");
+    const int ho = (h + 1) / 2, wo = w / 2;
+    TS_REQUIRE(ho >= 3 && wo >= 3 && hp == (ho - 3) / 2 + 1 && wp == (wo - 3) / 2 + 1, "tedspad_stem_pt_pool_fwd: 3x3 stride-2 unpadded pool of the ceil(h/2) x w/2 stem output");
+    TS_REQUIRE(ldy >= 64 && ldy % 8 == 0 && ((uintptr_t)x_tp | (uintptr_t)w_img | (uintptr_t)y | (uintptr_t)side) % 16 == 0, "tedspad_stem_pt_pool_fwd: 64 output channels, 16-byte aligned pointers");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_stem_pt_pool_fwd: bad dtype");
+    TS_REQUIRE((long)h * w * PT_REC < (1L << 31), "tedspad_stem_pt_pool_fwd: frame too large for 32-bit halo offsets");
+    return stem_pt_launch("tedspad_stem_pt_pool_fwd", x_tp, w_img, scale, shift, y, side, n, t_pairs, h, w, ho, wo, hp, wp, ldy, 1, nwg, variant, dtype, true,
+                          (hipStream_t)stream);
 }

@@ -26,6 +26,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
+STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
@@ -673,6 +674,21 @@ class StemPT:
         check(_lib.lib().tedspad_stem_pt_fwd(xtp.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, tp, h, w,
                                              ho, wo, out.ld, int(relu), self.nwg, self.VARIANT if variant is None else variant,
                                              self.dtype_code, _stream_ptr()), "tedspad_stem_pt_fwd")
+        return out
+
+    def conv_pool(self, xtp: torch.Tensor, variant=None) -> Act:
+        """conv1 + bn1 + ReLU + MaxPool3d((2,3,3), 2) (large_i3d.py:229-232) in one pass over the frame-pair layout:
+        Act (n, To // 2, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1, 64)."""
+        n, tp, h, _, wq, _ = xtp.shape
+        w = 2 * wq
+        ho, wo = (h + 1) // 2, wq
+        assert ho >= 3 and wo >= 3, "StemPT.conv_pool: the stem output must hold one 3x3 window"
+        hp, wp = (ho - 3) // 2 + 1, (wo - 3) // 2 + 1
+        out = Act.empty(n, tp, hp, wp, 64, self.torch_dtype, xtp.device)
+        side = torch.empty(_lib.lib().tedspad_stem_pt_side_bytes(n, tp, h, w), dtype=torch.uint8, device=xtp.device)
+        check(_lib.lib().tedspad_stem_pt_pool_fwd(xtp.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr,
+                                                  side.data_ptr(), n, tp, h, w, hp, wp, out.ld, self.nwg, self.VARIANT if variant is None else variant,
+                                                  self.dtype_code, _stream_ptr()), "tedspad_stem_pt_pool_fwd")
         return out
 
     def __call__(self, x: torch.Tensor, relu=True) -> Act:

@@ -114,10 +114,13 @@ class I3Res50(nn.Module):
             raise ValueError("W must be even")
         P = self.packed()
         if E.STEM_PT and taps is None and P["stem_pt"].applies(x):
-            # conv1 + bn1 + ReLU on the persistent stem kernel with the temporal half of maxpool1 fused (large_i3d.py:229-232):
-            # the 112 x 112 x 8-frame stem tensor is never written, only its frame-pair maximum
-            a = P["stem_pt"](x)
-            a = E.maxpool(a, (1, 3, 3), (1, 2, 2))                       # the spatial half of MaxPool3d((2,3,3), 2)
+            # conv1 + bn1 + ReLU + maxpool1 on the persistent stem kernel (large_i3d.py:229-232): the 112 x 112 x 8-frame stem tensor
+            # is never written
+            st = P["stem_pt"]
+            if E.STEM_POOL and x.shape[3] >= 5 and x.shape[4] >= 6:
+                a = st.conv_pool(st.layout(x))                           # ... and the spatial half: only the pooled tensor is written
+            else:
+                a = E.maxpool(st(x), (1, 3, 3), (1, 2, 2))               # the spatial half of MaxPool3d((2,3,3), 2)
         else:
             a = E.clip_to_act(x, cpad=4, dtype=self.compute_dtype)       # (B,T,H,W/2, 2px x 4ch)
             a = P["stem"](a, pads=(2, 3, P["stem"].pair_pw), pads_back=(2, 3, 1))   # the same conv in pixel-pair form, K = 5*7*4*8

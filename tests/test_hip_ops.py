@@ -105,7 +105,8 @@ def test_stem_pixel_pair_rewrite(arch, k, pw):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("variant", [0, 2])
-@pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (1, 3, 16, 120, 88), (3, 3, 5, 18, 72), (1, 2, 8, 66, 24), (1, 3, 16, 224, 224), (40, 3, 16, 40, 40)])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 32, 32), (1, 3, 16, 120, 88), (3, 3, 5, 18, 72), (1, 2, 8, 66, 24), (1, 3, 16, 224, 224), (40, 3, 16, 40, 40),
+                                   (30, 3, 8, 24, 160)])
 def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
     """engine.StemPT (csrc/conv_stem_pt.hip): conv1 5x7x7/2 + bn1 + ReLU of large_i3d.py:133-137 with the temporal half of
     maxpool1 (large_i3d.py:138) fused, against the oracle's Conv3d followed by a max over output-frame pairs: ragged patches,
@@ -138,6 +139,11 @@ def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
         new = E.maxpool(got_a, (1, 3, 3), (1, 2, 2)).buf.float().cpu()
         assert new.shape == old.shape
         assert bool(((new - old).abs() <= ulp * old.abs() + 1e-3).all())
+        # the whole pool inside the stem kernel (column strips, rows carried between patches, the shared column joined by the
+        # fix-up launch): the SAME 16-bit values as pooling the stem kernel's own output
+        fused = st.conv_pool(st.layout(clip.cuda()), variant=variant).buf.float().cpu()
+        assert fused.shape == new.shape
+        assert torch.equal(fused, new)
 
 
 def test_clip_to_frame_pair_layout():
