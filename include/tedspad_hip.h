@@ -148,7 +148,9 @@ int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
  * accumulator tile is consumed as the next MFMA's operand), columns 64 + c = conv_d weight of input channel c. scale3 / scale_d are the two
  * BatchNorm scales, shift3 the sum of the shifts. The 64-channel tensor between conv2 and conv3 is never written.
  * variant bit 0 (plain block) / bit 1 (second source): residual and result rows go through wave-private LDS images so that every global
- * access moves whole 128-byte lines; 0: 16-byte accesses straight in the accumulator layout (same results). */
+ * access moves whole 128-byte lines; 0: 16-byte accesses straight in the accumulator layout (same results).
+ * variant bit 2 (plain block only, t even): MaxPool3d((2,1,1), stride (2,1,1)) of the block's output fused (large_i3d.py:139):
+ * y[n][t/2][h][w][ldy] = max over the frame pair; a workgroup runs conv2 for the same 256 pixels of both frames and stores once. */
 int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,
                                const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual, int32_t ldres,
                                const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu, int32_t variant, void *stream);

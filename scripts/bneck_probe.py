@@ -29,3 +29,6 @@ print("unfused dual : conv2 (same) + dual pointwise %.0f us" % timed(lambda: c3.
 for v in (0, 1, 2, 3):
     E.BneckTail.VARIANT = v
     print("variant %d: fused plain %.0f us, fused dual %.0f us" % (v, timed(lambda: tp(x, residual=res)), timed(lambda: td(x, x2=x2))))
+E.BneckTail.VARIANT = 3
+print("maxpool2 fused: conv2 (above) + conv3+res+pool %.0f us unfused; fused tail + pool %.0f us" % (
+    timed(lambda: c3.call_pool_t2(h, residual=res, relu=True)), timed(lambda: tp(x, residual=res, pool_t2=True))))

@@ -46,18 +46,37 @@ struct BneckKP {
     uint16_t *y;
     int M, Kpad, W, H, kh, kw, ph, pw, ldx, ldres, ldx2, ldy, cout3, relu;
     int R, NP, ntaps;           // flat-halo geometry (conv_flat.hip)
+    int HW, tpf;                // POOLT: pixels / tiles per frame
 };
 
 // STAGED: residual rows in / result rows out through wave-private LDS images (whole 128-byte lines per access); otherwise 16-byte
 // loads / stores straight in the accumulator layout (32-byte pieces per pixel) and the whole weight image resident.
-template <typename T, bool DUAL, bool STAGED>
+// POOLT (plain block, STAGED): MaxPool3d((2,1,1), stride (2,1,1)) of the block's output fused (large_i3d.py:139 after layer1): a workgroup
+// owns 256 pixels of an even frame AND the same pixels of the next frame: stage A runs twice (the second halo lands where the first
+// was), both 64-channel tiles stay in registers as conv3 operands, stage B computes every 64-channel step for both frames and stores
+// their maximum: the 256-channel tensor is written once, pooled (half the bytes of the unfused conv3 + pool pair's traffic again).
+template <typename T, bool DUAL, bool STAGED, bool POOLT>
 __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p) {
-    constexpr int NT = 256, WS = 3, KB = DUAL ? 2 : 1;
+    static_assert(!POOLT || (!DUAL && STAGED), "the pooled variant is the plain block with staged rows");
+    constexpr int NT = 256, WS = 3, KB = DUAL ? 2 : 1, NF = POOLT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int q0 = tile * BT_BM;
+    int q0f[NF];                                        // first pixel of the tile (in each of the two frames)
+    int lim;                                            // valid pixels of the tile
+    size_t obase;                                       // first output row
+    if (POOLT) {
+        const int fp = tile / p.tpf, j = tile - fp * p.tpf;       // frame pair (n, t / 2), tile of the frame
+        q0f[0] = 2 * fp * p.HW + j * BT_BM;
+        q0f[NF - 1] = q0f[0] + p.HW;
+        lim = min(BT_BM, p.HW - j * BT_BM);
+        obase = (size_t)fp * p.HW + j * BT_BM;
+    } else {
+        q0f[0] = tile * BT_BM;
+        lim = min(BT_BM, p.M - q0f[0]);
+        obase = (size_t)q0f[0];
+    }
     const int S = (p.NP + 1) * 8;                       // 16-byte slots: the halo + one zero position
     const int Sr = (S + 63) / 64 * 64;
     const int halo_bytes = Sr * 16;
@@ -74,80 +93,105 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
         lds_dma16(wsrc + kt * BK, dst);
         lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));
     };
-    issue_w(0, 0);                                       // issue order w(0), halo, w(1): the counted waits below rely on it
-    const int NH = (Sr + NT - 1) / NT;
-    for (int i = 0; i < NH; ++i) {
-        if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
-        const int s = i * NT + tid;
-        const int pos = s >> 3, cs = s & 7;
-        const int q = q0 - p.R + pos;
-        const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
-        const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
-        lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
-    }
-    if (p.ntaps > 1) issue_w(1, 1);
-
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
-    int pj[2];
-    unsigned vmask[2];        // bit (dh*kw + dw): the tap lies inside the frame
+    const int NH = (Sr + NT - 1) / NT;
+    uint4 y2[NF][4][2];       // relu(bn2(conv2)) packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel half a
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int j = wave * 64 + b * 32 + l31;
-        pj[b] = j;
-        const int q = q0 + j;
-        unsigned mk = 0;
-        if (q < p.M) {
-            const int r1 = q / p.W, w = q - r1 * p.W;
-            const int h = r1 % p.H;
-            for (int dh = 0; dh < p.kh; ++dh)
-                for (int dw = 0; dw < p.kw; ++dw)
-                    if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+    for (int f = 0; f < NF; ++f) {
+        const int q0 = q0f[f];
+        issue_w(0, 0);                                       // issue order w(0), halo, w(1): the counted waits below rely on it
+        for (int i = 0; i < NH; ++i) {
+            if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
+            const int s = i * NT + tid;
+            const int pos = s >> 3, cs = s & 7;
+            const int q = q0 - p.R + pos;
+            const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
+            const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
+            lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
         }
-        vmask[b] = mk;
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        if (p.ntaps > 1) issue_w(1, 1);
 
-    if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int dh = 0, dw = 0;
-    for (int kt = 0; kt < p.ntaps; ++kt) {
-        const int delta = dh * p.W + dw;
-        unsigned xoff[2], xswz[2];
+        int pj[2];
+        unsigned vmask[2];        // bit (dh*kw + dw): the tap lies inside the frame
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
-            xoff[b] = (unsigned)pos * 128u;
-            xswz[b] = (unsigned)(pos >> 1) & 7u;
+            const int j = wave * 64 + b * 32 + l31;
+            pj[b] = j;
+            const int q = q0 + j;
+            unsigned mk = 0;
+            if (q < p.M) {
+                const int r1 = q / p.W, w = q - r1 * p.W;
+                const int h = r1 % p.H;
+                for (int dh = 0; dh < p.kh; ++dh)
+                    for (int dw = 0; dw < p.kw; ++dw)
+                        if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+            }
+            vmask[b] = mk;
         }
-        if (kt + 1 < p.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
-        __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < p.ntaps) issue_w(kt + 2, (kt + 2) % WS);
-        const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * BT_WSTAGE) + l31 * BK;
+        int dh = 0, dw = 0;
+        for (int kt = 0; kt < p.ntaps; ++kt) {
+            const int delta = dh * p.W + dw;
+            unsigned xoff[2], xswz[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const unsigned c = (unsigned)((ks << 1) | lh);
-            uint4 fa[2], fw[2];
+            for (int b = 0; b < 2; ++b) {
+                const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+                xoff[b] = (unsigned)pos * 128u;
+                xswz[b] = (unsigned)(pos >> 1) & 7u;
+            }
+            if (kt + 1 < p.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
+            __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
+            asm volatile("" ::: "memory");
+            if (kt + 2 < p.ntaps) issue_w(kt + 2, (kt + 2) % WS);
+            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * BT_WSTAGE) + l31 * BK;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+                for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+            }
+            if (++dw == p.kw) { dw = 0; ++dh; }
         }
-        if (++dw == p.kw) { dw = 0; ++dh; }
+        __syncthreads();          // every wave is done with the halo and the weight ring: the next frame's halo / the conv3 weight image lands there
+        // ---- relu(bn2(.)) of the conv2 tile, packed to 16 bits ---------------------------------------------------------------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float sc[16], sf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sc[r] = p.scale2[c];
+                sf[r] = p.shift2[c];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s + j] * sc[8 * s + j] + sf[8 * s + j], 0.f);
+                    y2[f][a * 2 + s][b] = pack8<T>(v);
+                }
+        }
     }
-    __syncthreads();          // every wave is done with the halo and the weight ring: their LDS now takes the conv3 weight image
 
     // ================================ stage B: conv3 (+ downsample branch) on the register tile ================================
     // ---- conv3 weight image: tiles of [64 co'][64 k] (the swizzled image of every weight tile above), HG output-channel groups of 64
@@ -177,9 +221,9 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     bool inb[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int q = q0 + wave * 64 + b * 32 + l31;
-        inb[b] = q < p.M;
-        mpx[b] = (size_t)(inb[b] ? q : 0);
+        const int j = wave * 64 + b * 32 + l31;
+        inb[b] = j < lim;
+        mpx[b] = (size_t)(inb[b] ? q0f[0] + j : 0);
     }
     uint4 xin[4][2];
     if (DUAL) {
@@ -187,27 +231,6 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int b = 0; b < 2; ++b) xin[ks][b] = *reinterpret_cast<const uint4 *>(p.x2 + mpx[b] * p.ldx2 + (ks * 2 + lh) * 8);
-    }
-    // ---- relu(bn2(.)) of the conv2 tile, packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel half a ---------------
-    uint4 y2[4][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        float sc[16], sf[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sc[r] = p.scale2[c];
-            sf[r] = p.shift2[c];
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s + j] * sc[8 * s + j] + sf[8 * s + j], 0.f);
-                y2[a * 2 + s][b] = pack8<T>(v);
-            }
     }
     wait_vmcnt<0>();
     __syncthreads();           // weight image + BN vectors visible
@@ -221,16 +244,22 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     const bool has_res = !DUAL && p.res != nullptr;
     // row-layout role of this lane in instruction k: pixel row k*8 + (lane >> 3) of the wave, physical chunk lane & 7
     const int rrow = lane >> 3, rch = lane & 7;
-    auto issue_res = [&](int g) {
+    // row k*8 + rrow: chunk swizzle (row >> 1) & 7 = (rrow >> 1) ^ 4 (k & 1); the addresses are rebuilt from ONE base per call (an opaque
+    // zero keeps hipcc from carrying 8 row pointers per frame across the loop -- the pooled variant spilled them, and every reload drained
+    // the DMA queue)
+    const int c0 = rch ^ (rrow >> 1);
+    const int limw = lim - wave * 64;                   // valid rows of this wave
+    auto issue_res = [&](int g, int f) {
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const uint16_t *base = p.res + (size_t)(q0f[f] + wave * 64 + rrow + opq) * p.ldres + 64 * g;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int row = k * 8 + rrow;
-            const int q = q0 + wave * 64 + row;
-            const uint16_t *src = q < p.M ? p.res + (size_t)q * p.ldres + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3) : zero;
+            const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
             lds_dma16(src, wbuf_lds + k * 1024);
         }
     };
-    if (STAGED && has_res) issue_res(0);
+    if (STAGED && has_res) issue_res(0, 0);
     const int ng = p.cout3 / 64;
     for (int g = 0; g < ng; ++g) {
         if (g && g % HG == 0) {                  // the next HG groups of the weight image (second-source variant only)
@@ -240,81 +269,111 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
             __syncthreads();
         }
         unsigned d[2][2][4][2];                  // [tile of the pair][pixel group][q][h]: packed results in the accumulator layout
-        if (STAGED && has_res) {
-            if (g == 0) wait_vmcnt<0>(); else wait_vmcnt<8>();      // the residual rows of this step landed; the previous step's 8 stores stay in flight
-            asm volatile("" ::: "memory");
-        }
+        unsigned dk[POOLT ? 2 : 1][2][4][2];     // POOLT: the first frame's
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int t = 2 * g + tt;
-            const unsigned char *Wt = dsm + (g % HG) * BT_WSTAGE + (tt * 32 + l31) * (BK * 2);
-            f32x16 a3[2], ad[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { a3[b][r] = 0.f; ad[b][r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const unsigned c = (unsigned)((ks << 1) | lh);
-                const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 4));
-#pragma unroll
-                for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[ks][b], a3[b]);
-                if (DUAL) {
-                    const uint4 fd = *reinterpret_cast<const uint4 *>(Wt + HG * BT_WSTAGE + ((c ^ swz) << 4));
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) ad[b] = T::mfma(fd, xin[ks][b], ad[b]);
-                }
-            }
-            // lane (l31, lh) holds channels 32 t + 8 q + 4 lh + {0..3}, q = 0..3
-            f32x4 s3[4], b3[4], sd[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = 32 * t + 8 * q + 4 * lh;
-                s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
-                b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
-                if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+        for (int f = 0; f < NF; ++f) {
+            if (STAGED && has_res) {
+                // the residual rows of this step landed; the previous 64-channel step's 8 stores (issued after the first frame's rows) stay in flight
+                if (f == 0 && g > 0) wait_vmcnt<8>(); else wait_vmcnt<0>();
+                asm volatile("" ::: "memory");
             }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-                if (has_res) {
-                    // residual chunks in the STORE layout (lane: channels 16 qq + 8 lh .. + 7 of the tile), swapped back into the accumulator layout
+            for (int tt = 0; tt < 2; ++tt) {
+                if (POOLT) __builtin_amdgcn_sched_barrier(0);       // keep the two tiles' live ranges apart (the pooled variant is register-bound)
+                const int t = 2 * g + tt;
+                const unsigned char *Wt = dsm + (g % HG) * BT_WSTAGE + (tt * 32 + l31) * (BK * 2);
+                f32x16 a3[2], ad[2];
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
-                        uint4 L = make_uint4(0u, 0u, 0u, 0u);
-                        if (STAGED) L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
-                        else if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
-                        auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
-                        auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
-                        rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
-                        rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { a3[b][r] = 0.f; ad[b][r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const unsigned c = (unsigned)((ks << 1) | lh);
+                    const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 4));
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[f][ks][b], a3[b]);
+                    if (DUAL) {
+                        const uint4 fd = *reinterpret_cast<const uint4 *>(Wt + HG * BT_WSTAGE + ((c ^ swz) << 4));
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) ad[b] = T::mfma(fd, xin[ks][b], ad[b]);
                     }
                 }
+                // lane (l31, lh) holds channels 32 t + 8 q + 4 lh + {0..3}, q = 0..3
+                f32x4 s3[4], b3[4], sd[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * t + 8 * q + 4 * lh;
+                    s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
+                    b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
+                    if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+                }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        float v[2];
+                for (int b = 0; b < 2; ++b) {
+                    unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                    if (has_res) {
+                        // residual chunks in the STORE layout (lane: channels 16 qq + 8 lh .. + 7 of the tile), swapped back into the accumulator layout
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int r = 4 * q + 2 * h + e;
-                            float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
-                            if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
-                            if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
-                            v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                        for (int qq = 0; qq < 2; ++qq) {
+                            const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                            uint4 L = make_uint4(0u, 0u, 0u, 0u);
+                            if (STAGED) L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
+                            else if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
+                            auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                            auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                            rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
+                            rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
                         }
-                        d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
                     }
 #pragma unroll
-                for (int q = 0; q < 4; q += 2)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        auto sw = __builtin_amdgcn_permlane32_swap(d[tt][b][q][h], d[tt][b][q + 1][h], false, false);
-                        d[tt][b][q][h] = sw[0];
-                        d[tt][b][q + 1][h] = sw[1];
-                    }
+                        for (int h = 0; h < 2; ++h) {
+                            float v[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int r = 4 * q + 2 * h + e;
+                                float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
+                                if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
+                                if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
+                                v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                            }
+                            d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                        }
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            auto sw = __builtin_amdgcn_permlane32_swap(d[tt][b][q][h], d[tt][b][q + 1][h], false, false);
+                            d[tt][b][q][h] = sw[0];
+                            d[tt][b][q + 1][h] = sw[1];
+                        }
+                }
             }
+            if (POOLT && f == 0) {                   // keep the first frame's results; its residual rows are consumed: the second frame's may land
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) dk[tt][b][q][h] = d[tt][b][q][h];
+                if (has_res) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue_res(g, 1);
+                }
+            }
+        }
+        if (POOLT) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) d[tt][b][q][h] = T::pk_max(d[tt][b][q][h], dk[tt][b][q][h]);
         }
         if (!STAGED) {                            // 16-byte stores straight from the registers (lane: channels 16 qq + 8 lh .. + 7 of tile tt)
 #pragma unroll
@@ -343,19 +402,19 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 #pragma unroll
         for (int k = 0; k < 8; ++k) rowv[k] = *reinterpret_cast<const uint4 *>(wbuf + k * 1024 + lane * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the image is read back: the next step's residual rows may overwrite it
-        if (has_res && g + 1 < ng) issue_res(g + 1);
+        if (has_res && g + 1 < ng) issue_res(g + 1, 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int row = k * 8 + rrow;
-            const int q = q0 + wave * 64 + row;
-            uint16_t *dst = q < p.M ? p.y + (size_t)q * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
-                                    : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;      // rows past M: a scratch line, so that every wave issues 8 stores
+            const int j = wave * 64 + row;
+            uint16_t *dst = j < lim ? p.y + (obase + j) * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
+                                    : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;      // rows past the tile: a scratch line, so that every wave issues 8 stores
             gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
         }
     }
 }
 
-template <typename T, bool DUAL, bool STAGED>
+template <typename T, bool DUAL, bool STAGED, bool POOLT = false>
 int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
     const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * BT_WSTAGE;
@@ -367,7 +426,7 @@ int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
         return TEDSPAD_EINVAL;
     }
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_bneck_tail_kernel<T, DUAL, STAGED>;
+    auto kfn = conv_bneck_tail_kernel<T, DUAL, STAGED, POOLT>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
@@ -375,7 +434,8 @@ int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
         }
         attr_set[T::kDtype] = 1;
     }
-    hipLaunchKernelGGL(kfn, dim3((p.M + BT_BM - 1) / BT_BM), dim3(256), lds, s, p);
+    const int tiles = POOLT ? (p.M / (2 * p.HW)) * p.tpf : (p.M + BT_BM - 1) / BT_BM;
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(256), lds, s, p);
     return check_launch("tedspad_bneck_tail_fwd");
 }
 
@@ -410,7 +470,12 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     p.ldx = d2->ldx; p.ldres = ldres; p.ldx2 = ldx2; p.ldy = ldy; p.cout3 = cout3; p.relu = relu;
     p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
     TS_REQUIRE(p.Kpad == p.ntaps * 64, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
+    p.HW = d2->h * d2->w; p.tpf = (p.HW + BT_BM - 1) / BT_BM;
     hipStream_t s = (hipStream_t)stream;
+    if (variant & 4) {
+        TS_REQUIRE(!x2 && d2->t % 2 == 0, "tedspad_bneck_tail_fwd: the temporal-pool variant takes the plain block (no second source) and an even frame count");
+        return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, false, true, true>(p, s) : launch_bneck<BF16, false, true, true>(p, s);
+    }
     const bool staged = x2 ? (variant & 2) != 0 : (variant & 1) != 0;
     const bool f16 = d2->dtype == TEDSPAD_F16;
     if (x2) {

@@ -26,6 +26,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
+BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # layer1's last block: the fused tail with maxpool2 inside; 0: conv2 + (conv3 + pool) launches (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
@@ -540,10 +541,12 @@ class BneckTail:
         return (x.c == 64 and pads[0] == 0 and pads[1] < kh and pads[2] < kw and 2 * pads[1] == kh - 1 and 2 * pads[2] == kw - 1 and
                 flat_halo <= 80 * 1024 and n * t * h * w * max(x.ld, self.cout3) < MAX_ELEMS)
 
-    def __call__(self, x: Act, pads=(0, 1, 1), residual: Optional[Act] = None, x2: Optional[Act] = None, relu=True) -> Act:
+    def __call__(self, x: Act, pads=(0, 1, 1), residual: Optional[Act] = None, x2: Optional[Act] = None, relu=True, pool_t2=False) -> Act:
+        """pool_t2: MaxPool3d((2,1,1), (2,1,1)) of the block's output fused (large_i3d.py:139): result (n, t // 2, h, w, cout3)."""
         n, t, h, w = x.dims
         assert self.applies(x, pads) and (x2 is not None) == self.dual and not (self.dual and residual is not None)
-        out = Act.empty(n, t, h, w, self.cout3, self.conv2.torch_dtype, x.buf.device)
+        assert not pool_t2 or (not self.dual and t % 2 == 0), "BneckTail: the temporal pool goes with the plain block and an even frame count"
+        out = Act.empty(n, t // 2 if pool_t2 else t, h, w, self.cout3, self.conv2.torch_dtype, x.buf.device)
         for o in (residual, x2):
             if o is not None:
                 assert o.dims == x.dims
@@ -557,7 +560,8 @@ class BneckTail:
                                                 self.scale3.data_ptr(), self.shift3.data_ptr(), self.cout3,
                                                 residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
                                                 x2.ptr if x2 is not None else None, x2.ld if x2 is not None else 0,
-                                                self.scale_d.data_ptr() if self.dual else None, out.ptr, out.ld, int(relu), self.VARIANT, _stream_ptr()),
+                                                self.scale_d.data_ptr() if self.dual else None, out.ptr, out.ld, int(relu),
+                                                self.VARIANT | (4 if pool_t2 else 0), _stream_ptr()),
               "tedspad_bneck_tail_fwd")
         return out
 

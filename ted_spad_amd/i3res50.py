@@ -139,10 +139,15 @@ class I3Res50(nn.Module):
                 h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
                 tail = P.get(p + "tail") if (E.BNECK_TAIL and taps is None) else None
                 fuse_pool = li == 1 and i == len(layer) - 1          # the last layer1 block fuses maxpool2 into its conv3 instead (below)
-                if tail is not None and not fuse_pool and tail.applies(h, (0, 1, 1)):
+                if tail is not None and tail.applies(h, (0, 1, 1)) and (not fuse_pool or (E.BNECK_TAIL_POOL and not tail.dual and h.dims[1] % 2 == 0)):
                     # conv2 + bn2 + ReLU + conv3 + bn3 + (residual | downsample branch) + ReLU in one launch: the 64-channel tensor between
-                    # the two convolutions is never written (large_i3d.py:69-84)
-                    a = tail(h, pads=(0, 1, 1), x2=a) if tail.dual else tail(h, pads=(0, 1, 1), residual=a)
+                    # the two convolutions is never written (large_i3d.py:69-84); the last block of layer1 pools over frame pairs as
+                    # well (maxpool2, large_i3d.py:139)
+                    if tail.dual:
+                        a = tail(h, pads=(0, 1, 1), x2=a)
+                    else:
+                        a = tail(h, pads=(0, 1, 1), residual=a, pool_t2=fuse_pool)
+                        pooled = pooled or fuse_pool
                     continue
                 h = P[p + "conv2"](h, pads=(0, 1, 1))
                 if blk.downsample is not None and taps is None and P[p + "conv3"].dual_supported(P[p + "down"], h, a):

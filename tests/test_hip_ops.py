@@ -164,7 +164,7 @@ def test_clip_to_frame_pair_layout():
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("dual", [False, True])
 @pytest.mark.parametrize("staged", [0, 3])
-@pytest.mark.parametrize("dims", [(3, 4, 55, 55), (2, 3, 7, 9), (1, 1, 16, 16), (5, 2, 28, 30)])
+@pytest.mark.parametrize("dims", [(3, 4, 55, 55), (2, 3, 7, 9), (1, 1, 16, 16), (5, 2, 28, 30), (3, 6, 9, 11)])
 def test_bottleneck_tail_fused_vs_oracle_and_unfused(dims, staged, dual, dtype, monkeypatch):
     """engine.BneckTail (csrc/conv_bneck.hip): conv2 1x3x3 (64 -> 64) + bn2 + ReLU -> conv3 1x1x1 (64 -> 256) + bn3 + (residual | downsample
     branch) + ReLU of a layer1 bottleneck (large_i3d.py:69-84) in one launch, against the oracle (the 64-channel tensor rounded to the
@@ -216,6 +216,12 @@ def test_bottleneck_tail_fused_vs_oracle_and_unfused(dims, staged, dual, dtype, 
         old = c3(h2, residual=E.Act(res.to(tdt).cuda(), 256), relu=True)
     old = old.buf.float().cpu()
     assert bool(((got - old).abs() <= ulp * old.abs() + 1e-3).all())
+    if not dual and t % 2 == 0:
+        # maxpool2 (MaxPool3d((2,1,1), stride (2,1,1)), large_i3d.py:139) fused as well: the SAME values as pooling the fused output
+        pooled = tail(xa, residual=E.Act(res.to(tdt).cuda(), 256), pool_t2=True).buf.float().cpu()
+        want = torch.maximum(got[:, 0::2], got[:, 1::2])
+        assert pooled.shape == want.shape
+        assert torch.equal(pooled, want)
 
 
 POOLS = [
