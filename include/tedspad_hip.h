@@ -307,6 +307,11 @@ int32_t tedspad_global_avgpool_bwd(const float *dfeat, const void *mask, int32_t
 int32_t tedspad_upsample_nearest2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t ldy,
                                        void *stream);
 int32_t tedspad_copy_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, void *stream);
+/* Their backward passes (the autograd of F.interpolate(nearest) and of a tensor with several consumers; the train-mode anonymizer,
+ * train_anonymizer.py:73-123): dx[n][h][w] (+)= the fp32 sum of the 2 x 2 block of dy; y[:, 0..c) += x[:, 0..c). */
+int32_t tedspad_upsample_nearest2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldy, int32_t ldx,
+                                       int32_t accumulate, int32_t dtype, void *stream);
+int32_t tedspad_add_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, int32_t dtype, void *stream);
 
 /* Backward of tedspad_upsample_bilinear2x_fwd: dy is the (n,ho,wo,c) slice the forward wrote, dx is (n,h,w,c). */
 int32_t tedspad_upsample_bilinear2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c,

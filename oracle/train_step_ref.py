@@ -15,7 +15,14 @@ Follows anonymization_training/train_anonymizer.py:
 """
 import torch
 
-from . import i3res50_ref, losses_ref, resnet50_ref, unet_ref
+from . import i3res50_ref, losses_ref, resnet50_ref, unet_ref, unetpp_ref
+
+
+def _fa(x, sd, train):
+    """The anonymizer the state dict belongs to: UNet (arch='unet') or the default smp UnetPlusPlus (model_loaders.py:17-30)."""
+    if "encoder.conv1.weight" in sd:
+        return unetpp_ref.forward(x, sd, train=train)
+    return unet_ref.forward(x, sd, train=train)
 
 
 def _grad_sd(sd):
@@ -37,11 +44,11 @@ def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_fra
     fa = _grad_sd(fa_sd)
     loss_fb = None
     if vispr is not None:
-        z = [resnet50_ref.forward(unet_ref.forward(x, fa, train=True), fb_sd, train=False) for x in vispr]
+        z = [resnet50_ref.forward(_fa(x, fa, True), fb_sd, train=False) for x in vispr]
         loss_fb = losses_ref.nt_xent_torch(z[0], z[1], 0.1)
     v = video_b48.permute(0, 2, 1, 3, 4)
     b, c, t, h, w = v.shape
-    anon = unet_ref.forward(v.reshape(-1, c, h, w), fa, train=True).reshape(b, c, t, h, w)
+    anon = _fa(v.reshape(-1, c, h, w), fa, True).reshape(b, c, t, h, w)
     anon.retain_grad()
     clips = torch.split(anon, [num_frames] * 3, dim=2)
     loss_ft, ce, trip = _utility(ft_sd, clips, labels, train=False, tlw=tlw)
@@ -59,7 +66,7 @@ def phase2_fb(vispr, fa_sd, fb_sd):
     Returns (loss_fb, grads of fb parameters)."""
     fb = _grad_sd(fb_sd)
     with torch.no_grad():
-        x = [unet_ref.forward(v, fa_sd, train=False) for v in vispr]
+        x = [_fa(v, fa_sd, False) for v in vispr]
     z = [resnet50_ref.forward(xi, fb, train=True) for xi in x]
     loss_fb = losses_ref.nt_xent_torch(z[0], z[1], 0.1)
     loss_fb.backward()
@@ -71,7 +78,7 @@ def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
     v = video_b48.permute(0, 2, 1, 3, 4)
     b, c, t, h, w = v.shape
     with torch.no_grad():
-        anon = unet_ref.forward(v.reshape(-1, c, h, w), fa_sd, train=False).reshape(b, c, t, h, w)
+        anon = _fa(v.reshape(-1, c, h, w), fa_sd, False).reshape(b, c, t, h, w)
     clips = torch.split(anon, [num_frames] * 3, dim=2)
     loss_ft, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw)
     loss_ft.backward()
@@ -88,7 +95,7 @@ def action_step(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
     v = video_b48.permute(0, 2, 1, 3, 4)
     b, c, t, h, w = v.shape
     with torch.no_grad():
-        anon = unet_ref.forward(v.reshape(-1, c, h, w), fa_sd, train=False).reshape(b, c, t, h, w)
+        anon = _fa(v.reshape(-1, c, h, w), fa_sd, False).reshape(b, c, t, h, w)
     clips = torch.split(anon, [num_frames] * 3, dim=2)
     loss, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw, frozen_bn=True)
     loss.backward()

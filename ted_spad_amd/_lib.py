@@ -82,6 +82,8 @@ SYMBOLS = {
     "tedspad_stem_pt_pool_fwd": (_I32, [_P] * 6 + [_I32] * 10 + [_P]),
     "tedspad_upsample_nearest2x_fwd": (_I32, [_P, _P] + [_I32] * 6 + [_P]),
     "tedspad_copy_channels": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _P]),
+    "tedspad_upsample_nearest2x_bwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
+    "tedspad_add_channels": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     "tedspad_bn_fold": (_I32, [_P, _P, _P, _P, _P, C.c_double, _I32, _P, _P, _P]),
     "tedspad_resize_aa_taps": (_I32, [_I32, _I32]),
     "tedspad_resize_aa_table": (_I32, [_I32, _I32, _P]),

@@ -14,7 +14,7 @@ backward passes into the same parameters -- the three clips of a step -- add up)
 remains the fast path (no autograd bookkeeping, one flush of the packed weight gradients per step).
 
 Modes, as the reference's modules behave under `train()` / `eval()`:
-    UNet                train: batch-statistics BatchNorm2d, running stats updated, parameter gradients
+    UNet / UnetPlusPlus train: batch-statistics BatchNorm2d, running stats updated, parameter gradients
     wrapper_i3d         train: the same + dropout before fc; `freeze_bn(ft)` (train_anonymized_action.py:39-40) -> 'frozen'
                         eval with an input that requires grad (phase 1): BN folded, gradient w.r.t. the INPUT only
                         (the reference also accumulates never-used weight gradients there)
@@ -110,6 +110,16 @@ def unet_forward(module, x):
         raise NotImplementedError("UNet: gradient w.r.t. the INPUT frames is not built (the reference never needs it: fa's input "
                                   "is data, train_anonymizer.py:80,92)")
     tr = _trainer(module, UNetTrainer)
+    return _UNetFn.apply(tr, x, *module.parameters())
+
+
+def unetpp_forward(module, x):
+    """UnetPlusPlus (the default `fa`) in train(): the same autograd node, UNetPPTrainer underneath."""
+    from .train_nets import UNetPPTrainer
+    if x.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("UnetPlusPlus: gradient w.r.t. the INPUT frames is not built (the reference never needs it: fa's input "
+                                  "is data, train_anonymizer.py:80,92)")
+    tr = _trainer(module, UNetPPTrainer)
     return _UNetFn.apply(tr, x, *module.parameters())
 
 

@@ -374,6 +374,48 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const uint4 *x, uint
     }
 }
 
+// Backward of the nearest x2 upsample: dx[n][h][w] = (dx +) the sum of the 2 x 2 block of dy it was copied to (fp32 sum, one rounding).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nearest2x_bwd_kernel(const uint4 *dy, uint4 *dx, int h, int w, int C8, int ldy8, int ldx8, int acc, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int wi = (int)(r % w); r /= w;
+        const int hi = (int)(r % h);
+        const long n = r / h;
+        float s[8], v[8];
+        uint4 *dst = dx + ((n * h + hi) * w + wi) * ldx8 + c8;
+        if (acc) unpack8<T>(*dst, s);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                unpack8<T>(dy[((n * 2 * h + 2 * hi + a) * 2 * w + 2 * wi + b) * ldy8 + c8], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += v[i];
+            }
+        *dst = pack8<T>(s);
+    }
+}
+
+// y[:, :c] += x[:, :c] (a gradient that reaches a tensor through a second consumer)
+template <typename T>
+__global__ __launch_bounds__(256) void add_channels_kernel(const uint4 *x, uint4 *y, int C8, int ldx8, int ldy8, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long px = idx / C8;
+        const int c8 = (int)(idx - px * C8);
+        float a[8], b[8];
+        unpack8<T>(x[px * ldx8 + c8], a);
+        unpack8<T>(y[px * ldy8 + c8], b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] += a[i];
+        y[px * ldy8 + c8] = pack8<T>(b);
+    }
+}
 
 }  // namespace
 }  // namespace tedspad
@@ -515,6 +557,30 @@ extern "C" int32_t tedspad_copy_channels(const void *x, void *y, int64_t npix, i
     const long total = (long)npix * (c / 8);
     hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
     return check_launch("tedspad_copy_channels");
+}
+
+extern "C" int32_t tedspad_upsample_nearest2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldy, int32_t ldx,
+                                                  int32_t accumulate, int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c,
+               "tedspad_upsample_nearest2x_bwd: bad arguments");
+    TS_REQUIRE(((uintptr_t)dy | (uintptr_t)dx) % 16 == 0, "tedspad_upsample_nearest2x_bwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_upsample_nearest2x_bwd: bad dtype");
+    const long total = (long)n * h * w * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(upsample_nearest2x_bwd_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)dy, (uint4 *)dx, h, w, c / 8, ldy / 8, ldx / 8, accumulate, total);
+    else hipLaunchKernelGGL(upsample_nearest2x_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)dy, (uint4 *)dx, h, w, c / 8, ldy / 8, ldx / 8, accumulate, total);
+    return check_launch("tedspad_upsample_nearest2x_bwd");
+}
+
+extern "C" int32_t tedspad_add_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && npix > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "tedspad_add_channels: bad arguments");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_add_channels: pointers must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_add_channels: bad dtype");
+    const long total = (long)npix * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(add_channels_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
+    else hipLaunchKernelGGL(add_channels_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
+    return check_launch("tedspad_add_channels");
 }
 
 extern "C" int32_t tedspad_avgpool3d_s1_fwd(const void *x, float *y, int32_t n, int32_t t, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t kt,

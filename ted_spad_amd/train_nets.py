@@ -563,3 +563,215 @@ class UNetTrainer:
             if lvl > 0:
                 d = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], d, (1, 2, 2), (1, 2, 2), add=dskip[lvl - 1])
             done(8 - lvl, self.inc if lvl == 0 else self.down[lvl - 1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# UNet++ (the reference's default anonymizer, train mode)
+# ------------------------------------------------------------------------------------------------------------------
+
+class UNetPPTrainer:
+    """smp's UnetPlusPlus(resnet18, depth 4) of model_loaders.py:17-30 in train() mode (train_anonymizer.py:73-123 with the default
+    `arch`): batch-statistics BatchNorm2d everywhere (running stats updated once per call), forward with a tape and the explicit
+    backward of the dense skip pathway. The launch plan is unetpp.UnetPlusPlus.forward's: producers write into their channel slice
+    of the consumer's concat buffer; backward, the gradient of a concat buffer is cut into the same slices, every tensor with several
+    consumers (f1, f2, f3, x_1_1, x_2_2) sums its slices (tedspad_add_channels), the nearest x2 upsample sums its 2 x 2 blocks
+    (tedspad_upsample_nearest2x_bwd). `encoder.layer4.*` is not on the path (depth 4) and receives no gradient, as in smp."""
+
+    def __init__(self, m):
+        self.m = m
+        dt = m.compute_dtype
+        enc = m.encoder
+        CL = TE.ConvLayer
+        self.stem, self.stem_bn = CL(enc.conv1.weight, None, (1, 2, 2), (0, 3, 3), pair_w=3, dtype=dt), enc.bn1
+        self.blocks = []
+        for li in (1, 2, 3):
+            for bi, blk in enumerate(getattr(enc, "layer%d" % li)):
+                s = blk.stride
+                self.blocks.append(dict(
+                    li=li, bi=bi, bn1=blk.bn1, bn2=blk.bn2, bnd=blk.downsample[1] if blk.downsample is not None else None,
+                    c1=CL(blk.conv1.weight, None, (1, s, s), (0, 1, 1), dtype=dt), c2=CL(blk.conv2.weight, None, (1, 1, 1), (0, 1, 1), dtype=dt),
+                    cd=CL(blk.downsample[0].weight, None, (1, s, s), (0, 0, 0), dtype=dt) if blk.downsample is not None else None))
+        self.dec = {name: [(CL(b.conv1[0].weight, None, (1, 1, 1), (0, 1, 1), dtype=dt), b.conv1[1]),
+                           (CL(b.conv2[0].weight, None, (1, 1, 1), (0, 1, 1), dtype=dt), b.conv2[1])] for name, b in m.decoder.blocks.items()}
+        head_ = m.segmentation_head[0]
+        self.head = CL(head_.weight, head_.bias, (1, 1, 1), (0, 1, 1), dtype=dt)
+
+    # the decoder blocks in the order `backward` finishes them
+    DEC_ORDER = ("x_0_3", "x_0_2", "x_1_2", "x_0_1", "x_2_2", "x_1_1", "x_0_0")
+
+    def conv_layers(self):
+        out = [self.stem, self.head]
+        for d in self.blocks:
+            out += [d[k] for k in ("c1", "c2", "cd") if d[k] is not None]
+        for units in self.dec.values():
+            out += [c for c, _ in units]
+        return out
+
+    def flush_grads(self):
+        for c in self.conv_layers():
+            c.flush_grad()
+
+    def _stage_layers(self, li):
+        return [d[k] for d in self.blocks if d["li"] == li for k in ("c1", "c2", "cd") if d[k] is not None]
+
+    def off_path_params(self):
+        """`encoder.layer4.*`: smp's ResNetEncoder keeps it at depth 4 but never runs it -- no gradient (torch leaves .grad None)."""
+        return list(self.m.encoder.layer4.parameters())
+
+    def grad_buckets(self):
+        """Parameters in the order `backward` finishes them: [head + x_0_3, x_0_2, x_1_2, x_0_1, x_2_2, x_1_1, x_0_0, layer3, layer2, layer1, stem]."""
+        b = []
+        for i, name in enumerate(self.DEC_ORDER):
+            b.append(([self.head.weight, self.head.bias] if i == 0 else []) + UNetTrainer._unit_params(self.dec[name]))
+        for li in (3, 2, 1):
+            g = []
+            for d in self.blocks:
+                if d["li"] == li:
+                    for c, bn in ((d["c1"], d["bn1"]), (d["c2"], d["bn2"]), (d["cd"], d["bnd"])):
+                        if c is not None:
+                            g += [c.weight, bn.weight, bn.bias]
+            b.append(g)
+        b.append([self.stem.weight, self.stem_bn.weight, self.stem_bn.bias])
+        return b
+
+    def forward(self, x: torch.Tensor):
+        """x: (N,3,H,W) fp32, H and W multiples of 16 -> (y (N,3,H,W) fp32 (no activation), tape)."""
+        from .unetpp import UnetPlusPlus as U
+        m = self.m
+        E.require_cuda(x, "UNetPPTrainer")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected (N,3,H,W), got %s" % (tuple(x.shape),))
+        n, _, H, W = x.shape
+        if H % 16 or W % 16:
+            raise RuntimeError("Wrong input shape height=%d, width=%d. Expected image height and width divisible by 16." % (H, W))
+        tdt = E.DTYPES[m.compute_dtype][0]
+
+        def buf(c, div):
+            return Act.empty(n, 1, H // div, W // div, c, tdt, x.device)
+
+        B00, B11, B22 = buf(384, 8), buf(192, 4), buf(128, 2)
+        B01, B12, B02 = buf(384, 4), buf(192, 2), buf(320, 2)
+        tape = dict(n=n, H=H, W=W, enc=[], dec={})
+        a = E.clip_to_act(x.unsqueeze(2), cpad=4, dtype=m.compute_dtype)
+        f1, tape["stem"] = TE.conv_bn_act_train(self.stem, self.stem_bn, a, out=B22.slice(64, 64))
+        cur, tape["idx1"] = E.maxpool(f1, (1, 3, 3), (1, 2, 2), pads=(0, 1, 1), return_idx=True)
+        outs = {1: B11.slice(128, 64), 2: B00.slice(256, 128), 3: None}
+        feats = {1: f1}
+        for d in self.blocks:
+            rec = {}
+            h, rec["u1"] = TE.conv_bn_act_train(d["c1"], d["bn1"], cur)
+            if d["cd"] is not None:
+                r, rec["ud"] = TE.conv_bn_act_train(d["cd"], d["bnd"], cur, relu=False)
+            else:
+                r = cur
+            cur, rec["u2"] = TE.conv_bn_act_train(d["c2"], d["bn2"], h, relu=True, residual=r, out=outs[d["li"]] if d["bi"] == 1 else None)
+            tape["enc"].append(rec)
+            if d["bi"] == 1:
+                feats[d["li"] + 1] = cur
+        f2, f3, f4 = feats[2], feats[3], feats[4]
+        tape["f1"] = f1
+
+        def block(name, cat, out=None):
+            (c1, bn1), (c2, bn2) = self.dec[name]
+            mid, u1 = TE.conv_bn_act_train(c1, bn1, cat)
+            y, u2 = TE.conv_bn_act_train(c2, bn2, mid, out=out)
+            tape["dec"][name] = (u1, u2)
+            return y
+
+        U._up_into(f4, B00.slice(0, 256))
+        x00 = block("x_0_0", B00)
+        U._up_into(f3, B11.slice(0, 128))
+        x11 = block("x_1_1", B11, out=B01.slice(256, 64))
+        U._up_into(f2, B22.slice(0, 64))
+        x22 = block("x_2_2", B22, out=B12.slice(64, 64))
+        U._copy_into(f2, B01.slice(320, 64))
+        U._up_into(x00, B01.slice(0, 256))
+        x01 = block("x_0_1", B01)
+        U._copy_into(f1, B12.slice(128, 64))
+        U._up_into(x11, B12.slice(0, 64))
+        x12 = block("x_1_2", B12, out=B02.slice(128, 64))
+        U._copy_into(Act(B12.buf, 128, B12.coff + 64), B02.slice(192, 128))
+        U._up_into(x01, B02.slice(0, 128))
+        x02 = block("x_0_2", B02)
+        B03 = buf(64, 1)
+        U._up_into(x02, B03)
+        x03 = block("x_0_3", B03)
+        tape["x03"] = x03
+        y = self.head.forward(x03, relu=False)
+        TE.flush_counters()
+        return E.act_to_nchw(y, 3).squeeze(2), tape
+
+    def backward(self, tape, dy: torch.Tensor, on_bucket_done=None):
+        """dy: (N,3,H,W) fp32 gradient w.r.t. the output; accumulates every on-path parameter's .grad.
+        on_bucket_done(k): the k-th group of `grad_buckets()` is final and flushed (last backward pass of a step only)."""
+        n, H, W = tape["n"], tape["H"], tape["W"]
+        code = _lib.F16 if self.m.compute_dtype == "f16" else _lib.BF16
+        G = {}
+
+        def acc(name, g: Act):
+            if name not in G:
+                G[name] = g
+            else:
+                t = G[name]
+                nn_, _, h, w = g.dims
+                check(_lib.lib().tedspad_add_channels(g.ptr, t.ptr, nn_ * h * w, g.c, g.ld, t.ld, code, _stream_ptr()), "tedspad_add_channels")
+
+        def up_bwd(d: Act) -> Act:
+            nn_, _, ho, wo = d.dims
+            dx = Act.empty(nn_, 1, ho // 2, wo // 2, d.c, d.buf.dtype, d.buf.device)
+            check(_lib.lib().tedspad_upsample_nearest2x_bwd(d.ptr, dx.ptr, nn_, ho // 2, wo // 2, d.c, d.ld, dx.ld, 0, code, _stream_ptr()),
+                  "tedspad_upsample_nearest2x_bwd")
+            return dx
+
+        def block_bwd(name, d: Act) -> Act:
+            u1, u2 = tape["dec"][name]
+            dmid, _ = TE.conv_bn_act_train_bwd(u2, d)
+            dcat, _ = TE.conv_bn_act_train_bwd(u1, dmid)
+            return dcat
+
+        def done(k, layers):
+            if on_bucket_done is not None:
+                for c in layers:
+                    c.flush_grad()
+                on_bucket_done(k)
+
+        dl = TE.nchw_grad_to_act(dy, None, (1, H, W), dtype=self.m.compute_dtype)
+        x03 = tape["x03"]
+        self.head.wgrad(x03, dl)
+        d = self.head.dgrad(dl, x03.dims[1:])
+        dB = block_bwd("x_0_3", d)
+        acc("x02", up_bwd(dB))
+        done(0, [self.head] + [c for c, _ in self.dec["x_0_3"]])
+        dB = block_bwd("x_0_2", G["x02"])                                   # [up(x01) | x12 | x22 | f1]
+        acc("x01", up_bwd(dB.slice(0, 128))); acc("x12", dB.slice(128, 64)); acc("x22", dB.slice(192, 64)); acc("f1", dB.slice(256, 64))
+        done(1, [c for c, _ in self.dec["x_0_2"]])
+        dB = block_bwd("x_1_2", G["x12"])                                   # [up(x11) | x22 | f1]
+        acc("x11", up_bwd(dB.slice(0, 64))); acc("x22", dB.slice(64, 64)); acc("f1", dB.slice(128, 64))
+        done(2, [c for c, _ in self.dec["x_1_2"]])
+        dB = block_bwd("x_0_1", G["x01"])                                   # [up(x00) | x11 | f2]
+        acc("x00", up_bwd(dB.slice(0, 256))); acc("x11", dB.slice(256, 64)); acc("f2", dB.slice(320, 64))
+        done(3, [c for c, _ in self.dec["x_0_1"]])
+        dB = block_bwd("x_2_2", G["x22"])                                   # [up(f2) | f1]
+        acc("f2", up_bwd(dB.slice(0, 64))); acc("f1", dB.slice(64, 64))
+        done(4, [c for c, _ in self.dec["x_2_2"]])
+        dB = block_bwd("x_1_1", G["x11"])                                   # [up(f3) | f2]
+        acc("f3", up_bwd(dB.slice(0, 128))); acc("f2", dB.slice(128, 64))
+        done(5, [c for c, _ in self.dec["x_1_1"]])
+        dB = block_bwd("x_0_0", G["x00"])                                   # [up(f4) | f3]
+        acc("f4", up_bwd(dB.slice(0, 256))); acc("f3", dB.slice(256, 128))
+        done(6, [c for c, _ in self.dec["x_0_0"]])
+        # ---- encoder: layer3 <- d(f4); its input gradient joins d(f3); ... -----------------------------------------------------------
+        d = G["f4"]
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk, rec = self.blocks[i], tape["enc"][i]
+            dh, dres = TE.conv_bn_act_train_bwd(rec["u2"], d)
+            t = TE.conv_bn_act_train_bwd(rec["ud"], dres)[0] if "ud" in rec else dres
+            d, _ = TE.conv_bn_act_train_bwd(rec["u1"], dh, dx_residual=t)
+            if blk["bi"] == 0:
+                done(7 + 3 - blk["li"], self._stage_layers(blk["li"]))
+                if blk["li"] > 1:
+                    acc("f%d" % blk["li"], d)
+                    d = G["f%d" % blk["li"]]
+        d = TE.maxpool_bwd(tape["f1"], tape["idx1"], d, (1, 3, 3), (1, 2, 2), pads=(0, 1, 1), add=G["f1"])
+        TE.conv_bn_act_train_bwd(tape["stem"], d, need_dx=False)
+        done(10, [self.stem])

@@ -36,7 +36,7 @@ import torch.distributed as dist
 from .grad_reduce import GradBucketReducer
 from .losses import CrossEntropyLoss, NTXentLoss, TripletMarginLoss
 from . import train_engine as TE
-from .train_nets import FBTrainer, I3DTrainer, UNetTrainer
+from .train_nets import FBTrainer, I3DTrainer, UNetPPTrainer, UNetTrainer
 
 # anonymization_training/params_anonymization.py:28-62
 DEFAULT_PARAMS = SimpleNamespace(num_frames=16, learning_rate=1e-5, learning_rate_fa=0.4e-5, learning_rate_fb=1e-5,
@@ -68,8 +68,10 @@ class AnonymizerTrainStep:
     def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 1.0):
         self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
         self.loss_scale = float(loss_scale)
-        self.fa_tr, self.ft_tr = UNetTrainer(fa_model), I3DTrainer(ft_model)
+        from .unetpp import UnetPlusPlus
+        self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
         self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
+        self._fa_off_path = self.fa_tr.off_path_params() if hasattr(self.fa_tr, "off_path_params") else []   # unet++: encoder.layer4 (never run)
         self.opt_fa = torch.optim.Adam(fa_model.parameters(), lr=params.learning_rate_fa)     # train_anonymizer.py:377-380
         self.opt_ft = torch.optim.Adam(ft_model.parameters(), lr=params.learning_rate_ft)
         self.opt_fb = torch.optim.Adam(fb_model.parameters(), lr=params.learning_rate_fb) if fb_model is not None else None
@@ -134,7 +136,7 @@ class AnonymizerTrainStep:
         for opt in self._opts():
             opt.zero_grad(set_to_none=True)
         TE.ARENA.reset(inputs_video.device)
-        self.red_fa.prepare()                                         # fa's gradients: zeroed views into the buckets
+        self.red_fa.prepare(exclude=self._fa_off_path)                # fa's gradients: zeroed views into the buckets
         fb_ctx, loss_fb = [], None
         if views is not None:                                         # :80-84: fa (train mode) on each view, frozen fb
             for v in views:

@@ -12,7 +12,8 @@ The `state_dict` key names are smp's (`encoder.layer1.0.conv1.weight`, `decoder.
 `fa_model_state_dict` checkpoints load with strict=True. `encoder_weights='imagenet'` is a download in smp; there is no network in
 this build: the encoder starts from torchvision's random init and says so.
 
-forward((N,3,H,W)) -> (N,3,H,W), H and W multiples of 16 (smp's check_input_shape), NO output activation.
+forward((N,3,H,W)) -> (N,3,H,W), H and W multiples of 16 (smp's check_input_shape), NO output activation. In train() the forward
+goes through the autograd bridge (autograd.unetpp_forward -> train_nets.UNetPPTrainer: batch-statistics BatchNorm, tape, backward).
 
 Launch plan: every conv3x3 + BN + ReLU is one fused implicit-GEMM launch (2-D = kt 1); BasicBlock tails fuse bn2 + residual + ReLU;
 every tensor that is concatenated is written by its producer straight into its channel slice of the consumer's concat buffer, the
@@ -156,8 +157,10 @@ class UnetPlusPlus(nn.Module):
 
     def forward(self, x: torch.Tensor, taps=None) -> torch.Tensor:
         if self.training:
-            raise NotImplementedError("UnetPlusPlus in train() mode (batch-statistics BatchNorm + backward) is not built; the trainable "
-                                      "anonymizer of this build is arch='unet' (model_loaders.load_fa_model). Call .eval().")
+            # train(): batch-statistics BatchNorm + a tape for loss.backward() (train_anonymizer.py:73-123); under no_grad the same
+            # forward runs (running statistics still move, as in torch) and the tape is dropped
+            from .autograd import unetpp_forward
+            return unetpp_forward(self, x)
         E.require_cuda(x, "UnetPlusPlus")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected (N,3,H,W), got %s" % (tuple(x.shape),))

@@ -53,7 +53,7 @@ def reference_step1(fa_model, fb_model, ft_model, optimizer_fa, optimizer_fb, op
     loss_ft = loss_ft + params.temporal_loss_weight * loss_temporal
     loss_fa = -params.fb_loss_weight * loss_fb + params.ft_loss_weight * loss_ft
     loss_fa.backward()
-    grads = {k: p.grad.detach().clone() for k, p in fa_model.named_parameters()}
+    grads = {k: p.grad.detach().clone() for k, p in fa_model.named_parameters() if p.grad is not None}
     optimizer_fa.step()
     return dict(loss_fa=loss_fa.item(), loss_fb=loss_fb.item(), loss_ft=loss_ft.item(), loss_temporal=loss_temporal.item()), grads
 
@@ -122,6 +122,33 @@ def test_reference_phase1_statements_through_autograd():
     assert all(torch.equal(now[k], v) for k, v in frozen.items())                             # ft, fb untouched (eval mode, no step)
     assert all(p.grad is None for m in (fb, ft) for p in m.parameters())                      # Q8: the unused gradients are not formed
     assert int(fa.inc.double_conv[1].num_batches_tracked) == 3                                # Q14
+
+
+def test_reference_phase1_statements_with_the_default_unetpp_anonymizer():
+    """The same statements with `fa_model = load_fa_model()` -- the reference's default arch='unet++' (train_anonymizer.py:331,
+    model_loaders.py:17-30): UnetPlusPlus.forward in train() mode goes through the autograd bridge (UNetPPTrainer underneath)."""
+    from oracle import train_step_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.synth import synth_state_dict
+    _, fb, ft, opt, vispr, _, sd_l, sd_b = _setup()
+    fa = load_fa_model()
+    sd_u = synth_state_dict(fa.state_dict(), 0)
+    fa.load_state_dict(sd_u)
+    fa = fa.cuda()
+    opt[0] = torch.optim.Adam(fa.parameters(), lr=0.4e-5)
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, {k: v.clone() for k, v in sd_u.items()}, sd_l, vispr=vispr, fb_sd=sd_b)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    out, grads = reference_step1(fa, fb, ft, *opt, [v.cuda() for v in vispr], video.cuda(), labels.cuda())
+    assert abs(out["loss_fb"] - ref_l["loss_fb"]) < 1e-2 * abs(ref_l["loss_fb"])
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 1e-2 * abs(ref_l["loss_ft"])
+    assert set(grads) == set(ref_g) and not any(k.startswith("encoder.layer4.") for k in grads)
+    errs = _report("autograd phase 1: unet++ grads", grads, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.3 and max(errs.values()) < 0.45          # measured 0.20 / 0.28, min cosine 0.961
+    moved = {k: float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()}
+    assert all(v == 0.0 for k, v in moved.items() if k.startswith("encoder.layer4.")) and 0 < max(moved.values()) <= 1.05 * 0.4e-5
+    assert int(fa.encoder.bn1.num_batches_tracked) == 3                                       # Q14: two views + the video batch
 
 
 def test_reference_phase2_statements_through_autograd():

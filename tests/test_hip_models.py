@@ -117,10 +117,26 @@ def test_unetpp_eval_vs_oracle(unetpp, shape):
     assert rel_l2(y.cpu(), ref) < 2e-3
     with pytest.raises(RuntimeError):
         unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
-    unetpp.train()
-    with pytest.raises(NotImplementedError):
-        unetpp(frames.cuda())
-    unetpp.eval()
+    # train(): batch-statistics BatchNorm (train_anonymizer.py:73 puts fa in train mode), running statistics moved once per call
+    before = {k: v.clone() for k, v in unetpp.state_dict().items()}
+    try:
+        unetpp.train()
+        with torch.no_grad():
+            yt = unetpp(frames.cuda())
+            sd_t = {k: v.clone() for k, v in sd.items()}
+            ref_t = unetpp_ref.forward(frames, sd_t, train=True)
+        # batch statistics over as few as 2 x 14 x 14 values per channel renormalise every layer's 16-bit rounding error: 5e-3 measured at
+        # (2,3,224,224); the backward chain is held to the oracle in tests/test_hip_train_step.py::test_unetpp_backward_chain_tight_on_a_smooth_network
+        assert rel_l2(yt.cpu(), ref_t) < 1.2e-2
+        after = unetpp.state_dict()
+        for k in ("encoder.bn1.running_mean", "encoder.layer3.1.bn2.running_var", "decoder.blocks.x_0_2.conv1.1.running_mean",
+                  "decoder.blocks.x_0_3.conv2.1.running_var"):
+            assert rel_l2(after[k].cpu(), sd_t[k]) < 5e-3, k
+        assert int(after["encoder.bn1.num_batches_tracked"]) == int(before["encoder.bn1.num_batches_tracked"]) + 1
+        assert torch.equal(after["encoder.layer4.0.bn1.running_mean"], before["encoder.layer4.0.bn1.running_mean"])     # not on the path at depth 4
+    finally:
+        unetpp.load_state_dict(before)
+        unetpp.eval()
 
 
 def test_anonymized_extraction_with_unetpp(wrapper, unetpp):

@@ -82,6 +82,36 @@ def test_phase1_update_fa_vs_oracle(loss_scale):
     assert int(fa.inc.double_conv[1].num_batches_tracked) == 1   # UNet BN saw the B*48 pseudo-images once (Q14)
 
 
+def test_phase1_with_the_default_unetpp_anonymizer_vs_oracle():
+    """Phase 1 (train_anonymizer.py:73-123) with the reference's DEFAULT fa (arch='unet++', model_loaders.py:17-30) in the step driver:
+    losses and the gradients of every on-path unet++ parameter against the oracle (unetpp_ref in train mode -> i3res50_ref eval), the
+    Adam update, `encoder.layer4.*` untouched (no gradient: off the path at encoder_depth 4)."""
+    from oracle import train_step_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    _, ft, _, sd_l = _models()
+    fa = load_fa_model()
+    sd_u = synth_state_dict(fa.state_dict(), 0)
+    fa.load_state_dict(sd_u)
+    fa = fa.cuda()
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, sd_u, sd_l)
+    assert not any(k.startswith("encoder.layer4.") for k in ref_g) and "encoder.layer3.1.conv2.weight" in ref_g
+    step = AnonymizerTrainStep(fa, ft)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert out["phase"] == 1 and out["skipped"] is False
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 1e-2 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 1e-2 * abs(ref_l["loss_fa"])
+    errs = _report("phase1 unet++ grads", {k: p.grad for k, p in fa.named_parameters() if p.grad is not None}, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.3 and max(errs.values()) < 0.45      # measured 0.20 / 0.26, min cosine 0.964
+    moved = {k: float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()}
+    assert all(v == 0.0 for k, v in moved.items() if k.startswith("encoder.layer4."))
+    assert 0 < max(moved.values()) <= 1.05 * step.params.learning_rate_fa
+    assert int(fa.encoder.bn1.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize("loss_scale", [1.0, 256.0])
 def test_phase2_update_ft_vs_oracle(loss_scale):
     from oracle import train_step_ref
@@ -176,6 +206,39 @@ def test_unet_backward_chain_tight_on_a_smooth_network():
     errs = _report("unet chain (smooth)", {k: p.grad for k, p in fa.named_parameters()}, {k: v.grad for k, v in sdg.items() if v.requires_grad},
                    min_cos=0.998, med_cos=0.9998)
     assert max(errs.values()) < 5e-2 and float(np.median(list(errs.values()))) < 8e-3
+
+
+def test_unetpp_backward_chain_tight_on_a_smooth_network():
+    """UNetPPTrainer -- the reference's DEFAULT anonymizer (smp UnetPlusPlus, model_loaders.py:17-30) in train mode: train-mode BN,
+    BasicBlock residuals and strided downsample branches, the 3x3/2 max-pool, nearest upsampling, the dense skip pathway (tensors with
+    up to four consumers sum their gradient slices), dgrad + wgrad of all 30 on-path convs. `encoder.layer4.*` is off the path
+    (encoder_depth 4) and gets no gradient on either side."""
+    from oracle import unetpp_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.train_nets import UNetPPTrainer
+    fa = load_fa_model()
+    sd = _smooth(synth_state_dict(fa.state_dict(), 0))
+    fa.load_state_dict(sd)
+    fa = fa.cuda().train()
+    x = synth_tensor(0, "dbgupp", (6, 3, 64, 64))
+    sdg = _grad_sd(sd)
+    y = unetpp_ref.forward(x, sdg, train=True)
+    dy = synth_tensor(0, "dyupp", tuple(y.shape), -1, 1)
+    (y * dy).sum().backward()
+    tr = UNetPPTrainer(fa)
+    yy, tape = tr.forward(x.cuda())
+    assert rel_l2(yy.cpu(), y.detach()) < 3e-3
+    tr.backward(tape, dy.cuda())
+    tr.flush_grads()
+    ref = {k: v.grad for k, v in sdg.items() if v.requires_grad and v.grad is not None}
+    got = {k: p.grad for k, p in fa.named_parameters()}
+    assert all((got[k] is None) == (k not in ref) for k in got), [k for k in got if (got[k] is None) != (k not in ref)]
+    assert all(k.startswith("encoder.layer4.") for k in got if got[k] is None)
+    errs = _report("unet++ chain (smooth)", got, ref, min_cos=0.995, med_cos=0.9995)
+    assert max(errs.values()) < 8e-2 and float(np.median(list(errs.values()))) < 1.2e-2
+    after = fa.state_dict()
+    for k in ("encoder.bn1.running_var", "encoder.layer2.0.downsample.1.running_mean", "decoder.blocks.x_1_2.conv2.1.running_var"):
+        assert rel_l2(after[k].cpu(), sdg[k]) < 5e-3, k
 
 
 def test_i3d_backward_chains_tight_on_a_smooth_network():
