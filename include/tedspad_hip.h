@@ -106,6 +106,9 @@ typedef struct tedspad_conv_extras {
                             batch mean flips ReLU branches (DESIGN.md "training precision"). */
     int32_t     ldmask, stats_ld, ldy32;
     int32_t     out_strided, ost, osh, osw, oot, ooh, oow, tf, hf, wf;
+    int32_t     stats_rows;  /* 0: one set of statistics over all output rows. > 0 (>= 256): output rows [g*stats_rows, (g+1)*stats_rows) are
+                                statistics GROUP g and accumulate into stats + g*2*stats_ld -- the three clips of a training step run through the
+                                network as ONE batch while their BatchNorms keep separate batch statistics (train_anonymizer.py:169-175) */
 } tedspad_conv_extras;
 
 int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed,
@@ -263,7 +266,9 @@ int32_t tedspad_cross_entropy_fwd_bwd(const float *logits, const int64_t *labels
 int32_t tedspad_bn_train_apply(const float *z, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
                                float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
                                const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
-                               int32_t dtype, void *stream);
+                               int32_t groups, int32_t dtype, void *stream);
+/* groups (here and in the two backward entries below): the tensors hold `groups` consecutive blocks of `pixels` rows, each normalised with its OWN
+ * statistics (stats / sums: [groups][2][ld], mean / invstd: [groups][Cz]); the running statistics take the groups' momentum updates in order. */
 
 /* From the per-channel sum / sum-of-squares the conv epilogue accumulated (tedspad_conv_extras.stats) over
  * `count` pixels: batch mean / biased variance -> scale = gamma*invstd, shift = beta - mean*scale; updates
@@ -281,13 +286,13 @@ int32_t tedspad_scale_shift_act(const float *z, const float *scale, const float 
  * (second row skipped when z == NULL: plain per-channel sum = bias gradient). `sums` pre-zeroed. */
 int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
                               float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
-                              int32_t ldz, int32_t relu, int32_t dtype, void *stream);
+                              int32_t ldz, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 
 /* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input). */
 int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
                              const float *gamma, const float *sums, int32_t sums_ld, void *dz, void *dres,
                              int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
-                             int32_t lddres, int32_t relu, int32_t dtype, void *stream);
+                             int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 
 /* dx[i] = (add ? add[i] : 0) + sum over pooling windows o containing i of dy[o]*[argmax(o) == i]; `d` = forward
  * desc, idx from tedspad_maxpool_fwd_idx (first maximum wins, as torch). relu_mask != 0 additionally zeroes dx

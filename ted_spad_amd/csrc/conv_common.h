@@ -26,6 +26,7 @@ struct ConvKP {
     float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)
     float *y32;             // optional fp32 copy of the output (train-mode BN keeps the pre-normalisation conv output exact)
     int ldmask, stats_ld, ldy32;
+    int stats_rows;         // rows per statistics GROUP (0: all rows one group); group g accumulates into stats + g * 2 * stats_ld. A tile may straddle ONE boundary
     int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
     int ost, osh, osw, oot, ooh, oow, TF, HF, WF;
     // second source of the dual pointwise launch (conv_pw.hip, DUAL): x2 has the pixel grid of x, cin2 = 64

@@ -305,9 +305,11 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         __syncthreads();
     }
 
-    float s1[8], s2[8];
+    float s1[8], s2[8], t1[8], t2[8];      // t*: the rows of the tile that belong to the NEXT statistics group (grouped batch statistics)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; t1[i] = 0.f; t2[i] = 0.f; }
+    const int sgrp = p.stats_rows ? m0 / p.stats_rows : 0;
+    const int smb = p.stats_rows ? (sgrp + 1) * p.stats_rows : 0x7fffffff;     // first row of the next group
     auto out_row = [&](const int it, const uint4 rpre) {
         const int r = r0 + it * RPP;
         const int m = m0 + r;
@@ -325,8 +327,13 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
         if (p.stats) {
+            if (m < smb) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { t1[i] += v[i]; t2[i] += v[i] * v[i]; }
+            }
         }
         if (p.res) {
             float rr[8];
@@ -375,11 +382,27 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
             red[(RPP + r0) * BN + cc * 8 + i] = s2[i];
         }
         __syncthreads();
+        float *so = p.stats + (size_t)sgrp * 2 * p.stats_ld;
         if (tid < BN && n0 + tid < p.Cout) {
             float a = 0.f, b = 0.f;
             for (int r = 0; r < RPP; ++r) { a += red[r * BN + tid]; b += red[(RPP + r) * BN + tid]; }
-            atomicAdd(p.stats + n0 + tid, a);
-            atomicAdd(p.stats + p.stats_ld + n0 + tid, b);
+            atomicAdd(so + n0 + tid, a);
+            atomicAdd(so + p.stats_ld + n0 + tid, b);
+        }
+        if (smb < m0 + BM && smb < p.M) {       // the tile straddles a group boundary (workgroup-uniform)
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[r0 * BN + cc * 8 + i] = t1[i];
+                red[(RPP + r0) * BN + cc * 8 + i] = t2[i];
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.Cout) {
+                float a = 0.f, b = 0.f;
+                for (int r = 0; r < RPP; ++r) { a += red[r * BN + tid]; b += red[(RPP + r) * BN + tid]; }
+                atomicAdd(so + 2 * p.stats_ld + n0 + tid, a);
+                atomicAdd(so + 3 * p.stats_ld + n0 + tid, b);
+            }
         }
     }
 }
@@ -824,7 +847,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     p.tiles_n = 0;
     p.cin = d->cin; p.utap = (d->cin % BK == 0) ? 1 : 0;
     p.inv_wo = 1.0f / (float)d->wo; p.inv_ho = 1.0f / (float)d->ho; p.inv_to = 1.0f / (float)d->to;
-    p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
+    p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.stats_rows = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
     p.x2 = p.w2 = nullptr; p.scale2 = p.shift2 = nullptr; p.ldx2 = 0; p.nk1 = 0; p.Hi2 = p.Wi2 = 0; p.sh2 = p.sw2 = 1;
     if (dual && dual->nk1 > 0) {      // K-concatenated pair on the ping-pong kernel (tedspad_conv_p8_dual_fwd)
@@ -846,6 +869,8 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         TS_REQUIRE(!ex->stats || ex->stats_ld >= d->cout, "tedspad_conv_fwd_ex: stats_ld must be >= cout");
         TS_REQUIRE(!ex->y32 || (ex->ldy32 % 4 == 0 && ex->ldy32 >= d->cout && (uintptr_t)ex->y32 % 16 == 0), "tedspad_conv_fwd_ex: bad y32");
         p.mask = (const uint16_t *)ex->mask; p.ldmask = ex->ldmask; p.stats = ex->stats; p.stats_ld = ex->stats_ld;
+        p.stats_rows = ex->stats ? ex->stats_rows : 0;
+        TS_REQUIRE(p.stats_rows >= 0 && (p.stats_rows == 0 || p.stats_rows >= 256), "tedspad_conv_fwd_ex: stats_rows must be 0 or >= 256 (a tile of up to 256 rows may straddle one group boundary)");
         p.y32 = ex->y32; p.ldy32 = ex->ldy32;
         if (ex->out_strided) {
             TS_REQUIRE(ex->ost > 0 && ex->osh > 0 && ex->osw > 0 && ex->oot >= 0 && ex->ooh >= 0 && ex->oow >= 0 &&

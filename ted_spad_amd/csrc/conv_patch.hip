@@ -190,9 +190,16 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             }
         __syncthreads();
         const int nch = n0 + pass * 64 + cc * 8;
-        float s1[8], s2[8];
+        float s1[8], s2[8], t1[8], t2[8];       // t*: rows of the NEXT statistics group (grouped batch statistics; a tile straddles at most one boundary)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; t1[i] = 0.f; t2[i] = 0.f; }
+        size_t mfirst;                           // smallest output row of this tile
+        if (TEMP) {
+            const int nclip = tile_lin / g.tiles_w;
+            mfirst = (size_t)nclip * g.T * g.HW + (size_t)(tile_lin - nclip * g.tiles_w) * g.PXF;
+        } else mfirst = FLAT ? (size_t)q0 : ((size_t)b * p.Ho + ho0) * p.Wo + wo0;
+        const size_t sgrp = p.stats_rows ? mfirst / (size_t)p.stats_rows : 0;
+        const size_t smb = p.stats_rows ? (sgrp + 1) * (size_t)p.stats_rows : ~(size_t)0;
         if (nch < p.Cout) {
             float sc[8], sf[8];
 #pragma unroll
@@ -217,8 +224,13 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
                 if (p.stats) {          // batch statistics of the pre-activation (train-mode BatchNorm), as the generic epilogue
+                    if (m < smb) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                        for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { t1[i] += v[i]; t2[i] += v[i] * v[i]; }
+                    }
                 }
                 if (p.res) {
                     float rr[8];
@@ -252,11 +264,27 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 red[(32 + r0) * 64 + cc * 8 + i] = s2[i];
             }
             __syncthreads();
+            float *so = p.stats + sgrp * 2 * p.stats_ld;
             if (tid < 64 && n0 + pass * 64 + tid < p.Cout) {
                 float sa = 0.f, sb = 0.f;
                 for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
-                atomicAdd(p.stats + n0 + pass * 64 + tid, sa);
-                atomicAdd(p.stats + p.stats_ld + n0 + pass * 64 + tid, sb);
+                atomicAdd(so + n0 + pass * 64 + tid, sa);
+                atomicAdd(so + p.stats_ld + n0 + pass * 64 + tid, sb);
+            }
+            if (FLAT && p.stats_rows && smb < (size_t)q0 + 256 && smb < (size_t)p.M) {     // only flat tiles cross samples (workgroup-uniform)
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    red[r0 * 64 + cc * 8 + i] = t1[i];
+                    red[(32 + r0) * 64 + cc * 8 + i] = t2[i];
+                }
+                __syncthreads();
+                if (tid < 64 && n0 + pass * 64 + tid < p.Cout) {
+                    float sa = 0.f, sb = 0.f;
+                    for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
+                    atomicAdd(so + 2 * p.stats_ld + n0 + pass * 64 + tid, sa);
+                    atomicAdd(so + 3 * p.stats_ld + n0 + pass * 64 + tid, sb);
+                }
             }
         }
     }

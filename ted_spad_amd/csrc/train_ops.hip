@@ -79,20 +79,30 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, con
                                                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                                                               float *mean_out, float *invstd_out, int C, const uint16_t *res, uint16_t *y, long pixels,
                                                               int C8, int ldz, int ldres, int ldy, int relu) {
-    if (blockIdx.x == 0) {
+    // statistics GROUPS (gridDim.y): group g = rows [g * pixels, (g + 1) * pixels) with its own sums, mean and invstd -- the three clips
+    // of a training step normalised separately in one launch (train_anonymizer.py:169-175 calls ft_model three times)
+    const int grp = blockIdx.y;
+    if (blockIdx.x == 0 && grp == 0) {
         for (int c = threadIdx.x; c < C; c += 256) {
-            const float mean = stats[c] / count;
-            float var = stats[stats_ld + c] / count - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            mean_out[c] = mean;
-            invstd_out[c] = rsqrtf(var + eps);
-            if (running_mean) {
-                const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+            for (int g = 0; g < (int)gridDim.y; ++g) {                       // the running statistics take the groups' updates in order
+                const float *st = stats + (size_t)g * 2 * stats_ld;
+                const float mean = st[c] / count;
+                float var = st[stats_ld + c] / count - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                mean_out[(size_t)g * C8 * 8 + c] = mean;
+                invstd_out[(size_t)g * C8 * 8 + c] = rsqrtf(var + eps);
+                if (running_mean) {
+                    const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+                }
             }
         }
     }
+    stats += (size_t)grp * 2 * stats_ld;
+    z += (size_t)grp * pixels * ldz;
+    y += (size_t)grp * pixels * ldy;
+    if (res) res += (size_t)grp * pixels * ldres;
     const long total = pixels * C8;
     const long stride = (long)gridDim.x * 256;
     const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration
@@ -154,6 +164,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
     const int cg = blockIdx.x % cgroups;
     const int pb = blockIdx.x / cgroups, pblocks = gridDim.x / cgroups;
     const int c8 = cg * C8L + cl;
+    {   // statistics group (gridDim.y): rows [grp * pixels, (grp + 1) * pixels), its own mean / invstd / sums
+        const int grp = blockIdx.y;
+        dy += (size_t)grp * pixels * lddy;
+        if (y) y += (size_t)grp * pixels * ldy;
+        if (z) { z += (size_t)grp * pixels * ldz; mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8; }
+        out += (size_t)grp * 2 * out_ld;
+    }
     float s0[8], s1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
@@ -202,6 +219,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
                                                             const float *invstd, const float *gamma, const float *sums, int sums_ld,
                                                             float inv_count, uint16_t *dz, uint16_t *dres, long pixels, int C8, int lddy,
                                                             int ldy, int ldz, int lddz, int lddres, int relu) {
+    {   // statistics group (gridDim.y)
+        const int grp = blockIdx.y;
+        dy += (size_t)grp * pixels * lddy;
+        if (y) y += (size_t)grp * pixels * ldy;
+        z += (size_t)grp * pixels * ldz;
+        mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8;
+        sums += (size_t)grp * 2 * sums_ld;
+        dz += (size_t)grp * pixels * lddz;
+        if (dres) dres += (size_t)grp * pixels * lddres;
+    }
     const long total = pixels * C8;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c8 = (int)(idx % C8);
@@ -440,26 +467,26 @@ extern "C" int32_t tedspad_scale_shift_act(const float *z, const float *scale, c
 
 extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, float *sums,
                                          int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t relu,
-                                         int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && (!z || (mean && invstd)) && sums_ld >= C,
+                                         int32_t groups, int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && (!z || (mean && invstd)) && sums_ld >= C && groups >= 1 && groups < 65536,
                "tedspad_bn_bwd_reduce: bad arguments");
     const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
     long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
     if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups)), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd,
+    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd,
              sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
     return check_launch("tedspad_bn_bwd_reduce");
 }
 
 extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, const float *gamma,
                                         const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
-                                        int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y),
+                                        int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && groups >= 1 && groups < 65536,
                "tedspad_bn_bwd_apply: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8))), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd, gamma,
+    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8)), groups), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd, gamma,
              sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
     return check_launch("tedspad_bn_bwd_apply");
 }
@@ -519,12 +546,12 @@ extern "C" int32_t tedspad_channels_last_to_nchw_strided(const void *x, float *y
 extern "C" int32_t tedspad_bn_train_apply(const float *z, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
                                           float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
                                           const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
-                                          int32_t dtype, void *stream) {
+                                          int32_t groups, int32_t dtype, void *stream) {
     TS_REQUIRE(z && stats && gamma && beta && mean && invstd && y && count > 0 && pixels > 0 && C > 0 && Cz >= C && Cz % 8 == 0 && stats_ld >= C && ldz % 4 == 0 &&
-                   ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0,
+                   ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0 && groups >= 1 && groups < 65536,
                "tedspad_bn_train_apply: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8))), z, stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
+    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8)), groups), z, stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
              running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
     return check_launch("tedspad_bn_train_apply");
 }

@@ -446,8 +446,12 @@ class PackedConv:
             if mask is not None:
                 ex.mask, ex.ldmask = mask.ptr, mask.ld
             if stats is not None:
-                assert stats.dtype == torch.float32 and stats.dim() == 2 and stats.shape[0] == 2 and stats.shape[1] >= self.cout
-                ex.stats, ex.stats_ld = stats.data_ptr(), stats.shape[1]
+                assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[-2] == 2 and stats.shape[-1] >= self.cout
+                ex.stats, ex.stats_ld = stats.data_ptr(), stats.shape[-1]
+                if stats.dim() == 3 and stats.shape[0] > 1:          # (G, 2, ld): G groups of consecutive samples with their own statistics
+                    rows = n * o[0] * o[1] * o[2]
+                    assert n % stats.shape[0] == 0 and rows // stats.shape[0] >= 256, "grouped batch statistics need >= 256 output rows per group"
+                    ex.stats_rows = rows // stats.shape[0]
             if out_map is not None:
                 (ex.ost, ex.osh, ex.osw), (ex.oot, ex.ooh, ex.oow) = out_map
                 ex.out_strided = 1
@@ -494,6 +498,7 @@ class PackedConv:
         if n * worst < MAX_ELEMS:               # the common case: one launch
             self._run(x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid)
         else:
+            assert stats is None or stats.dim() == 2 or stats.shape[0] == 1, "grouped batch statistics: the batch must fit one launch"
             nc = batch_chunk(n, [worst], MAX_ELEMS)
             sub = lambda a, n0, n1: None if a is None else Act(a.buf[n0:n1], a.c, a.coff)
             for n0 in range(0, n, nc):

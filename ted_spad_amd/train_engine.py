@@ -304,42 +304,49 @@ class ConvLayer:
 
 # ---- per-channel reductions / BatchNorm ---------------------------------------------------------------
 
-def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = None, mean=None, invstd=None, relu=False) -> torch.Tensor:
+def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = None, mean=None, invstd=None, relu=False, groups: int = 1) -> torch.Tensor:
     """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu).
-    z: the fp32 (n,t,h,w,C) pre-normalisation conv output."""
+    z: the fp32 (n,t,h,w,C) pre-normalisation conv output. groups > 1: (groups, 2, C), one set per block of n / groups samples."""
     n, t, h, w = dy.dims
-    sums = ARENA.take((2, dy.c), dy.buf.device)
+    sums = ARENA.take((2, dy.c) if groups == 1 else (groups, 2, dy.c), dy.buf.device)
     check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.data_ptr() if z is not None else None,
                                            mean.data_ptr() if mean is not None else None, invstd.data_ptr() if invstd is not None else None,
-                                           sums.data_ptr(), dy.c, n * t * h * w, dy.c, dy.ld, y.ld if y is not None else 0,
-                                           z.shape[-1] if z is not None else 0, int(relu), _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
+                                           sums.data_ptr(), dy.c, n * t * h * w // groups, dy.c, dy.ld, y.ld if y is not None else 0,
+                                           z.shape[-1] if z is not None else 0, int(relu), groups, _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
     return sums
 
 
 class BNTrainCtx:
-    __slots__ = ("x", "z", "y", "mean", "invstd", "bn", "conv", "relu", "has_res")
+    __slots__ = ("x", "z", "y", "mean", "invstd", "bn", "conv", "relu", "has_res", "groups")
 
 
-def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional[Act] = None, out: Optional[Act] = None):
+def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional[Act] = None, out: Optional[Act] = None, groups: int = 1):
     """conv -> BatchNorm(batch statistics, running stats updated) -> (+residual) -> ReLU. Returns (y, ctx).
-    The pre-normalisation conv output z stays in fp32 (it is re-read by the BN apply and by the backward)."""
+    The pre-normalisation conv output z stays in fp32 (it is re-read by the BN apply and by the backward).
+    groups > 1: the batch is `groups` consecutive blocks of samples, each normalised with its own batch statistics and the running
+    statistics updated once per block, in order -- `groups` separate forward calls of the module (the three clips of a training step,
+    train_anonymizer.py:169-175) as ONE launch sequence."""
     pc = conv.fwd_conv()
-    stats = ARENA.take((2, pc.cpad), x.buf.device)
+    stats = ARENA.take((2, pc.cpad) if groups == 1 else (groups, 2, pc.cpad), x.buf.device)
     z = conv.forward(x, stats=stats, y32=True)                       # (n,t,h,w,cout) fp32
     n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
-    mean, invstd = ARENA.take((2, cz), x.buf.device).unbind(0)
-    bump_counter(bn.num_batches_tracked)
+    assert n % groups == 0
+    mean, invstd = ARENA.take((2, groups, cz), x.buf.device).unbind(0)
+    for _ in range(groups):
+        bump_counter(bn.num_batches_tracked)
     tdt = E.DTYPES[conv.dtype][0]
     y = out if out is not None else Act.empty(n, t, h, w, cz, tdt, z.device)
     # batch mean / variance -> scale / shift, the running-statistics update and the normalisation itself in ONE launch
-    check(_lib.lib().tedspad_bn_train_apply(z.data_ptr(), stats.data_ptr(), pc.cpad, n * t * h * w, bn.weight.data_ptr(), bn.bias.data_ptr(),
+    rows = n * t * h * w // groups
+    check(_lib.lib().tedspad_bn_train_apply(z.data_ptr(), stats.data_ptr(), pc.cpad, rows, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                             C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                             mean.data_ptr(), invstd.data_ptr(), c, residual.ptr if residual is not None else None, y.ptr,
-                                            n * t * h * w, cz, cz, residual.ld if residual is not None else 0, y.ld, int(relu), _code(y.buf),
+                                            rows, cz, cz, residual.ld if residual is not None else 0, y.ld, int(relu), groups, _code(y.buf),
                                             _stream_ptr()), "tedspad_bn_train_apply")
     ctx = BNTrainCtx()
     ctx.x, ctx.z, ctx.y, ctx.mean, ctx.invstd, ctx.bn, ctx.conv, ctx.relu, ctx.has_res = x, z, y, mean, invstd, bn, conv, relu, residual is not None
+    ctx.groups = groups
     return y, ctx
 
 
@@ -350,7 +357,8 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
     bn, z, y = ctx.bn, ctx.z, ctx.y
     n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
-    sums = channel_sums(dy, y, z, ctx.mean, ctx.invstd, relu=ctx.relu)
+    G = ctx.groups
+    sums = channel_sums(dy, y, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G)
     dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
     dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
     if cz == c:
@@ -359,11 +367,12 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
         gam = torch.zeros(cz, dtype=torch.float32, device=z.device)
         gam[:c] = bn.weight.detach()
     check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, y.ptr, z.data_ptr(), ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
-                                          sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w, cz,
-                                          dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu),
+                                          sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w // G, cz,
+                                          dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu), G,
                                           _code(y.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
-    defer_grad(bn.bias, sums[0, :c])
-    defer_grad(bn.weight, sums[1, :c])
+    for sg in (sums.unbind(0) if G > 1 else (sums,)):                # d(beta), d(gamma): the groups' sums add up
+        defer_grad(bn.bias, sg[0, :c])
+        defer_grad(bn.weight, sg[1, :c])
     ctx.conv.wgrad(ctx.x, dz)
     dx = None
     if need_dx:

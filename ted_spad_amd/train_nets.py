@@ -63,6 +63,25 @@ def _bn1d_train_bwd(ctx, bn, dy):
     return dx, dg, db
 
 
+def _bn1d_train_groups(x, bn, relu, groups):
+    """BatchNorm1d in train mode on `groups` consecutive row blocks of x, each with its own batch statistics (the module called once per
+    block, in order: the running statistics take one momentum update per block)."""
+    if groups == 1:
+        y, ctx = _bn1d_train(x, bn, relu)
+        return y, [ctx]
+    nb = x.shape[0] // groups
+    parts = [_bn1d_train(x[g * nb:(g + 1) * nb], bn, relu) for g in range(groups)]
+    return torch.cat([p[0] for p in parts]), [p[1] for p in parts]
+
+
+def _bn1d_train_bwd_groups(ctxs, bn, dy):
+    if len(ctxs) == 1:
+        return _bn1d_train_bwd(ctxs[0], bn, dy)
+    nb = dy.shape[0] // len(ctxs)
+    parts = [_bn1d_train_bwd(c, bn, dy[g * nb:(g + 1) * nb]) for g, c in enumerate(ctxs)]
+    return torch.cat([p[0] for p in parts]), sum(p[1] for p in parts), sum(p[2] for p in parts)
+
+
 def _l2norm_bwd(x, dy, eps=1e-12):
     dx = torch.empty_like(x)
     dy = dy.contiguous().float()
@@ -116,14 +135,15 @@ class BottleneckTrunk:
             self._folds[id(bn)] = hit
         return hit[1], hit[2]
 
-    def forward(self, a: Act, train: bool, frozen: bool = False):
-        """a: the pixel-pair input Act. Returns (f (B,C) fp32 pooled feature, tape)."""
+    def forward(self, a: Act, train: bool, frozen: bool = False, groups: int = 1):
+        """a: the pixel-pair input Act. Returns (f (B,C) fp32 pooled feature, tape).
+        groups (train mode): the batch is `groups` blocks of samples whose BatchNorms keep separate batch statistics (TE.conv_bn_act_train)."""
         assert not (train and frozen)
         tape = dict(train=train, frozen=frozen, units=[], clip=a)
 
         def unit(conv, bn, xin, relu=True, residual=None):
             if train:
-                return TE.conv_bn_act_train(conv, bn, xin, relu=relu, residual=residual)
+                return TE.conv_bn_act_train(conv, bn, xin, relu=relu, residual=residual, groups=groups)
             s, b = self.fold(bn)
             return conv.forward(xin, scale=s, shift=b, relu=relu, residual=residual), (conv, s)
 
@@ -282,20 +302,43 @@ class I3DTrainer:
     def _fold(self, bn):
         return self.trunk.fold(bn)
 
+    def min_group_rows(self, x_shape, groups: int) -> int:
+        """Rows (samples x output positions) per statistics group at the SMALLEST BatchNorm of the trunk (layer4) for an input of
+        `x_shape` split into `groups` blocks: grouped statistics need >= 256 of them (one tile straddles at most one group boundary)."""
+        B, _, t, h, w = x_shape
+        co = E.conv_out
+        st = self.stem
+        (kt, kh, kw), (s0, s1, s2), (p0, p1, p2) = tuple(st._w5().shape[2:]), st.stride, st.pads
+        t, h, w = co(t, kt, s0, p0, p0), co(h, kh, s1, p1, p1), co(w, kw, s2, p2, p2)
+        (k, s, pd) = self.trunk.pool1
+        t, h, w = co(t, k[0], s[0], pd[0], pd[0]), co(h, k[1], s[1], pd[1], pd[1]), co(w, k[2], s[2], pd[2], pd[2])
+        for d in self.blocks:
+            if d["pre_pool"] is not None:
+                (k, s) = d["pre_pool"]
+                t, h, w = co(t, k[0], s[0], 0, 0), co(h, k[1], s[1], 0, 0), co(w, k[2], s[2], 0, 0)
+            s2_ = d["c2"].stride
+            h, w = co(h, 3, s2_[1], 1, 1), co(w, 3, s2_[2], 1, 1)
+        return (B // groups) * t * h * w
+
     # ---- forward ---------------------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, mode: str, drop_mask: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, mode: str, drop_mask: Optional[torch.Tensor] = None, groups: int = 1):
         """x: (B,3,T,H,W) fp32 (any strides: a `torch.split` view is fine).
-        Returns (pred (B,nc), feat (B,128), tape)."""
+        Returns (pred (B,nc), feat (B,128), tape).
+        groups > 1: x holds `groups` batches of B / groups clips that the reference passes through the module in SEPARATE calls (the three
+        clips of an iteration, train_anonymizer.py:169-175): every train-mode BatchNorm (3d in the trunk, 1d in the mlp head) normalises each
+        block with its own batch statistics and updates its running statistics once per block, in order -- the same arithmetic as the
+        separate calls, a third of the launches, three times the work per launch."""
         assert mode in ("eval", "train", "frozen")
         i3d, mlp = self.m.i3d, self.m.mlp
         E.require_cuda(x, "I3DTrainer")
-        if x.shape[0] < 2:
+        if x.shape[0] < 2 * groups or x.shape[0] % groups:
             raise ValueError("wrapper_i3d.forward needs B >= 2 (BatchNorm1d; SURVEY.md Q3)")
         # 'frozen' (train_anonymized_action.py:39-40): freeze_bn swaps only the BatchNorm3d modules of the trunk; dropout and the
         # mlp head's BatchNorm1d keep following the module's train flag, i.e. behave as in 'train'
         train = mode in ("train", "frozen")
-        f, tape = self.trunk.forward(E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype), mode == "train", frozen=mode == "frozen")   # feat = x.squeeze() BEFORE dropout
-        tape["mode"], tape["x_shape"] = mode, tuple(x.shape)
+        f, tape = self.trunk.forward(E.clip_to_act(x, cpad=4, dtype=i3d.compute_dtype), mode == "train", frozen=mode == "frozen",
+                                     groups=groups if mode == "train" else 1)                  # feat = x.squeeze() BEFORE dropout
+        tape["mode"], tape["x_shape"], tape["groups"] = mode, tuple(x.shape), groups
         # ---- head: fc on dropout(f) ; mlp on f ---------------------------------------------------------------------
         fd = f
         if train and i3d.drop_p > 0:
@@ -306,9 +349,9 @@ class I3DTrainer:
         pred = head.linear(fd, i3d.fc.weight, i3d.fc.bias)
         if train:
             z1 = head.linear(f, mlp.fc1.weight, mlp.fc1.bias)
-            h, tape["bn1"] = _bn1d_train(z1, mlp.bn1, relu=True)
+            h, tape["bn1"] = _bn1d_train_groups(z1, mlp.bn1, True, groups)
             z2 = head.linear(h, mlp.fc2.weight, None)
-            g, tape["bn2"] = _bn1d_train(z2, mlp.bn2, relu=False)
+            g, tape["bn2"] = _bn1d_train_groups(z2, mlp.bn2, False, groups)
             tape["h"], tape["g"] = h, g
             feat = head.l2_normalize(g)
         else:
@@ -346,11 +389,11 @@ class I3DTrainer:
         if dfeat is not None:
             dg = _l2norm_bwd(g, dfeat)
             if train:
-                dz2, dgam, dbet = _bn1d_train_bwd(tape["bn2"], mlp.bn2, dg)
+                dz2, dgam, dbet = _bn1d_train_bwd_groups(tape["bn2"], mlp.bn2, dg)
                 _acc_grad(mlp.bn2.weight, dgam); _acc_grad(mlp.bn2.bias, dbet)
                 dh, dw2, _ = _linear_bwd(h, mlp.fc2.weight, dz2)
                 _acc_grad(mlp.fc2.weight, dw2)
-                dz1, dgam, dbet = _bn1d_train_bwd(tape["bn1"], mlp.bn1, dh)
+                dz1, dgam, dbet = _bn1d_train_bwd_groups(tape["bn1"], mlp.bn1, dh)
                 _acc_grad(mlp.bn1.weight, dgam); _acc_grad(mlp.bn1.bias, dbet)
                 dfm, dw1, db1 = _linear_bwd(f, mlp.fc1.weight, dz1)
                 _acc_grad(mlp.fc1.weight, dw1); _acc_grad(mlp.fc1.bias, db1)

@@ -30,6 +30,8 @@ from __future__ import annotations
 
 from types import SimpleNamespace
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -68,6 +70,7 @@ class AnonymizerTrainStep:
     def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 1.0):
         self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
         self.loss_scale = float(loss_scale)
+        self.batch_clips = os.environ.get("TEDSPAD_TRAIN_BATCH_CLIPS", "1") != "0"   # the three clips of an iteration as one ft batch (0: three passes, A/B)
         from .unetpp import UnetPlusPlus
         self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
         self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
@@ -149,10 +152,16 @@ class AnonymizerTrainStep:
         anon = anon_flat.reshape(shape)                               # :92
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)          # :94 (non-contiguous views, Q15)
         tapes, leaves = [], []
-        for c in clips:
-            pred, feat, tape = self.ft_tr.forward(c, "eval")
-            tapes.append(tape)
-            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
+        if self.batch_clips:          # ft is frozen here (BatchNorm folded): the three clips are independent samples of ONE batch
+            nb = clips[0].shape[0]
+            pred, feat, tape3 = self.ft_tr.forward(torch.cat(clips, dim=0), "eval")
+            P3, F3 = pred.detach().requires_grad_(), feat.detach().requires_grad_()
+            leaves = [(P3[k * nb:(k + 1) * nb], F3[k * nb:(k + 1) * nb]) for k in range(3)]
+        else:
+            for c in clips:
+                pred, feat, tape = self.ft_tr.forward(c, "eval")
+                tapes.append(tape)
+                leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
         loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
         loss_fa = p.ft_loss_weight * loss_ft                          # :119
         if loss_fb is not None:
@@ -160,9 +169,13 @@ class AnonymizerTrainStep:
         loss_fa.backward()
         for tape_u, tape_b, z in fb_ctx:
             self.fa_tr.backward(tape_u, self.fb_tr.backward(tape_b, self._scaled(z.grad)))
-        danon = torch.zeros(shape, dtype=torch.float32, device=anon.device)
-        for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
-            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad), dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
+        if self.batch_clips:
+            d3 = self.ft_tr.backward(tape3, self._scaled(P3.grad), self._scaled(F3.grad))                    # (3B,3,16,H,W)
+            danon = torch.cat(torch.split(d3, d3.shape[0] // 3, dim=0), dim=2)                              # (B,3,48,H,W)
+        else:
+            danon = torch.zeros(shape, dtype=torch.float32, device=anon.device)
+            for k, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
+                self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad), dx_out=danon[:, :, k * p.num_frames:(k + 1) * p.num_frames])
         self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape), on_bucket_done=self.red_fa.bucket_ready)   # fa's last backward pass of the step
         self.fa_tr.flush_grads()
         self.red_fa.finish()
@@ -172,6 +185,33 @@ class AnonymizerTrainStep:
         self.iteration += 1
         return dict(phase=1, loss_fa=float(loss_fa.detach()), loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
                     loss_fb=None if loss_fb is None else float(loss_fb.detach()), skipped=not ok)
+
+    def _three_clips(self, clips, labels, mode, drop_masks):
+        """Forward + loss + backward of ft ('train' / 'frozen') on the three clips of an iteration (:169-175 / action :64-84). The reference
+        calls ft_model once per clip; here the three calls are ONE launch sequence over a batch of three GROUPS whose train-mode
+        BatchNorms keep separate batch statistics and update their running statistics group after group (I3DTrainer.forward, groups=3) --
+        whenever every BatchNorm of the trunk sees >= 256 values per channel and group; otherwise three passes as before."""
+        nb = clips[0].shape[0]
+        shape3 = (3 * nb,) + tuple(clips[0].shape[1:])
+        if self.batch_clips and (mode == "frozen" or self.ft_tr.min_group_rows(shape3, 3) >= 256):
+            dm = None if drop_masks is None else torch.cat([m for m in drop_masks], dim=0)
+            pred, feat, tape = self.ft_tr.forward(torch.cat(clips, dim=0), mode, drop_mask=dm, groups=3)
+            P3, F3 = pred.detach().requires_grad_(), feat.detach().requires_grad_()
+            losses = self._utility_losses([(P3[k * nb:(k + 1) * nb], F3[k * nb:(k + 1) * nb]) for k in range(3)], labels)
+            losses[0].backward()
+            self.ft_tr.backward(tape, self._scaled(P3.grad), self._scaled(F3.grad), on_bucket_done=self.red_ft.bucket_ready)
+            return losses
+        tapes, leaves = [], []
+        for k, c in enumerate(clips):
+            pred, feat, tape = self.ft_tr.forward(c, mode, drop_mask=None if drop_masks is None else drop_masks[k])
+            tapes.append(tape)
+            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
+        losses = self._utility_losses(leaves, labels)
+        losses[0].backward()
+        for j, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):     # the third clip's pass finishes every bucket -> all-reduce under it
+            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad),
+                                on_bucket_done=self.red_ft.bucket_ready if j == len(tapes) - 1 else None)
+        return losses
 
     # ---- phase 2 --------------------------------------------------------------------------------------------------
     def step_ft(self, inputs_video, labels, drop_masks=None, inputs_vispr=None):
@@ -207,16 +247,7 @@ class AnonymizerTrainStep:
             if ok_fb:
                 self.opt_fb.step()
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)
-        tapes, leaves = [], []
-        for k, c in enumerate(clips):
-            pred, feat, tape = self.ft_tr.forward(c, "train", drop_mask=None if drop_masks is None else drop_masks[k])
-            tapes.append(tape)
-            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
-        loss_ft, loss_ce, loss_trip = self._utility_losses(leaves, labels)
-        loss_ft.backward()                                            # :191
-        for j, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):     # the third clip's pass finishes every bucket -> all-reduce under it
-            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad),
-                                on_bucket_done=self.red_ft.bucket_ready if j == len(tapes) - 1 else None)
+        loss_ft, loss_ce, loss_trip = self._three_clips(clips, labels, "train", drop_masks)             # :169-175,191
         self.ft_tr.flush_grads()
         self.red_ft.finish()
         ok = self._unscale(self.ft)
@@ -241,16 +272,7 @@ class AnonymizerTrainStep:
         with torch.no_grad():
             anon = self.fa(frames).reshape(shape)                     # :56-57
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)          # :62
-        tapes, leaves = [], []
-        for k, c in enumerate(clips):
-            pred, feat, tape = self.ft_tr.forward(c, "frozen", drop_mask=None if drop_masks is None else drop_masks[k])
-            tapes.append(tape)
-            leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
-        loss, loss_ce, loss_trip = self._utility_losses(leaves, labels)
-        loss.backward()
-        for j, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):
-            self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad),
-                                on_bucket_done=self.red_ft.bucket_ready if j == len(tapes) - 1 else None)
+        loss, loss_ce, loss_trip = self._three_clips(clips, labels, "frozen", drop_masks)
         self.ft_tr.flush_grads()
         self.red_ft.finish()
         ok = self._unscale(self.ft)

@@ -126,6 +126,52 @@ def test_conv_bn_relu_train_fwd_bwd(with_res):
         assert rel_l2(nc(dres), res.grad) < 1e-3
 
 
+@pytest.mark.parametrize("k,cfg", [((1, 3, 3), None), ((1, 1, 1), None), ((1, 3, 3), 32), ((1, 3, 3), 33), ((1, 3, 3), 3), ((1, 1, 1), 1)])
+def test_conv_bn_relu_train_grouped_statistics(k, cfg, monkeypatch):
+    """groups = 3: ONE launch sequence over a batch of three blocks of samples, each normalised with its own batch statistics and the
+    running statistics updated block after block -- against torch calling conv + BatchNorm3d(train) three times (the three clips of a
+    training iteration, train_anonymizer.py:169-175). 576 rows per group: the 256-row tiles straddle the group boundaries."""
+    from ted_spad_amd import engine as E, train_engine as TE
+    from ted_spad_amd.params import BNParams
+    monkeypatch.setattr(E, "FORCE_TILE_CFG", cfg)        # the generic tiles (64 .. 256 rows) and the chunk-major patch / flat tiles: both epilogues
+    cin, cout, thw, G = 64, 128, (2, 12, 12), 3
+    pad = (0, k[1] // 2, k[2] // 2)
+    x = synth_tensor(4, "gx", (2 * G, cin) + thw, -1, 1).to(H).float().requires_grad_()
+    w = (synth_tensor(4, "gw", (cout, cin) + k, -1, 1) * (0.06 if k[1] == 3 else 0.15)).to(H).float().requires_grad_()
+    g = synth_tensor(4, "gg", (cout,), 0.5, 1.5).requires_grad_()
+    be = synth_tensor(4, "gbe", (cout,), -0.3, 0.3).requires_grad_()
+    rm, rv = synth_tensor(4, "grm", (cout,), -0.1, 0.1), synth_tensor(4, "grv", (cout,), 0.5, 1.5)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    gain = torch.tensor([1.0, 0.5, 2.0]).repeat_interleave(2).view(-1, 1, 1, 1, 1)          # the groups have different statistics
+    z = F.conv3d(x * gain, w, None, padding=pad)
+    u = torch.cat([F.batch_norm(z[2 * i:2 * i + 2], rm_ref, rv_ref, g, be, training=True, momentum=0.1, eps=1e-5) for i in range(G)])
+    res = synth_tensor(4, "gres", tuple(u.shape), -1, 1).to(H).float().requires_grad_()
+    y = F.relu(u + res)
+    dy = synth_tensor(4, "gdy", tuple(y.shape), -1, 1).to(H).float() * ((u + res).detach().abs() > 0.02)
+    y.backward(dy)
+    bn = BNParams(cout).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(g); bn.bias.copy_(be); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    wp = torch.nn.Parameter(w.detach().clone().cuda())
+    layer = TE.ConvLayer(wp, None, (1, 1, 1), pad)
+    xin = cl((x.detach() * gain).to(H).float())
+    ya, ctx = TE.conv_bn_act_train(layer, bn, xin, relu=True, residual=cl(res.detach()), groups=G)
+    assert rel_l2(nc(ya), y.detach()) < 2e-3
+    for i in range(G):                                   # every group on its own: a wrong group boundary shows here first
+        assert rel_l2(nc(ya)[2 * i:2 * i + 2], y.detach()[2 * i:2 * i + 2]) < 2e-3, i
+    assert rel_l2(bn.running_mean.cpu(), rm_ref) < 1e-3 and rel_l2(bn.running_var.cpu(), rv_ref) < 1e-3
+    TE.flush_deferred()
+    assert int(bn.num_batches_tracked) == G
+    dx, dres = TE.conv_bn_act_train_bwd(ctx, cl(dy))
+    layer.flush_grad()
+    TE.flush_deferred()
+    xg = x.grad / gain                                    # d/d(x * gain)
+    assert rel_l2(nc(dx), xg) < 5e-3
+    assert rel_l2(wp.grad.cpu(), w.grad) < 5e-3
+    assert rel_l2(bn.weight.grad.cpu(), g.grad) < 5e-3 and rel_l2(bn.bias.grad.cpu(), be.grad) < 5e-3
+    assert rel_l2(nc(dres), res.grad) < 1e-3
+
+
 def test_pool_and_upsample_backward():
     from ted_spad_amd import engine as E, train_engine as TE
     # max-pool (2,3,3)/(2,2,2) with overlapping windows + accumulated extra gradient + ReLU mask
