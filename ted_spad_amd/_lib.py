@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
 
 class ConvExtras(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("stats", C.c_void_p), ("y32", C.c_void_p)] + [(n, C.c_int32) for n in (
-        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "stats_rows")]
+        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "fold_hw", "fold_c", "fold_ldy", "stats_rows")]
 
 
 class PoolDesc(C.Structure):

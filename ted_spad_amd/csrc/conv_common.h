@@ -26,6 +26,9 @@ struct ConvKP {
     float *stats;           // [2][stats_ld]: per-channel sum / sum of squares of the pre-activation (BatchNorm batch statistics)
     float *y32;             // optional fp32 copy of the output (train-mode BN keeps the pre-normalisation conv output exact)
     int ldmask, stats_ld, ldy32;
+    int fold_hw, fold_c, fold_f;   // ping-pong kernel only: output channel n of row m = sample * fold_hw + px is stored as channel n % fold_c of row
+                            // (sample * fold_f + n / fold_c) * fold_hw + px (fold_f = cout / fold_c output FRAMES folded into the channel dimension);
+                            // scale / shift are fold_c long. 0: off
     int stats_rows;         // rows per statistics GROUP (0: all rows one group); group g accumulates into stats + g * 2 * stats_ld. A tile may straddle ONE boundary
     int ostrided;           // output pixel (n,to,ho,wo) -> (n, to*ost+oot, ho*osh+ooh, wo*osw+oow) of a (TF,HF,WF) tensor
     int ost, osh, osw, oot, ooh, oow, TF, HF, WF;

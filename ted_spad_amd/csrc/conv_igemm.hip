@@ -848,6 +848,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     p.cin = d->cin; p.utap = (d->cin % BK == 0) ? 1 : 0;
     p.inv_wo = 1.0f / (float)d->wo; p.inv_ho = 1.0f / (float)d->ho; p.inv_to = 1.0f / (float)d->to;
     p.mask = nullptr; p.stats = nullptr; p.ldmask = 0; p.stats_ld = 0; p.stats_rows = 0; p.ostrided = 0; p.y32 = nullptr; p.ldy32 = 0;
+    p.fold_hw = 0; p.fold_c = 0; p.fold_f = 1;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
     p.x2 = p.w2 = nullptr; p.scale2 = p.shift2 = nullptr; p.ldx2 = 0; p.nk1 = 0; p.Hi2 = p.Wi2 = 0; p.sh2 = p.sw2 = 1;
     if (dual && dual->nk1 > 0) {      // K-concatenated pair on the ping-pong kernel (tedspad_conv_p8_dual_fwd)
@@ -881,6 +882,14 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
             p.TF = ex->tf; p.HF = ex->hf; p.WF = ex->wf;
         }
         extras = p.mask || p.stats || p.ostrided || p.y32;
+        if (ex->fold_hw > 0) {
+            TS_REQUIRE(!extras && !residual && !sigmoid && !pool_t && ex->fold_c > 0 && d->cout % ex->fold_c == 0 && ex->fold_c % 256 == 0 &&
+                           ex->fold_ldy >= ex->fold_c && ex->fold_ldy % 8 == 0 && (long)d->to * d->ho * d->wo == ex->fold_hw &&
+                           (long)d->n * ex->fold_hw * (d->cout / ex->fold_c) * ex->fold_ldy < (1L << 31),
+                       "tedspad_conv_fwd_ex: folded output frames: plain epilogue, fold_hw = to*ho*wo, fold_c %% 256 == 0 dividing cout, fold_ldy >= fold_c");
+            p.fold_hw = ex->fold_hw; p.fold_c = ex->fold_c; p.fold_f = d->cout / ex->fold_c;
+            p.ldy = ex->fold_ldy;                  // row stride of the folded tensor (d->ldy only has to satisfy the descriptor check)
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     if (pool_t) {
@@ -888,6 +897,10 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         return launch_conv_pw(d->dtype, p, s, true);
     }
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
+    if (p.fold_hw) {
+        if (d->tile_cfg <= 0) cfg = 25;
+        TS_REQUIRE(cfg == 25 || cfg == 26, "tedspad_conv_fwd_ex: folded output frames run on the ping-pong kernel only (tile_cfg 25 / 26)");
+    }
     if (cfg == 9 || cfg == 20 || cfg == 21 || (cfg >= 29 && cfg <= 31)) {
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
         TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");

@@ -27,6 +27,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
 BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # layer1's last block: the fused tail with maxpool2 inside; 0: conv2 + (conv3 + pool) launches (A/B)
+TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
@@ -506,6 +507,46 @@ class PackedConv:
                 self._run(sub(x, n0, n1), pads, o, sub(out, n0, n1), sub(residual, n0, n1), sub(mask, n0, n1), stats, out_map,
                           None if z32 is None else z32[n0:n1], relu, sigmoid)
         return z32 if y32 else out
+
+
+class TPairConv:
+    """A kt x 1 x 1 = 3 x 1 x 1 'same' (pad 1, stride 1) convolution + BN + ReLU on a TWO-frame tensor -- conv1 of the temporal bottlenecks of
+    I3Res50's layer3 / layer4 after maxpool2 (large_i3d.py:61-68 with T = 2) -- as ONE GEMM over both frames with K = 2 * cin:
+        out[0] = W1 . x[0] + W2 . x[1],    out[1] = W0 . x[0] + W1 . x[1]
+    (the third tap of either frame multiplies zero padding: a third of the K = 3 * cin products of the plain form). The kernel sees a
+    kt = 2, pad 0 conv with 2 * cout output channels [W1 W2 ; W0 W1] whose two channel halves are the two output frames
+    (tedspad_conv_extras.fold_hw, ping-pong kernel): the rows of a pixel's two frames are gathered once and feed both frames' outputs."""
+
+    def __init__(self, weight: torch.Tensor, scale, shift, dtype: str = DEFAULT_DTYPE, device="cuda"):
+        assert self.supported(weight)
+        co = weight.shape[0]
+        w = weight.detach()
+        wf = torch.cat([torch.stack([w[:, :, 1], w[:, :, 2]], dim=2), torch.stack([w[:, :, 0], w[:, :, 1]], dim=2)], dim=0)    # (2co, ci, 2, 1, 1)
+        rep = lambda v: None if v is None else torch.cat([v.detach().float(), v.detach().float()])
+        self.pc = PackedConv(wf, rep(scale), rep(shift), dtype=dtype, device=device)
+        self.cout = co
+
+    @staticmethod
+    def supported(weight: torch.Tensor) -> bool:
+        co, ci, kt, kh, kw = weight.shape
+        return (kt, kh, kw) == (3, 1, 1) and ci % 64 == 0 and co % 256 == 0
+
+    def applies(self, x: Act, pads) -> bool:
+        n, t, h, w = x.dims
+        return (TPAIR and t == 2 and tuple(pads) == (1, 0, 0) and x.c == self.pc.cin and h * w * 2 >= 1 and
+                n * 2 * h * w * max(x.ld, self.cout) < MAX_ELEMS)
+
+    def __call__(self, x: Act, relu=True) -> Act:
+        n, t, h, w = x.dims
+        assert t == 2
+        pc = self.pc
+        out = Act.empty(n, 2, h, w, self.cout, pc.torch_dtype, x.buf.device)
+        d = pc._desc(n, 2, h, w, x.ld, (0, 0, 0), (1, h, w), pc.cout, 0, relu)
+        ex = _lib.ConvExtras()
+        ex.fold_hw, ex.fold_c, ex.fold_ldy = h * w, self.cout, out.ld
+        args = (C.byref(d), x.ptr, pc.w.data_ptr(), pc._ktab(d).data_ptr(), pc.scale.data_ptr(), pc.shift.data_ptr(), None, out.ptr, 0, C.byref(ex))
+        pc._launch_tuned((n, h, w, x.ld, out.ld, "tpair"), d, args)
+        return out
 
 
 class BneckTail:

@@ -77,6 +77,8 @@ class I3Res50(nn.Module):
                     p = "layer%d.%d." % (li, i)
                     s, b = self._bn_fold(blk.bn1)
                     P[p + "conv1"] = E.PackedConv(blk.conv1.weight, s, b, dtype=self.compute_dtype, device=dev)
+                    if li >= 2 and blk.temp_conv and E.TPairConv.supported(blk.conv1.weight):      # layers behind maxpool2: T = 2 at 16-frame clips
+                        P[p + "conv1_tp"] = E.TPairConv(blk.conv1.weight, s, b, dtype=self.compute_dtype, device=dev)
                     s, b = self._bn_fold(blk.bn2)
                     P[p + "conv2"] = E.PackedConv(blk.conv2.weight, s, b, stride=(1, blk.stride, blk.stride),
                                                   dtype=self.compute_dtype, device=dev)
@@ -136,7 +138,11 @@ class I3Res50(nn.Module):
             layer = getattr(self, "layer%d" % li)
             for i, blk in enumerate(layer):
                 p = "layer%d.%d." % (li, i)
-                h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
+                tp = P.get(p + "conv1_tp") if taps is None else None
+                if tp is not None and tp.applies(a, (blk.temp_conv, 0, 0)):
+                    h = tp(a)                                             # two frames: both outputs from ONE K = 2*cin GEMM, no products on zero padding
+                else:
+                    h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
                 tail = P.get(p + "tail") if (E.BNECK_TAIL and taps is None) else None
                 fuse_pool = li == 1 and i == len(layer) - 1          # the last layer1 block fuses maxpool2 into its conv3 instead (below)
                 if tail is not None and tail.applies(h, (0, 1, 1)) and (not fuse_pool or (E.BNECK_TAIL_POOL and not tail.dual and h.dims[1] % 2 == 0)):

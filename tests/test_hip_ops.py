@@ -146,6 +146,41 @@ def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
         assert torch.equal(fused, new)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dims", [(3, 14, 14, 1024, 256), (5, 7, 7, 2048, 512), (2, 28, 28, 512, 256), (1, 5, 3, 128, 256)])
+def test_temporal_conv_on_two_frames_as_one_folded_gemm(dims, dtype, monkeypatch):
+    """engine.TPairConv: a 3x1x1 'same' conv + BN + ReLU on a 2-frame tensor (conv1 of layer3 / layer4's temporal bottlenecks,
+    large_i3d.py:61-68 with T = 2 behind maxpool2) as ONE K = 2*cin GEMM over both frames whose 2*cout output channels are the two
+    output frames (tedspad_conv_extras.fold_hw on the ping-pong kernel) -- against the oracle's Conv3d and against the K = 3*cin launch it
+    replaces (same products minus the ones on zero padding: one f16 rounding step apart at most)."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, h, w, cin, cout = dims
+    name = "tp%d%d" % (h, cin)
+    x = _round(synth_tensor(9, name + "x", (n, 2, h, w, cin), -1, 1), tdt)
+    wgt = _round(synth_tensor(9, name + "w", (cout, cin, 3, 1, 1), -1, 1) * (2.0 / (3 * cin)) ** 0.5, tdt)
+    scale, shift = synth_tensor(9, name + "s", (cout,), 0.5, 1.5), synth_tensor(9, name + "b", (cout,), -0.3, 0.3)
+    ref = conv_cl(x, wgt, scale, shift, (1, 1, 1), (1, 0, 0), (1, 0, 0), None, relu=True)
+    tp = E.TPairConv(wgt, scale, shift, dtype=dtype, device="cuda")
+    xa = E.Act(x.to(tdt).cuda(), cin)
+    assert tp.applies(xa, (1, 0, 0)) and not tp.applies(xa, (0, 0, 0))
+    for cfg in (25, 26, None):                      # both MFMA shapes of the ping-pong kernel, then the tuner's own pick
+        monkeypatch.setattr(E, "FORCE_TILE_CFG", cfg)
+        got = tp(xa).buf.float().cpu()
+        assert got.shape == ref.shape
+        ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+        err = (got - ref).abs()
+        assert bool((err <= ulp * ref.abs() + 2e-3).all()), "cfg %s: max err %g" % (cfg, float(err.max()))
+        assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
+    monkeypatch.setattr(E, "FORCE_TILE_CFG", None)
+    old = E.PackedConv(wgt, scale, shift, dtype=dtype, device="cuda")(xa, pads=(1, 0, 0)).buf.float().cpu()
+    assert bool(((got - old).abs() <= ulp * old.abs() + 1e-3).all())
+    monkeypatch.setattr(E, "FORCE_TILE_CFG", 22)    # any other tile refuses the folded epilogue
+    with pytest.raises(RuntimeError):
+        tp(xa)
+
+
 def test_clip_to_frame_pair_layout():
     """tedspad_clip_to_tp: record (tp, h, b, wq) value dt*3 + c = x[n][c][4*tp - 2 + dt][h][2*wq + b], zeros outside the clip;
     strided (Q15) input views, a ragged last tile."""
