@@ -153,27 +153,48 @@ class BottleneckTrunk:
         a, tape["idx1"] = E.maxpool(y, k, s, pads=pads, return_idx=True)
         after_pool = True
         for d in self.blocks:
-            rec = dict(d=d)
-            if d["pre_pool"] is not None:
-                rec["pool_in"] = a
-                a, rec["pool_idx"] = E.maxpool(a, d["pre_pool"][0], d["pre_pool"][1], return_idx=True)
-                after_pool = True
-            rec["a_in"], rec["after_pool"] = a, after_pool       # after_pool: the block input is a max-pool output, not a ReLU output
+            a, rec = self.block_forward(d, a, unit, after_pool)
             after_pool = False
-            h1, rec["u1"] = unit(d["c1"], d["bn1"], a)
-            h2, rec["u2"] = unit(d["c2"], d["bn2"], h1)
-            if d["cd"] is not None:
-                r, rec["ud"] = unit(d["cd"], d["bnd"], a, relu=False)
-            else:
-                r = a
-            a, rec["u3"] = unit(d["c3"], d["bn3"], h2, relu=True, residual=r)
-            rec["h1"], rec["h2"], rec["out"] = h1, h2, a
             tape["units"].append(rec)
         f = E.global_avgpool(a)
         tape["f"] = f
         if train:
             TE.flush_counters()
         return f, tape
+
+    @staticmethod
+    def block_forward(d, a: Act, unit, after_pool: bool):
+        """One bottleneck (large_i3d.py:61-84; with `pre_pool`, maxpool2 in front of it): conv1-bn1-relu, conv2-bn2-relu, conv3-bn3 (+ downsample
+        branch | identity) - relu. `unit(conv, bn, x, relu=, residual=)` is the conv+BN(+residual)+ReLU launch pair of the current mode.
+        Returns (block output, tape record)."""
+        rec = dict(d=d)
+        if d["pre_pool"] is not None:
+            rec["pool_in"] = a
+            a, rec["pool_idx"] = E.maxpool(a, d["pre_pool"][0], d["pre_pool"][1], return_idx=True)
+            after_pool = True
+        rec["a_in"], rec["after_pool"] = a, after_pool           # after_pool: the block input is a max-pool output, not a ReLU output
+        h1, rec["u1"] = unit(d["c1"], d["bn1"], a)
+        h2, rec["u2"] = unit(d["c2"], d["bn2"], h1)
+        if d["cd"] is not None:
+            r, rec["ud"] = unit(d["cd"], d["bnd"], a, relu=False)
+        else:
+            r = a
+        a, rec["u3"] = unit(d["c3"], d["bn3"], h2, relu=True, residual=r)
+        rec["h1"], rec["h2"], rec["out"] = h1, h2, a
+        return a, rec
+
+    @staticmethod
+    def block_backward_train(rec, da: Act) -> Act:
+        """Train-mode backward of one bottleneck: da = gradient w.r.t. the block output; accumulates the block's parameter gradients and
+        returns the gradient w.r.t. the block input (in front of `pre_pool` if the block has one)."""
+        dh2, dres = TE.conv_bn_act_train_bwd(rec["u3"], da)
+        dh1, _ = TE.conv_bn_act_train_bwd(rec["u2"], dh2)
+        t = TE.conv_bn_act_train_bwd(rec["ud"], dres)[0] if "ud" in rec else dres
+        da, _ = TE.conv_bn_act_train_bwd(rec["u1"], dh1, dx_residual=t)
+        if "pool_idx" in rec:
+            pk, ps = rec["d"]["pre_pool"]
+            da = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], da, pk, ps)
+        return da
 
     def stage_params(self):
         """Parameter groups in the order their gradients become final in `backward`: [layer4, layer3, layer2, layer1, stem]."""
@@ -205,13 +226,7 @@ class BottleneckTrunk:
         if tape["train"]:
             da = TE.global_avgpool_bwd(df, last)
             for rec in reversed(tape["units"]):
-                dh2, dres = TE.conv_bn_act_train_bwd(rec["u3"], da)
-                dh1, _ = TE.conv_bn_act_train_bwd(rec["u2"], dh2)
-                t = TE.conv_bn_act_train_bwd(rec["ud"], dres)[0] if "ud" in rec else dres
-                da, _ = TE.conv_bn_act_train_bwd(rec["u1"], dh1, dx_residual=t)
-                if "pool_idx" in rec:
-                    pk, ps = rec["d"]["pre_pool"]
-                    da = TE.maxpool_bwd(rec["pool_in"], rec["pool_idx"], da, pk, ps)
+                da = self.block_backward_train(rec, da)
                 if on_stage_done is not None and rec["d"]["bi"] == 0:       # first block of a stage = the last one backward reaches
                     self._flush_stage(rec["d"]["li"])
                     on_stage_done(stages.index(rec["d"]["li"]))

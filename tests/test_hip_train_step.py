@@ -212,6 +212,57 @@ def test_unet_backward_chain_tight_on_a_smooth_network():
     assert max(errs.values()) < 5e-2 and float(np.median(list(errs.values()))) < 8e-3
 
 
+@pytest.mark.parametrize("name,dims", [("layer1.0", (4, 4, 28, 28)), ("layer1.2", (4, 4, 28, 28)), ("layer2.0", (4, 4, 28, 28)), ("layer3.1", (6, 2, 14, 14)),
+                                       ("layer4.0", (8, 2, 8, 8))])
+def test_every_bottleneck_type_backward_on_the_oracles_own_inputs(name, dims):
+    """ONE bottleneck of the real (not smoothed) I3Res50 in train mode, fed the same input and upstream gradient as torch autograd on the
+    oracle's block (oracle.i3res50_ref.bottleneck with batch-statistics BN): block output, input gradient and every parameter gradient of
+    the block. Only the block's own three ReLU layers can flip, so a missing residual / downsample term, a wrong stride or a wrong
+    maxpool2 routing (layer2.0) shows as an O(1) error against a 5e-2 bound -- which the end-to-end comparisons above cannot resolve.
+    Covers: downsample branch at stride 1 (layer1.0) and stride 2 (layer4.0), identity residual with / without a temporal conv1
+    (layer1.2, layer3.1), maxpool2 in front of the block (layer2.0)."""
+    import torch.nn.functional as F
+    from oracle import i3res50_ref
+    from ted_spad_amd import engine as E, train_engine as TE
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.train_nets import BottleneckTrunk, I3DTrainer
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    ft.load_state_dict(sd)
+    ft = ft.cuda().train()
+    tr = I3DTrainer(ft)
+    li, bi = int(name[5]), int(name[7])
+    d = next(b for b in tr.blocks if (b["li"], b["bi"]) == (li, bi))
+    blk = getattr(ft.i3d, "layer%d" % li)[bi]
+    n, t, h, w = dims
+    cin = blk.conv1.weight.shape[1]
+    x = torch.relu(synth_tensor(11, name + "x", (n, cin, t, h, w), -0.6, 1.0)).half().float().requires_grad_()      # a ReLU output, as in the network
+    p = "i3d.%s." % name
+    sdg = {k: (v.clone().requires_grad_() if (k.startswith(p) and v.is_floating_point() and "running" not in k) else v) for k, v in sd.items()}
+    sdb = {k[4:]: v for k, v in sdg.items() if k.startswith("i3d.")}
+    xin = F.max_pool3d(x, (2, 1, 1), (2, 1, 1)) if d["pre_pool"] is not None else x
+    y = i3res50_ref.bottleneck(xin, sdb, name + ".", blk.stride, blk.temp_conv, blk.downsample is not None, bn=i3res50_ref._bn_train)
+    dy = synth_tensor(11, name + "dy", tuple(y.shape), -1, 1).half().float()
+    y.backward(dy)
+    TE.ARENA.reset(torch.device("cuda"))
+    xa = E.Act(x.detach().permute(0, 2, 3, 4, 1).contiguous().half().cuda(), cin)
+    unit = lambda conv, bn, xi, relu=True, residual=None: TE.conv_bn_act_train(conv, bn, xi, relu=relu, residual=residual)
+    ya, rec = BottleneckTrunk.block_forward(d, xa, unit, after_pool=False)
+    got_y = ya.buf.float().cpu().permute(0, 4, 1, 2, 3)
+    assert rel_l2(got_y, y.detach()) < 3e-3
+    dxa = BottleneckTrunk.block_backward_train(rec, E.Act(dy.permute(0, 2, 3, 4, 1).contiguous().half().cuda(), dy.shape[1]))
+    for k in ("c1", "c2", "c3", "cd"):
+        if d[k] is not None:
+            d[k].flush_grad()
+    TE.flush_deferred()
+    assert rel_l2(dxa.buf.float().cpu().permute(0, 4, 1, 2, 3), x.grad) < 5e-2
+    got = {k: q.grad for k, q in ft.named_parameters() if k.startswith(p)}
+    ref = {k: v.grad for k, v in sdg.items() if k.startswith(p) and v.requires_grad}
+    assert set(got) == set(ref) and all(g is not None for g in got.values())
+    errs = _report("block %s on the oracle's inputs" % name, got, ref, min_cos=0.998, med_cos=0.9995)
+    assert max(errs.values()) < 5e-2, max(errs.items(), key=lambda kv: kv[1])
+
+
 def test_unetpp_backward_chain_tight_on_a_smooth_network():
     """UNetPPTrainer -- the reference's DEFAULT anonymizer (smp UnetPlusPlus, model_loaders.py:17-30) in train mode: train-mode BN,
     BasicBlock residuals and strided downsample branches, the 3x3/2 max-pool, nearest upsampling, the dense skip pathway (tensors with
