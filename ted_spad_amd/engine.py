@@ -533,8 +533,7 @@ class TPairConv:
 
     def applies(self, x: Act, pads) -> bool:
         n, t, h, w = x.dims
-        return (TPAIR and t == 2 and tuple(pads) == (1, 0, 0) and x.c == self.pc.cin and h * w * 2 >= 1 and
-                n * 2 * h * w * max(x.ld, self.cout) < MAX_ELEMS)
+        return (TPAIR and t == 2 and tuple(pads) == (1, 0, 0) and x.c == self.pc.cin and n * 2 * h * w * max(x.ld, self.cout) < MAX_ELEMS)
 
     def __call__(self, x: Act, relu=True) -> Act:
         n, t, h, w = x.dims
