@@ -108,7 +108,7 @@ typedef struct tedspad_conv_extras {
     int32_t     out_strided, ost, osh, osw, oot, ooh, oow, tf, hf, wf;
     int32_t     fold_hw, fold_c, fold_ldy;  /* fold_hw > 0 (tile_cfg 25 / 26 only, plain epilogue): the conv's output channels hold cout / fold_c output FRAMES of
                                 fold_c channels: channel n of output row m = sample*fold_hw + px (fold_hw = to*ho*wo) is stored as channel n % fold_c of row
-                                (sample * (cout / fold_c) + n / fold_c) * fold_hw + px with row stride fold_ldy (d->ldy is not used); scale / shift are fold_c long. Lets a 3x1x1 'same' conv on a
+                                (sample * (cout / fold_c) + n / fold_c) * fold_hw + px with row stride fold_ldy (d->ldy is not used); scale / shift are fold_c long; fold_c a multiple of 128 (an epilogue pass of the kernel). Lets a 3x1x1 'same' conv on a
                                 2-frame tensor (layer3 / layer4 of I3Res50 after maxpool2) run as ONE GEMM with K = 2*cin over both frames -- out[0] =
                                 [W1 W2].[x0;x1], out[1] = [W0 W1].[x0;x1] -- instead of K = 3*cin with a third of the products on zero padding */
     int32_t     stats_rows;  /* 0: one set of statistics over all output rows. > 0 (>= 256): output rows [g*stats_rows, (g+1)*stats_rows) are

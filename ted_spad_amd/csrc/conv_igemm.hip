@@ -883,10 +883,10 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         }
         extras = p.mask || p.stats || p.ostrided || p.y32;
         if (ex->fold_hw > 0) {
-            TS_REQUIRE(!extras && !residual && !sigmoid && !pool_t && ex->fold_c > 0 && d->cout % ex->fold_c == 0 && ex->fold_c % 256 == 0 &&
+            TS_REQUIRE(!extras && !residual && !sigmoid && !pool_t && ex->fold_c > 0 && d->cout % ex->fold_c == 0 && ex->fold_c % 128 == 0 &&
                            ex->fold_ldy >= ex->fold_c && ex->fold_ldy % 8 == 0 && (long)d->to * d->ho * d->wo == ex->fold_hw &&
                            (long)d->n * ex->fold_hw * (d->cout / ex->fold_c) * ex->fold_ldy < (1L << 31),
-                       "tedspad_conv_fwd_ex: folded output frames: plain epilogue, fold_hw = to*ho*wo, fold_c %% 256 == 0 dividing cout, fold_ldy >= fold_c");
+                       "tedspad_conv_fwd_ex: folded output frames: plain epilogue, fold_hw = to*ho*wo, fold_c %% 128 == 0 dividing cout, fold_ldy >= fold_c");
             p.fold_hw = ex->fold_hw; p.fold_c = ex->fold_c; p.fold_f = d->cout / ex->fold_c;
             p.ldy = ex->fold_ldy;                  // row stride of the folded tensor (d->ldy only has to satisfy the descriptor check)
         }

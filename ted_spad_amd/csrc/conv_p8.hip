@@ -331,12 +331,12 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
                 if (m < p.M) rres[j][i] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n0 + 128 * j + cc * 8);
             }
     }
-    // folded output frames (tedspad_conv_extras.fold_hw): this 256-channel tile is output frame `nsel`, channels nbase .. nbase + 255
-    int nsel = 0, nbase = n0;
-    if (p.fold_hw) { nsel = n0 / p.fold_c; nbase = n0 - nsel * p.fold_c; }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = nbase + 128 * j + cc * 8;
+        // folded output frames (tedspad_conv_extras.fold_hw): this pass's 128 channels are channels nbase .. nbase + 127 of output frame `nsel`
+        int nsel = 0, nbase = n0 + 128 * j;
+        if (p.fold_hw) { nsel = nbase / p.fold_c; nbase -= nsel * p.fold_c; }
+        const int n = nbase + cc * 8;
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
         const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
         if (j) __syncthreads();        // pass 0's rows have been read
@@ -443,8 +443,8 @@ int32_t launch_conv_p8(int dtype, const ConvKP &p, hipStream_t s, int mf) {
         set_error("tedspad_conv_p8_dual_fwd: two 1x1x1 convs (the first with stride 1), no residual");
         return TEDSPAD_EINVAL;
     }
-    if (p.fold_hw && (p.res || p.x2 || p.fold_c % 256 != 0 || p.Cout % p.fold_c != 0)) {
-        set_error("tedspad_conv_fwd_ex: folded output frames need fold_c %% 256 == 0, cout %% fold_c == 0, no residual");
+    if (p.fold_hw && (p.res || p.x2 || p.fold_c % 128 != 0 || p.Cout % p.fold_c != 0)) {
+        set_error("tedspad_conv_fwd_ex: folded output frames need fold_c %% 128 == 0, cout %% fold_c == 0, no residual");
         return TEDSPAD_EINVAL;
     }
     if (!p.utap || p.nk < 2 || p.Cout % 256 != 0 || p.sigmoid || p.mask || p.stats || p.ostrided || p.y32 || !p.y) {

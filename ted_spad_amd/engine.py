@@ -27,6 +27,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
 BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # layer1's last block: the fused tail with maxpool2 inside; 0: conv2 + (conv3 + pool) launches (A/B)
+TPAIR_MIN_COUT = int(os.environ.get("TEDSPAD_TPAIR_MIN_COUT", "128"))   # smallest cout that takes the folded form (256: layer2's 128-channel temporal convs stay on the temporal chunk-major tile)
 TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
@@ -529,11 +530,12 @@ class TPairConv:
     @staticmethod
     def supported(weight: torch.Tensor) -> bool:
         co, ci, kt, kh, kw = weight.shape
-        return (kt, kh, kw) == (3, 1, 1) and ci % 64 == 0 and co % 256 == 0
+        return (kt, kh, kw) == (3, 1, 1) and ci % 64 == 0 and co % 128 == 0
 
     def applies(self, x: Act, pads) -> bool:
         n, t, h, w = x.dims
-        return (TPAIR and t == 2 and tuple(pads) == (1, 0, 0) and x.c == self.pc.cin and n * 2 * h * w * max(x.ld, self.cout) < MAX_ELEMS)
+        return (TPAIR and self.cout >= TPAIR_MIN_COUT and t == 2 and tuple(pads) == (1, 0, 0) and x.c == self.pc.cin and
+                n * 2 * h * w * max(x.ld, self.cout) < MAX_ELEMS)
 
     def __call__(self, x: Act, relu=True) -> Act:
         n, t, h, w = x.dims

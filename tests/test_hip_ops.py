@@ -147,7 +147,7 @@ def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("dims", [(3, 14, 14, 1024, 256), (5, 7, 7, 2048, 512), (2, 28, 28, 512, 256), (1, 5, 3, 128, 256)])
+@pytest.mark.parametrize("dims", [(3, 14, 14, 1024, 256), (5, 7, 7, 2048, 512), (2, 28, 28, 512, 256), (1, 5, 3, 128, 256), (2, 28, 28, 256, 128), (3, 9, 11, 512, 384)])
 def test_temporal_conv_on_two_frames_as_one_folded_gemm(dims, dtype, monkeypatch):
     """engine.TPairConv: a 3x1x1 'same' conv + BN + ReLU on a 2-frame tensor (conv1 of layer3 / layer4's temporal bottlenecks,
     large_i3d.py:61-68 with T = 2 behind maxpool2) as ONE K = 2*cin GEMM over both frames whose 2*cout output channels are the two
