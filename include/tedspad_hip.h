@@ -186,6 +186,12 @@ int32_t tedspad_stem_pt_fwd(const void *x_tp, const void *w_img, const float *sc
  * to bottom, pool each patch over columns in registers and over rows through LDS (the rows a window shares with the patch above are
  * carried); the pooled column a patch shares with its right neighbour is joined by a second small launch from `side`
  * (tedspad_stem_pt_side_bytes() bytes of scratch, 16-byte aligned). The 112 x 112 stem tensor never reaches HBM. */
+/* variant bit 2 (with the 8 waves of bit 1): the same taps on v_mfma_f32_16x16x32 -- one MFMA sums a PAIR of taps (K = 32); the chip holds a ~12 % higher
+ * clock on that shape under load. w_img then is the tap-pair image (tedspad_stem_pt_wimg16_bytes() bytes): [pair 0..24][co][chunk q][8] 16-bit with chunk
+ * q = 2 * (tap of the pair) + (8-value half of its 16 values dt*3 + ci), chunk q of row co stored at chunk q ^ (2 * ((co >> 3) & 1)); pairs in the order
+ * phase 0 (dh even): ((dh, 1), (dh, 2)), ((dh, 3), (dh, 4)), ((dh, 5), (dh, 6)) for dh = 0, 2, 4, 6, then ((0, 0), (2, 0)), ((4, 0), (6, 0)); phase 1 (dh odd)
+ * likewise for dh = 1, 3, 5, then ((1, 0), (3, 0)), ((5, 0), zeros). Sums the 49 taps in another order than the 32x32x16 form (fp32: one f16 step apart). */
+int32_t tedspad_stem_pt_wimg16_bytes(void);
 int64_t tedspad_stem_pt_side_bytes(int32_t n, int32_t t_pairs, int32_t h, int32_t w);
 int32_t tedspad_stem_pt_pool_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
                                  int32_t t_pairs, int32_t h, int32_t w, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,

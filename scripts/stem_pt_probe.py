@@ -45,6 +45,10 @@ for v in (0, 2):
     print("variant %d, pool fused: stem + pool %.0f us; identical to the separate pool: %s" % (
         v, timed(lambda: st.conv_pool(xtc, variant=v)), bool(torch.equal(f.buf, p_new.buf))))
     del f
+f16 = st.conv_pool(xtc, variant=6)
+print("variant 6 (16x16x32 MFMAs), pool fused: %.0f us; max |diff| vs variant 2: %.3g" % (
+    timed(lambda: st.conv_pool(xtc, variant=6)), float((f16.buf.float() - st.conv_pool(xtc, variant=2).buf.float()).abs().max())))
+del f16
 for nwg in (256, 512):
     st.nwg = nwg
     print("nwg %d: stem %.0f us (4 waves), %.0f us (8 waves)" % (nwg, timed(lambda: st.conv(xtc, variant=0)), timed(lambda: st.conv(xtc, variant=2))))

@@ -77,6 +77,7 @@ SYMBOLS = {
     "tedspad_bneck_tail_fwd": (_I32, [C.POINTER(ConvDesc)] + [_P] * 7 + [_I32, _P, _I32, _P, _I32, _P, _P, _I32, _I32, _I32, _P]),
     "tedspad_clip_to_tp": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 4 + [_P]),
     "tedspad_stem_pt_wimg_bytes": (_I32, []),
+    "tedspad_stem_pt_wimg16_bytes": (_I32, []),
     "tedspad_stem_pt_fwd": (_I32, [_P] * 5 + [_I32] * 11 + [_P]),
     "tedspad_stem_pt_side_bytes": (_I64, [_I32] * 4),
     "tedspad_stem_pt_pool_fwd": (_I32, [_P] * 6 + [_I32] * 10 + [_P]),

@@ -51,10 +51,17 @@ __host__ __device__ constexpr int pt_jobs(int par) { return (2 * pt_frame(par) +
 __host__ __device__ constexpr int pt_off(int par) { return par == 0 ? 0 : pt_jobs(0) * 1024; }
 constexpr int PT_W_OFF = pt_off(1) + pt_jobs(1) * 1024;
 constexpr int PT_LDS = PT_W_OFF + PT_W_BYTES;
+// MF = 16 (v_mfma_f32_16x16x32): one MFMA sums TWO taps (K = 32); the 49 taps are 25 pairs (the last one with a zero partner)
+constexpr int PT_NPAIR = 25;
+constexpr int PT_W16_BYTES = PT_NPAIR * 64 * 64;      // [pair][co][4 chunks of 8 values]: 102400
+__host__ __device__ constexpr int pt_wbytes(int mf) { return mf == 16 ? PT_W16_BYTES : PT_W_BYTES; }
 // POOL: the patch's column-pooled rows [8 rows][9 slots][64 channels] 16-bit (slots 0..6: complete 3-column windows, 7: columns
 // 14, 15 of the window the next patch to the right completes, 8: column 0 alone, that patch's contribution to its left neighbour)
-constexpr int PT_XB_OFF = PT_LDS, PT_XB_ROW = 9 * 128, PT_XB_BYTES = PT_TH * PT_XB_ROW;
-constexpr int PT_LDS_POOL = PT_LDS + PT_XB_BYTES;
+constexpr int PT_XB_ROW = 9 * 128, PT_XB_BYTES = PT_TH * PT_XB_ROW;
+__host__ __device__ constexpr int pt_xb_off(int mf) { return PT_W_OFF + pt_wbytes(mf); }
+__host__ __device__ constexpr int pt_lds_pool(int mf) { return pt_xb_off(mf) + PT_XB_BYTES; }
+constexpr int PT_LDS_POOL = pt_lds_pool(32);
+static_assert(pt_lds_pool(16) <= 160 * 1024 && pt_xb_off(16) % 128 == 0 && pt_xb_off(32) % 128 == 0, "MF = 16 image: exactly 160 KB");
 constexpr int PT_POOL_PIECES = 4 * 9 * 8;            // 16-byte pieces a patch hands to the pooled tensor (4 pooled rows x 9 slots x 8)
 static_assert(PT_LDS_POOL <= 160 * 1024, "weights + halo (+ pooled rows) must fit the CU's LDS");
 static_assert(PT_W_BYTES % 1024 == 0 && (4 * PT_ROWB) % 256 == 0, "LDS image alignment");
@@ -109,6 +116,52 @@ __device__ __forceinline__ void stem_pt_phase(const unsigned char *dsm, const in
     }
 }
 
+// MF = 16: the same taps on v_mfma_f32_16x16x32 (K = 32 = two taps per instruction; under load the chip holds a ~12 % higher clock on this
+// shape than on 32x32x16 at the same FLOP per cycle -- MI355X guide, DVFS (7); measured here: the same instruction mix runs the kernel in
+// 1 887 instead of 2 137 us). Lane l: pixel column l & 15 (B operand) / output channel l & 15 (A operand), k-block q = l >> 4: tap q >> 1 of
+// the pair, 8-value half q & 1 of its 16 values. The taps of a pair differ by a CONSTANT LDS offset (dw odd -> dw + 1: the other column-parity
+// plane; dw = 0: the next row of the same parity), which sits in the per-lane base register (sel = q >> 1 times the offset): no per-read
+// address arithmetic. A wave (8 per workgroup) owns 32 output channels x {2 rows x 2 frames} of 16 columns: 2 weight + 4 pixel fragments
+// per 8 MFMAs. Pairs of phase PAR (dh = 2 dhh + PAR): i < 3*ND: (dhh = i / 3, dw = 1 + 2 (i % 3)) with (dhh, dw + 1); then dw = 0:
+// (dhh = 2 k, 0) with (2 k + 1, 0); the last pair of phase 1 is (dhh = 2, dw = 0) with a zero-weight partner.
+template <typename T, int PAR>
+__device__ __forceinline__ void stem_pt_phase16(const unsigned char *dsm, const int (&pb)[5], const int wa, f32x4 (&acc)[2][2][2]) {
+    constexpr int ND = PAR == 0 ? 4 : 3;
+    constexpr int NP = PAR == 0 ? 14 : 11;
+    constexpr int PBASE = PAR == 0 ? 0 : 14;
+    constexpr int FR = pt_frame(PAR);
+    uint4 fx[2][4], fw[2][2];
+    auto load = [&](int i, uint4 (&xa)[4], uint4 (&xw)[2]) {
+        int bi, off;
+        if (i < 3 * ND) { bi = i % 3; off = (i / 3) * PT_ROWB; }
+        else if (PAR == 0 || i == 3 * ND) { bi = 3; off = 2 * (i - 3 * ND) * PT_ROWB + PT_PP * 32; }
+        else { bi = 4; off = 2 * PT_ROWB + PT_PP * 32; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) xa[r * 2 + f] = *reinterpret_cast<const uint4 *>(dsm + pb[bi] + (pt_off(PAR) + off + f * FR + r * 4 * PT_ROWB));
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) xw[cb] = *reinterpret_cast<const uint4 *>(dsm + wa + (PBASE + i) * 4096 + cb * 1024);
+    };
+    load(0, fx[0], fw[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i + 1 < NP) load(i + 1, fx[(i + 1) & 1], fw[(i + 1) & 1]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[cb][r][f] = T::mfma16(fw[i & 1][cb], fx[i & 1][r * 2 + f], acc[cb][r][f]);
+        // the next pair's six reads in two groups of three between the two halves of this pair's MFMAs (6 | 8 groups measured the same)
+        if (i + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (i + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+}
+
 // NW = 4: one wave per SIMD, every wave multiplies all 64 output channels of its 64 pixels (4 fragment reads per 4 MFMAs).
 // NW = 8: two waves per SIMD; waves w and w + 4 own the same pixels and the output channels [0,32) / [32,64) (3 reads per 2
 // MFMAs: 192 B/clk of the CU's 256 B/clk LDS at full MFMA rate): one wave's epilogue, DMA issue and patch arithmetic run
@@ -120,9 +173,11 @@ __device__ __forceinline__ void stem_pt_phase(const unsigned char *dsm, const in
 // bytes each: pooled rows 4*th .. 4*th + 2 from this patch, row 4*th - 1 from rows 6, 7 of the patch above (carried in registers)
 // and row 0 of this one. The window a patch shares with its right neighbour is written as two partial maxima (slot 7 into the
 // pooled tensor, slot 8 into the side buffer) that stem_pool_fix_kernel joins. 1.44 GB per 225 clips no longer leave the chip.
-template <typename T, int NW, bool POOL>
+template <typename T, int NW, bool POOL, int MF = 32>
 __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
+    static_assert(MF == 32 || (MF == 16 && NW == 8 && POOL), "the 16x16x32 form is built for 8 waves with the pool fused");
     constexpr int NA = NW == 8 ? 1 : 2;
+    constexpr int XB_OFF = pt_xb_off(MF);
     constexpr int PIT = (PT_POOL_PIECES + 64 * NW - 1) / (64 * NW);
     constexpr int ROUNDS = (pt_jobs(0) + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -140,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     if (k >= lim) return;                                   // workgroup-uniform, before any barrier
 
     // ---- resident weights: a linear 98 KB copy --------------------------------------------------------------------------------
-    for (int j = wave; j < PT_W_BYTES / 1024; j += NW) lds_dma16(p.wimg + j * 1024 + lane * 16, lds0 + PT_W_OFF + j * 1024);
+    for (int j = wave; j < pt_wbytes(MF) / 1024; j += NW) lds_dma16(p.wimg + j * 1024 + lane * 16, lds0 + PT_W_OFF + j * 1024);
 
     // ---- halo DMA slots of this lane (patch-invariant): LDS slot s of a region = (frame, row, plane, position, half) --------------
     int off[2][ROUNDS], rc[2][ROUNDS];
@@ -155,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
             const int b = q & 1; q >>= 1;
             const int row = q % pt_rows(par), f = q / pt_rows(par);
             const int hr = 2 * row + par;                               // halo row 0..20 (input row ih0 + hr); plane column wo0 - 2 + pos
-            const int hf = hs ^ ((pos >> 3) & 1);
+            const int hf = MF == 16 ? hs : hs ^ ((pos >> 3) & 1);   // MF = 16: unswizzled (see stem_pt_phase16)
             const bool ok = f < 2;
             off[par][i] = ok ? f * 12 + hf * 16 + hr * p.sH + b * p.sP + (pos - 2) * PT_REC : 0;
             rc[par][i] = ok ? (hr << 8) | pos : (1 << 28);              // a row far outside any clip: the slot reads the zero page
@@ -221,13 +276,32 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
 #pragma unroll
     for (int a = 0; a < NA; ++a) wa[a] = PT_W_OFF + ((a0 + a) * 32 + l31) * 32 + 16 * (lh ^ ((((a0 + a) * 32 + l31) >> 4) & 1));
 
-    // BatchNorm scale / shift of this lane's output channels: co = a*32 + (r & 3) + 8*(r >> 2) + 4*lh
+    // MF = 16: per-lane bases of the pixel fragments ([0..2]: the dw pairs at plane position a = 1..3, [3]: the dw = 0 row pair, [4]: the
+    // single dw = 0 tap) and of the weight fragments. Bank conflicts: a ds_read_b128 is served in the lane groups {0-3,12-15,20-27},
+    // {4-11,16-19,28-31} (+32): 8 lanes of one k-half on columns {0-3,12-15} and 8 lanes of the OTHER half on columns {4-11}. Sixteen
+    // consecutive 32-byte positions with that half assignment cover all 64 banks when the halves are stored UNswizzled (columns c and c + 8
+    // always sit in different halves); for the 64-byte weight rows the chunk index is XOR-ed with 2 * bit 3 of co
+    const int q4 = lane >> 4;
+    int pb16[5], wa16 = 0;
+    if (MF == 16) {
+        const int sel = q4 >> 1, hf = q4 & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pos = l15 + (j == 3 ? 0 : j + 1);
+            const int base = (wave & 3) * PT_ROWB + pos * 32 + 16 * hf;
+            pb16[j] = base + sel * (j == 3 ? PT_ROWB : PT_PP * 32);
+            if (j == 3) pb16[4] = base;
+        }
+        const int co0 = a0 * 32 + l15;
+        wa16 = PT_W_OFF + co0 * 64 + 16 * (q4 ^ (2 * ((co0 >> 3) & 1)));
+    }
+    // BatchNorm scale / shift of this lane's output channels: co = a*32 + (r & 3) + 8*(r >> 2) + 4*lh (MF = 16: a0*32 + 16*(r >> 2) + 4*q4 + (r & 3))
     float sc[NA][16], sf[NA][16];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = (a0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = MF == 16 ? a0 * 32 + 16 * ((r >> 2) & 1) + 4 * q4 + (r & 3) : (a0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             sc[a][r] = p.scale[co];
             sf[a][r] = p.shift[co];
         }
@@ -248,7 +322,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         const int u = tid + it * 64 * NW;
         psl[it] = (u >> 3) % 9;
         pi[it] = u < PT_POOL_PIECES ? (u >> 3) / 9 : -1;
-        pxo[it] = PT_XB_OFF + psl[it] * 128 + (u & 7) * 16;
+        pxo[it] = XB_OFF + psl[it] * 128 + (u & 7) * 16;
         carry[it] = make_uint4(0, 0, 0, 0);
     }
     auto pool_rows = [&](const Patch &q) {
@@ -287,23 +361,59 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         if (POOL && pending) pool_rows(prev);               // before this patch's mid barrier; the epilogue after it rewrites the rows
 
         f32x16 acc[NA][2];
+        f32x4 acc16[2][2][2];              // MF = 16: [16-channel block][row r / r + 4][frame]
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][g][r] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc16[cb][r][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        if (!(p.dbg & 4)) stem_pt_phase<T, 0, NA>(dsm, pa, wa, acc);             // taps dh = 0, 2, 4, 6 on the even halo rows
+        if (MF == 16) { if (!(p.dbg & 4)) stem_pt_phase16<T, 0>(dsm, pb16, wa16, acc16); }
+        else if (!(p.dbg & 4)) stem_pt_phase<T, 0, NA>(dsm, pa, wa, acc);             // taps dh = 0, 2, 4, 6 on the even halo rows
         wait_vmcnt<0>();                                    // odd rows of this patch (the youngest operation of this wave) landed
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the even rows
         asm volatile("" ::: "memory");
         if (more && dma) issue(0, nxt);                     // even rows of the NEXT patch land under the odd taps + epilogue
-        if (!(p.dbg & 4)) stem_pt_phase<T, 1, NA>(dsm, pa, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
+        if (MF == 16) { if (!(p.dbg & 4)) stem_pt_phase16<T, 1>(dsm, pb16, wa16, acc16); }
+        else if (!(p.dbg & 4)) stem_pt_phase<T, 1, NA>(dsm, pa, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
 
         // ---- epilogue: relu(bn(.)) of both frames, max over the two frames (the temporal window of maxpool1), 16-byte stores --------
         bool stored = false;
-        if (POOL) {
+        if (POOL && MF == 16) {
+            // lane: column l15 (= its DPP row position), channels a0*32 + 16 cb + 4 q4 + {0..3} of rows (wave & 3) + 4 r
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float s_ = sc[0][4 * cb + i], b_ = sf[0][4 * cb + i];
+                        v[i] = __builtin_fmaxf(__builtin_fmaxf(acc16[cb][r][0][i] * s_ + b_, acc16[cb][r][1][i] * s_ + b_), 0.f);
+                    }
+                    const unsigned d0 = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                    const unsigned d1 = (unsigned)T::from_f32(v[2]) | ((unsigned)T::from_f32(v[3]) << 16);
+                    unsigned m[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned d = h ? d1 : d0;
+                        const unsigned s1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x101, 0xf, 0xf, true);
+                        const unsigned s2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x102, 0xf, 0xf, true);
+                        m[h] = T::pk_max(T::pk_max(d, s1), s2);
+                    }
+                    unsigned char *xb = dsm + XB_OFF + ((wave & 3) + 4 * r) * PT_XB_ROW + (a0 * 32 + cb * 16 + 4 * q4) * 2;
+                    if (!(l15 & 1)) *reinterpret_cast<uint2 *>(xb + (l15 >> 1) * 128) = make_uint2(m[0], m[1]);
+                    if (l15 == 0) *reinterpret_cast<uint2 *>(xb + 8 * 128) = make_uint2(d0, d1);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (POOL) {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 unsigned d[4][2];
@@ -338,7 +448,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
                         const unsigned s2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d[q][h], 0x102, 0xf, 0xf, true);
                         m[q][h] = T::pk_max(T::pk_max(d[q][h], s1), s2);
                     }
-                unsigned char *xb = dsm + PT_XB_OFF + prow * PT_XB_ROW + ((a0 + a) * 32 + 8 * lh) * 2;
+                unsigned char *xb = dsm + XB_OFF + prow * PT_XB_ROW + ((a0 + a) * 32 + 8 * lh) * 2;
                 if (!(l15 & 1)) {
                     *reinterpret_cast<uint4 *>(xb + (l15 >> 1) * 128) = make_uint4(m[0][0], m[0][1], m[1][0], m[1][1]);
                     *reinterpret_cast<uint4 *>(xb + (l15 >> 1) * 128 + 32) = make_uint4(m[2][0], m[2][1], m[3][0], m[3][1]);
@@ -490,6 +600,7 @@ extern "C" int32_t tedspad_clip_to_tp(const float *x, void *y, int32_t n, int32_
 }
 
 extern "C" int32_t tedspad_stem_pt_wimg_bytes(void) { return PT_W_BYTES; }
+extern "C" int32_t tedspad_stem_pt_wimg16_bytes(void) { return PT_W16_BYTES; }
 
 // shared launcher: pool = the spatial 3x3 / 2 max-pool fused as well (y is the pooled tensor then, side its scratch)
 static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
@@ -514,6 +625,20 @@ static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_i
     static thread_local int attr_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int w8 = (variant >> 1) & 1;
     p.dbg = (variant >> 8) & 7;
+    if (pool && (variant & 4)) {           // 16x16x32 MFMA form (8 waves; w_img in the tap-pair layout)
+        static thread_local int attr16[2] = {0, 0};
+        const int ti = dtype == TEDSPAD_F16 ? 0 : 1;
+        const void *fn16 = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16>;
+        if (!attr16[ti]) {
+            if (hipFuncSetAttribute(fn16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("%s: cannot raise the dynamic LDS limit", who);
+                return TEDSPAD_ELAUNCH;
+            }
+            attr16[ti] = 1;
+        }
+        if (ti == 0) hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true, 16>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+        else hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+    } else {
     const int di = ((dtype == TEDSPAD_F16 ? 0 : 1) * 2 + w8) * 2 + (pool ? 1 : 0);
     const void *fns[8] = {(const void *)conv_stem_pt_kernel<F16, 4, false>, (const void *)conv_stem_pt_kernel<F16, 4, true>,
                           (const void *)conv_stem_pt_kernel<F16, 8, false>, (const void *)conv_stem_pt_kernel<F16, 8, true>,
@@ -537,6 +662,7 @@ static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_i
         case 5: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 4, true>), g, b, lds, s, p); break;
         case 6: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, false>), g, b, lds, s, p); break;
         default: hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true>), g, b, lds, s, p); break;
+    }
     }
     int32_t rc = check_launch(who);
     if (rc != TEDSPAD_OK || !pool || p.tiles_w < 2) return rc;

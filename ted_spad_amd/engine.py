@@ -669,7 +669,10 @@ class StemPT:
     (csrc/conv_stem_pt.hip), inference only, with the TEMPORAL half of maxpool1 (large_i3d.py:138,232) fused: the result is
     max(frame 2k, frame 2k+1) of the stem output, (n, To // 2, ho, wo, 64); `engine.maxpool(., (1,3,3), (1,2,2))` finishes the pool.
     K = 7*7*16 = 784 (temporal taps x channels folded into one 32-byte position), all weights resident in LDS."""
-    VARIANT = int(os.environ.get("TEDSPAD_STEM_PT_VARIANT", "2"))      # bit 1: 8 waves per workgroup
+    VARIANT = int(os.environ.get("TEDSPAD_STEM_PT_VARIANT", "6"))      # bit 1: 8 waves per workgroup; bit 2 (pool-fused entry, 8 waves): 16x16x32 MFMAs
+    # tap pairs of the 16x16x32 form, in the kernel's order (csrc/conv_stem_pt.hip, stem_pt_phase16): ((dh, dw), (dh, dw) | None)
+    PAIRS = ([((2 * (i // 3), 1 + 2 * (i % 3)), (2 * (i // 3), 2 + 2 * (i % 3))) for i in range(12)] + [((0, 0), (2, 0)), ((4, 0), (6, 0))] +
+             [((2 * (i // 3) + 1, 1 + 2 * (i % 3)), (2 * (i // 3) + 1, 2 + 2 * (i % 3))) for i in range(9)] + [((1, 0), (3, 0)), ((5, 0), None)])
 
     def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(2, 2, 2), pads=(2, 3, 3),
                  dtype: str = DEFAULT_DTYPE, device="cuda"):
@@ -686,6 +689,12 @@ class StemPT:
         swap = ((torch.arange(64, device=device) >> 4) & 1).bool().view(1, 64, 1, 1)
         self.wimg = torch.where(swap, w.flip(2), w).to(self.torch_dtype).contiguous()   # halves of a row swapped when (co >> 4) & 1
         assert self.wimg.numel() * 2 == _lib.lib().tedspad_stem_pt_wimg_bytes()
+        # 16x16x32 form: [pair][co][chunk q = 2 * (tap of the pair) + half][8]; chunk q of row co is stored at chunk q ^ (2 * ((co >> 3) & 1))
+        zero = torch.zeros(64, 2, 8, device=device)
+        L = torch.stack([torch.cat([w[a[0] * 7 + a[1]], w[b[0] * 7 + b[1]] if b is not None else zero], dim=1) for a, b in self.PAIRS])   # (25, 64, 4, 8)
+        src = torch.arange(4, device=device).view(1, 4) ^ (2 * ((torch.arange(64, device=device).view(64, 1) >> 3) & 1))                # physical chunk p <- logical p ^ ...
+        self.wimg16 = torch.gather(L, 2, src.view(1, 64, 4, 1).expand(len(self.PAIRS), 64, 4, 8)).to(self.torch_dtype).contiguous()
+        assert self.wimg16.numel() * 2 == _lib.lib().tedspad_stem_pt_wimg16_bytes()
         self.scale = _padded_vec(scale, co, 64, device, 1.0)
         self.shift = _padded_vec(shift, co, 64, device, 0.0)
         self.nwg = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
@@ -723,7 +732,7 @@ class StemPT:
         ho, wo = (h + 1) // 2, wq
         out = Act.empty(n, tp, ho, wo, 64, self.torch_dtype, xtp.device)
         check(_lib.lib().tedspad_stem_pt_fwd(xtp.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, n, tp, h, w,
-                                             ho, wo, out.ld, int(relu), self.nwg, self.VARIANT if variant is None else variant,
+                                             ho, wo, out.ld, int(relu), self.nwg, (self.VARIANT if variant is None else variant) & ~4,
                                              self.dtype_code, _stream_ptr()), "tedspad_stem_pt_fwd")
         return out
 
@@ -737,9 +746,12 @@ class StemPT:
         hp, wp = (ho - 3) // 2 + 1, (wo - 3) // 2 + 1
         out = Act.empty(n, tp, hp, wp, 64, self.torch_dtype, xtp.device)
         side = torch.empty(_lib.lib().tedspad_stem_pt_side_bytes(n, tp, h, w), dtype=torch.uint8, device=xtp.device)
-        check(_lib.lib().tedspad_stem_pt_pool_fwd(xtp.data_ptr(), self.wimg.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), out.ptr,
-                                                  side.data_ptr(), n, tp, h, w, hp, wp, out.ld, self.nwg, self.VARIANT if variant is None else variant,
-                                                  self.dtype_code, _stream_ptr()), "tedspad_stem_pt_pool_fwd")
+        v = self.VARIANT if variant is None else variant
+        if v & 4:
+            v |= 2                                          # the 16x16x32 form is the 8-wave kernel
+        check(_lib.lib().tedspad_stem_pt_pool_fwd(xtp.data_ptr(), (self.wimg16 if v & 4 else self.wimg).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                                  out.ptr, side.data_ptr(), n, tp, h, w, hp, wp, out.ld, self.nwg, v, self.dtype_code, _stream_ptr()),
+              "tedspad_stem_pt_pool_fwd")
         return out
 
     def __call__(self, x: torch.Tensor, relu=True) -> Act:

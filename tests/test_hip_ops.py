@@ -144,6 +144,14 @@ def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
         fused = st.conv_pool(st.layout(clip.cuda()), variant=variant).buf.float().cpu()
         assert fused.shape == new.shape
         assert torch.equal(fused, new)
+        # ... and on 16x16x32 MFMAs (variant bit 2: two taps per instruction, another fp32 summation order): against the oracle's pooled tensor
+        ref_pool = torch.nn.functional.max_pool3d(ref.permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2)).permute(0, 2, 3, 4, 1)
+        f16x = st.conv_pool(st.layout(clip.cuda()), variant=variant | 4).buf.float().cpu()
+        assert f16x.shape == ref_pool.shape
+        for got_p in (fused, f16x):
+            assert bool(((got_p - ref_pool).abs() <= ulp * ref_pool.abs() + 2e-3).all()), "max err %g" % float((got_p - ref_pool).abs().max())
+            assert rel_l2(got_p, ref_pool) < (4e-4 if dtype == "f16" else 3e-3)
+        assert bool(((f16x - fused).abs() <= ulp * fused.abs() + 1e-3).all())
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
