@@ -32,3 +32,14 @@ for v in (0, 1, 2, 3):
 E.BneckTail.VARIANT = 3
 print("maxpool2 fused: conv2 (above) + conv3+res+pool %.0f us unfused; fused tail + pool %.0f us" % (
     timed(lambda: c3.call_pool_t2(h, residual=res, relu=True)), timed(lambda: tp(x, residual=res, pool_t2=True))))
+# ---- layer2's plain block: 128 mid channels at 28 x 28 x 2 frames ----
+x128 = E.Act(synth_tensor(1, "x128", (n, 2, 28, 28, 128), -1, 1, device=dev).half(), 128)
+res512 = E.Act(synth_tensor(1, "r512", (n, 2, 28, 28, 512), -1, 1, device=dev).half(), 512)
+w2b = synth_tensor(1, "w2b", (128, 128, 1, 3, 3), -0.04, 0.04); w3b = synth_tensor(1, "w3b", (512, 128, 1, 1, 1), -0.08, 0.08)
+one128, zero128, one512, zero512 = torch.ones(128), torch.zeros(128), torch.ones(512), torch.zeros(512)
+c2b = E.PackedConv(w2b, one128, zero128, dtype="f16", device=dev); c3b = E.PackedConv(w3b, one512, zero512, dtype="f16", device=dev)
+tb = E.BneckTail(c2b, w3b, one512, zero512)
+for _ in range(60):
+    hb = c2b(x128, pads=(0, 1, 1)); c3b(hb, residual=res512, relu=True)
+print("layer2 block: conv2 %.0f us + conv3+res %.0f us unfused; fused %.0f us" % (
+    timed(lambda: c2b(x128, pads=(0, 1, 1))), timed(lambda: c3b(hb, residual=res512, relu=True)), timed(lambda: tb(x128, residual=res512))))

@@ -414,6 +414,297 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     }
 }
 
+// The same tail for 128 mid channels (layer2's plain bottlenecks: conv2 1 x 3 x 3 128 -> 128, conv3 128 -> 512 + residual; large_i3d.py:69-84).
+// Stage A = the chunk-major flat tile of conv_patch.hip (tile_cfg 33): for each 64-channel chunk of the input the contiguous halo run is
+// fetched once and serves all taps, the [128 co][64 k] weight tile of a (chunk, tap) streams through a two-slot ring; a wave ends with
+// 128 co x 64 px in 128 accumulator registers. Stage B as above with eight k-steps (fragment a*2 + s = rows 16 s .. of channel quarter a) and
+// the conv3 weight image ([64 co'][2 x 64 k] per output group) streamed two groups at a time. 72 KB of LDS in either stage: two workgroups
+// per CU.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckKP p) {
+    constexpr int NT = 256, WSTAGE = 128 * BK * 2, HG = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int q0 = tile * BT_BM;
+    const int lim = min(BT_BM, p.M - q0);
+    const int S = (p.NP + 1) * 8;
+    const int Sr = (S + 63) / 64 * 64;
+    const int halo_bytes = Sr * 16;
+    unsigned char *wring = dsm + halo_bytes;            // [2][128][64] 16-bit
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16b);
+
+    // ================================ stage A: conv2, chunk-major on the flat halo (conv_patch_kernel<T, 128, FLAT>) ================================
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w2 + (size_t)rsub * p.Kpad + kc * 8;
+    auto issue_w = [&](int ch, int tap, int slot) {
+        const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
+        const uint16_t *src = wsrc + tap * 128 + ch * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16(src + (size_t)(j * 32) * p.Kpad, dst + j * 32 * (BK * 2));
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int NH = (Sr + NT - 1) / NT;
+    int pj[2];
+    unsigned vmask[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = wave * 64 + b * 32 + l31;
+        pj[b] = j;
+        const int q = q0 + j;
+        unsigned mk = 0;
+        if (q < p.M) {
+            const int r1 = q / p.W, w = q - r1 * p.W;
+            const int h = r1 % p.H;
+            for (int dh = 0; dh < p.kh; ++dh)
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+        }
+        vmask[b] = mk;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int ch = 0; ch < 2; ++ch) {
+        if (ch) __builtin_amdgcn_s_barrier();              // every wave has read the previous chunk's halo and weight slots
+        asm volatile("" ::: "memory");
+        issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
+        for (int i = 0; i < NH; ++i) {
+            if (i * NT + wave * 64 >= Sr) break;           // wave-uniform
+            const int s = i * NT + tid;
+            const int pos = s >> 3, cs = s & 7;
+            const int q = q0 - p.R + pos;
+            const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
+            const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ch * 64 + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
+            lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
+        }
+        if (p.ntaps > 1) issue_w(ch, 1, 1);
+        int dh = 0, dw = 0;
+        for (int kt = 0; kt < p.ntaps; ++kt) {
+            const int delta = dh * p.W + dw;
+            unsigned xoff[2], xswz[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+                xoff[b] = (unsigned)pos * 128u;
+                xswz[b] = (unsigned)(pos >> 1) & 7u;
+            }
+            if (kt + 1 < p.ntaps) wait_vmcnt<4>(); else wait_vmcnt<0>();   // stage kt (and, on kt = 0, the halo) landed; stage kt+1 (4 instructions) may stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt & 1) * WSTAGE) + l31 * BK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+            }
+            if (kt + 1 < p.ntaps) {                        // two slots: stage kt+2 can only be issued once every wave has read stage kt
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < p.ntaps) issue_w(ch, kt + 2, kt & 1);
+            }
+            if (++dw == p.kw) { dw = 0; ++dh; }
+        }
+    }
+    __syncthreads();          // every wave is done with the halo and the weight ring
+
+    // ================================ stage B: conv3 + residual on the register tile ================================
+    const int n3 = p.cout3 / 64;
+    auto load_w3 = [&](int g0) {                           // groups g0, g0 + 1: slot kb * HG + (g - g0), kb = the k half
+        for (int i = wave; i < 2 * HG * 8; i += 4) {
+            const int tl = i >> 3, sub = i & 7;
+            const int kb = tl / HG, g = g0 + tl - kb * HG;
+            if (g >= n3) continue;
+            const int row = sub * 8 + (lane >> 3);
+            const int chn = (lane & 7) ^ ((row >> 1) & 7);
+            lds_dma16(p.w3p + (size_t)(g * 64 + row) * 128 + kb * 64 + chn * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
+        }
+    };
+    load_w3(0);
+    float *bnv = reinterpret_cast<float *>(dsm + 2 * HG * BT_WSTAGE);     // [2][cout3]: scale3, shift3
+    for (int i = tid; i < p.cout3; i += NT) {
+        bnv[i] = p.scale3[i];
+        bnv[p.cout3 + i] = p.shift3[i];
+    }
+    // relu(bn2(.)) of the conv2 tile, packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel quarter a
+    uint4 y2[8][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float sc[16], sf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sc[r] = p.scale2[c];
+            sf[r] = p.shift2[c];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s2 + j] * sc[8 * s2 + j] + sf[8 * s2 + j], 0.f);
+                y2[a * 2 + s2][b] = pack8<T>(v);
+            }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();           // weight image + BN vectors visible
+
+    unsigned char *wbuf = dsm + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
+    const unsigned wbuf_lds = lds0 + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
+    const bool has_res = p.res != nullptr;
+    const int rrow = lane >> 3, rch = lane & 7;
+    const int c0 = rch ^ (rrow >> 1);
+    const int limw = lim - wave * 64;
+    auto issue_res = [&](int g) {
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const uint16_t *base = p.res + (size_t)(q0 + wave * 64 + rrow + opq) * p.ldres + 64 * g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
+            lds_dma16(src, wbuf_lds + k * 1024);
+        }
+    };
+    if (has_res) issue_res(0);
+    for (int g = 0; g < n3; ++g) {
+        if (g && g % HG == 0) {                  // the next two groups of the weight image
+            __syncthreads();
+            load_w3(g);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        unsigned d[2][2][4][2];
+        if (has_res) {
+            if (g == 0 || g % HG == 0) wait_vmcnt<0>(); else wait_vmcnt<8>();   // the residual rows of this step landed; the previous step's 8 stores stay in flight
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * g + tt;
+            const unsigned char *Wt = dsm + (g % HG) * BT_WSTAGE + (tt * 32 + l31) * (BK * 2);
+            f32x16 a3[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a3[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const unsigned c = (unsigned)(((ks & 3) << 1) | lh);
+                const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + (ks >> 2) * HG * BT_WSTAGE + ((c ^ swz) << 4));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[ks][b], a3[b]);
+            }
+            f32x4 s3[4], b3[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * t + 8 * q + 4 * lh;
+                s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
+                b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                if (has_res) {
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                        const uint4 L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
+                        auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                        rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
+                        rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 4 * q + 2 * h + e;
+                            float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
+                            if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
+                            v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                        }
+                        d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(d[tt][b][q][h], d[tt][b][q + 1][h], false, false);
+                        d[tt][b][q][h] = sw[0];
+                        d[tt][b][q + 1][h] = sw[1];
+                    }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                    *reinterpret_cast<uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4)) =
+                        make_uint4(d[tt][b][2 * qq][0], d[tt][b][2 * qq][1], d[tt][b][2 * qq + 1][0], d[tt][b][2 * qq + 1][1]);
+                }
+        uint4 rowv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rowv[k] = *reinterpret_cast<const uint4 *>(wbuf + k * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (has_res && g + 1 < n3) issue_res(g + 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = k * 8 + rrow;
+            const int j = wave * 64 + row;
+            uint16_t *dst = j < lim ? p.y + ((size_t)q0 + j) * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
+                                    : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;
+            gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
+        }
+    }
+}
+
+template <typename T>
+int32_t launch_bneck128(const BneckKP &p, hipStream_t s) {
+    const int S = (p.NP + 1) * 8;
+    const int main_bytes = (S + 63) / 64 * 64 * 16 + 2 * 128 * BK * 2;
+    const int tail_bytes = 2 * 2 * BT_WSTAGE + 2 * p.cout3 * 4 + 4 * 8192;
+    const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
+    if (lds > 160 * 1024) {
+        set_error("tedspad_bneck_tail_fwd: halo does not fit LDS (%d bytes)", lds);
+        return TEDSPAD_EINVAL;
+    }
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_bneck_tail128_kernel<T>;
+    if (!attr_set[T::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 1;
+    }
+    hipLaunchKernelGGL(kfn, dim3((p.M + BT_BM - 1) / BT_BM), dim3(256), lds, s, p);
+    return check_launch("tedspad_bneck_tail_fwd");
+}
+
 template <typename T, bool DUAL, bool STAGED, bool POOLT = false>
 int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
@@ -450,9 +741,11 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
                                           int32_t variant, void *stream) {
     TS_REQUIRE(d2 && x && w2_packed && scale2 && shift2 && w3p && scale3 && shift3 && y, "tedspad_bneck_tail_fwd: null pointer");
     const bool same = d2->to == d2->t && d2->ho == d2->h && d2->wo == d2->w && d2->pt == 0 && d2->ph < d2->kh && d2->pw < d2->kw;
-    TS_REQUIRE(d2->cin == 64 && d2->cout == 64 && d2->kt == 1 && d2->st == 1 && d2->sh == 1 && d2->sw == 1 && same && d2->kh * d2->kw >= 2 &&
-                   d2->kh * d2->kw <= 32 && d2->ldx >= 64 && d2->ldx % 8 == 0,
-               "tedspad_bneck_tail_fwd: conv2 must be a stride-1 'same' 1 x kh x kw conv with 64 input and 64 output channels");
+    const bool c128 = d2->cin == 128 && d2->cout == 128;
+    TS_REQUIRE(((d2->cin == 64 && d2->cout == 64) || c128) && d2->kt == 1 && d2->st == 1 && d2->sh == 1 && d2->sw == 1 && same && d2->kh * d2->kw >= 2 &&
+                   d2->kh * d2->kw <= 32 && d2->ldx >= d2->cin && d2->ldx % 8 == 0,
+               "tedspad_bneck_tail_fwd: conv2 must be a stride-1 'same' 1 x kh x kw conv with 64 -> 64 or 128 -> 128 channels");
+    TS_REQUIRE(!c128 || (!x2 && !(variant & 4)), "tedspad_bneck_tail_fwd: the 128-channel form is the plain block (no second source, no temporal pool)");
     TS_REQUIRE(cout3 > 0 && cout3 % 64 == 0 && cout3 <= 512 && ldy >= cout3 && ldy % 8 == 0, "tedspad_bneck_tail_fwd: cout3 a multiple of 64 (<= 512), ldy >= cout3");
     TS_REQUIRE(!(residual && x2), "tedspad_bneck_tail_fwd: either a residual tensor or the second (downsample) source, not both");
     TS_REQUIRE(!residual || (ldres >= cout3 && ldres % 8 == 0), "tedspad_bneck_tail_fwd: bad ldres");
@@ -469,7 +762,8 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     p.M = (int)M; p.Kpad = tedspad_conv_kpad(d2); p.W = d2->w; p.H = d2->h; p.kh = d2->kh; p.kw = d2->kw; p.ph = d2->ph; p.pw = d2->pw;
     p.ldx = d2->ldx; p.ldres = ldres; p.ldx2 = ldx2; p.ldy = ldy; p.cout3 = cout3; p.relu = relu;
     p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
-    TS_REQUIRE(p.Kpad == p.ntaps * 64, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
+    TS_REQUIRE(p.Kpad == p.ntaps * d2->cin, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
+    if (c128) return d2->dtype == TEDSPAD_F16 ? launch_bneck128<F16>(p, (hipStream_t)stream) : launch_bneck128<BF16>(p, (hipStream_t)stream);
     p.HW = d2->h * d2->w; p.tpf = (p.HW + BT_BM - 1) / BT_BM;
     hipStream_t s = (hipStream_t)stream;
     if (variant & 4) {

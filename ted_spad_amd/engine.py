@@ -26,6 +26,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
 BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
+BNECK_TAIL128 = os.environ.get("TEDSPAD_BNECK_TAIL128", "1") != "0"   # layer2's plain blocks (128 mid channels) on the fused tail as well; 0: conv2 + conv3 launches (A/B)
 BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # layer1's last block: the fused tail with maxpool2 inside; 0: conv2 + (conv3 + pool) launches (A/B)
 TPAIR_MIN_COUT = int(os.environ.get("TEDSPAD_TPAIR_MIN_COUT", "128"))   # smallest cout that takes the folded form (256: layer2's 128-channel temporal convs stay on the temporal chunk-major tile)
 TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
@@ -557,14 +558,15 @@ class BneckTail:
 
     VARIANT = int(os.environ.get("TEDSPAD_BNECK_VARIANT", "3"))    # bit 0: staged rows for the plain block, bit 1: for the block with the downsample branch
     # column kk = ((a*2 + s)*2 + h)*8 + j of the conv3 weight image <- input channel 32 a + 16 s + 8 (j >> 2) + 4 h + (j & 3)
-    PERM = [32 * a + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for a in range(2) for s in range(2) for h in range(2) for j in range(8)]
+    PERM = [32 * a + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for a in range(4) for s in range(2) for h in range(2) for j in range(8)]   # first 64: the 64-channel form
 
     def __init__(self, conv2: "PackedConv", w3: torch.Tensor, scale3, shift3, wd: Optional[torch.Tensor] = None, scale_d=None, shift_d=None):
         assert self.supported(conv2, w3, wd)
         dev = conv2.device
         self.conv2 = conv2
         self.cout3 = int(w3.shape[0])
-        w3m = w3.detach().to(dev, torch.float32).reshape(self.cout3, 64)[:, torch.tensor(self.PERM, device=dev)]
+        self.cmid = conv2.cin                        # 64 (layer1) or 128 (layer2's plain blocks: chunk-major stage A, conv3 weights streamed)
+        w3m = w3.detach().to(dev, torch.float32).reshape(self.cout3, self.cmid)[:, torch.tensor(self.PERM[:self.cmid], device=dev)]
         self.dual = wd is not None
         if self.dual:
             w3m = torch.cat([w3m, wd.detach().to(dev, torch.float32).reshape(self.cout3, 64)], dim=1)
@@ -577,22 +579,22 @@ class BneckTail:
     @staticmethod
     def supported(conv2: "PackedConv", w3: torch.Tensor, wd=None) -> bool:
         kt, kh, kw = conv2.k
-        return (conv2.cin == 64 and conv2.cout == 64 and kt == 1 and 2 <= kh * kw <= 32 and conv2.stride == (1, 1, 1) and not conv2.pair and
-                tuple(w3.shape[1:]) == (64, 1, 1, 1) and w3.shape[0] % 64 == 0 and w3.shape[0] <= 512 and
-                (wd is None or tuple(wd.shape) == tuple(w3.shape)))
+        return (conv2.cin in (64, 128) and conv2.cout == conv2.cin and kt == 1 and 2 <= kh * kw <= 32 and conv2.stride == (1, 1, 1) and not conv2.pair and
+                tuple(w3.shape[1:]) == (conv2.cin, 1, 1, 1) and w3.shape[0] % 64 == 0 and w3.shape[0] <= 512 and
+                (wd is None or (conv2.cin == 64 and tuple(wd.shape) == tuple(w3.shape))))
 
     def applies(self, x: Act, pads) -> bool:
         n, t, h, w = x.dims
         kt, kh, kw = self.conv2.k
-        flat_halo = (256 + (kh - 1) * w + (kw - 1) + 1) * 128 + 3 * 8192
-        return (x.c == 64 and pads[0] == 0 and pads[1] < kh and pads[2] < kw and 2 * pads[1] == kh - 1 and 2 * pads[2] == kw - 1 and
+        flat_halo = (256 + (kh - 1) * w + (kw - 1) + 1) * 128 + (3 * 8192 if self.cmid == 64 else 2 * 16384)
+        return (x.c == self.cmid and pads[0] == 0 and pads[1] < kh and pads[2] < kw and 2 * pads[1] == kh - 1 and 2 * pads[2] == kw - 1 and
                 flat_halo <= 80 * 1024 and n * t * h * w * max(x.ld, self.cout3) < MAX_ELEMS)
 
     def __call__(self, x: Act, pads=(0, 1, 1), residual: Optional[Act] = None, x2: Optional[Act] = None, relu=True, pool_t2=False) -> Act:
         """pool_t2: MaxPool3d((2,1,1), (2,1,1)) of the block's output fused (large_i3d.py:139): result (n, t // 2, h, w, cout3)."""
         n, t, h, w = x.dims
         assert self.applies(x, pads) and (x2 is not None) == self.dual and not (self.dual and residual is not None)
-        assert not pool_t2 or (not self.dual and t % 2 == 0), "BneckTail: the temporal pool goes with the plain block and an even frame count"
+        assert not pool_t2 or (not self.dual and t % 2 == 0 and self.cmid == 64), "BneckTail: the temporal pool goes with the plain 64-channel block and an even frame count"
         out = Act.empty(n, t // 2 if pool_t2 else t, h, w, self.cout3, self.conv2.torch_dtype, x.buf.device)
         for o in (residual, x2):
             if o is not None:
@@ -602,7 +604,7 @@ class BneckTail:
         if x2 is not None:
             assert x2.c == 64
         c2 = self.conv2
-        d = c2._desc(n, t, h, w, x.ld, pads, (t, h, w), 64, 0, True)
+        d = c2._desc(n, t, h, w, x.ld, pads, (t, h, w), self.cmid, 0, True)
         check(_lib.lib().tedspad_bneck_tail_fwd(C.byref(d), x.ptr, c2.w.data_ptr(), c2.scale.data_ptr(), c2.shift.data_ptr(), self.w3p.data_ptr(),
                                                 self.scale3.data_ptr(), self.shift3.data_ptr(), self.cout3,
                                                 residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,

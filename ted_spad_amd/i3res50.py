@@ -88,7 +88,7 @@ class I3Res50(nn.Module):
                         s, b = self._bn_fold(blk.downsample[1])
                         P[p + "down"] = E.PackedConv(blk.downsample[0].weight, s, b, stride=(1, blk.stride, blk.stride),
                                                      dtype=self.compute_dtype, device=dev)
-                    if li == 1 and E.BneckTail.supported(P[p + "conv2"], blk.conv3.weight, blk.downsample[0].weight if blk.downsample is not None else None):
+                    if li in (1, 2) and E.BneckTail.supported(P[p + "conv2"], blk.conv3.weight, blk.downsample[0].weight if blk.downsample is not None else None):
                         s3, b3 = self._bn_fold(blk.bn3)
                         if blk.downsample is not None and blk.stride == 1:
                             sd_, bd_ = self._bn_fold(blk.downsample[1])
@@ -144,6 +144,8 @@ class I3Res50(nn.Module):
                 else:
                     h = P[p + "conv1"](a, pads=(blk.temp_conv, 0, 0))
                 tail = P.get(p + "tail") if (E.BNECK_TAIL and taps is None) else None
+                if tail is not None and tail.cmid == 128 and not E.BNECK_TAIL128:
+                    tail = None
                 fuse_pool = li == 1 and i == len(layer) - 1          # the last layer1 block fuses maxpool2 into its conv3 instead (below)
                 if tail is not None and tail.applies(h, (0, 1, 1)) and (not fuse_pool or (E.BNECK_TAIL_POOL and not tail.dual and h.dims[1] % 2 == 0)):
                     # conv2 + bn2 + ReLU + conv3 + bn3 + (residual | downsample branch) + ReLU in one launch: the 64-channel tensor between

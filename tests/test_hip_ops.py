@@ -155,6 +155,43 @@ def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dims", [(3, 2, 28, 28), (2, 3, 7, 9), (1, 1, 16, 16), (4, 2, 14, 30), (1, 2, 56, 56)])
+def test_bottleneck_tail_128_mid_channels_vs_oracle_and_unfused(dims, dtype, monkeypatch):
+    """engine.BneckTail with 128 mid channels (csrc/conv_bneck.hip, conv_bneck_tail128_kernel): conv2 1x3x3 (128 -> 128) + bn2 + ReLU -> conv3
+    (128 -> 512) + bn3 + residual + ReLU of layer2's plain bottlenecks (large_i3d.py:69-84) in one launch -- chunk-major stage A, eight-step
+    stage B with the conv3 weights streamed two output groups at a time -- against the oracle (the 128-channel tensor rounded where the
+    unfused path stores it) and against the two launches it replaces."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, t, h, w = dims
+    name = "bt128_%d" % h
+    x = _round(synth_tensor(8, name + "x", (n, t, h, w, 128), -1, 1), tdt)
+    w2 = _round(synth_tensor(8, name + "w2", (128, 128, 1, 3, 3), -1, 1) * (2.0 / 1152) ** 0.5, tdt)
+    w3 = _round(synth_tensor(8, name + "w3", (512, 128, 1, 1, 1), -1, 1) * (2.0 / 128) ** 0.5, tdt)
+    s2, b2 = synth_tensor(8, name + "s2", (128,), 0.5, 1.5), synth_tensor(8, name + "b2", (128,), -0.3, 0.3)
+    s3, b3 = synth_tensor(8, name + "s3", (512,), 0.5, 1.5), synth_tensor(8, name + "b3", (512,), -0.3, 0.3)
+    res = _round(synth_tensor(8, name + "r", (n, t, h, w, 512), -1, 1), tdt)
+    mid = _round(conv_cl(x, w2, s2, b2, (1, 1, 1), (0, 1, 1), (0, 1, 1), None, relu=True), tdt)
+    ref = conv_cl(mid, w3, s3, b3, (1, 1, 1), (0, 0, 0), (0, 0, 0), res, relu=True)
+    c2 = E.PackedConv(w2, s2, b2, dtype=dtype, device="cuda")
+    tail = E.BneckTail(c2, w3, s3, b3)
+    xa = E.Act(x.to(tdt).cuda(), 128)
+    assert tail.cmid == 128 and tail.applies(xa, (0, 1, 1))
+    got = tail(xa, residual=E.Act(res.to(tdt).cuda(), 512)).buf.float().cpu()
+    assert got.shape == ref.shape
+    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    err = (got - ref).abs()
+    assert bool((err <= ulp * ref.abs() + 2e-3).all()), "max err %g" % float(err.max())
+    assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
+    monkeypatch.setattr(E, "FORCE_TILE_CFG", None)
+    h2 = c2(xa, pads=(0, 1, 1))
+    old = E.PackedConv(w3, s3, b3, dtype=dtype, device="cuda")(h2, residual=E.Act(res.to(tdt).cuda(), 512), relu=True).buf.float().cpu()
+    # the unfused conv2 may run a K-order-preserving tile, the fused stage A walks (chunk, tap): the 16-bit intermediate can differ by one step
+    assert rel_l2(got, old) < (6e-4 if dtype == "f16" else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("dims", [(3, 14, 14, 1024, 256), (5, 7, 7, 2048, 512), (2, 28, 28, 512, 256), (1, 5, 3, 128, 256), (2, 28, 28, 256, 128), (3, 9, 11, 512, 384)])
 def test_temporal_conv_on_two_frames_as_one_folded_gemm(dims, dtype, monkeypatch):
     """engine.TPairConv: a 3x1x1 'same' conv + BN + ReLU on a 2-frame tensor (conv1 of layer3 / layer4's temporal bottlenecks,
