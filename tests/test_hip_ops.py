@@ -390,6 +390,7 @@ AGREE = [
     ("a_p8_3x1x1_c128_res", (2, 4, 9, 11), 128, 512, (3, 1, 1), (1, 0, 0), True),     # ... two channel tiles, residual, 6 K tiles
     ("a_p8_1x1x1_k128", (5, 2, 17, 9), 128, 256, (1, 1, 1), (0, 0, 0), True),         # ... the shortest K it takes (2 K tiles)
     ("a_p8_1x1x1_k192", (1, 1, 5, 7), 192, 256, (1, 1, 1), (0, 0, 0), False),         # ... odd number of K tiles, one ragged pixel tile
+    ("a_pw_1x1x1_c256_res", (3, 2, 13, 11), 256, 1024, (1, 1, 1), (0, 0, 0), True),   # layer3's conv3 shape (cin 256 -> 1024 + residual): ragged M, every generic tile
 ]
 
 
@@ -669,3 +670,5 @@ def test_hand_counted_waits_are_race_free_over_many_launches():
     xtp = spt.layout(synth_tensor(17, "rc", (6, 3, 16, 224, 224), device="cuda"))
     for variant in (0, 2):
         repeat(lambda: spt.conv(xtp, variant=variant).buf, n=30)
+    for variant in (2, 6):                               # ... with the whole pool fused, on 32x32x16 and on 16x16x32 MFMAs
+        repeat(lambda: spt.conv_pool(xtp, variant=variant).buf, n=30)
