@@ -21,6 +21,8 @@ constexpr int PT_S = 16;                 // patch side
 
 struct PatchGeo {
     int HH, WH, NP, ntaps, nchunks, tiles_h, tiles_w, tiles_n;
+    long xelems;             // ... elements of the input tensor (M * ldx)
+    int ncc, fstride;        // patch mode with kt > 1 (3 x 3 x 3 convs): channel chunks per temporal tap (nchunks = kt * ncc), elements per input frame
     int R;                   // FLAT: halo positions in front of the tile (ph * W + pw)
     int T, HW, PXF;          // TEMPORAL: frames of a clip, pixels of a frame, pixels per frame in a tile (256 / T rounded to a power of two)
 };
@@ -81,9 +83,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int rsub = wave * 8 + (lane >> 3);
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
     const uint16_t *wsrc = p.w + (size_t)(n0 + rsub) * p.Kpad + kc * 8;
-    auto issue_w = [&](int ch, int tap, int slot) {
+    auto issue_w = [&](int ch, int tap, int slot) {          // ch: chunk index; patch mode with kt > 1: (dt, channel chunk) -> K offset ((dt * taps + tap) * cin + chunk * 64)
         const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
-        const uint16_t *src = wsrc + tap * p.cin + ch * 64;
+        const int dtw = TEMP ? 0 : ch / g.ncc;
+        const uint16_t *src = wsrc + (dtw * g.ntaps + tap) * p.cin + (ch - dtw * g.ncc) * 64;
 #pragma unroll
         for (int j = 0; j < WL; ++j) lds_dma16(src + (size_t)(j * 32) * p.Kpad, dst + j * 32 * (BK * 2));
     };
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
 #pragma unroll
     for (int bq = 0; bq < 2; ++bq) pbase[bq] = (FLAT || TEMP) ? wave * 64 + bq * 32 + l31 : (4 * wave + 2 * bq + (l31 >> 4)) * g.WH + (l31 & 15);
     unsigned vmask[2] = {0u, 0u};      // FLAT: bit (dh*kw + dw): the tap lies inside the frame
+    int tq[2] = {0, 0};                // FLAT with kt > 1: the frame index of the pixel inside its clip
     if (FLAT) {
 #pragma unroll
         for (int bq = 0; bq < 2; ++bq) {
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             if (q < p.M) {
                 const int r1 = q / p.Wi, w = q - r1 * p.Wi;
                 const int h = r1 % p.Hi;
+                tq[bq] = (r1 / p.Hi) % p.Ti;
                 for (int dh = 0; dh < p.kh; ++dh)
                     for (int dw = 0; dw < p.kw; ++dw)
                         if ((unsigned)(h + dh - p.ph) < (unsigned)p.Hi && (unsigned)(w + dw - p.pw) < (unsigned)p.Wi) vmask[bq] |= 1u << (dh * p.kw + dw);
@@ -116,14 +121,33 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][bq][r] = 0.f;
 
+    bool started = false;
     for (int ch = 0; ch < g.nchunks; ++ch) {
-        if (ch) __builtin_amdgcn_s_barrier();              // every wave has read the previous chunk's halo and weight slots
+        // patch mode with kt > 1 (the 3 x 3 x 3 convs of InceptionI3d, i3d.py Unit3D): chunk = (temporal tap dt, channel chunk); the halo of
+        // input frame t + dt - pt is fetched like any other chunk's, a tap that leaves the clip is skipped by the whole workgroup
+        long fshift = 0;
+        int chc = ch, dtc = p.pt;
+        if (!TEMP && g.ncc != g.nchunks) {
+            dtc = ch / g.ncc;
+            if (!FLAT && (unsigned)(b % p.Ti + dtc - p.pt) >= (unsigned)p.Ti) continue;      // the patch is one frame: the whole chunk leaves the clip
+            fshift = (long)(dtc - p.pt) * g.fstride;
+            chc = ch - dtc * g.ncc;
+        }
+        // FLAT with kt > 1: a tile may span frames and clips, so the temporal tap's validity is per pixel (like the spatial taps')
+        bool fv[2] = {true, true};
+        if (FLAT && g.ncc != g.nchunks) {
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) fv[bq] = (unsigned)(tq[bq] + dtc - p.pt) < (unsigned)p.Ti;
+        }
+        if (started) __builtin_amdgcn_s_barrier();         // every wave has read the previous chunk's halo and weight slots
+        started = true;
         asm volatile("" ::: "memory");
         issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
 #pragma unroll
         for (int i = 0; i < NHMAX; ++i) {
             if (i * NT + wave * 64 >= Sr) break;           // wave-uniform
-            lds_dma16(hsrc[i] >= 0 ? p.x + hsrc[i] + ch * 64 : zero, lds0 + (i * NT + wave * 64) * 16);
+            const long so = hsrc[i] + fshift;            // FLAT: the shifted run may leave the tensor at either end
+            lds_dma16((hsrc[i] >= 0 && so >= 0 && so < g.xelems) ? p.x + so + chc * 64 : zero, lds0 + (i * NT + wave * 64) * 16);
         }
         if (g.ntaps > 1) issue_w(ch, 1, 1);
         int dh = 0, dw = 0;
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             unsigned xoff[2], xswz[2];
 #pragma unroll
             for (int bq = 0; bq < 2; ++bq) {
-                const int pos = (!FLAT || ((vmask[bq] >> kt) & 1u)) ? pbase[bq] + delta : g.NP;
+                const int pos = (!FLAT || (((vmask[bq] >> kt) & 1u) && fv[bq])) ? pbase[bq] + delta : g.NP;
                 xoff[bq] = (unsigned)pos * 128u;
                 xswz[bq] = (unsigned)(pos >> 1) & 7u;
             }
@@ -297,6 +321,8 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
     g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
     g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.R = 0; g.tiles_n = (p.Cout + BN - 1) / BN;
     if (FLAT) { g.WH = p.Wi; g.NP = 256 + (p.kh - 1) * p.Wi + (p.kw - 1); g.R = p.ph * p.Wi + p.pw; g.tiles_h = 1; g.tiles_w = 1; }
+    g.ncc = g.nchunks; g.fstride = p.Hi * p.Wi * p.ldx; g.xelems = (long)p.M * p.ldx;
+    if (MODE != 2 && p.kt > 1) g.nchunks = p.kt * g.ncc;       // 3 x 3 x 3: (temporal tap, channel chunk)
     g.T = p.Ti; g.HW = p.Hi * p.Wi; g.PXF = p.Ti <= 1 ? 256 : p.Ti == 2 ? 128 : 64;
     if (TEMP) { g.ntaps = p.kt; g.NP = g.T * g.PXF; g.tiles_h = 1; g.tiles_w = (g.HW + g.PXF - 1) / g.PXF; }
     const int S = (g.NP + (FLAT ? 1 : 0)) * 8, Sr = (S + 63) / 64 * 64;
@@ -335,10 +361,11 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
         if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64, 2>(p, frames, cin, s) : launch_patch_t<BF16, 64, 2>(p, frames, cin, s);
         return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128, 2>(p, frames, cin, s) : launch_patch_t<BF16, 128, 2>(p, frames, cin, s);
     }
-    const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt == 0 && p.ph < p.kh && p.pw < p.kw;
-    if (cin % 64 != 0 || p.kt != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 512 ||
-        p.Kpad != p.kh * p.kw * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
-        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' 1 x kh x kw conv with cin %% 64 == 0, cout <= 512 (mask / stats / fp32 output allowed, no strided output map)");
+    const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.pt < p.kt && p.ph < p.kh && p.pw < p.kw;
+    const bool kt_ok = p.kt == 1 ? p.pt == 0 : (p.kt <= 3 && (long)p.Ti * p.Hi * p.Wi * p.ldx * N < (1L << 31));
+    if (cin % 64 != 0 || !kt_ok || p.st != 1 || p.sh != 1 || p.sw != 1 || !same || p.kh * p.kw < 2 || p.kh * p.kw > 16 || p.Cout > 512 ||
+        p.Kpad != p.kt * p.kh * p.kw * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32)) {
+        set_error("tedspad_conv_fwd: patch-halo config needs a stride-1 'same' kt x kh x kw conv (kt <= 3) with cin %% 64 == 0, cout <= 512 (mask / stats / fp32 output allowed, no strided output map)");
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;

@@ -391,6 +391,10 @@ AGREE = [
     ("a_p8_1x1x1_k128", (5, 2, 17, 9), 128, 256, (1, 1, 1), (0, 0, 0), True),         # ... the shortest K it takes (2 K tiles)
     ("a_p8_1x1x1_k192", (1, 1, 5, 7), 192, 256, (1, 1, 1), (0, 0, 0), False),         # ... odd number of K tiles, one ragged pixel tile
     ("a_pw_1x1x1_c256_res", (3, 2, 13, 11), 256, 1024, (1, 1, 1), (0, 0, 0), True),   # layer3's conv3 shape (cin 256 -> 1024 + residual): ragged M, every generic tile
+    ("a_patch_3x3x3_c64_n192", (2, 4, 20, 19), 64, 192, (3, 3, 3), (1, 1, 1), False),   # patch tile (32) with temporal taps as chunks: InceptionI3d's Conv3d_2c_3x3 (64 -> 192), ragged patches
+    ("a_patch_3x3x3_c128_t2", (3, 2, 9, 17), 128, 96, (3, 3, 3), (1, 1, 1), True),      # ... two channel chunks per temporal tap, T = 2 (every frame skips a tap), ragged N, residual
+    ("a_patch_3x3x3_c64_t1", (2, 1, 16, 16), 64, 64, (3, 3, 3), (1, 1, 1), False),      # ... a single frame: only the centre temporal tap runs
+    ("a_cflat_3x3x3_c64_n192", (3, 4, 9, 13), 64, 192, (3, 3, 3), (1, 1, 1), True),     # flat tile (33) with temporal taps: tiles span frames AND clips (per-pixel frame validity)
 ]
 
 
