@@ -12,6 +12,8 @@ branches of an Inception block write straight into their channel slice of the bl
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -38,6 +40,9 @@ PLAN = (
     ("Mixed_5b", "mixed", (832, (256, 160, 320, 32, 128, 128))),
     ("Mixed_5c", "mixed", (832, (384, 192, 384, 48, 128, 128))),
 )
+
+
+FUSE_REDUCE = os.environ.get("TEDSPAD_I3D_FUSE_REDUCE", "1") != "0"   # Mixed_*: the b1a / b2a 1x1x1 convs as one GEMM (0: two launches, A/B)
 
 
 class Unit3D(nn.Module):
@@ -106,6 +111,14 @@ class InceptionI3d(nn.Module):
                 elif kind == "mixed":
                     for b in ("b0", "b1a", "b1b", "b2a", "b2b", "b3b"):
                         P[name_ + "." + b] = self._pack_unit(getattr(m, b), dev)
+                    # the two 1x1x1 "reduce" convs in front of the 3x3x3 branches read the same tensor: ONE GEMM over [W_1a ; W_2a] whose output
+                    # the two 3x3x3 convs read as channel slices (the module input is read twice instead of three times, one launch less)
+                    ua, ub = m.b1a, m.b2a
+                    if ua.conv3d.weight.shape[0] % 8 == 0 and tuple(ua.s) == tuple(ub.s) == (1, 1, 1):
+                        sa, ba = E.fold_bn(ua.bn.weight, ua.bn.bias, ua.bn.running_mean, ua.bn.running_var, ua.bn.eps)
+                        sb, bb = E.fold_bn(ub.bn.weight, ub.bn.bias, ub.bn.running_mean, ub.bn.running_var, ub.bn.eps)
+                        P[name_ + ".b12a"] = E.PackedConv(torch.cat([ua.conv3d.weight, ub.conv3d.weight]), torch.cat([sa, sb]), torch.cat([ba, bb]),
+                                                          dtype=self.compute_dtype, device=dev)
             self._packed, self._packed_sig = P, sig
         return self._packed
 
@@ -145,9 +158,13 @@ class InceptionI3d(nn.Module):
                 n, t, h, w = a.dims
                 out = E.Act.empty(n, t, h, w, oc[0] + oc[2] + oc[4] + oc[5], a.buf.dtype, a.buf.device)
                 self._unit(P[name_ + ".b0"], a, one, one, out=out.slice(0, oc[0]))
-                t1 = self._unit(P[name_ + ".b1a"], a, one, one)
+                if (name_ + ".b12a") in P and taps is None and FUSE_REDUCE:
+                    t12 = self._unit(P[name_ + ".b12a"], a, one, one)
+                    t1, t2 = t12.slice(0, oc[1]), t12.slice(oc[1], oc[3])
+                else:
+                    t1 = self._unit(P[name_ + ".b1a"], a, one, one)
+                    t2 = self._unit(P[name_ + ".b2a"], a, one, one)
                 self._unit(P[name_ + ".b1b"], t1, three, one, out=out.slice(oc[0], oc[2]))
-                t2 = self._unit(P[name_ + ".b2a"], a, one, one)
                 self._unit(P[name_ + ".b2b"], t2, three, one, out=out.slice(oc[0] + oc[2], oc[4]))
                 pf, pb = self._same(a.dims[1:], three, one)
                 t3 = E.maxpool(a, three, one, pf, pb, pad_zero=True)
