@@ -294,14 +294,16 @@ int32_t tedspad_scale_shift_act(const float *z, const float *scale, const float 
                                 int32_t dtype, void *stream);
 
 /* sums[0][c] += sum_px g, sums[1][c] += sum_px g*xhat  with g = dy*(y>0 if relu), xhat = (z-mean)*invstd
- * (second row skipped when z == NULL: plain per-channel sum = bias gradient). `sums` pre-zeroed. */
+ * (second row skipped when z == NULL: plain per-channel sum = bias gradient). `sums` pre-zeroed.
+ * relu with y == NULL (units without a residual input): the mask is recomputed as z*s + b > 0 with the forward pass's own s = gamma*invstd,
+ * b = beta - mean*s (gamma / beta: C floats) -- the 16-bit output is not re-read (2 of the 8 bytes per element this pass moves). */
 int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
-                              float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
+                              const float *gamma, const float *beta, float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
                               int32_t ldz, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 
-/* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input). */
+/* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input); y == NULL with relu as above. */
 int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
-                             const float *gamma, const float *sums, int32_t sums_ld, void *dz, void *dres,
+                             const float *gamma, const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres,
                              int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
                              int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 

@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, con
 // block = 256 threads = (256 / C8L) pixel lanes x C8L channel chunks, C8L = min(C8, 32)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const float *z, const float *mean,
-                                                             const float *invstd, float *out, int out_ld, long pixels, int C8, int lddy,
-                                                             int ldy, int ldz, int relu) {
+                                                             const float *invstd, const float *gamma, const float *beta, float *out, int out_ld, long pixels,
+                                                             int C8, int lddy, int ldy, int ldz, int relu) {
     __shared__ float red[2][256][8];
     const int C8L = C8 < 32 ? C8 : 32;
     const int PL = 256 / C8L;
@@ -175,13 +175,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
     if (c8 < C8 && pl < PL) {
-        float mu[8], is[8];
+        // y == NULL with relu (units without a residual input): the ReLU mask is recomputed from z with the forward pass's own scale / shift
+        // (tedspad_bn_train_apply: s = gamma * invstd, b = beta - mean * s, y = relu(z * s + b)) instead of re-reading the 16-bit output
+        const bool remask = relu && !y;
+        float mu[8], is[8], ms[8], mb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { mu[i] = z ? mean[c8 * 8 + i] : 0.f; is[i] = z ? invstd[c8 * 8 + i] : 0.f; }
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = z ? mean[c8 * 8 + i] : 0.f; is[i] = z ? invstd[c8 * 8 + i] : 0.f;
+            ms[i] = remask ? gamma[c8 * 8 + i] * is[i] : 0.f;
+            mb[i] = remask ? beta[c8 * 8 + i] - mu[i] * ms[i] : 0.f;
+        }
         for (long px = (long)pb * PL + pl; px < pixels; px += (long)pblocks * PL) {
-            float g[8];
+            float g[8], zz[8];
             unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
-            if (relu) {
+            if (z) {
+                const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
+            }
+            if (remask) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] = zz[i] * ms[i] + mb[i] > 0.f ? g[i] : 0.f;
+            } else if (relu) {
                 float yy[8];
                 unpack8<T>(*reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8), yy);
 #pragma unroll
@@ -190,9 +205,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) s0[i] += g[i];
             if (z) {
-                const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { s1[i] += g[i] * (za[i] - mu[i]) * is[i]; s1[i + 4] += g[i + 4] * (zb[i] - mu[i + 4]) * is[i + 4]; }
+                for (int i = 0; i < 8; ++i) s1[i] += g[i] * (zz[i] - mu[i]) * is[i];
             }
         }
     }
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 //   train BN: k = gamma*invstd, a = dbeta/M, b = dgamma/M
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const float *z, const float *mean,
-                                                            const float *invstd, const float *gamma, const float *sums, int sums_ld,
+                                                            const float *invstd, const float *gamma, const float *beta, const float *sums, int sums_ld,
                                                             float inv_count, uint16_t *dz, uint16_t *dres, long pixels, int C8, int lddy,
                                                             int ldy, int ldz, int lddz, int lddres, int relu) {
     {   // statistics group (gridDim.y)
@@ -235,18 +249,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
         const long px = idx / C8;
         float g[8], zz[8], o[8];
         unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
-        if (relu) {
+        {
+            const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
+        }
+        if (relu && !y) {             // the forward pass's own expression (see bn_bwd_reduce_kernel)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c8 * 8 + i;
+                const float s_ = gamma[c] * invstd[c];
+                g[i] = zz[i] * s_ + (beta[c] - mean[c] * s_) > 0.f ? g[i] : 0.f;
+            }
+        } else if (relu) {
             float yy[8];
             unpack8<T>(*reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8), yy);
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
         }
         if (dres) *reinterpret_cast<uint4 *>(dres + px * lddres + c8 * 8) = pack8<T>(g);
-        {
-            const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
-        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = c8 * 8 + i;
@@ -465,29 +486,30 @@ extern "C" int32_t tedspad_scale_shift_act(const float *z, const float *scale, c
     return check_launch("tedspad_scale_shift_act");
 }
 
-extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, float *sums,
+extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, const float *gamma,
+                                         const float *beta, float *sums,
                                          int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t relu,
                                          int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && (!z || (mean && invstd)) && sums_ld >= C && groups >= 1 && groups < 65536,
-               "tedspad_bn_bwd_reduce: bad arguments");
+    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || (z && gamma && beta)) && (!z || (mean && invstd)) && sums_ld >= C && groups >= 1 && groups < 65536,
+               "tedspad_bn_bwd_reduce: bad arguments (relu needs y, or z + gamma + beta to recompute the mask)");
     const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
     long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
     if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;
     LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd,
-             sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
+             gamma, beta, sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
     return check_launch("tedspad_bn_bwd_reduce");
 }
 
 extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, const float *gamma,
-                                        const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
+                                        const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
                                         int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y) && groups >= 1 && groups < 65536,
-               "tedspad_bn_bwd_apply: bad arguments");
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536,
+               "tedspad_bn_bwd_apply: bad arguments (relu needs y, or beta to recompute the mask)");
     hipStream_t s = (hipStream_t)stream;
     LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8)), groups), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd, gamma,
-             sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
+             beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
     return check_launch("tedspad_bn_bwd_apply");
 }
 

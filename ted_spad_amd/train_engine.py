@@ -304,14 +304,15 @@ class ConvLayer:
 
 # ---- per-channel reductions / BatchNorm ---------------------------------------------------------------
 
-def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = None, mean=None, invstd=None, relu=False, groups: int = 1) -> torch.Tensor:
+def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = None, mean=None, invstd=None, relu=False, groups: int = 1,
+                 gamma=None, beta=None) -> torch.Tensor:
     """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu).
     z: the fp32 (n,t,h,w,C) pre-normalisation conv output. groups > 1: (groups, 2, C), one set per block of n / groups samples."""
     n, t, h, w = dy.dims
     sums = ARENA.take((2, dy.c) if groups == 1 else (groups, 2, dy.c), dy.buf.device)
     check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.data_ptr() if z is not None else None,
                                            mean.data_ptr() if mean is not None else None, invstd.data_ptr() if invstd is not None else None,
-                                           sums.data_ptr(), dy.c, n * t * h * w // groups, dy.c, dy.ld, y.ld if y is not None else 0,
+                                           gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, sums.data_ptr(), dy.c, n * t * h * w // groups, dy.c, dy.ld, y.ld if y is not None else 0,
                                            z.shape[-1] if z is not None else 0, int(relu), groups, _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
     return sums
 
@@ -358,16 +359,20 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
     n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
     G = ctx.groups
-    sums = channel_sums(dy, y, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G)
-    dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
-    dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
     if cz == c:
-        gam = bn.weight.detach()
+        gam, bet = bn.weight.detach(), bn.bias.detach()
     else:
         gam = torch.zeros(cz, dtype=torch.float32, device=z.device)
         gam[:c] = bn.weight.detach()
-    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, y.ptr, z.data_ptr(), ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
-                                          sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w // G, cz,
+        bet = torch.zeros(cz, dtype=torch.float32, device=z.device)
+        bet[:c] = bn.bias.detach()
+    # a unit without a residual input recomputes its ReLU mask from z (already read) instead of re-reading the 16-bit output y
+    ymask = y if (ctx.has_res or not ctx.relu) else None
+    sums = channel_sums(dy, ymask, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G, gamma=gam, beta=bet)
+    dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
+    dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
+    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ymask.ptr if ymask is not None else None, z.data_ptr(), ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
+                                          bet.data_ptr(), sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w // G, cz,
                                           dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu), G,
                                           _code(y.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
     for sg in (sums.unbind(0) if G > 1 else (sums,)):                # d(beta), d(gamma): the groups' sums add up
