@@ -371,6 +371,43 @@ int32_t tedspad_pack_conv_weights(const float *w, const float *scale, void *out,
                                   int32_t rows, int32_t rows_pad, int32_t kpad, const int32_t *dgrad_geo, int32_t dtype,
                                   void *stream);
 
+/* ---- multi-job weight refresh (csrc/pack.hip) -------------------------------------------------------------------
+ * After an optimizer step every 16-bit weight image of the updated network is stale: the reference simply reads its fp32
+ * parameters again (nn.Conv3d / FrozenBN in large_i3d.py:8-38, 61-84; train_anonymizer.py:123,193 `optimizer.step()`), here the
+ * images and the folded BatchNorm vectors are rewritten IN PLACE by ONE launch per kind, from a job table that stays on the
+ * device (every address in it is static). `jobs`: HOST array (the library validates it and fills block0 / nblocks);
+ * `table_dev`: njobs * sizeof(job) device bytes; upload != 0 copies jobs -> table_dev on `stream` first (needed once, and again
+ * only when a job changed). */
+typedef struct tedspad_pack_job {           /* one tedspad_pack_conv_weights call */
+    const float *w, *scale;
+    void *out;
+    int32_t co, ci, kt, kh, kw, cink, kwk, pair_shift, mode, rows, rows_pad, kpad;
+    int32_t geo[9];                         /* mode 1 (data gradient): {Et,Eh,Ew, ct,ch,cw, st,sh,sw} */
+    int32_t dtype;
+    int32_t block0, nblocks;                /* filled by the library */
+} tedspad_pack_job;
+int32_t tedspad_pack_multi(tedspad_pack_job *jobs, int32_t njobs, void *table_dev, int32_t upload, void *stream);
+
+typedef struct tedspad_fold_job {           /* one tedspad_bn_fold call, written zero-padded to n (and n2) floats */
+    const float *gamma, *beta, *mean, *var, *conv_bias;   /* gamma NULL: no BatchNorm -- scale = 1, shift = conv_bias (or 0) */
+    float *scale, *shift;                   /* n floats each (either may be NULL) */
+    float *scale2, *shift2;                 /* optional second copy, n2 floats each */
+    double eps;
+    int32_t C, n, n2, reserved;
+} tedspad_fold_job;
+int32_t tedspad_fold_multi(tedspad_fold_job *jobs, int32_t njobs, void *table_dev, int32_t upload, void *stream);
+
+/* packed fp32 weight-gradient accumulators of tedspad_conv_wgrad ([co_pad][kpad], K ordered (dt,dh,dw,c) over cink channels) ->
+ * the parameters' gradients in the reference layout (co, ci, kt, kh, kw): grad = (accumulate ? grad : 0) + dw * row_scale[co]. */
+typedef struct tedspad_wgrad_unpack_job {
+    const float *dw;
+    float *grad;
+    const float *row_scale;                 /* per output channel, may be NULL */
+    int32_t co, ci, kt, kh, kw, cink, kpad, accumulate;
+    int32_t block0, nblocks;                /* filled by the library */
+} tedspad_wgrad_unpack_job;
+int32_t tedspad_wgrad_unpack_multi(tedspad_wgrad_unpack_job *jobs, int32_t njobs, void *table_dev, int32_t upload, void *stream);
+
 /* Eval-mode BatchNorm folded to y = x*scale + shift (fp64 inside, rounded once): scale = gamma/sqrt(var+eps),
  * shift = beta - mean*scale (+ conv_bias*scale). FrozenBN / .eval() semantics (large_i3d.py:8-38, i3d.py:113-116). */
 int32_t tedspad_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, const float *conv_bias,

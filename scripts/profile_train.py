@@ -24,4 +24,4 @@ for name, fn in (('phase1', step.step_fa), ('phase2', step.step_ft)):
     print('  -- by device time')
     for e in sorted(kern, key=lambda e: -e.device_time_total)[:16]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
     print('  -- by launch count')
-    for e in sorted(kern, key=lambda e: -e.count)[:16]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
+    for e in sorted(kern, key=lambda e: -e.count)[:45]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))

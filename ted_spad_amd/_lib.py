@@ -24,6 +24,22 @@ class ConvExtras(C.Structure):
         "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "fold_hw", "fold_c", "fold_ldy", "stats_rows")]
 
 
+class PackJob(C.Structure):              # tedspad_pack_job
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("out", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "co", "ci", "kt", "kh", "kw", "cink", "kwk", "pair_shift", "mode", "rows", "rows_pad", "kpad")] + [
+        ("geo", C.c_int32 * 9), ("dtype", C.c_int32), ("block0", C.c_int32), ("nblocks", C.c_int32)]
+
+
+class FoldJob(C.Structure):              # tedspad_fold_job
+    _fields_ = [(n, C.c_void_p) for n in ("gamma", "beta", "mean", "var", "conv_bias", "scale", "shift", "scale2", "shift2")] + [
+        ("eps", C.c_double), ("C", C.c_int32), ("n", C.c_int32), ("n2", C.c_int32), ("reserved", C.c_int32)]
+
+
+class WgradUnpackJob(C.Structure):       # tedspad_wgrad_unpack_job
+    _fields_ = [("dw", C.c_void_p), ("grad", C.c_void_p), ("row_scale", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "co", "ci", "kt", "kh", "kw", "cink", "kpad", "accumulate", "block0", "nblocks")]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "t", "h", "w", "c", "ldx", "ldy",
@@ -86,6 +102,9 @@ SYMBOLS = {
     "tedspad_upsample_nearest2x_bwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
     "tedspad_add_channels": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     "tedspad_bn_fold": (_I32, [_P, _P, _P, _P, _P, C.c_double, _I32, _P, _P, _P]),
+    "tedspad_pack_multi": (_I32, [_P, _I32, _P, _I32, _P]),
+    "tedspad_fold_multi": (_I32, [_P, _I32, _P, _I32, _P]),
+    "tedspad_wgrad_unpack_multi": (_I32, [_P, _I32, _P, _I32, _P]),
     "tedspad_resize_aa_taps": (_I32, [_I32, _I32]),
     "tedspad_resize_aa_table": (_I32, [_I32, _I32, _P]),
     "tedspad_frames_crop_resize": (_I32, [_P] + [_I32] * 11 + [_P, _P, C.c_float, _I32, _P] + [_I64] * 4 + [_P]),

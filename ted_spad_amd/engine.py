@@ -128,9 +128,14 @@ def fold_bn(gamma, beta, mean, var, eps, conv_bias=None):
     if gamma.is_cuda:
         g, b, m, v = (t.detach().float().contiguous() for t in (gamma, beta, mean, var))
         cb = conv_bias.detach().float().contiguous() if conv_bias is not None else None
-        scale, shift = torch.empty_like(g), torch.empty_like(g)
+        n = g.numel()
+        store = torch.zeros((2, (n + 127) // 128 * 128), dtype=torch.float32, device=g.device)
+        scale, shift = store[0, :n], store[1, :n]
+        # zero-padded to the conv kernels' row padding: a PackedConv built from these takes them as its own scale / shift vectors (no copy),
+        # so a later in-place re-fold (FoldRefresh / tedspad_fold_multi) is all a changed BatchNorm needs
+        scale._tedspad_padded = shift._tedspad_padded = store.shape[1]
         check(_lib.lib().tedspad_bn_fold(g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), cb.data_ptr() if cb is not None else None,
-                                         C.c_double(eps), g.numel(), scale.data_ptr(), shift.data_ptr(), _stream_ptr()), "tedspad_bn_fold")
+                                         C.c_double(eps), n, scale.data_ptr(), shift.data_ptr(), _stream_ptr()), "tedspad_bn_fold")
         return scale, shift
     inv = gamma.double() / torch.sqrt(var.double() + eps)
     shift = beta.double() - mean.double() * inv
@@ -152,8 +157,79 @@ def _padded_vec(v, n, npad, device, fill):
             t[:n] = fill
             _CONST_VECS[key] = t
         return t
+    if getattr(v, "_tedspad_padded", 0) >= npad and v.device == torch.device(device) and v.numel() >= n:
+        return torch.as_strided(v, (npad,), (1,), v.storage_offset())                    # fold_bn output: already zero-padded storage
     v = v.detach().to(device=device, dtype=torch.float32)
     return v.contiguous() if npad == n else torch.nn.functional.pad(v, (0, npad - n))     # at most one launch
+
+
+class JobTable:
+    """A static job table of one of the multi-job launches (tedspad_pack_multi / _fold_multi / _wgrad_unpack_multi): built once from ctypes
+    job structs, uploaded by its first launch, then re-launched as is (every address in it is persistent)."""
+    FN = {_lib.PackJob: "tedspad_pack_multi", _lib.FoldJob: "tedspad_fold_multi", _lib.WgradUnpackJob: "tedspad_wgrad_unpack_multi"}
+
+    def __init__(self, jobs, keep=()):
+        self.n = len(jobs)
+        self.keep = list(keep)                      # tensors the jobs point at
+        if self.n:
+            kind = type(jobs[0])
+            self.fn = self.FN[kind]
+            self.arr = (kind * self.n)(*jobs)
+            self.dev = None
+
+    def launch(self, device):
+        if not self.n:
+            return
+        upload = self.dev is None
+        if upload:
+            self.dev = torch.empty(C.sizeof(self.arr), dtype=torch.uint8, device=device)
+        check(getattr(_lib.lib(), self.fn)(C.cast(self.arr, C.c_void_p), self.n, self.dev.data_ptr(), int(upload), _stream_ptr()), self.fn)
+
+
+class PackedRefresh:
+    """In-place refresh of the images of an eval-mode network (`packed()` of unet.py / unetpp.py) after its parameters changed: the folds
+    and weight images recorded while the network was packed are rewritten by one tedspad_fold_multi + one tedspad_pack_multi launch; the
+    PackedConv objects -- buffers, gather tables, tuned tile choices -- stay."""
+
+    def __init__(self):
+        self.fj, self.pj, self.keep, self.tabs = [], [], [], None
+
+    def fold(self, bn, conv_bias, scale, shift):
+        self.fj.append(fold_job(bn, conv_bias, scale, shift))
+        self.keep += [scale, shift]
+
+    def bias(self, pc: "PackedConv", bias):
+        """A conv without BatchNorm whose shift vector is (a padded copy of) its bias."""
+        assert bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous()
+        self.fj.append(_lib.FoldJob(gamma=None, beta=None, mean=None, var=None, conv_bias=bias.data_ptr(), scale=None, shift=pc.shift.data_ptr(),
+                                    scale2=None, shift2=None, eps=0.0, C=bias.numel(), n=pc.shift.numel(), n2=0, reserved=0))
+        self.keep.append(pc)
+
+    def pack(self, pc: "PackedConv", weight, wscale=None):
+        self.pj.append(pc.pack_job(weight.detach(), wscale))
+        self.keep.append(pc)
+
+    def run(self, device):
+        if self.tabs is None:
+            self.tabs = (JobTable(self.fj), JobTable(self.pj))
+        for t in self.tabs:
+            t.launch(device)
+
+
+def same_storage(sig_a, sig_b) -> bool:
+    """Two `params_signature`s that differ in version counters only (in-place updates: an optimizer step, running statistics)."""
+    return len(sig_a) == len(sig_b) and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(sig_a, sig_b))
+
+
+def fold_job(bn, conv_bias, scale, shift):
+    """FoldJob re-folding `bn` (+ conv bias) into the zero-padded (scale, shift) vectors `fold_bn` returned for it."""
+    ts = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv_bias] if conv_bias is not None else [])
+    for t in ts:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "fold refresh needs contiguous fp32 CUDA BatchNorm tensors"
+    n = int(getattr(scale, "_tedspad_padded", scale.numel()))
+    return _lib.FoldJob(gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), mean=bn.running_mean.data_ptr(), var=bn.running_var.data_ptr(),
+                        conv_bias=conv_bias.data_ptr() if conv_bias is not None else None, scale=scale.data_ptr(), shift=shift.data_ptr(),
+                        scale2=None, shift2=None, eps=float(bn.eps), C=bn.weight.numel(), n=n, n2=0, reserved=0)
 
 
 def stem_pair_form(w: torch.Tensor, pair_w: int):
@@ -221,6 +297,7 @@ class PackedConv:
             check(_lib.lib().tedspad_pack_conv_weights(wc.data_ptr(), None, self.w.data_ptr(), cout, cin, kt, kh, kw, cin_k, kw_k, pair_shift,
                                                        0, cout, self.cpad, self.kpad, None, self.dtype_code, _stream_ptr()),
                   "tedspad_pack_conv_weights")
+            self._pack_args = dict(co=cout, ci=cin, kt=kt, kh=kh, kw=kw, cink=cin_k, kwk=kw_k, pair_shift=pair_shift, mode=0, rows=cout, geo=(0,) * 9)
         else:                          # host packing (CPU tests of the layout)
             if self.pair:
                 w, _, _ = stem_pair_form(w, pair_w)
@@ -262,11 +339,27 @@ class PackedConv:
         check(_lib.lib().tedspad_pack_conv_weights(wc.data_ptr(), wscale.data_ptr() if wscale is not None else None, self.w.data_ptr(), co, ci,
                                                    kt, kh, kw, cin_k, kw_k, pair_shift, 1, cin_k, self.cpad, self.kpad, g, self.dtype_code,
                                                    _stream_ptr()), "tedspad_pack_conv_weights")
+        self._pack_args = dict(co=co, ci=ci, kt=kt, kh=kh, kw=kw, cink=cin_k, kwk=kw_k, pair_shift=pair_shift, mode=1, rows=cin_k, geo=tuple(geo))
         self.scale = _padded_vec(None, cin_k, self.cpad, dev, 1.0)
         self.shift = _padded_vec(None, cin_k, self.cpad, dev, 0.0)
         self.device = dev
         self._ktabs, self._cfgs = {}, _Cfgs()
         return self
+
+    def pack_job(self, w: torch.Tensor, wscale=None) -> "_lib.PackJob":
+        """The PackJob that rewrites this object's weight image in place from the fp32 parameter `w` (the tensor -- or one of the same shape --
+        it was built from) and the per-output-channel scale folded into it (data-gradient images of a frozen BatchNorm)."""
+        a = getattr(self, "_pack_args", None)
+        if a is None:
+            raise _lib.TedSpadHipError("PackedConv.pack_job: this image was not packed on the device")
+        assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == a["co"] * a["ci"] * a["kt"] * a["kh"] * a["kw"], \
+            "pack_job needs the contiguous fp32 CUDA parameter this image was built from"
+        j = _lib.PackJob(w=w.data_ptr(), scale=wscale.data_ptr() if wscale is not None else None, out=self.w.data_ptr(),
+                         co=a["co"], ci=a["ci"], kt=a["kt"], kh=a["kh"], kw=a["kw"], cink=a["cink"], kwk=a["kwk"], pair_shift=a["pair_shift"],
+                         mode=a["mode"], rows=a["rows"], rows_pad=self.cpad, kpad=self.kpad, dtype=self.dtype_code, block0=0, nblocks=0)
+        for i, g in enumerate(a["geo"]):
+            j.geo[i] = g
+        return j
 
     def _desc(self, n, t, h, w, ldx, pads, out, ldy, ldres, relu):
         kt, kh, kw = self.k

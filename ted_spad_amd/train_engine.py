@@ -70,6 +70,8 @@ ARENA = ZeroArena()
 # Tiny per-BatchNorm updates are collected and applied with multi-tensor launches: `num_batches_tracked += 1`
 # (one launch per BN per forward otherwise) and d(gamma) / d(beta), whose per-call sums live in the arena (one clone
 # or add launch per tensor per clip otherwise).
+REFRESH_IN_PLACE = os.environ.get("TEDSPAD_WEIGHT_REFRESH", "1") != "0"     # 0: every stale image rebuilt by the lazy path (A/B timing)
+IMAGES_GEN = 0          # bumped whenever a ConvLayer builds a NEW kernel-form image (WeightRefresh then rebuilds its job tables)
 _PENDING_COUNT = {}     # id(tensor) -> [tensor, increments]
 _PENDING_GRAD = {}      # id(param)  -> [param, [arena slices]]
 
@@ -192,9 +194,9 @@ class ConvLayer:
         self.stride, self.pads = tuple(stride), tuple(pads)
         self.pads_back = self.pads if pads_back is None else tuple(pads_back)
         self.pair_w, self.dtype = pair_w, dtype
-        self._fwd = None
-        self._fwd_sig = None
-        self._dgrad = {}
+        self._fwd = {}            # flavour (scale is None, shift is None) -> [sig, PackedConv, scale, shift]
+        self._last = None         # the forward image used last (geometry queries)
+        self._dgrad = {}          # (x dims, dy dims, scale is None) -> [sig, DgradPlan, scale]
 
     # ---- kernel-form weights ------------------------------------------------------------------------
     def _w5(self):
@@ -202,23 +204,34 @@ class ConvLayer:
         return w.unsqueeze(2) if w.dim() == 4 else w
 
     def _sig(self, scale, shift):
-        def v(t):
-            return None if t is None else (t.data_ptr(), t._version)
+        def v(t):       # _tedspad_rev: in-place re-folds of a BatchNorm vector (cached_fold / WeightRefresh), which torch's version counter does not see
+            return None if t is None else (t.data_ptr(), t._version, getattr(t, "_tedspad_rev", 0))
         return (v(self.weight), v(self.bias), v(scale), v(shift))
 
     def fwd_conv(self, scale=None, shift=None) -> PackedConv:
-        """scale/shift None -> (1, bias): the raw conv of the train-mode path."""
+        """scale/shift None -> (1, bias): the raw conv of the train-mode path. One image per flavour (train mode / folded BatchNorm):
+        a network that alternates between them (ft: frozen in phase 1, trained in phase 2) keeps both, and `WeightRefresh` rewrites them
+        in place after an optimizer step; this lazy path only builds what does not exist yet (or was built for other tensors)."""
+        global IMAGES_GEN
+        key = (scale is None, shift is None)
         sig = self._sig(scale, shift)
-        if self._fwd is None or self._fwd_sig != sig:
+        ent = self._fwd.get(key)
+        if ent is None or ent[0] != sig:
             w = self._w5()
-            sc = scale                                                          # None: the cached all-ones vector (no launch)
             sf = (self.bias.detach() if self.bias is not None else None) if shift is None else shift
-            old = self._fwd
-            self._fwd = PackedConv(w, sc, sf, stride=self.stride, dtype=self.dtype, device=w.device, pair_w=self.pair_w)
+            pc = PackedConv(w, scale, sf, stride=self.stride, dtype=self.dtype, device=w.device, pair_w=self.pair_w)
+            old = ent[1] if ent is not None else self._last
             if old is not None:   # same geometry: keep the gather tables and the tuned tile choice
-                self._fwd._ktabs, self._fwd._cfgs = old._ktabs, old._cfgs
-            self._fwd_sig = sig
-        return self._fwd
+                pc._ktabs, pc._cfgs = old._ktabs, old._cfgs
+            ent = [sig, pc, scale, shift]
+            self._fwd[key] = ent
+            IMAGES_GEN += 1
+        self._last = ent[1]
+        return ent[1]
+
+    def geom_conv(self) -> PackedConv:
+        """Any forward image of this conv (kernel-form geometry, gather tables, K padding: the same for every flavour)."""
+        return self._last if self._last is not None else self.fwd_conv()
 
     def _pads_k(self, pc: PackedConv):
         if self.pair_w is None:
@@ -233,24 +246,26 @@ class ConvLayer:
     # ---- backward -----------------------------------------------------------------------------------
     def dgrad(self, dy: Act, x_dims, scale=None, residual=None, mask=None, out=None) -> Act:
         """d(input) (kernel-form channels: the stem returns the (n,t,h,w/2,8) pixel-pair tensor == (n,t,h,w,4))."""
-        key = (tuple(x_dims), dy.dims[1:])
+        global IMAGES_GEN
+        key = (tuple(x_dims), dy.dims[1:], scale is None)
         sig = self._sig(scale, None)
         plan = self._dgrad.get(key)
         if plan is None or plan[0] != sig:
-            pc = self.fwd_conv()
+            pc = self.geom_conv()
             p_k, _ = self._pads_k(pc)
             new = DgradPlan(self._w5().float(), scale, pc.stride, p_k, x_dims, dy.dims[1:], self.dtype, pair_w=self.pair_w)
             if plan is not None:
                 for (_, pc_new, _, _), (_, pc_old, _, _) in zip(new.subs, plan[1].subs):
                     pc_new._ktabs, pc_new._cfgs = pc_old._ktabs, pc_old._cfgs
-            plan = (sig, new)
+            plan = [sig, new, scale]
             self._dgrad[key] = plan
+            IMAGES_GEN += 1
         return plan[1].run(dy, residual=residual, mask=mask, out=out)
 
     def wgrad(self, x: Act, dy: Act):
         """Accumulates d(weight) in the packed [cout_pad][kpad] fp32 layout (float atomics); several calls per step
         (the three clips) add into the same matrix. `flush_grad()` converts it to the parameter layout once."""
-        pc = self.fwd_conv()
+        pc = self.geom_conv()
         n, t, h, w = x.dims
         pk, _ = self._pads_k(pc)
         if getattr(self, "_dwp_gen", -1) != ARENA.gen or self._dwp is None:     # new step, or flushed since (one flush per backward pass in the autograd path)
@@ -275,7 +290,7 @@ class ConvLayer:
         flush_deferred()
         if getattr(self, "_dwp_gen", -1) != ARENA.gen or self._dwp is None:
             return
-        pc = self.fwd_conv()
+        pc = self.geom_conv()
         w5 = self._w5()
         co, ci, kt, kh, kw = w5.shape
         kt_, kh_, kw_ = pc.k
@@ -300,6 +315,154 @@ class ConvLayer:
             else:
                 self.bias.grad.add_(db)
         self._dwp = None
+
+
+def flush_conv_grads(layers):
+    """`flush_grad()` of every layer in ONE launch (tedspad_wgrad_unpack_multi): the packed accumulators of this step -> the parameters'
+    .grad (accumulated when .grad exists -- a view into a gradient bucket, grad_reduce.py -- else created). The stem's pixel-pair form
+    keeps the per-layer path; bias gradients are added with one multi-tensor launch. The job table is cached while the accumulators and gradients keep their addresses
+    (the arena hands out the same slices every step)."""
+    flush_deferred()
+    jobs, keep, key, slow, badd = [], [], [], [], ([], [])
+    for L in layers:
+        if getattr(L, "_dwp_gen", -1) != ARENA.gen or L._dwp is None:
+            continue
+        if L.pair_w is not None or not L.weight.is_contiguous():
+            slow.append(L)
+            continue
+        pc = L.geom_conv()
+        co, ci, kt, kh, kw = L._w5().shape
+        rs = getattr(L, "_grad_row_scale", None)
+        acc = L.weight.grad is not None
+        if acc and (not L.weight.grad.is_contiguous() or L.weight.grad.dtype != torch.float32):
+            slow.append(L)
+            continue
+        if not acc:
+            L.weight.grad = torch.empty_like(L.weight)
+        g = L.weight.grad
+        jobs.append(_lib.WgradUnpackJob(dw=L._dwp.data_ptr(), grad=g.data_ptr(), row_scale=rs.data_ptr() if rs is not None else None,
+                                        co=co, ci=ci, kt=kt, kh=kh, kw=kw, cink=pc.cin, kpad=pc.kpad, accumulate=int(acc), block0=0, nblocks=0))
+        keep += [L._dwp, g, rs]
+        key.append((L._dwp.data_ptr(), g.data_ptr(), rs.data_ptr() if rs is not None else 0, acc, id(L)))
+        L._grad_row_scale = None
+        L._dwp = None
+        if L.bias is not None and L._db is not None:
+            db = L._db[:co]
+            if L.bias.grad is None:
+                L.bias.grad = db.clone()
+            else:
+                badd[0].append(L.bias.grad)
+                badd[1].append(db)
+    if badd[0]:
+        torch._foreach_add_(badd[0], badd[1])
+    if jobs:
+        key = tuple(key)
+        tab = _UNPACK_TABLES.get(key)
+        if tab is None:
+            if len(_UNPACK_TABLES) > 64:
+                _UNPACK_TABLES.clear()
+            tab = _UNPACK_TABLES[key] = E.JobTable(jobs)
+        tab.keep = keep                     # this step's tensors (same addresses as the cached table's)
+        tab.launch(keep[0].device)
+    for L in slow:
+        L.flush_grad()
+
+
+_UNPACK_TABLES = {}
+
+
+class WeightRefresh:
+    """In-place refresh of every kernel-form image a set of ConvLayers holds (forward images of both flavours, data-gradient images) and
+    of the folded BatchNorm vectors they were built with, after an optimizer step: ONE tedspad_fold_multi + ONE tedspad_pack_multi launch
+    from static job tables instead of a rebuild (new buffers, one launch each, ~100 us of host time per image) by the lazy path. `folds`:
+    the owner's fold cache {id(bn): [sig, scale, shift, bn, conv_bias]}. The lazy path stays responsible for images that do not exist yet;
+    whenever it builds one (IMAGES_GEN moves) the tables are rebuilt."""
+
+    def __init__(self, layers_fn, folds=None):
+        self.layers_fn, self.folds = layers_fn, folds if folds is not None else {}
+        self.gen, self.nfolds, self.fold_tab, self.pack_tab = -1, -1, None, None
+
+    def _build(self, layers):
+        fj, keep = [], []
+        for ent in self.folds.values():
+            _, s, b, bn, cb = ent
+            fj.append(E.fold_job(bn, cb, s, b))
+            keep += [s, b]
+        pj = []
+        for L in layers:
+            w = L._w5()
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise _lib.TedSpadHipError("WeightRefresh: a conv parameter is not a contiguous fp32 CUDA tensor")
+            for ent in L._fwd.values():
+                _, pc, scale, shift = ent
+                pj.append(pc.pack_job(w, None))
+                if shift is None and L.bias is not None:          # train flavour of a conv with bias: the image's shift vector is a padded copy
+                    fj.append(_lib.FoldJob(gamma=None, beta=None, mean=None, var=None, conv_bias=L.bias.data_ptr(), scale=None, shift=pc.shift.data_ptr(),
+                                           scale2=None, shift2=None, eps=0.0, C=L.bias.numel(), n=pc.shift.numel(), n2=0, reserved=0))
+                elif scale is not None and (getattr(scale, "_tedspad_padded", 0) < pc.cpad or (shift is not None and getattr(shift, "_tedspad_padded", 0) < pc.cpad)):
+                    raise _lib.TedSpadHipError("WeightRefresh: a folded image whose scale / shift are private copies (not engine.fold_bn outputs)")
+                keep += [pc, scale, shift]
+            for ent in L._dgrad.values():
+                _, plan, scale = ent
+                for _, pc, _, _ in plan.subs:
+                    pj.append(pc.pack_job(w, scale))
+                    keep.append(pc)
+                keep.append(scale)
+        self.fold_tab, self.pack_tab = E.JobTable(fj, keep), E.JobTable(pj)
+        self.gen, self.nfolds = IMAGES_GEN, len(self.folds)
+
+    def stale(self, layers) -> bool:
+        for L in layers:
+            for ent in L._fwd.values():
+                if ent[0] != L._sig(ent[2], ent[3]):
+                    return True
+            for ent in L._dgrad.values():
+                if ent[0] != L._sig(ent[2], None):
+                    return True
+        for ent in self.folds.values():
+            if ent[0] != fold_sig(ent[3], ent[4]):
+                return True
+        return False
+
+    def run(self):
+        if not REFRESH_IN_PLACE:
+            return False
+        layers = self.layers_fn()
+        if not layers or not self.stale(layers):
+            return False
+        if self.gen != IMAGES_GEN or self.nfolds != len(self.folds) or self.pack_tab is None:
+            self._build(layers)
+        dev = layers[0].weight.device
+        self.fold_tab.launch(dev)
+        self.pack_tab.launch(dev)
+        for L in layers:
+            for ent in L._fwd.values():
+                ent[0] = L._sig(ent[2], ent[3])
+            for ent in L._dgrad.values():
+                ent[0] = L._sig(ent[2], None)
+        for ent in self.folds.values():
+            ent[0] = fold_sig(ent[3], ent[4])
+        return True
+
+
+def fold_sig(bn, conv_bias=None):
+    return tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((conv_bias,) if conv_bias is not None else ()))
+
+
+def cached_fold(folds: dict, bn, conv_bias=None):
+    """Eval-mode BatchNorm (+ conv bias) as zero-padded fp32 (scale, shift) from the cache `folds` ({id(bn): [sig, scale, shift, bn, conv_bias]}):
+    folded once; re-folded INTO THE SAME TENSORS when the BatchNorm changed (the images built from them alias these vectors)."""
+    sig = fold_sig(bn, conv_bias)
+    hit = folds.get(id(bn))
+    if hit is None:
+        s, b = E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, conv_bias=conv_bias)
+        hit = folds[id(bn)] = [sig, s, b, bn, conv_bias]
+    elif hit[0] != sig:
+        E.JobTable([E.fold_job(bn, conv_bias, hit[1], hit[2])]).launch(hit[1].device)
+        hit[0] = sig
+        for t in hit[1:3]:
+            t._tedspad_rev = getattr(t, "_tedspad_rev", 0) + 1       # images with the old scale folded in are stale
+    return hit[1], hit[2]
 
 
 # ---- per-channel reductions / BatchNorm ---------------------------------------------------------------

@@ -114,6 +114,7 @@ class BottleneckTrunk:
         pre_pool ((kernel, stride) | None)."""
         self.stem, self.stem_bn, self.pool1, self.blocks = stem, stem_bn, pool1, blocks
         self._folds = {}
+        self.refresh = TE.WeightRefresh(self.conv_layers, self._folds)
 
     def conv_layers(self):
         out = [self.stem]
@@ -123,22 +124,17 @@ class BottleneckTrunk:
 
     def flush_grads(self):
         """Convert the packed weight-gradient accumulators of this step into the parameters' .grad."""
-        for c in self.conv_layers():
-            c.flush_grad()
+        TE.flush_conv_grads(self.conv_layers())
 
     def fold(self, bn):
-        """Eval-mode BN as fp32 (scale, shift); cached while the BN tensors are unchanged."""
-        sig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
-        hit = self._folds.get(id(bn))
-        if hit is None or hit[0] != sig:
-            hit = (sig,) + E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-            self._folds[id(bn)] = hit
-        return hit[1], hit[2]
+        """Eval-mode BN as fp32 (scale, shift); cached, re-folded in place when the BN tensors changed."""
+        return TE.cached_fold(self._folds, bn)
 
     def forward(self, a: Act, train: bool, frozen: bool = False, groups: int = 1):
         """a: the pixel-pair input Act. Returns (f (B,C) fp32 pooled feature, tape).
         groups (train mode): the batch is `groups` blocks of samples whose BatchNorms keep separate batch statistics (TE.conv_bn_act_train)."""
         assert not (train and frozen)
+        self.refresh.run()              # after an optimizer step: every existing weight image / BatchNorm fold rewritten in place, two launches
         tape = dict(train=train, frozen=frozen, units=[], clip=a)
 
         def unit(conv, bn, xin, relu=True, residual=None):
@@ -209,11 +205,7 @@ class BottleneckTrunk:
         return out
 
     def _flush_stage(self, li):
-        for d in self.blocks:
-            if d["li"] == li:
-                for k in ("c1", "c2", "c3", "cd"):
-                    if d[k] is not None:
-                        d[k].flush_grad()
+        TE.flush_conv_grads([d[k] for d in self.blocks if d["li"] == li for k in ("c1", "c2", "c3", "cd") if d[k] is not None])
 
     def backward(self, tape, df: torch.Tensor, on_stage_done=None):
         """df: (B,C) fp32 gradient w.r.t. the pooled feature. 'train' tape: accumulates the parameter gradients,
@@ -514,6 +506,7 @@ class UNetTrainer:
         self.down = [dc(getattr(unet, "down%d" % i).maxpool_conv[1]) for i in (1, 2, 3, 4)]
         self.up = [dc(getattr(unet, "up%d" % i).conv) for i in (1, 2, 3, 4)]
         self.outc = TE.ConvLayer(unet.outc.conv.weight, unet.outc.conv.bias, (1, 1, 1), (0, 0, 0), dtype=dt)
+        self.refresh = TE.WeightRefresh(self.conv_layers)
 
     def conv_layers(self):
         out = [c for c, _ in self.inc] + [self.outc]
@@ -522,14 +515,14 @@ class UNetTrainer:
         return out
 
     def flush_grads(self):
-        for c in self.conv_layers():
-            c.flush_grad()
+        TE.flush_conv_grads(self.conv_layers())
 
     def forward(self, x: torch.Tensor):
         """x: (N,3,H,W) fp32 -> (y (N,3,H,W) fp32, tape). BatchNorm2d uses the batch statistics of this call
         and updates the running stats once (the reference calls fa on the B*48 pseudo-images at once, Q2/Q14)."""
         m = self.m
         E.require_cuda(x, "UNetTrainer")
+        self.refresh.run()
         n, _, H, W = x.shape
         tdt = E.DTYPES[m.compute_dtype][0]
         a = E.clip_to_act(x.unsqueeze(2), cpad=8, dtype=m.compute_dtype)
@@ -590,10 +583,7 @@ class UNetTrainer:
         on_bucket_done(k): the k-th group of `grad_buckets()` is final and flushed (last backward pass of a step only)."""
         def done(k, units, extra=()):
             if on_bucket_done is not None:
-                for c, _ in units:
-                    c.flush_grad()
-                for c in extra:
-                    c.flush_grad()
+                TE.flush_conv_grads([c for c, _ in units] + list(extra))
                 on_bucket_done(k)
 
         n, H, W = tape["n"], tape["H"], tape["W"]
@@ -653,6 +643,7 @@ class UNetPPTrainer:
                            (CL(b.conv2[0].weight, None, (1, 1, 1), (0, 1, 1), dtype=dt), b.conv2[1])] for name, b in m.decoder.blocks.items()}
         head_ = m.segmentation_head[0]
         self.head = CL(head_.weight, head_.bias, (1, 1, 1), (0, 1, 1), dtype=dt)
+        self.refresh = TE.WeightRefresh(self.conv_layers)
 
     # the decoder blocks in the order `backward` finishes them
     DEC_ORDER = ("x_0_3", "x_0_2", "x_1_2", "x_0_1", "x_2_2", "x_1_1", "x_0_0")
@@ -666,8 +657,7 @@ class UNetPPTrainer:
         return out
 
     def flush_grads(self):
-        for c in self.conv_layers():
-            c.flush_grad()
+        TE.flush_conv_grads(self.conv_layers())
 
     def _stage_layers(self, li):
         return [d[k] for d in self.blocks if d["li"] == li for k in ("c1", "c2", "cd") if d[k] is not None]
@@ -697,6 +687,7 @@ class UNetPPTrainer:
         from .unetpp import UnetPlusPlus as U
         m = self.m
         E.require_cuda(x, "UNetPPTrainer")
+        self.refresh.run()
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected (N,3,H,W), got %s" % (tuple(x.shape),))
         n, _, H, W = x.shape
@@ -789,8 +780,7 @@ class UNetPPTrainer:
 
         def done(k, layers):
             if on_bucket_done is not None:
-                for c in layers:
-                    c.flush_grad()
+                TE.flush_conv_grads(layers)
                 on_bucket_done(k)
 
         dl = TE.nchw_grad_to_act(dy, None, (1, H, W), dtype=self.m.compute_dtype)

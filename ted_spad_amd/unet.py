@@ -76,19 +76,27 @@ class UNet(nn.Module):
             conv, bn = dc.double_conv[ci], dc.double_conv[bi]
             s, b = E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, conv_bias=conv.bias)
             out.append(E.PackedConv(conv.weight.unsqueeze(2), s, b, dtype=self.compute_dtype, device=dev))
+            self._refresh.fold(bn, conv.bias, s, b)
+            self._refresh.pack(out[-1], conv.weight)
         return out
 
     def packed(self):
         sig = (params_signature(self), self.compute_dtype)
+        if self._packed is not None and self._packed_sig != sig and sig[1] == self._packed_sig[1] and E.same_storage(sig[0], self._packed_sig[0]):
+            self._refresh.run(self.outc.conv.weight.device)        # updated in place (the other phase's optimizer step): two launches
+            self._packed_sig = sig
         if self._packed is None or self._packed_sig != sig:
             dev = self.outc.conv.weight.device
             E.require_cuda(self.outc.conv.weight, "UNet")
+            self._refresh = E.PackedRefresh()
             P = {"inc": self._pack_dc(self.inc, dev)}
             for i in (1, 2, 3, 4):
                 P["down%d" % i] = self._pack_dc(getattr(self, "down%d" % i).maxpool_conv[1], dev)
                 P["up%d" % i] = self._pack_dc(getattr(self, "up%d" % i).conv, dev)
             w = self.outc.conv.weight
             P["outc"] = E.PackedConv(w.unsqueeze(2), torch.ones(w.shape[0]), self.outc.conv.bias, dtype=self.compute_dtype, device=dev)
+            self._refresh.pack(P["outc"], w)
+            self._refresh.bias(P["outc"], self.outc.conv.bias)
             self._packed, self._packed_sig = P, sig
         return self._packed
 

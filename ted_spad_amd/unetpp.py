@@ -117,13 +117,20 @@ class UnetPlusPlus(nn.Module):
     # ---- weights resident in the kernels' layout (BatchNorm folded) ----------------------------------------------------------------
     def packed(self):
         sig = (params_signature(self), self.compute_dtype)
+        if self._packed is not None and self._packed_sig != sig and sig[1] == self._packed_sig[1] and E.same_storage(sig[0], self._packed_sig[0]):
+            self._refresh.run(self.encoder.conv1.weight.device)    # updated in place (the other phase's optimizer step): two launches
+            self._packed_sig = sig
         if self._packed is None or self._packed_sig != sig:
             E.require_cuda(self.encoder.conv1.weight, "UnetPlusPlus")
             dev, dt = self.encoder.conv1.weight.device, self.compute_dtype
+            R = self._refresh = E.PackedRefresh()
 
             def pc(conv, bn, stride=1, pair_w=None):
                 s, b = E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-                return E.PackedConv(conv.weight.detach().unsqueeze(2), s, b, stride=(1, stride, stride), dtype=dt, device=dev, pair_w=pair_w)
+                c = E.PackedConv(conv.weight.detach().unsqueeze(2), s, b, stride=(1, stride, stride), dtype=dt, device=dev, pair_w=pair_w)
+                R.fold(bn, None, s, b)
+                R.pack(c, conv.weight)
+                return c
 
             enc = self.encoder
             P = {"stem": pc(enc.conv1, enc.bn1, 2, pair_w=3)}
@@ -139,6 +146,8 @@ class UnetPlusPlus(nn.Module):
                 P[name + ".conv2"] = pc(blk.conv2[0], blk.conv2[1])
             head = self.segmentation_head[0]
             P["head"] = E.PackedConv(head.weight.detach().unsqueeze(2), torch.ones(head.weight.shape[0]), head.bias, dtype=dt, device=dev)
+            R.pack(P["head"], head.weight)
+            R.bias(P["head"], head.bias)
             self._packed, self._packed_sig = P, sig
         return self._packed
 
