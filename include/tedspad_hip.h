@@ -26,7 +26,7 @@ extern "C" {
 
 #define TEDSPAD_ABI_VERSION 1
 
-enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1 };
+enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
 
 /* Geometry of one convolution in channels-last form.  2-D convs (UNet) use t = kt = 1. */
@@ -272,9 +272,11 @@ int32_t tedspad_cross_entropy_fwd_bwd(const float *logits, const int64_t *labels
 
 /* tedspad_bn_finalize + tedspad_scale_shift_act as ONE launch: y = act((z - mean) * gamma * invstd + beta (+ res)) with mean / invstd from the
  * batch sums `stats` ([2][stats_ld]: sum, sum of squares over `count` values per channel); writes mean / invstd (C floats each, kept for the
- * backward pass) and updates running_mean / running_var in place (momentum, unbiased variance; NULL: not tracked). z: fp32 (pixels, Cz)
- * with Cz >= C channels per pixel (channels >= C come out as 0). nn.BatchNorm{2,3}d in train() mode. */
-int32_t tedspad_bn_train_apply(const float *z, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+ * backward pass) and updates running_mean / running_var in place (momentum, unbiased variance; NULL: not tracked). z: (pixels, Cz)
+ * with Cz >= C channels per pixel (channels >= C come out as 0); zdtype TEDSPAD_F32, or `dtype` (16-bit conv output, ldz % 8 == 0 -- what
+ * the reference's autocast region holds in front of its BatchNorms, train_anonymizer.py:78,151; the batch sums come from the conv's fp32
+ * accumulators either way). nn.BatchNorm{2,3}d in train() mode. */
+int32_t tedspad_bn_train_apply(const void *z, int32_t zdtype, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
                                float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
                                const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
                                int32_t groups, int32_t dtype, void *stream);
@@ -297,12 +299,12 @@ int32_t tedspad_scale_shift_act(const float *z, const float *scale, const float 
  * (second row skipped when z == NULL: plain per-channel sum = bias gradient). `sums` pre-zeroed.
  * relu with y == NULL (units without a residual input): the mask is recomputed as z*s + b > 0 with the forward pass's own s = gamma*invstd,
  * b = beta - mean*s (gamma / beta: C floats) -- the 16-bit output is not re-read (2 of the 8 bytes per element this pass moves). */
-int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
+int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd,
                               const float *gamma, const float *beta, float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
                               int32_t ldz, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 
 /* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input); y == NULL with relu as above. */
-int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd,
+int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd,
                              const float *gamma, const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres,
                              int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
                              int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream);

@@ -74,8 +74,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *z, const flo
 // derives scale / shift of its 8 channels from the batch sums itself (2 divisions and an rsqrt per channel: nothing beside the 32 + 16
 // bytes it moves per channel), so the separate per-layer finalize launch (159 per phase-2 iteration of cfg3) disappears; workgroup 0
 // also writes mean / invstd for the backward pass and updates the running statistics.
+// z, the conv output in front of the BatchNorm: fp32, or 16-bit (z16: the dtype of y) -- what the reference's autocast region keeps
+// (train_anonymizer.py:78,151: conv outputs are half tensors there); the batch statistics come from the conv's fp32 accumulators either way.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, const float *stats, int stats_ld, float count, const float *gamma,
+__device__ __forceinline__ void load_z8(const void *z, bool z16, size_t off, float (&v)[8]) {
+    if (z16) {
+        unpack8<T>(*reinterpret_cast<const uint4 *>((const uint16_t *)z + off), v);
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>((const float *)z + off), b = *reinterpret_cast<const f32x4 *>((const float *)z + off + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int z16, const float *stats, int stats_ld, float count, const float *gamma,
                                                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                                                               float *mean_out, float *invstd_out, int C, const uint16_t *res, uint16_t *y, long pixels,
                                                               int C8, int ldz, int ldres, int ldy, int relu) {
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, con
         }
     }
     stats += (size_t)grp * 2 * stats_ld;
-    z += (size_t)grp * pixels * ldz;
+    const size_t zbase = (size_t)grp * pixels * ldz;
     y += (size_t)grp * pixels * ldy;
     if (res) res += (size_t)grp * pixels * ldres;
     const long total = pixels * C8;
@@ -128,11 +141,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, con
             have = c8;
         }
         float v[8];
-        {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), b = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
-        }
+        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sf[i];
         if (res) {
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *z, con
 //   g = dy * (y > 0 if relu),  xhat = (z - mean) * invstd  (xhat term skipped when z == nullptr)
 // block = 256 threads = (256 / C8L) pixel lanes x C8L channel chunks, C8L = min(C8, 32)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const float *z, const float *mean,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
                                                              const float *invstd, const float *gamma, const float *beta, float *out, int out_ld, long pixels,
                                                              int C8, int lddy, int ldy, int ldz, int relu) {
     __shared__ float red[2][256][8];
@@ -168,9 +177,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
         const int grp = blockIdx.y;
         dy += (size_t)grp * pixels * lddy;
         if (y) y += (size_t)grp * pixels * ldy;
-        if (z) { z += (size_t)grp * pixels * ldz; mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8; }
+        if (z) { mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8; }
         out += (size_t)grp * 2 * out_ld;
     }
+    const size_t zbase = (size_t)blockIdx.y * pixels * ldz;
     float s0[8], s1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
@@ -188,11 +198,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
         for (long px = (long)pb * PL + pl; px < pixels; px += (long)pblocks * PL) {
             float g[8], zz[8];
             unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
-            if (z) {
-                const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
-            }
+            if (z) load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, zz);
             if (remask) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) g[i] = zz[i] * ms[i] + mb[i] > 0.f ? g[i] : 0.f;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 // dz = k[c] * (g - a[c] - xhat * b[c]),  g = dy * (y > 0 if relu);  optionally dres = g
 //   train BN: k = gamma*invstd, a = dbeta/M, b = dgamma/M
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const float *z, const float *mean,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
                                                             const float *invstd, const float *gamma, const float *beta, const float *sums, int sums_ld,
                                                             float inv_count, uint16_t *dz, uint16_t *dres, long pixels, int C8, int lddy,
                                                             int ldy, int ldz, int lddz, int lddres, int relu) {
@@ -237,23 +243,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
         const int grp = blockIdx.y;
         dy += (size_t)grp * pixels * lddy;
         if (y) y += (size_t)grp * pixels * ldy;
-        z += (size_t)grp * pixels * ldz;
         mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8;
         sums += (size_t)grp * 2 * sums_ld;
         dz += (size_t)grp * pixels * lddz;
         if (dres) dres += (size_t)grp * pixels * lddres;
     }
     const long total = pixels * C8;
+    const size_t zbase = (size_t)blockIdx.y * pixels * ldz;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c8 = (int)(idx % C8);
         const long px = idx / C8;
         float g[8], zz[8], o[8];
         unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
-        {
-            const f32x4 za = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), zb = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
-        }
+        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, zz);
         if (relu && !y) {             // the forward pass's own expression (see bn_bwd_reduce_kernel)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -438,6 +440,7 @@ __global__ __launch_bounds__(256) void cl_to_nchw_strided_kernel(const uint16_t 
 using namespace tedspad;
 
 #define TS_DT(code) ((code) == TEDSPAD_F16 || (code) == TEDSPAD_BF16)
+#define TS_ZDT(zcode, code, ldz) ((zcode) == TEDSPAD_F32 || ((zcode) == (code) && (ldz) % 8 == 0))
 #define LAUNCH_T(dtype, KERN, grid, ...)                                                               \
     do {                                                                                               \
         if ((dtype) == TEDSPAD_F16) hipLaunchKernelGGL(KERN<F16>, grid, dim3(256), 0, s, __VA_ARGS__); \
@@ -486,30 +489,30 @@ extern "C" int32_t tedspad_scale_shift_act(const float *z, const float *scale, c
     return check_launch("tedspad_scale_shift_act");
 }
 
-extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, const float *gamma,
+extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
                                          const float *beta, float *sums,
                                          int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t relu,
                                          int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || (z && gamma && beta)) && (!z || (mean && invstd)) && sums_ld >= C && groups >= 1 && groups < 65536,
+    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || (z && gamma && beta)) && (!z || (mean && invstd && TS_ZDT(zdtype, dtype, ldz))) && sums_ld >= C && groups >= 1 && groups < 65536,
                "tedspad_bn_bwd_reduce: bad arguments (relu needs y, or z + gamma + beta to recompute the mask)");
     const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
     long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
     if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd,
-             gamma, beta, sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
+    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z,
+             (int)(zdtype != TEDSPAD_F32), mean, invstd, gamma, beta, sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
     return check_launch("tedspad_bn_bwd_reduce");
 }
 
-extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const float *z, const float *mean, const float *invstd, const float *gamma,
+extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
                                         const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
                                         int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536,
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
                "tedspad_bn_bwd_apply: bad arguments (relu needs y, or beta to recompute the mask)");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8)), groups), (const uint16_t *)dy, (const uint16_t *)y, z, mean, invstd, gamma,
-             beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
+    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8)), groups), (const uint16_t *)dy, (const uint16_t *)y, z, (int)(zdtype != TEDSPAD_F32), mean,
+             invstd, gamma, beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
     return check_launch("tedspad_bn_bwd_apply");
 }
 
@@ -565,15 +568,15 @@ extern "C" int32_t tedspad_channels_last_to_nchw_strided(const void *x, float *y
     return check_launch("tedspad_channels_last_to_nchw_strided");
 }
 
-extern "C" int32_t tedspad_bn_train_apply(const float *z, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+extern "C" int32_t tedspad_bn_train_apply(const void *z, int32_t zdtype, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
                                           float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
                                           const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
                                           int32_t groups, int32_t dtype, void *stream) {
     TS_REQUIRE(z && stats && gamma && beta && mean && invstd && y && count > 0 && pixels > 0 && C > 0 && Cz >= C && Cz % 8 == 0 && stats_ld >= C && ldz % 4 == 0 &&
-                   ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0 && groups >= 1 && groups < 65536,
-               "tedspad_bn_train_apply: bad arguments");
+                   ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0 && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
+               "tedspad_bn_train_apply: bad arguments (z is fp32, or 16-bit of y's dtype with ldz % 8 == 0)");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8)), groups), z, stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
+    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8)), groups), z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
              running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
     return check_launch("tedspad_bn_train_apply");
 }

@@ -70,6 +70,9 @@ ARENA = ZeroArena()
 # Tiny per-BatchNorm updates are collected and applied with multi-tensor launches: `num_batches_tracked += 1`
 # (one launch per BN per forward otherwise) and d(gamma) / d(beta), whose per-call sums live in the arena (one clone
 # or add launch per tensor per clip otherwise).
+# the conv output in front of a train-mode BatchNorm (re-read by the BN apply and twice by the backward) kept in the 16-bit activation dtype, as
+# the reference's autocast region holds it (train_anonymizer.py:78,151), instead of fp32: 2 of the 6-8 bytes per element each of those passes moves
+TRAIN_Z16 = os.environ.get("TEDSPAD_TRAIN_Z16", "1") != "0"
 REFRESH_IN_PLACE = os.environ.get("TEDSPAD_WEIGHT_REFRESH", "1") != "0"     # 0: every stale image rebuilt by the lazy path (A/B timing)
 IMAGES_GEN = 0          # bumped whenever a ConvLayer builds a NEW kernel-form image (WeightRefresh then rebuilds its job tables)
 _PENDING_COUNT = {}     # id(tensor) -> [tensor, increments]
@@ -468,12 +471,12 @@ def cached_fold(folds: dict, bn, conv_bias=None):
 # ---- per-channel reductions / BatchNorm ---------------------------------------------------------------
 
 def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = None, mean=None, invstd=None, relu=False, groups: int = 1,
-                 gamma=None, beta=None) -> torch.Tensor:
+                 gamma=None, beta=None, zcode=_lib.F32) -> torch.Tensor:
     """(2, C) fp32: row 0 = sum g, row 1 = sum g * xhat (zeros when z is None); g = dy * (y > 0 if relu).
     z: the fp32 (n,t,h,w,C) pre-normalisation conv output. groups > 1: (groups, 2, C), one set per block of n / groups samples."""
     n, t, h, w = dy.dims
     sums = ARENA.take((2, dy.c) if groups == 1 else (groups, 2, dy.c), dy.buf.device)
-    check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.data_ptr() if z is not None else None,
+    check(_lib.lib().tedspad_bn_bwd_reduce(dy.ptr, y.ptr if y is not None else None, z.data_ptr() if z is not None else None, zcode,
                                            mean.data_ptr() if mean is not None else None, invstd.data_ptr() if invstd is not None else None,
                                            gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, sums.data_ptr(), dy.c, n * t * h * w // groups, dy.c, dy.ld, y.ld if y is not None else 0,
                                            z.shape[-1] if z is not None else 0, int(relu), groups, _code(dy.buf), _stream_ptr()), "tedspad_bn_bwd_reduce")
@@ -481,18 +484,24 @@ def channel_sums(dy: Act, y: Optional[Act] = None, z: Optional[torch.Tensor] = N
 
 
 class BNTrainCtx:
-    __slots__ = ("x", "z", "y", "mean", "invstd", "bn", "conv", "relu", "has_res", "groups")
+    __slots__ = ("x", "z", "y", "mean", "invstd", "bn", "conv", "relu", "has_res", "groups", "zcode")
 
 
 def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional[Act] = None, out: Optional[Act] = None, groups: int = 1):
     """conv -> BatchNorm(batch statistics, running stats updated) -> (+residual) -> ReLU. Returns (y, ctx).
-    The pre-normalisation conv output z stays in fp32 (it is re-read by the BN apply and by the backward).
+    The pre-normalisation conv output z (re-read by the BN apply and twice by the backward) is kept in the 16-bit activation dtype
+    (TRAIN_Z16, the reference's autocast behaviour) or in fp32 (TEDSPAD_TRAIN_Z16=0); the batch sums come from the fp32 accumulators.
     groups > 1: the batch is `groups` consecutive blocks of samples, each normalised with its own batch statistics and the running
     statistics updated once per block, in order -- `groups` separate forward calls of the module (the three clips of a training step,
     train_anonymizer.py:169-175) as ONE launch sequence."""
     pc = conv.fwd_conv()
     stats = ARENA.take((2, pc.cpad) if groups == 1 else (groups, 2, pc.cpad), x.buf.device)
-    z = conv.forward(x, stats=stats, y32=True)                       # (n,t,h,w,cout) fp32
+    if TRAIN_Z16:
+        za = conv.forward(x, stats=stats)                            # Act, 16-bit; the batch sums in `stats` come from the fp32 accumulators
+        z, zcode = za.buf, _code(za.buf)
+        assert za.coff == 0 and za.ld == za.c
+    else:
+        z, zcode = conv.forward(x, stats=stats, y32=True), _lib.F32  # (n,t,h,w,cout) fp32
     n, t, h, w, cz = z.shape
     c = bn.weight.shape[0]
     assert n % groups == 0
@@ -503,14 +512,14 @@ def conv_bn_act_train(conv: ConvLayer, bn, x: Act, relu=True, residual: Optional
     y = out if out is not None else Act.empty(n, t, h, w, cz, tdt, z.device)
     # batch mean / variance -> scale / shift, the running-statistics update and the normalisation itself in ONE launch
     rows = n * t * h * w // groups
-    check(_lib.lib().tedspad_bn_train_apply(z.data_ptr(), stats.data_ptr(), pc.cpad, rows, bn.weight.data_ptr(), bn.bias.data_ptr(),
+    check(_lib.lib().tedspad_bn_train_apply(z.data_ptr(), zcode, stats.data_ptr(), pc.cpad, rows, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                             C.c_float(bn.eps), C.c_float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                             mean.data_ptr(), invstd.data_ptr(), c, residual.ptr if residual is not None else None, y.ptr,
                                             rows, cz, cz, residual.ld if residual is not None else 0, y.ld, int(relu), groups, _code(y.buf),
                                             _stream_ptr()), "tedspad_bn_train_apply")
     ctx = BNTrainCtx()
     ctx.x, ctx.z, ctx.y, ctx.mean, ctx.invstd, ctx.bn, ctx.conv, ctx.relu, ctx.has_res = x, z, y, mean, invstd, bn, conv, relu, residual is not None
-    ctx.groups = groups
+    ctx.groups, ctx.zcode = groups, zcode
     return y, ctx
 
 
@@ -531,10 +540,10 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
         bet[:c] = bn.bias.detach()
     # a unit without a residual input recomputes its ReLU mask from z (already read) instead of re-reading the 16-bit output y
     ymask = y if (ctx.has_res or not ctx.relu) else None
-    sums = channel_sums(dy, ymask, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G, gamma=gam, beta=bet)
+    sums = channel_sums(dy, ymask, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G, gamma=gam, beta=bet, zcode=ctx.zcode)
     dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
     dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
-    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ymask.ptr if ymask is not None else None, z.data_ptr(), ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
+    check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ymask.ptr if ymask is not None else None, z.data_ptr(), ctx.zcode, ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
                                           bet.data_ptr(), sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w // G, cz,
                                           dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu), G,
                                           _code(y.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
