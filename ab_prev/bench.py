@@ -1,0 +1,338 @@
+"""Headline benchmark (BASELINE.json): clips/sec of 16x224^2 I3D feature extraction on
+1/2/4/8 MI355X, with the feature relative-L2 against the fp32 CPU path and the CPU
+extractor timed beside it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic UCF-Crime-length video per GPU:
+225 clip times x 10 crops = 2250 clip-forwards of (3,16,224,224) fp32 (cfg2), inputs
+resident in HBM before the timed region, features all-gathered over RCCL when N > 1 (cfg4;
+weak scaling: the video grows with N, each rank keeps 225 clip times) and copied to the host
+(the .npy rows). Prints ONE JSON line on rank 0. At N = 1 the line also carries `train_cfg3`: the anonymizer training
+iteration of BASELINE.json configs[2] (UNet + I3Res50 + CE/triplet, batch 8 x 48 x 112^2), timed per phase after the
+headline measurement (`--no-train` skips it, `--train` runs only it).
+
+`--dry-run-cpu` rehearses the N > 1 control flow (process group, sharding, barrier, MAX-reduce of the time, rank-0-only JSON) on the
+CPU with the gloo backend and a stub feature extractor: no kernel runs, the numbers mean nothing (tests/test_bench_dry_run.py).
+"""
+import argparse
+import contextlib
+import glob
+import hashlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_CLIP = {"largei3d": 32.829145088, "i3d": 55.575138304}  # BASELINE.md §2 (conv MACs x 2)
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
+TRAIN_TFLOP = {"phase1": 18.040, "phase2": 6.480}                 # BASELINE.md §2, cfg3 (fb branch excluded)
+
+
+def kernel_sources_sha() -> str:
+    """Identity of the kernels a PMC traffic figure belongs to: csrc/ + the launch-sequence files."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "ted_spad_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "ted_spad_amd", f) for f in ("engine.py", "i3res50.py", "inception_i3d.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def bench_train(dev, steps=10, warmup=45):
+    """cfg3 on this GPU: ms per phase-1 / phase-2 iteration, algorithmic TFLOP/s, kernel launches per iteration."""
+    from ted_spad_amd import engine as E
+    from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
+    from ted_spad_amd.synth import synth_state_dict, synth_train_video
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    with contextlib.redirect_stdout(io.StringIO()):
+        fa, ft = load_fa_model(arch="unet"), load_ft_model("largei3d", num_classes=102)
+    fa.load_state_dict(synth_state_dict(fa.state_dict(), 0))
+    ft.load_state_dict(synth_state_dict(ft.state_dict(), 0))
+    fa, ft = fa.to(dev), ft.to(dev)
+    step = AnonymizerTrainStep(fa, ft)
+    video = synth_train_video(0, "bench_train", (8, 48, 3, 112, 112), device=dev)
+    labels = torch.randint(1, 102, (8,), device=dev)
+    out = {"config": "cfg3 train_anonymizer.py iteration: UNet anonymizer + I3Res50 + CE + 0.1 x triplet, batch 8 x 48 x 112^2, f16 "
+                     "activations / fp32 accumulate, fb branch excluded, Adam step included", "steps": steps}
+    for name, fn in (("phase1", step.step_fa), ("phase2", step.step_ft)):
+        for i in range(4 * warmup):              # until the tile tuner has settled every conv geometry of this phase
+            if i >= warmup and not E.tuning_pending():
+                break
+            fn(video, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn(video, labels)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[name + "_ms"] = round(ms, 3)
+        out[name + "_tflops"] = round(TRAIN_TFLOP[name] / ms * 1e3, 1)
+        out[name + "_mfma_frac"] = round(TRAIN_TFLOP[name] / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
+        out[name + "_loss"] = round(r["loss_ft"], 5)
+    # the reference's loop runs BOTH phases per batch (train_anonymizer.py:87-123 then :137-191): each phase then starts from the
+    # other network's fresh weights (frozen-BN folds and 16-bit weight images rebuilt), which the per-phase loops above never pay
+    for _ in range(max(3, warmup // 8)):
+        step.step_fa(video, labels); step.step_ft(video, labels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step_fa(video, labels); step.step_ft(video, labels)
+    torch.cuda.synchronize()
+    out["iteration_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--arch", default="largei3d", choices=["largei3d", "i3d"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--batch", type=int, default=225, help="clips per forward (225: the 256 x 256 ping-pong tiles of layer3/4 need >= 1 workgroup per CU)")
+    ap.add_argument("--clip-times", type=int, default=225, help="clip times per GPU (7200 frames / 32)")
+    ap.add_argument("--crops", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the clip batches alternate over (fills the tail of one forward with the next)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the cfg3 training-iteration timing appended at N = 1")
+    ap.add_argument("--train", action="store_true", help="only the cfg3 training-iteration timing (one JSON line)")
+    ap.add_argument("--act-range", action="store_true", help="add the per-stage max |activation| of one forward (f16 head-room) to the line")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on CPU/gloo with a stub extractor")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dry = args.dry_run_cpu
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    if args.train:
+        assert world == 1 and not dry, "--train is a single-GPU measurement"
+        print(json.dumps({"metric": "cfg3 training iteration", "unit": "ms", "n_gpus": 1, "higher_is_better": False, "dtype": args.dtype,
+                          "data": "synthetic", "train_cfg3": bench_train(dev, steps=max(args.steps, 5))}))
+        return
+
+    from ted_spad_amd import sharding
+    from ted_spad_amd.synth import synth_clips, synth_state_dict
+
+    F = 2048 if args.arch == "largei3d" else 1024
+    shape = (3, 16, 224, 224) if not dry else (3, 2, 4, 4)
+    if dry:
+        sd = None
+        proj = torch.linspace(-1.0, 1.0, F).view(1, F)
+
+        def fx(x):          # stub: a deterministic function of the clip (so the gathered rows can be checked), NOT a kernel
+            return (x.flatten(1).mean(1, keepdim=True) * proj).view(-1, F, 1, 1, 1)
+    else:
+        from ted_spad_amd.model_loaders import load_ft_model
+        with contextlib.redirect_stdout(io.StringIO()):
+            ft = load_ft_model(args.arch, num_classes=102)
+        sd = synth_state_dict(ft.state_dict(), 0)
+        ft.load_state_dict(sd, strict=True)
+        for m in ft.modules():
+            if hasattr(m, "compute_dtype"):
+                m.compute_dtype = args.dtype
+        ft = ft.to(dev).eval()
+        fx = ft.extract_features if hasattr(ft, "extract_features") else ft.i3d.extract_features
+
+    # ---- this rank's shard of the synthetic video, resident in HBM -------------------------------
+    T_total = args.clip_times * world
+    lo, hi = sharding.shard_range(T_total, rank, world)
+    n_local = (hi - lo) * args.crops
+    clips = torch.empty((n_local,) + shape, dtype=torch.float32, device=dev)
+    for i in range(0, n_local, 25):
+        k = min(25, n_local - i)
+        clips[i:i + k] = synth_clips(0, k, shape, device=dev, first=lo * args.crops + i)
+    sync()
+
+    feats = torch.empty((n_local, F), dtype=torch.float32, device=dev)
+    # rank 0's host copy of the gathered (T,10,F) block: pinned, so the device->host copy of a step is an asynchronous 18 MB DMA
+    # (a pageable `.cpu()` took ~5 ms of every 144 ms step with the GPU idle); it completes inside the timed region (final synchronize)
+    host_feats = torch.empty((T_total, args.crops, F), dtype=torch.float32, pin_memory=not dry) if rank == 0 else None
+    ev = []
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))] if not dry else []
+    # rank 0's device->host copy of a step runs on its own stream, under the next step's forwards (it still completes inside the timed
+    # region: the final synchronize waits for every stream); on the launching stream the forward streams of the next step would wait for it
+    # (0.7 ms of a 102 ms step at N = 1, N x 18 MB = ~6 ms at N = 8)
+    copy_stream = torch.cuda.Stream(device=dev) if (not dry and rank == 0) else None
+
+    def step(timed):
+        if dry:
+            for i in range(0, n_local, args.batch):
+                f = fx(clips[i:i + args.batch]).flatten(1)
+                feats[i:i + f.shape[0]] = f
+        else:
+            main_s = torch.cuda.current_stream()
+            if timed:   # HIP events on the launching (main) stream around the fork/join of the forward streams
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main_s)
+            for st in streams:
+                st.wait_stream(main_s)
+            for j, i in enumerate(range(0, n_local, args.batch)):
+                with torch.cuda.stream(streams[j % len(streams)]):
+                    f = fx(clips[i:i + args.batch]).flatten(1)
+                    feats[i:i + f.shape[0]] = f
+            for st in streams:
+                main_s.wait_stream(st)
+            if timed:
+                e1.record(main_s)
+                ev.append((e0, e1, n_local))
+        full = sharding.gather_video_features(feats.view(hi - lo, args.crops, F), T_total)
+        if rank == 0:                               # the .npy rows reach the host on rank 0
+            if copy_stream is None:
+                host_feats.copy_(full.view(T_total, args.crops, F), non_blocking=True)
+            else:
+                if full.data_ptr() == feats.data_ptr():     # N = 1: the "gathered" block IS the buffer the next step's forwards write: snapshot it (18 MB on the device)
+                    full = full.clone()
+                copy_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(copy_stream):
+                    host_feats.copy_(full.view(T_total, args.crops, F), non_blocking=True)
+                full.record_stream(copy_stream)     # the gathered block is freed by the launching stream's allocator: not before the copy ran
+            return host_feats
+        return full
+
+    with torch.no_grad():
+        if not dry:
+            # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are
+            # chosen in context during the first ~45 forwards of every conv geometry; do that before the counted warm-up
+            from ted_spad_amd import engine as _E
+            for i in range(0, args.batch * 96, args.batch):   # > number of tile configurations + TUNE_REPS pruned passes
+                if not _E.AUTOTUNE:
+                    break
+                multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
+                with torch.cuda.stream(streams[(i // args.batch) % len(streams) if multi and i else 0]):
+                    fx(clips[:args.batch])
+            rem = n_local % args.batch              # a ragged last batch is its own conv geometry: tune it too
+            for i in range(96 if (rem and _E.AUTOTUNE) else 0):
+                multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
+                with torch.cuda.stream(streams[i % len(streams) if multi and i else 0]):
+                    fx(clips[:rem])
+        sync()
+        for _ in range(args.warmup):
+            step(False)
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(True)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    total_clips = T_total * args.crops * args.steps
+    value = total_clips / dt
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    res = {"metric": "clips/sec (16x224^2 I3D features)", "value": round(value, 2), "unit": "clips/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": ("DRY RUN (CPU, stub extractor, no kernels): " if dry else "") +
+                                  "cfg2 dali_extraction path: %s extract_features, %d clip times x %d crops = %d clip-forwards of "
+                                  "3x16x224x224 per GPU per step, random-init weights" % (args.arch, args.clip_times, args.crops, n_local),
+                      "global_batch": args.batch * world, "clips_per_step": T_total * args.crops,
+                      "parallelism": "clip-sharded x%d + RCCL all-gather of (T,10,F) features" % world}}
+
+    if dry:
+        # the stub's rows are a known function of the global clip index: the gathered (T, crops, F) block must be complete and ordered
+        want = torch.cat([synth_clips(0, min(25, T_total * args.crops - i), shape, first=i).flatten(1).mean(1, keepdim=True) for i in range(0, T_total * args.crops, 25)])
+        res["dry_run"] = True
+        res["gather_ok"] = bool(torch.allclose(out.reshape(-1, F), want * proj))
+        print(json.dumps(res))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the conv stack: algorithmic FLOPs of a forward / its device time (HIP events) ---
+    fwd_ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+    fwd_clips = sum(n for _, _, n in ev)
+    achieved = fwd_clips * GFLOP_PER_CLIP[args.arch] / fwd_ms  # GFLOP / ms == TFLOP/s
+    n_fwd = len(ev) * ((n_local + args.batch - 1) // args.batch)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # PMC result of the same command (scripts/profile_bench.sh)
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        # a traffic figure is only quoted for the kernels it was measured on: the profile stores the hash of the kernel sources
+        if (tj.get("arch") == args.arch and tj.get("batch") == args.batch and tj.get("dtype") == args.dtype and
+                tj.get("kernel_sources_sha") == kernel_sources_sha()):
+            traffic = tj["conv_traffic_bytes_per_forward"]
+    res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                       "kernel": "conv stack of one batch forward (conv_stem_pt_kernel + conv_p8 / conv_patch / conv_flat / conv_igemm / conv_pw "
+                                 "launches; layout, max-pool and average-pool passes included in the time)",
+                       "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}
+
+    # ---- CPU baseline + parity on a bounded sample: the oracle on this box's host cores ------------
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: at N > 1 the other ranks must not wait for it
+        from oracle import i3res50_ref, inception_i3d_ref
+        ncpu = os.cpu_count() or 1
+        cores = min(ncpu, 32)  # measured on the GPU box's host (128 hardware threads): 8/16/32/64/128 threads -> 6.6/9.2/10.2/7.7/4.0 clips/s
+        torch.set_num_threads(cores)
+        xs = clips[:10].cpu()
+        if args.arch == "largei3d":
+            sdc = {k[4:]: v for k, v in sd.items() if k.startswith("i3d.")}
+            cpu_fx = lambda x: i3res50_ref.extract_features(x, sdc)
+        else:
+            cpu_fx = lambda x: inception_i3d_ref.extract_features(x, sd)
+        with torch.no_grad():
+            ref = cpu_fx(xs)  # warm-up (also the parity reference)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cpu_fx(xs)
+            cdt = time.perf_counter() - t0
+        ref = ref.flatten(1)
+        got = out.reshape(-1, F)[:10]
+        rel = ((got.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1))
+        res["cpu_baseline"] = {"value": round(30.0 / cdt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+                               "sample": "oracle (fp32 torch CPU restatement) on the first 10 clips (one 10-crop group), 1 warm-up + 3 timed passes; "
+                                         "%d of the host's %d hardware threads (the fastest thread count measured on this host type)" % (cores, ncpu)}
+        res["feature_rel_l2_max"] = float(rel.max())
+        res["feature_rel_l2_tol"] = 1e-3
+    if args.act_range and args.arch == "largei3d":
+        taps = {}
+        with torch.no_grad():
+            ft.i3d._trunk(clips[:10], taps=taps)
+        res["act_absmax"] = {k: round(float(v.buf.float().abs().max()), 3) for k, v in taps.items()}   # f16 saturates at 65504
+    if world == 1 and not args.no_train:
+        del clips, feats
+        torch.cuda.empty_cache()
+        res["train_cfg3"] = bench_train(dev)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""ORACLE (test infrastructure, never shipped as product): CPU restatement of the
+reference's 2-D UNet anonymizer `fa` (arch='unet') in plain torch fp32.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Parity is PINNED by tests/test_oracle_golden.py against vectors captured from the
+reference itself (tests/golden/make_golden.py).
+
+Follows (reference file:line):
+  * DoubleConv   aux_code/models/unet_parts.py:8-25   (conv3x3 pad1 +bias -> BN2d -> ReLU) x2
+  * Down         aux_code/models/unet_parts.py:28-39  (MaxPool2d(2) -> DoubleConv)
+  * Up           aux_code/models/unet_parts.py:42-68  (bilinear x2 align_corners=True, pad to
+                                                       the skip, cat([skip, up]), DoubleConv mid=in/2)
+  * OutConv      aux_code/models/unet_parts.py:71-77
+  * UNet.forward aux_code/models/unet_model.py:26-37  (sigmoid output)
+"""
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+def _id(t, kind):
+    return t
+
+
+def _bn2d(x, sd, p, train):
+    if train:
+        mean = x.mean((0, 2, 3), keepdim=True)
+        var = x.var((0, 2, 3), unbiased=False, keepdim=True)
+        return (x - mean) / torch.sqrt(var + BN_EPS) * sd[p + "weight"].view(1, -1, 1, 1) + sd[p + "bias"].view(1, -1, 1, 1)
+    inv = sd[p + "weight"] / torch.sqrt(sd[p + "running_var"] + BN_EPS)
+    sh = sd[p + "bias"] - sd[p + "running_mean"] * inv
+    return x * inv.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+
+
+def double_conv(x, sd, p, q=_id, train=False):
+    for c, b in (("0.", "1."), ("3.", "4.")):
+        x = F.conv2d(q(x, "act"), q(sd[p + c + "weight"], "w"), sd[p + c + "bias"], padding=1)
+        x = q(F.relu(_bn2d(x, sd, p + b, train)), "act")
+    return x
+
+
+def up(x1, skip, sd, p, q=_id, train=False):
+    x1 = F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True)
+    dy, dx = skip.shape[2] - x1.shape[2], skip.shape[3] - x1.shape[3]
+    x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return double_conv(torch.cat([skip, x1], dim=1), sd, p + "conv.double_conv.", q, train)
+
+
+def forward(x, sd, q=_id, train=False, taps=None):
+    """x: (N,3,H,W) fp32 in [0,1] -> (N,3,H,W) in (0,1)."""
+    x1 = double_conv(x, sd, "inc.double_conv.", q, train)
+    feats = [x1]
+    h = x1
+    for i in (1, 2, 3, 4):
+        h = double_conv(F.max_pool2d(h, 2), sd, "down%d.maxpool_conv.1.double_conv." % i, q, train)
+        feats.append(h)
+    for i, skip in zip((1, 2, 3, 4), (feats[3], feats[2], feats[1], feats[0])):
+        h = up(h, skip, sd, "up%d." % i, q, train)
+        if taps is not None:
+            taps["up%d" % i] = h
+    logits = F.conv2d(q(h, "act"), q(sd["outc.conv.weight"], "w"), sd["outc.conv.bias"])
+    return torch.sigmoid(logits)

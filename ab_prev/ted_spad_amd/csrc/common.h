@@ -1,0 +1,117 @@
+// Shared helpers for the gfx950 kernels of libtedspad_hip.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "tedspad_hip.h"
+
+namespace tedspad {
+
+void set_error(const char *fmt, ...);
+
+#define TS_REQUIRE(cond, ...)                     \
+    do {                                          \
+        if (!(cond)) {                            \
+            tedspad::set_error(__VA_ARGS__);      \
+            return TEDSPAD_EINVAL;                \
+        }                                         \
+    } while (0)
+
+inline int32_t check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return TEDSPAD_ELAUNCH;
+    }
+    return TEDSPAD_OK;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-bit storage types. Both run the same MFMA rate on CDNA4; f16 carries 3 more mantissa
+// bits, which is what the 1e-3 feature-parity gate needs (DESIGN.md "precision").
+struct F16 {
+    static constexpr int kDtype = TEDSPAD_F16;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {   // 16x16x32: same FLOP per cycle, the chip holds a higher clock on it
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) {
+        f = __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);  // saturate instead of inf
+        return __builtin_bit_cast(uint16_t, (_Float16)f);
+    }
+    static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {   // element-wise max of two packed pairs
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)));
+    }
+};
+
+struct BF16 {
+    static constexpr int kDtype = TEDSPAD_BF16;
+    static __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+    static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+        const float lo = __builtin_fmaxf(__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, b << 16));
+        const float hi = __builtin_fmaxf(__builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b & 0xffff0000u));
+        return (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xffff0000u);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = T::to_f32((uint16_t)(w[i] & 0xffffu));
+        f[2 * i + 1] = T::to_f32((uint16_t)(w[i] >> 16));
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f32(f[2 * i]) | ((uint32_t)T::from_f32(f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pk_max8(uint4 a, uint4 b) {
+    return make_uint4(T::pk_max(a.x, b.x), T::pk_max(a.y, b.y), T::pk_max(a.z, b.z), T::pk_max(a.w, b.w));
+}
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_dst + lane*16].
+// Written as inline asm on purpose: hipcc treats the builtin form as an LDS store it must
+// drain (s_waitcnt vmcnt(0)) before ANY later ds_read of the same array, which serialises the
+// ring. In asm form the compiler does not count it; the kernel waits with counted vmcnt itself.
+// M0 (the DMA's LDS base) is compiler-reserved: saved/restored inside the same statement.
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+}  // namespace tedspad

@@ -1,0 +1,781 @@
+// Bottleneck tail for gfx950: conv2 (1 x 3 x 3, stride 1, 64 -> 64) + bn2 + ReLU -> conv3 (1 x 1 x 1, 64 -> 256) + bn3 (+ residual | +
+// the downsample branch) + ReLU of a layer1 bottleneck (aux_code/models/large_i3d.py:49-54,69-84) in ONE launch. The 64-channel tensor
+// between the two convolutions never leaves the registers.
+//
+// Why: layer1 is 31 % of an I3Res50 forward and HBM-bound (profiles/r02_bench_cfg2_kernels_1stream.md: the 64 -> 256 pointwise convs
+// run at 5.4 TB/s of their minimum bytes, conv2 at 32 % MFMA utilisation beside them). Separately the pair moves 1408 B per pixel
+// (conv2 reads 128 + writes 128, conv3 reads 128 + 512 residual + writes 512); fused it moves 1152, and -- with two workgroups per CU --
+// one workgroup's MFMA-bound conv2 loop runs under the other's memory-bound conv3 epilogue.
+//
+// Stage A = conv_flat_kernel (conv_flat.hip): a tile of 256 consecutive output pixels, its input halo one contiguous run in LDS, the
+// [64][64] weight tile of a tap streaming through a 3-slot ring; a wave ends with D[co][px] (64 co x 64 px) in 64 accumulator registers.
+// Stage B: `D = W2 . X` has its output channel on the accumulator ROWS, so the next product `Y3 = W3 . relu(bn2(D))` sums over rows and
+// takes the tile as its MFMA B operand WITHOUT any lane movement (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's
+// operand"): registers 8s .. 8s+7 of a 32 x 32 tile, packed to 16 bits, are the fragment of k-step s, in the k order
+//     element j of lane half h  <->  row 16 s + 8 (j >> 2) + 4 h + (j & 3)
+// which the host bakes into the column order of the conv3 weight image (`w3p`, tedspad_bneck_tail_fwd). The 256 x 64 (x 2 with the
+// downsample branch) weight image is copied into the LDS that stage A has finished with; a wave then walks the 256 output channels
+// in 4 steps of 64: 16 MFMAs (32 with the second source, whose pixel fragments come straight from global memory), bn3 scale / shift,
+// the residual (whole rows by LDS-DMA into a wave-private image, read in the store layout and brought into the accumulator layout by
+// v_permlane32_swap, which is its own inverse), ReLU, and the results leave through the same image as whole 128-byte rows.
+#include "conv_common.h"
+
+namespace tedspad {
+namespace {
+
+__device__ uint4 g_zero16b;
+__device__ uint4 g_sink16b[64];      // where the output rows past M go (never read)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BT_BM = 256;
+constexpr int BT_WSTAGE = 64 * BK * 2;
+
+__device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: the store reads its data registers late, hipcc pads nothing after an asm statement
+}
+
+struct BneckKP {
+    const uint16_t *x;          // conv2 input (n,t,h,w,64+) 16-bit, pixel stride ldx
+    const uint16_t *w2;         // conv2 weights, packed [>=64][Kpad] (K = (dh, dw, ci))
+    const float *scale2, *shift2;
+    const uint16_t *w3p;        // [cout3][KB*64]: columns 0..63 = conv3 weights in accumulator k order, 64..127 = downsample weights (natural order)
+    const float *scale3, *shift3, *scaled;    // shift3 already holds b3 (+ bd)
+    const uint16_t *res;        // residual (n,t,h,w,cout3) or NULL
+    const uint16_t *x2;         // second source of the downsample branch (same pixel grid, 64 channels) or NULL
+    uint16_t *y;
+    int M, Kpad, W, H, kh, kw, ph, pw, ldx, ldres, ldx2, ldy, cout3, relu;
+    int R, NP, ntaps;           // flat-halo geometry (conv_flat.hip)
+    int HW, tpf;                // POOLT: pixels / tiles per frame
+};
+
+// STAGED: residual rows in / result rows out through wave-private LDS images (whole 128-byte lines per access); otherwise 16-byte
+// loads / stores straight in the accumulator layout (32-byte pieces per pixel) and the whole weight image resident.
+// POOLT (plain block, STAGED): MaxPool3d((2,1,1), stride (2,1,1)) of the block's output fused (large_i3d.py:139 after layer1): a workgroup
+// owns 256 pixels of an even frame AND the same pixels of the next frame: stage A runs twice (the second halo lands where the first
+// was), both 64-channel tiles stay in registers as conv3 operands, stage B computes every 64-channel step for both frames and stores
+// their maximum: the 256-channel tensor is written once, pooled (half the bytes of the unfused conv3 + pool pair's traffic again).
+template <typename T, bool DUAL, bool STAGED, bool POOLT>
+__global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p) {
+    static_assert(!POOLT || (!DUAL && STAGED), "the pooled variant is the plain block with staged rows");
+    constexpr int NT = 256, WS = 3, KB = DUAL ? 2 : 1, NF = POOLT ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int q0f[NF];                                        // first pixel of the tile (in each of the two frames)
+    int lim;                                            // valid pixels of the tile
+    size_t obase;                                       // first output row
+    if (POOLT) {
+        const int fp = tile / p.tpf, j = tile - fp * p.tpf;       // frame pair (n, t / 2), tile of the frame
+        q0f[0] = 2 * fp * p.HW + j * BT_BM;
+        q0f[NF - 1] = q0f[0] + p.HW;
+        lim = min(BT_BM, p.HW - j * BT_BM);
+        obase = (size_t)fp * p.HW + j * BT_BM;
+    } else {
+        q0f[0] = tile * BT_BM;
+        lim = min(BT_BM, p.M - q0f[0]);
+        obase = (size_t)q0f[0];
+    }
+    const int S = (p.NP + 1) * 8;                       // 16-byte slots: the halo + one zero position
+    const int Sr = (S + 63) / 64 * 64;
+    const int halo_bytes = Sr * 16;
+    unsigned char *wring = dsm + halo_bytes;            // [WS][64][64] 16-bit
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16b);
+
+    // ================================ stage A: conv2 on the flat halo (conv_flat_kernel) ================================
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w2 + (size_t)rsub * p.Kpad + kc * 8;
+    auto issue_w = [&](int kt, int slot) {
+        const unsigned dst = lds0 + halo_bytes + slot * BT_WSTAGE + wave * 8 * (BK * 2);
+        lds_dma16(wsrc + kt * BK, dst);
+        lds_dma16(wsrc + (size_t)32 * p.Kpad + kt * BK, dst + 32 * (BK * 2));
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int NH = (Sr + NT - 1) / NT;
+    uint4 y2[NF][4][2];       // relu(bn2(conv2)) packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel half a
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int q0 = q0f[f];
+        issue_w(0, 0);                                       // issue order w(0), halo, w(1): the counted waits below rely on it
+        for (int i = 0; i < NH; ++i) {
+            if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
+            const int s = i * NT + tid;
+            const int pos = s >> 3, cs = s & 7;
+            const int q = q0 - p.R + pos;
+            const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
+            const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
+            lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
+        }
+        if (p.ntaps > 1) issue_w(1, 1);
+
+        int pj[2];
+        unsigned vmask[2];        // bit (dh*kw + dw): the tap lies inside the frame
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = wave * 64 + b * 32 + l31;
+            pj[b] = j;
+            const int q = q0 + j;
+            unsigned mk = 0;
+            if (q < p.M) {
+                const int r1 = q / p.W, w = q - r1 * p.W;
+                const int h = r1 % p.H;
+                for (int dh = 0; dh < p.kh; ++dh)
+                    for (int dw = 0; dw < p.kw; ++dw)
+                        if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+            }
+            vmask[b] = mk;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int dh = 0, dw = 0;
+        for (int kt = 0; kt < p.ntaps; ++kt) {
+            const int delta = dh * p.W + dw;
+            unsigned xoff[2], xswz[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+                xoff[b] = (unsigned)pos * 128u;
+                xswz[b] = (unsigned)(pos >> 1) & 7u;
+            }
+            if (kt + 1 < p.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
+            __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
+            asm volatile("" ::: "memory");
+            if (kt + 2 < p.ntaps) issue_w(kt + 2, (kt + 2) % WS);
+            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * BT_WSTAGE) + l31 * BK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+            }
+            if (++dw == p.kw) { dw = 0; ++dh; }
+        }
+        __syncthreads();          // every wave is done with the halo and the weight ring: the next frame's halo / the conv3 weight image lands there
+        // ---- relu(bn2(.)) of the conv2 tile, packed to 16 bits ---------------------------------------------------------------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float sc[16], sf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sc[r] = p.scale2[c];
+                sf[r] = p.shift2[c];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s + j] * sc[8 * s + j] + sf[8 * s + j], 0.f);
+                    y2[f][a * 2 + s][b] = pack8<T>(v);
+                }
+        }
+    }
+
+    // ================================ stage B: conv3 (+ downsample branch) on the register tile ================================
+    // ---- conv3 weight image: tiles of [64 co'][64 k] (the swizzled image of every weight tile above), HG output-channel groups of 64
+    // resident at a time: all of them for the plain block (32 KB), two at a time with the second source (2 x 2 x 8 KB), so that weight image
+    // + BatchNorm vectors + the waves' row images stay below the 80 KB that let two workgroups share a CU -------------------------------
+    const int n3 = p.cout3 / 64;                           // 64-channel groups of the output
+    const int HG = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    auto load_w3 = [&](int g0) {                           // groups g0 .. g0 + HG - 1: slot kb * HG + (g - g0)
+        for (int i = wave; i < KB * HG * 8; i += 4) {      // 8 wave-instructions (8 rows x 128 B) per tile
+            const int tl = i >> 3, sub = i & 7;
+            const int kb = tl / HG, g = g0 + tl - kb * HG;
+            if (g >= n3) continue;
+            const int row = sub * 8 + (lane >> 3);         // row of the tile
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            lds_dma16(p.w3p + (size_t)(g * 64 + row) * (KB * 64) + kb * 64 + ch * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
+        }
+    };
+    load_w3(0);
+    float *bnv = reinterpret_cast<float *>(dsm + KB * HG * BT_WSTAGE);     // [3][cout3]: scale3, shift3, scale of the second branch
+    for (int i = tid; i < p.cout3; i += NT) {
+        bnv[i] = p.scale3[i];
+        bnv[p.cout3 + i] = p.shift3[i];
+        bnv[2 * p.cout3 + i] = DUAL ? p.scaled[i] : 0.f;
+    }
+    // ---- this wave's pixels; the second source's pixel fragments (natural k order) straight from global memory --------------------------
+    size_t mpx[2];
+    bool inb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = wave * 64 + b * 32 + l31;
+        inb[b] = j < lim;
+        mpx[b] = (size_t)(inb[b] ? q0f[0] + j : 0);
+    }
+    uint4 xin[4][2];
+    if (DUAL) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xin[ks][b] = *reinterpret_cast<const uint4 *>(p.x2 + mpx[b] * p.ldx2 + (ks * 2 + lh) * 8);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();           // weight image + BN vectors visible
+
+    // ---- 64 output channels per step. Every global access of the step moves whole 128-byte lines: the residual rows arrive by LDS-DMA
+    // into a wave-private [64 px][64 ch] image (8 lanes per pixel row; the chunk swizzle of every other image here), the results leave
+    // through the same image and are stored 8 lanes per row. (First version: 16-byte loads / stores straight from the accumulator layout,
+    // one 32-byte piece per pixel and instruction -- 32 lines touched per instruction: 935 us for the plain block against 860 us unfused.)
+    unsigned char *wbuf = dsm + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
+    const unsigned wbuf_lds = lds0 + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
+    const bool has_res = !DUAL && p.res != nullptr;
+    // row-layout role of this lane in instruction k: pixel row k*8 + (lane >> 3) of the wave, physical chunk lane & 7
+    const int rrow = lane >> 3, rch = lane & 7;
+    // row k*8 + rrow: chunk swizzle (row >> 1) & 7 = (rrow >> 1) ^ 4 (k & 1); the addresses are rebuilt from ONE base per call (an opaque
+    // zero keeps hipcc from carrying 8 row pointers per frame across the loop -- the pooled variant spilled them, and every reload drained
+    // the DMA queue)
+    const int c0 = rch ^ (rrow >> 1);
+    const int limw = lim - wave * 64;                   // valid rows of this wave
+    auto issue_res = [&](int g, int f) {
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const uint16_t *base = p.res + (size_t)(q0f[f] + wave * 64 + rrow + opq) * p.ldres + 64 * g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
+            lds_dma16(src, wbuf_lds + k * 1024);
+        }
+    };
+    if (STAGED && has_res) issue_res(0, 0);
+    const int ng = p.cout3 / 64;
+    for (int g = 0; g < ng; ++g) {
+        if (g && g % HG == 0) {                  // the next HG groups of the weight image (second-source variant only)
+            __syncthreads();
+            load_w3(g);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        unsigned d[2][2][4][2];                  // [tile of the pair][pixel group][q][h]: packed results in the accumulator layout
+        unsigned dk[POOLT ? 2 : 1][2][4][2];     // POOLT: the first frame's
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (STAGED && has_res) {
+                // the residual rows of this step landed; the previous 64-channel step's 8 stores (issued after the first frame's rows) stay in flight
+                if (f == 0 && g > 0) wait_vmcnt<8>(); else wait_vmcnt<0>();
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                if (POOLT) __builtin_amdgcn_sched_barrier(0);       // keep the two tiles' live ranges apart (the pooled variant is register-bound)
+                const int t = 2 * g + tt;
+                const unsigned char *Wt = dsm + (g % HG) * BT_WSTAGE + (tt * 32 + l31) * (BK * 2);
+                f32x16 a3[2], ad[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { a3[b][r] = 0.f; ad[b][r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const unsigned c = (unsigned)((ks << 1) | lh);
+                    const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + ((c ^ swz) << 4));
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[f][ks][b], a3[b]);
+                    if (DUAL) {
+                        const uint4 fd = *reinterpret_cast<const uint4 *>(Wt + HG * BT_WSTAGE + ((c ^ swz) << 4));
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) ad[b] = T::mfma(fd, xin[ks][b], ad[b]);
+                    }
+                }
+                // lane (l31, lh) holds channels 32 t + 8 q + 4 lh + {0..3}, q = 0..3
+                f32x4 s3[4], b3[4], sd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * t + 8 * q + 4 * lh;
+                    s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
+                    b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
+                    if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                    if (has_res) {
+                        // residual chunks in the STORE layout (lane: channels 16 qq + 8 lh .. + 7 of the tile), swapped back into the accumulator layout
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                            uint4 L = make_uint4(0u, 0u, 0u, 0u);
+                            if (STAGED) L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
+                            else if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
+                            auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                            auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                            rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
+                            rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float v[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int r = 4 * q + 2 * h + e;
+                                float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
+                                if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
+                                if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
+                                v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                            }
+                            d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                        }
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            auto sw = __builtin_amdgcn_permlane32_swap(d[tt][b][q][h], d[tt][b][q + 1][h], false, false);
+                            d[tt][b][q][h] = sw[0];
+                            d[tt][b][q + 1][h] = sw[1];
+                        }
+                }
+            }
+            if (POOLT && f == 0) {                   // keep the first frame's results; its residual rows are consumed: the second frame's may land
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) dk[tt][b][q][h] = d[tt][b][q][h];
+                if (has_res) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue_res(g, 1);
+                }
+            }
+        }
+        if (POOLT) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) d[tt][b][q][h] = T::pk_max(d[tt][b][q][h], dk[tt][b][q][h]);
+        }
+        if (!STAGED) {                            // 16-byte stores straight from the registers (lane: channels 16 qq + 8 lh .. + 7 of tile tt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (inb[b]) {
+                        uint16_t *dst = p.y + mpx[b] * p.ldy + 64 * g + 32 * tt + 8 * lh;
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(d[tt][b][0][0], d[tt][b][0][1], d[tt][b][1][0], d[tt][b][1][1]);
+                        *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(d[tt][b][2][0], d[tt][b][2][1], d[tt][b][3][0], d[tt][b][3][1]);
+                    }
+            continue;
+        }
+        // ---- results -> the wave's image (every residual read above is complete: its data was consumed) -> whole rows -> global ------------
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                    *reinterpret_cast<uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4)) =
+                        make_uint4(d[tt][b][2 * qq][0], d[tt][b][2 * qq][1], d[tt][b][2 * qq + 1][0], d[tt][b][2 * qq + 1][1]);
+                }
+        uint4 rowv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rowv[k] = *reinterpret_cast<const uint4 *>(wbuf + k * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the image is read back: the next step's residual rows may overwrite it
+        if (has_res && g + 1 < ng) issue_res(g + 1, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = k * 8 + rrow;
+            const int j = wave * 64 + row;
+            uint16_t *dst = j < lim ? p.y + (obase + j) * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
+                                    : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;      // rows past the tile: a scratch line, so that every wave issues 8 stores
+            gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
+        }
+    }
+}
+
+// The same tail for 128 mid channels (layer2's plain bottlenecks: conv2 1 x 3 x 3 128 -> 128, conv3 128 -> 512 + residual; large_i3d.py:69-84).
+// Stage A = the chunk-major flat tile of conv_patch.hip (tile_cfg 33): for each 64-channel chunk of the input the contiguous halo run is
+// fetched once and serves all taps, the [128 co][64 k] weight tile of a (chunk, tap) streams through a two-slot ring; a wave ends with
+// 128 co x 64 px in 128 accumulator registers. Stage B as above with eight k-steps (fragment a*2 + s = rows 16 s .. of channel quarter a) and
+// the conv3 weight image ([64 co'][2 x 64 k] per output group) streamed two groups at a time. 72 KB of LDS in either stage: two workgroups
+// per CU.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckKP p) {
+    constexpr int NT = 256, WSTAGE = 128 * BK * 2, HG = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int q0 = tile * BT_BM;
+    const int lim = min(BT_BM, p.M - q0);
+    const int S = (p.NP + 1) * 8;
+    const int Sr = (S + 63) / 64 * 64;
+    const int halo_bytes = Sr * 16;
+    unsigned char *wring = dsm + halo_bytes;            // [2][128][64] 16-bit
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16b);
+
+    // ================================ stage A: conv2, chunk-major on the flat halo (conv_patch_kernel<T, 128, FLAT>) ================================
+    const int rsub = wave * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const uint16_t *wsrc = p.w2 + (size_t)rsub * p.Kpad + kc * 8;
+    auto issue_w = [&](int ch, int tap, int slot) {
+        const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
+        const uint16_t *src = wsrc + tap * 128 + ch * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16(src + (size_t)(j * 32) * p.Kpad, dst + j * 32 * (BK * 2));
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int NH = (Sr + NT - 1) / NT;
+    int pj[2];
+    unsigned vmask[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = wave * 64 + b * 32 + l31;
+        pj[b] = j;
+        const int q = q0 + j;
+        unsigned mk = 0;
+        if (q < p.M) {
+            const int r1 = q / p.W, w = q - r1 * p.W;
+            const int h = r1 % p.H;
+            for (int dh = 0; dh < p.kh; ++dh)
+                for (int dw = 0; dw < p.kw; ++dw)
+                    if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+        }
+        vmask[b] = mk;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int ch = 0; ch < 2; ++ch) {
+        if (ch) __builtin_amdgcn_s_barrier();              // every wave has read the previous chunk's halo and weight slots
+        asm volatile("" ::: "memory");
+        issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
+        for (int i = 0; i < NH; ++i) {
+            if (i * NT + wave * 64 >= Sr) break;           // wave-uniform
+            const int s = i * NT + tid;
+            const int pos = s >> 3, cs = s & 7;
+            const int q = q0 - p.R + pos;
+            const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
+            const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ch * 64 + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
+            lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
+        }
+        if (p.ntaps > 1) issue_w(ch, 1, 1);
+        int dh = 0, dw = 0;
+        for (int kt = 0; kt < p.ntaps; ++kt) {
+            const int delta = dh * p.W + dw;
+            unsigned xoff[2], xswz[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+                xoff[b] = (unsigned)pos * 128u;
+                xswz[b] = (unsigned)(pos >> 1) & 7u;
+            }
+            if (kt + 1 < p.ntaps) wait_vmcnt<4>(); else wait_vmcnt<0>();   // stage kt (and, on kt = 0, the halo) landed; stage kt+1 (4 instructions) may stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt & 1) * WSTAGE) + l31 * BK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+            }
+            if (kt + 1 < p.ntaps) {                        // two slots: stage kt+2 can only be issued once every wave has read stage kt
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < p.ntaps) issue_w(ch, kt + 2, kt & 1);
+            }
+            if (++dw == p.kw) { dw = 0; ++dh; }
+        }
+    }
+    __syncthreads();          // every wave is done with the halo and the weight ring
+
+    // ================================ stage B: conv3 + residual on the register tile ================================
+    const int n3 = p.cout3 / 64;
+    auto load_w3 = [&](int g0) {                           // groups g0, g0 + 1: slot kb * HG + (g - g0), kb = the k half
+        for (int i = wave; i < 2 * HG * 8; i += 4) {
+            const int tl = i >> 3, sub = i & 7;
+            const int kb = tl / HG, g = g0 + tl - kb * HG;
+            if (g >= n3) continue;
+            const int row = sub * 8 + (lane >> 3);
+            const int chn = (lane & 7) ^ ((row >> 1) & 7);
+            lds_dma16(p.w3p + (size_t)(g * 64 + row) * 128 + kb * 64 + chn * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
+        }
+    };
+    load_w3(0);
+    float *bnv = reinterpret_cast<float *>(dsm + 2 * HG * BT_WSTAGE);     // [2][cout3]: scale3, shift3
+    for (int i = tid; i < p.cout3; i += NT) {
+        bnv[i] = p.scale3[i];
+        bnv[p.cout3 + i] = p.shift3[i];
+    }
+    // relu(bn2(.)) of the conv2 tile, packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel quarter a
+    uint4 y2[8][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float sc[16], sf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sc[r] = p.scale2[c];
+            sf[r] = p.shift2[c];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s2 + j] * sc[8 * s2 + j] + sf[8 * s2 + j], 0.f);
+                y2[a * 2 + s2][b] = pack8<T>(v);
+            }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();           // weight image + BN vectors visible
+
+    unsigned char *wbuf = dsm + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
+    const unsigned wbuf_lds = lds0 + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
+    const bool has_res = p.res != nullptr;
+    const int rrow = lane >> 3, rch = lane & 7;
+    const int c0 = rch ^ (rrow >> 1);
+    const int limw = lim - wave * 64;
+    auto issue_res = [&](int g) {
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const uint16_t *base = p.res + (size_t)(q0 + wave * 64 + rrow + opq) * p.ldres + 64 * g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
+            lds_dma16(src, wbuf_lds + k * 1024);
+        }
+    };
+    if (has_res) issue_res(0);
+    for (int g = 0; g < n3; ++g) {
+        if (g && g % HG == 0) {                  // the next two groups of the weight image
+            __syncthreads();
+            load_w3(g);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        unsigned d[2][2][4][2];
+        if (has_res) {
+            if (g == 0 || g % HG == 0) wait_vmcnt<0>(); else wait_vmcnt<8>();   // the residual rows of this step landed; the previous step's 8 stores stay in flight
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * g + tt;
+            const unsigned char *Wt = dsm + (g % HG) * BT_WSTAGE + (tt * 32 + l31) * (BK * 2);
+            f32x16 a3[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a3[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const unsigned c = (unsigned)(((ks & 3) << 1) | lh);
+                const uint4 fw = *reinterpret_cast<const uint4 *>(Wt + (ks >> 2) * HG * BT_WSTAGE + ((c ^ swz) << 4));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) a3[b] = T::mfma(fw, y2[ks][b], a3[b]);
+            }
+            f32x4 s3[4], b3[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * t + 8 * q + 4 * lh;
+                s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
+                b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                unsigned rs[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                if (has_res) {
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                        const uint4 L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
+                        auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                        rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
+                        rs[2 * qq][1] = s1[0]; rs[2 * qq + 1][1] = s1[1];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float v[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 4 * q + 2 * h + e;
+                            float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
+                            if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
+                            v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                        }
+                        d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(d[tt][b][q][h], d[tt][b][q + 1][h], false, false);
+                        d[tt][b][q][h] = sw[0];
+                        d[tt][b][q + 1][h] = sw[1];
+                    }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
+                    *reinterpret_cast<uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4)) =
+                        make_uint4(d[tt][b][2 * qq][0], d[tt][b][2 * qq][1], d[tt][b][2 * qq + 1][0], d[tt][b][2 * qq + 1][1]);
+                }
+        uint4 rowv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rowv[k] = *reinterpret_cast<const uint4 *>(wbuf + k * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (has_res && g + 1 < n3) issue_res(g + 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = k * 8 + rrow;
+            const int j = wave * 64 + row;
+            uint16_t *dst = j < lim ? p.y + ((size_t)q0 + j) * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
+                                    : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;
+            gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
+        }
+    }
+}
+
+template <typename T>
+int32_t launch_bneck128(const BneckKP &p, hipStream_t s) {
+    const int S = (p.NP + 1) * 8;
+    const int main_bytes = (S + 63) / 64 * 64 * 16 + 2 * 128 * BK * 2;
+    const int tail_bytes = 2 * 2 * BT_WSTAGE + 2 * p.cout3 * 4 + 4 * 8192;
+    const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
+    if (lds > 160 * 1024) {
+        set_error("tedspad_bneck_tail_fwd: halo does not fit LDS (%d bytes)", lds);
+        return TEDSPAD_EINVAL;
+    }
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_bneck_tail128_kernel<T>;
+    if (!attr_set[T::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 1;
+    }
+    hipLaunchKernelGGL(kfn, dim3((p.M + BT_BM - 1) / BT_BM), dim3(256), lds, s, p);
+    return check_launch("tedspad_bneck_tail_fwd");
+}
+
+template <typename T, bool DUAL, bool STAGED, bool POOLT = false>
+int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
+    const int S = (p.NP + 1) * 8;
+    const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * BT_WSTAGE;
+    const int n3 = p.cout3 / 64, hg = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * p.cout3 * 4 + (STAGED ? 4 * 8192 : 0);     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)
+    const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
+    if (lds > 160 * 1024) {
+        set_error("tedspad_bneck_tail_fwd: halo / conv3 weight image does not fit LDS (%d bytes)", lds);
+        return TEDSPAD_EINVAL;
+    }
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_bneck_tail_kernel<T, DUAL, STAGED, POOLT>;
+    if (!attr_set[T::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 1;
+    }
+    const int tiles = POOLT ? (p.M / (2 * p.HW)) * p.tpf : (p.M + BT_BM - 1) / BT_BM;
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(256), lds, s, p);
+    return check_launch("tedspad_bneck_tail_fwd");
+}
+
+}  // namespace
+}  // namespace tedspad
+
+using namespace tedspad;
+
+extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,
+                                          const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual,
+                                          int32_t ldres, const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu,
+                                          int32_t variant, void *stream) {
+    TS_REQUIRE(d2 && x && w2_packed && scale2 && shift2 && w3p && scale3 && shift3 && y, "tedspad_bneck_tail_fwd: null pointer");
+    const bool same = d2->to == d2->t && d2->ho == d2->h && d2->wo == d2->w && d2->pt == 0 && d2->ph < d2->kh && d2->pw < d2->kw;
+    const bool c128 = d2->cin == 128 && d2->cout == 128;
+    TS_REQUIRE(((d2->cin == 64 && d2->cout == 64) || c128) && d2->kt == 1 && d2->st == 1 && d2->sh == 1 && d2->sw == 1 && same && d2->kh * d2->kw >= 2 &&
+                   d2->kh * d2->kw <= 32 && d2->ldx >= d2->cin && d2->ldx % 8 == 0,
+               "tedspad_bneck_tail_fwd: conv2 must be a stride-1 'same' 1 x kh x kw conv with 64 -> 64 or 128 -> 128 channels");
+    TS_REQUIRE(!c128 || (!x2 && !(variant & 4)), "tedspad_bneck_tail_fwd: the 128-channel form is the plain block (no second source, no temporal pool)");
+    TS_REQUIRE(cout3 > 0 && cout3 % 64 == 0 && cout3 <= 512 && ldy >= cout3 && ldy % 8 == 0, "tedspad_bneck_tail_fwd: cout3 a multiple of 64 (<= 512), ldy >= cout3");
+    TS_REQUIRE(!(residual && x2), "tedspad_bneck_tail_fwd: either a residual tensor or the second (downsample) source, not both");
+    TS_REQUIRE(!residual || (ldres >= cout3 && ldres % 8 == 0), "tedspad_bneck_tail_fwd: bad ldres");
+    TS_REQUIRE(!x2 || (scale_d && ldx2 >= 64 && ldx2 % 8 == 0), "tedspad_bneck_tail_fwd: second source needs its BatchNorm scale and ldx2 >= 64");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)w2_packed | (uintptr_t)w3p | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)x2 | (uintptr_t)scale3 | (uintptr_t)shift3) % 16 == 0,
+               "tedspad_bneck_tail_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(d2->dtype == TEDSPAD_F16 || d2->dtype == TEDSPAD_BF16, "tedspad_bneck_tail_fwd: bad dtype");
+    const long M = (long)d2->n * d2->t * d2->h * d2->w;
+    TS_REQUIRE(M * (d2->ldx > ldy ? d2->ldx : ldy) < (1L << 31) && (!residual || M * ldres < (1L << 31)), "tedspad_bneck_tail_fwd: tensor too large for 32-bit offsets; split the batch");
+    BneckKP p;
+    p.x = (const uint16_t *)x; p.w2 = (const uint16_t *)w2_packed; p.scale2 = scale2; p.shift2 = shift2;
+    p.w3p = (const uint16_t *)w3p; p.scale3 = scale3; p.shift3 = shift3; p.scaled = scale_d;
+    p.res = (const uint16_t *)residual; p.x2 = (const uint16_t *)x2; p.y = (uint16_t *)y;
+    p.M = (int)M; p.Kpad = tedspad_conv_kpad(d2); p.W = d2->w; p.H = d2->h; p.kh = d2->kh; p.kw = d2->kw; p.ph = d2->ph; p.pw = d2->pw;
+    p.ldx = d2->ldx; p.ldres = ldres; p.ldx2 = ldx2; p.ldy = ldy; p.cout3 = cout3; p.relu = relu;
+    p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
+    TS_REQUIRE(p.Kpad == p.ntaps * d2->cin, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
+    if (c128) return d2->dtype == TEDSPAD_F16 ? launch_bneck128<F16>(p, (hipStream_t)stream) : launch_bneck128<BF16>(p, (hipStream_t)stream);
+    p.HW = d2->h * d2->w; p.tpf = (p.HW + BT_BM - 1) / BT_BM;
+    hipStream_t s = (hipStream_t)stream;
+    if (variant & 4) {
+        TS_REQUIRE(!x2 && d2->t % 2 == 0, "tedspad_bneck_tail_fwd: the temporal-pool variant takes the plain block (no second source) and an even frame count");
+        return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, false, true, true>(p, s) : launch_bneck<BF16, false, true, true>(p, s);
+    }
+    const bool staged = x2 ? (variant & 2) != 0 : (variant & 1) != 0;
+    const bool f16 = d2->dtype == TEDSPAD_F16;
+    if (x2) {
+        if (staged) return f16 ? launch_bneck<F16, true, true>(p, s) : launch_bneck<BF16, true, true>(p, s);
+        return f16 ? launch_bneck<F16, true, false>(p, s) : launch_bneck<BF16, true, false>(p, s);
+    }
+    if (staged) return f16 ? launch_bneck<F16, false, true>(p, s) : launch_bneck<BF16, false, true>(p, s);
+    return f16 ? launch_bneck<F16, false, false>(p, s) : launch_bneck<BF16, false, false>(p, s);
+}

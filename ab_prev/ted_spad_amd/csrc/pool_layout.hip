@@ -1,0 +1,610 @@
+// HBM-bound helpers of the I3D / UNet forward path for gfx950: max-pool, global average
+// pool and the layout conversions at the module boundary.  All of them move 16 bytes per
+// lane (8 channels of one channels-last pixel) so every wave instruction is a run of
+// full 128-byte lines; grids are sized >> 256 workgroups.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace tedspad {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+struct PoolKP {
+    const uint16_t *x;
+    uint16_t *y;
+    unsigned char *idx;   // optional: window-local index of the FIRST maximum per output element (training)
+    int Ti, Hi, Wi, C8, ldx, ldy;
+    int To, Ho, Wo;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw;
+    int pad_zero;
+    long total;  // n*to*ho*wo*C8
+};
+
+// 8-lane 16-bit max without leaving the packed form where the ISA has it (v_pk_max_f16); bf16 goes through fp32.
+template <typename T> __device__ __forceinline__ uint4 max8(uint4 a, uint4 b);
+template <> __device__ __forceinline__ uint4 max8<F16>(uint4 a, uint4 b) {
+    return __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b)));
+}
+template <> __device__ __forceinline__ uint4 max8<BF16>(uint4 a, uint4 b) {
+    float fa[8], fb[8];
+    unpack8<BF16>(a, fa);
+    unpack8<BF16>(b, fb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = __builtin_fmaxf(fa[i], fb[i]);
+    return pack8<BF16>(fa);
+}
+
+// max over the window, 8 channels per thread. Padded taps contribute 0 when pad_zero
+// (MaxPool3dSamePadding pads with zeros BEFORE pooling, i3d.py:41-45), else are skipped
+// (nn.MaxPool3d semantics, large_i3d.py:138-139).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolKP p) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % p.C8);
+        long r = idx / p.C8;
+        const int wo = (int)(r % p.Wo); r /= p.Wo;
+        const int ho = (int)(r % p.Ho); r /= p.Ho;
+        const int to = (int)(r % p.To);
+        const int n = (int)(r / p.To);
+        float m[8];
+        int am[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { m[i] = -3.0e38f; am[i] = 0; }
+        bool padded = false;
+        for (int dt = 0; dt < p.kt; ++dt) {
+            const int it = to * p.st - p.pt + dt;
+            for (int dh = 0; dh < p.kh; ++dh) {
+                const int ih = ho * p.sh - p.ph + dh;
+                for (int dw = 0; dw < p.kw; ++dw) {
+                    const int iw = wo * p.sw - p.pw + dw;
+                    if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+                        const size_t off = ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.ldx + c8 * 8;
+                        float v[8];
+                        unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + off), v);
+                        const int li = (dt * p.kh + dh) * p.kw + dw;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (v[i] > m[i]) { m[i] = v[i]; am[i] = li; }   // strict: the first maximum wins (torch semantics)
+                        }
+                    } else {
+                        padded = true;
+                    }
+                }
+            }
+        }
+        if (padded && p.pad_zero) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (m[i] < 0.f) { m[i] = 0.f; am[i] = 255; }   // the zero padding wins: no input element gets the gradient
+            }
+        }
+        const size_t opix = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+        *reinterpret_cast<uint4 *>(p.y + opix * p.ldy + c8 * 8) = pack8<T>(m);
+        if (p.idx) {
+            uint2 pk;
+            pk.x = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+            pk.y = (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24);
+            *reinterpret_cast<uint2 *>(p.idx + (opix * p.C8 + c8) * 8) = pk;
+        }
+    }
+}
+
+// Forward-only variant (no arg-max record): the maximum stays in packed 16-bit form (v_pk_max_f16), ~6x fewer vector
+// instructions per tap than the fp32 compare-and-select above -- the inference pools are then bound by HBM, not by the VALU.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_noidx_kernel(const PoolKP p, const uint32_t ninf) {
+    const uint4 lo = make_uint4(ninf, ninf, ninf, ninf), zero = make_uint4(0, 0, 0, 0);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % p.C8);
+        long r = idx / p.C8;
+        const int wo = (int)(r % p.Wo); r /= p.Wo;
+        const int ho = (int)(r % p.Ho); r /= p.Ho;
+        const int to = (int)(r % p.To);
+        const int n = (int)(r / p.To);
+        uint4 m = lo;
+        bool padded = false;
+        for (int dt = 0; dt < p.kt; ++dt) {
+            const int it = to * p.st - p.pt + dt;
+            for (int dh = 0; dh < p.kh; ++dh) {
+                const int ih = ho * p.sh - p.ph + dh;
+                const bool rowok = (unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi;
+                const uint16_t *row = p.x + ((((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi) * p.ldx + c8 * 8;
+                for (int dw = 0; dw < p.kw; ++dw) {
+                    const int iw = wo * p.sw - p.pw + dw;
+                    if (rowok && (unsigned)iw < (unsigned)p.Wi) m = max8<T>(m, *reinterpret_cast<const uint4 *>(row + (size_t)iw * p.ldx));
+                    else padded = true;
+                }
+            }
+        }
+        if (padded && p.pad_zero) m = max8<T>(m, zero);
+        const size_t opix = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+        *reinterpret_cast<uint4 *>(p.y + opix * p.ldy + c8 * 8) = m;
+    }
+}
+
+// 3x3x3 / stride 1 / pad 1 max-pool (the pool branch of every InceptionModule, i3d.py:133-134,148: 9 of the 13 pools of
+// InceptionI3d). The generic kernel above reads 27 taps per output; here one thread walks a W row for TWO output rows
+// (h0, h0+1) of one 8-channel group: per column it loads the 3(t) x 4(h) inputs once, reduces them to the two column
+// maxima, and an output is the max of three consecutive column maxima kept in registers: 6 loads per output instead of
+// 27, all of them independent 16-byte loads that are contiguous across the lanes (channel-minor).
+// `padv` is what an out-of-range tap contributes: 0 (MaxPool3dSamePadding pads with zeros) or -inf (nn.MaxPool3d).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_k3s1_kernel(const uint16_t *x, uint16_t *y, int N, int Tn, int H, int W, int C8, int ldx, int ldy,
+                                                           uint32_t padw, int segs, int seglen, long total) {
+    const uint4 padv = make_uint4(padw, padw, padw, padw);
+    const int H2 = (H + 1) / 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long r = idx / C8;
+        const int seg = (int)(r % segs); r /= segs;          // a row is cut into `segs` runs of `seglen` columns (+1 halo column each side)
+        const int h0 = (int)(r % H2) * 2; r /= H2;
+        const int t = (int)(r % Tn);
+        const int n = (int)(r / Tn);
+        const int w0 = seg * seglen, w1 = min(W, w0 + seglen);
+        if (w0 >= W) continue;
+        const uint16_t *row[12];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int dh = 0; dh < 4; ++dh) {
+                const int it = t + dt - 1, ih = h0 + dh - 1;
+                row[dh * 3 + dt] = ((unsigned)it < (unsigned)Tn && (unsigned)ih < (unsigned)H)
+                                       ? x + (((size_t)n * Tn + it) * H + ih) * (size_t)W * ldx + c8 * 8 : nullptr;
+            }
+        uint16_t *o0 = y + (((size_t)n * Tn + t) * H + h0) * (size_t)W * ldy + c8 * 8;
+        uint16_t *o1 = o0 + (size_t)W * ldy;
+        const bool two = h0 + 1 < H;
+        uint4 cur[12], nxt[12];
+        auto load_col = [&](int w, uint4 (&v)[12]) {
+            const bool in = (unsigned)w < (unsigned)W;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) v[i] = (in && row[i]) ? *reinterpret_cast<const uint4 *>(row[i] + (size_t)w * ldx) : padv;
+        };
+        load_col(w0 - 1, cur);
+        uint4 a1 = padv, a2 = padv, b1 = padv, b2 = padv;        // column maxima at w-1 and w-2 (rows h0 / h0+1)
+        for (int w = w0 - 1; w <= w1; ++w) {
+            if (w < w1) load_col(w + 1, nxt);                     // in flight while column w is reduced
+            uint4 rm[4];
+#pragma unroll
+            for (int dh = 0; dh < 4; ++dh) rm[dh] = max8<T>(max8<T>(cur[dh * 3], cur[dh * 3 + 1]), cur[dh * 3 + 2]);
+            const uint4 mid = max8<T>(rm[1], rm[2]);
+            const uint4 a0 = max8<T>(rm[0], mid), b0 = max8<T>(mid, rm[3]);
+            if (w >= w0 + 1) {
+                *reinterpret_cast<uint4 *>(o0 + (size_t)(w - 1) * ldy) = max8<T>(max8<T>(a2, a1), a0);
+                if (two) *reinterpret_cast<uint4 *>(o1 + (size_t)(w - 1) * ldy) = max8<T>(max8<T>(b2, b1), b0);
+            }
+            a2 = a1; a1 = a0; b2 = b1; b1 = b0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) cur[i] = nxt[i];
+        }
+    }
+}
+
+// mean over `spatial` pixels, fp32 accumulate + output. A workgroup owns 64 8-channel chunks of one sample; its four waves take every fourth
+// pixel (four independent load streams per chunk: the one-thread-per-chunk form was latency-bound, 47 us for 90 MB at the bench size) and
+// are summed through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const uint16_t *x, float *y, int n, int spatial, int c8n, int ldx) {
+    __shared__ float red[3][64][8];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int cgroups = (c8n + 63) / 64;
+    const int b = blockIdx.x / cgroups, c8 = (blockIdx.x % cgroups) * 64 + cl;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c8 < c8n) {
+        const uint16_t *px = x + (size_t)b * spatial * ldx + c8 * 8;
+        for (int i = pl; i < spatial; i += 4) {
+            float v[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(px + (size_t)i * ldx), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+    }
+    if (pl) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[pl - 1][cl][j] = s[j];
+    }
+    __syncthreads();
+    if (pl == 0 && c8 < c8n) {
+        const float inv = 1.f / (float)spatial;
+        float *py = y + (size_t)b * c8n * 8 + c8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) py[j] = (s[j] + red[0][cl][j] + red[1][cl][j] + red[2][cl][j]) * inv;
+    }
+}
+
+// nn.AvgPool3d(kernel (kt,kh,kw), stride 1, no padding) of InceptionI3d.extract_features on maps larger than the kernel
+// (aux_code/models/i3d.py:293-295,336-340): x (n,t,h,w,c) 16-bit channels-last -> y fp32 (n,c,to,ho,wo) contiguous (the NCTHW tensor
+// the reference returns). One thread per (output position, 8-channel chunk), fp32 accumulate.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3d_s1_kernel(const uint16_t *x, float *y, int t, int h, int w, int c8n, int ldx, int kt, int kh, int kw,
+                                                           int to, int ho, int wo, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int c8 = (int)(r % c8n); r /= c8n;
+        const int ow = (int)(r % wo); r /= wo;
+        const int oh = (int)(r % ho); r /= ho;
+        const int ot = (int)(r % to);
+        const long n = r / to;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < kt; ++a)
+            for (int b = 0; b < kh; ++b)
+                for (int d = 0; d < kw; ++d) {
+                    float v[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(x + ((((n * t + ot + a) * h + oh + b) * w + ow + d) * (long)ldx + c8 * 8)), v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += v[j];
+                }
+        const float inv = 1.f / (float)(kt * kh * kw);
+        const long plane = (long)to * ho * wo;
+        float *py = y + ((n * c8n * 8 + c8 * 8) * plane + ((long)ot * ho + oh) * wo + ow);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) py[j * plane] = s[j] * inv;
+    }
+}
+
+// fp32 (n,c,t,h,w) with arbitrary element strides -> 16-bit (n,t,h,w,cpad).
+// One thread per 8 output channels-last elements: cpad=4 -> two pixels, cpad=8 -> one.
+template <typename T>
+__global__ __launch_bounds__(256) void to_channels_last_kernel(const float *x, uint16_t *y, int c, int t, int h, int w, long sn,
+                                                                long sc, long st, long sh, long sw, int cpad, long total8) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
+        const int ppt = 8 / cpad;  // pixels per thread
+        long pix = idx * ppt;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        for (int j = 0; j < ppt; ++j) {
+            long r = pix + j;
+            const int iw = (int)(r % w); r /= w;
+            const int ih = (int)(r % h); r /= h;
+            const int it = (int)(r % t);
+            const long n = r / t;
+            const float *px = x + n * sn + it * st + ih * sh + iw * sw;
+            for (int ch = 0; ch < c; ++ch) v[j * cpad + ch] = px[ch * sc];
+        }
+        *reinterpret_cast<uint4 *>(y + idx * 8) = pack8<T>(v);
+    }
+}
+
+// Fast path of the above for W-contiguous clips (sw == 1, w % 8 == 0, 16-byte aligned rows): a thread converts
+// 8 consecutive pixels of one row: two 16-byte loads per channel plane, 64 (cpad 4) or 128 (cpad 8) bytes stored.
+template <typename T, int CPAD>
+__global__ __launch_bounds__(256) void to_channels_last_w8_kernel(const float *x, uint16_t *y, int c, int t, int h, int w8, long sn, long sc,
+                                                                   long st, long sh, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int iw8 = (int)(r % w8); r /= w8;
+        const int ih = (int)(r % h); r /= h;
+        const int it = (int)(r % t);
+        const long n = r / t;
+        const float *px = x + n * sn + it * st + ih * sh + iw8 * 8;
+        float v[8][CPAD];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int ch = 0; ch < CPAD; ++ch) v[p][ch] = 0.f;
+        for (int ch = 0; ch < c; ++ch) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(px + ch * sc), b = *reinterpret_cast<const f32x4 *>(px + ch * sc + 4);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { v[p][ch] = a[p]; v[p + 4][ch] = b[p]; }
+        }
+        uint16_t *py = y + idx * 8 * CPAD;
+#pragma unroll
+        for (int q = 0; q < CPAD; ++q) {   // CPAD chunks of 8 output elements
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[(q * 8 + e) / CPAD][(q * 8 + e) % CPAD];
+            *reinterpret_cast<uint4 *>(py + q * 8) = pack8<T>(o);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_nchw_kernel(const uint16_t *x, float *y, int c, long thw, int ldx, long total) {
+    // idx over (n, c, thw): writes coalesced along thw, reads strided (tiny tensors only)
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx % thw;
+        const long r = idx / thw;
+        const int ch = (int)(r % c);
+        const long n = r / c;
+        y[idx] = T::to_f32(x[(n * thw + p) * ldx + ch]);
+    }
+}
+
+// Bilinear x2 upsample, align_corners=True (nn.Upsample in unet_parts.py:50), written into a
+// channel slice of the (larger, zero-padded) skip-concat buffer: unet_parts.py:56-67.
+// fp32 index/lambda arithmetic follows torch's area_pixel_compute_source_index.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t *x, uint16_t *y, int h, int w, int C8, int ldx, int ldy,
+                                                          int Ho, int Wo, int py, int px, long total) {
+    const int oh_sz = 2 * h, ow_sz = 2 * w;
+    const float rh = oh_sz > 1 ? (float)(h - 1) / (float)(oh_sz - 1) : 0.f;
+    const float rw = ow_sz > 1 ? (float)(w - 1) / (float)(ow_sz - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long r = idx / C8;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const long n = r / Ho;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        const int uh = oh - py, uw = ow - px;
+        if ((unsigned)uh < (unsigned)oh_sz && (unsigned)uw < (unsigned)ow_sz) {
+            const float h1r = rh * uh, w1r = rw * uw;
+            const int h1 = (int)h1r, w1 = (int)w1r;
+            const int h1p = h1 < h - 1 ? 1 : 0, w1p = w1 < w - 1 ? 1 : 0;
+            const float hl1 = h1r - h1, hl0 = 1.f - hl1, wl1 = w1r - w1, wl0 = 1.f - wl1;
+            const uint16_t *p00 = x + ((n * h + h1) * w + w1) * (long)ldx + c8 * 8;
+            float v00[8], v01[8], v10[8], v11[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00), v00);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00 + (long)w1p * ldx), v01);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00 + (long)h1p * w * ldx), v10);
+            unpack8<T>(*reinterpret_cast<const uint4 *>(p00 + ((long)h1p * w + w1p) * ldx), v11);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = hl0 * (wl0 * v00[i] + wl1 * v01[i]) + hl1 * (wl0 * v10[i] + wl1 * v11[i]);
+        }
+        *reinterpret_cast<uint4 *>(y + ((n * Ho + oh) * Wo + ow) * (long)ldy + c8 * 8) = pack8<T>(o);
+    }
+}
+
+inline int grid_for(long work_items) {
+    long g = (work_items + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;  // grid-stride the rest
+    return g < 1 ? 1 : (int)g;
+}
+
+// F.interpolate(scale_factor=2, mode="nearest") of smp's DecoderBlock (segmentation_models_pytorch 0.3.3, decoders/unetplusplus/decoder.py:
+// DecoderBlock.forward), written into its channel slice of the block's concat buffer; also the plain channel-slice copy that places a
+// tensor the UNet++ dense skip pathway concatenates twice. 16 bytes (8 channels) per thread, dtype-agnostic.
+__global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const uint4 *x, uint4 *y, int h, int w, int C8, int ldx8, int ldy8, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int wo = (int)(r % (2 * w)); r /= 2 * w;
+        const int ho = (int)(r % (2 * h));
+        const long n = r / (2 * h);
+        y[((n * 2 * h + ho) * 2 * w + wo) * ldy8 + c8] = x[((n * h + (ho >> 1)) * w + (wo >> 1)) * ldx8 + c8];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const uint4 *x, uint4 *y, int C8, int ldx8, int ldy8, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long px = idx / C8;
+        const int c8 = (int)(idx - px * C8);
+        y[px * ldy8 + c8] = x[px * ldx8 + c8];
+    }
+}
+
+// Backward of the nearest x2 upsample: dx[n][h][w] = (dx +) the sum of the 2 x 2 block of dy it was copied to (fp32 sum, one rounding).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nearest2x_bwd_kernel(const uint4 *dy, uint4 *dx, int h, int w, int C8, int ldy8, int ldx8, int acc, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int c8 = (int)(r % C8); r /= C8;
+        const int wi = (int)(r % w); r /= w;
+        const int hi = (int)(r % h);
+        const long n = r / h;
+        float s[8], v[8];
+        uint4 *dst = dx + ((n * h + hi) * w + wi) * ldx8 + c8;
+        if (acc) unpack8<T>(*dst, s);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                unpack8<T>(dy[((n * 2 * h + 2 * hi + a) * 2 * w + 2 * wi + b) * ldy8 + c8], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += v[i];
+            }
+        *dst = pack8<T>(s);
+    }
+}
+
+// y[:, :c] += x[:, :c] (a gradient that reaches a tensor through a second consumer)
+template <typename T>
+__global__ __launch_bounds__(256) void add_channels_kernel(const uint4 *x, uint4 *y, int C8, int ldx8, int ldy8, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long px = idx / C8;
+        const int c8 = (int)(idx - px * C8);
+        float a[8], b[8];
+        unpack8<T>(x[px * ldx8 + c8], a);
+        unpack8<T>(y[px * ldy8 + c8], b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] += a[i];
+        y[px * ldy8 + c8] = pack8<T>(b);
+    }
+}
+
+}  // namespace
+}  // namespace tedspad
+
+using namespace tedspad;
+
+extern "C" int32_t tedspad_abi_version(void) { return TEDSPAD_ABI_VERSION; }
+extern "C" const char *tedspad_last_error(void) { return g_err; }
+
+extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const void *x, void *y, uint8_t *idx, void *stream);
+
+extern "C" int32_t tedspad_maxpool_fwd(const tedspad_pool_desc *d, const void *x, void *y, void *stream) {
+    return tedspad_maxpool_fwd_idx(d, x, y, nullptr, stream);
+}
+
+extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const void *x, void *y, uint8_t *idx, void *stream) {
+    TS_REQUIRE(d && x && y, "tedspad_maxpool_fwd: null pointer");
+    TS_REQUIRE(!idx || (d->kt * d->kh * d->kw <= 255 && (uintptr_t)idx % 8 == 0), "tedspad_maxpool_fwd_idx: window too large for 8-bit indices");
+    TS_REQUIRE(d->c > 0 && d->c % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->c && d->ldy >= d->c,
+               "tedspad_maxpool_fwd: c/ldx/ldy must be multiples of 8");
+    TS_REQUIRE(d->n > 0 && d->to > 0 && d->ho > 0 && d->wo > 0 && d->kt > 0 && d->kh > 0 && d->kw > 0 && d->st > 0 && d->sh > 0 && d->sw > 0,
+               "tedspad_maxpool_fwd: bad geometry");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_maxpool_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(d->dtype == TEDSPAD_F16 || d->dtype == TEDSPAD_BF16, "tedspad_maxpool_fwd: bad dtype");
+    TS_REQUIRE(d->pt >= 0 && d->ph >= 0 && d->pw >= 0 && d->pt < d->kt && d->ph < d->kh && d->pw < d->kw,
+               "tedspad_maxpool_fwd: front padding must be smaller than the window");
+    PoolKP p;
+    p.x = (const uint16_t *)x; p.y = (uint16_t *)y; p.idx = idx;
+    p.Ti = d->t; p.Hi = d->h; p.Wi = d->w; p.C8 = d->c / 8; p.ldx = d->ldx; p.ldy = d->ldy;
+    p.To = d->to; p.Ho = d->ho; p.Wo = d->wo;
+    p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.st = d->st; p.sh = d->sh; p.sw = d->sw; p.pt = d->pt; p.ph = d->ph; p.pw = d->pw;
+    p.pad_zero = d->pad_zero;
+    p.total = (long)d->n * d->to * d->ho * d->wo * p.C8;
+    hipStream_t s = (hipStream_t)stream;
+    if (!idx && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 && d->ph == 1 && d->pw == 1 &&
+        d->to == d->t && d->ho == d->h && d->wo == d->w) {
+        long rows = (long)d->n * d->t * ((d->h + 1) / 2) * p.C8;
+        int segs = 1;                                             // enough threads for ~8 waves per SIMD on 256 CUs
+        while (rows * segs < 256L * 2048 && (d->w + segs - 1) / segs > 4) ++segs;
+        const int seglen = (d->w + segs - 1) / segs;
+        const long tot = rows * segs;
+        // a row whose window is entirely padding cannot occur (pad 1 < 3), so with "skip" semantics -inf never survives
+        const uint32_t ninf = d->dtype == TEDSPAD_F16 ? 0xFC00FC00u : 0xFF80FF80u;
+        const uint32_t padw = d->pad_zero ? 0u : ninf;
+        if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_k3s1_kernel<F16>, dim3(grid_for(tot)), dim3(256), 0, s, p.x, p.y, d->n, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw, segs, seglen, tot);
+        else hipLaunchKernelGGL(maxpool_k3s1_kernel<BF16>, dim3(grid_for(tot)), dim3(256), 0, s, p.x, p.y, d->n, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw, segs, seglen, tot);
+        return check_launch("tedspad_maxpool_fwd");
+    }
+    if (!idx) {
+        if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_noidx_kernel<F16>, dim3(grid_for(p.total)), dim3(256), 0, s, p, 0xFC00FC00u);
+        else hipLaunchKernelGGL(maxpool_noidx_kernel<BF16>, dim3(grid_for(p.total)), dim3(256), 0, s, p, 0xFF80FF80u);
+        return check_launch("tedspad_maxpool_fwd");
+    }
+    if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL(maxpool_kernel<F16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(maxpool_kernel<BF16>, dim3(grid_for(p.total)), dim3(256), 0, s, p);
+    return check_launch("tedspad_maxpool_fwd");
+}
+
+extern "C" int32_t tedspad_global_avgpool_fwd(const void *x, float *y, int32_t n, int32_t spatial, int32_t c, int32_t ldx,
+                                              int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && spatial > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldx >= c, "tedspad_global_avgpool_fwd: bad arguments");
+    TS_REQUIRE(((uintptr_t)x) % 16 == 0, "tedspad_global_avgpool_fwd: x must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_global_avgpool_fwd: bad dtype");
+    const int blocks = n * ((c / 8 + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(avgpool_kernel<F16>, dim3(blocks), dim3(256), 0, s, (const uint16_t *)x, y, n, spatial, c / 8, ldx);
+    else hipLaunchKernelGGL(avgpool_kernel<BF16>, dim3(blocks), dim3(256), 0, s, (const uint16_t *)x, y, n, spatial, c / 8, ldx);
+    return check_launch("tedspad_global_avgpool_fwd");
+}
+
+extern "C" int32_t tedspad_clip_to_channels_last(const float *x, void *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w,
+                                                 int64_t sn, int64_t sc, int64_t st_, int64_t sh, int64_t sw, int32_t cpad,
+                                                 int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && t > 0 && h > 0 && w > 0, "tedspad_clip_to_channels_last: bad arguments");
+    TS_REQUIRE((cpad == 4 || cpad == 8) && c <= cpad, "tedspad_clip_to_channels_last: cpad must be 4 or 8 and >= c");
+    TS_REQUIRE(cpad == 8 || w % 2 == 0, "tedspad_clip_to_channels_last: cpad=4 packs pixel pairs, w must be even");
+    TS_REQUIRE(((uintptr_t)y) % 16 == 0, "tedspad_clip_to_channels_last: y must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_clip_to_channels_last: bad dtype");
+    const long total8 = (long)n * t * h * w * cpad / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (sw == 1 && w % 8 == 0 && c <= 4 && ((uintptr_t)x % 16 == 0) && sn % 4 == 0 && sc % 4 == 0 && st_ % 4 == 0 && sh % 4 == 0) {
+        const long tot = (long)n * t * h * (w / 8);
+        const dim3 g(grid_for(tot));
+        if (cpad == 4) {
+            if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((to_channels_last_w8_kernel<F16, 4>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+            else hipLaunchKernelGGL((to_channels_last_w8_kernel<BF16, 4>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+        } else {
+            if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((to_channels_last_w8_kernel<F16, 8>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+            else hipLaunchKernelGGL((to_channels_last_w8_kernel<BF16, 8>), g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w / 8, (long)sn, (long)sc, (long)st_, (long)sh, tot);
+        }
+        return check_launch("tedspad_clip_to_channels_last");
+    }
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(to_channels_last_kernel<F16>, dim3(grid_for(total8)), dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, cpad, total8);
+    else hipLaunchKernelGGL(to_channels_last_kernel<BF16>, dim3(grid_for(total8)), dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, cpad, total8);
+    return check_launch("tedspad_clip_to_channels_last");
+}
+
+extern "C" int32_t tedspad_channels_last_to_nchw(const void *x, float *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w,
+                                                 int32_t ldx, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && t > 0 && h > 0 && w > 0 && ldx >= c, "tedspad_channels_last_to_nchw: bad arguments");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_channels_last_to_nchw: bad dtype");
+    const long thw = (long)t * h * w, total = (long)n * c * thw;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(to_nchw_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, c, thw, ldx, total);
+    else hipLaunchKernelGGL(to_nchw_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, c, thw, ldx, total);
+    return check_launch("tedspad_channels_last_to_nchw");
+}
+
+extern "C" int32_t tedspad_upsample_bilinear2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx,
+                                                   int32_t ldy, int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left,
+                                                   int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c,
+               "tedspad_upsample_bilinear2x_fwd: bad arguments");
+    TS_REQUIRE(pad_top >= 0 && pad_left >= 0 && ho >= 2 * h + pad_top && wo >= 2 * w + pad_left,
+               "tedspad_upsample_bilinear2x_fwd: output smaller than the upsampled map");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_upsample_bilinear2x_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_upsample_bilinear2x_fwd: bad dtype");
+    const long total = (long)n * ho * wo * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, (uint16_t *)y, h, w, c / 8, ldx, ldy, ho, wo, pad_top, pad_left, total);
+    else hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, (uint16_t *)y, h, w, c / 8, ldx, ldy, ho, wo, pad_top, pad_left, total);
+    return check_launch("tedspad_upsample_bilinear2x_fwd");
+}
+
+extern "C" int32_t tedspad_upsample_nearest2x_fwd(const void *x, void *y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t ldy,
+                                                  void *stream) {
+    TS_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c,
+               "tedspad_upsample_nearest2x_fwd: bad arguments");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_upsample_nearest2x_fwd: pointers must be 16-byte aligned");
+    const long total = (long)n * 2 * h * 2 * w * (c / 8);
+    hipLaunchKernelGGL(upsample_nearest2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y, h, w, c / 8,
+                       ldx / 8, ldy / 8, total);
+    return check_launch("tedspad_upsample_nearest2x_fwd");
+}
+
+extern "C" int32_t tedspad_copy_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, void *stream) {
+    TS_REQUIRE(x && y && npix > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "tedspad_copy_channels: bad arguments");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_copy_channels: pointers must be 16-byte aligned");
+    const long total = (long)npix * (c / 8);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
+    return check_launch("tedspad_copy_channels");
+}
+
+extern "C" int32_t tedspad_upsample_nearest2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldy, int32_t ldx,
+                                                  int32_t accumulate, int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c,
+               "tedspad_upsample_nearest2x_bwd: bad arguments");
+    TS_REQUIRE(((uintptr_t)dy | (uintptr_t)dx) % 16 == 0, "tedspad_upsample_nearest2x_bwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_upsample_nearest2x_bwd: bad dtype");
+    const long total = (long)n * h * w * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(upsample_nearest2x_bwd_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)dy, (uint4 *)dx, h, w, c / 8, ldy / 8, ldx / 8, accumulate, total);
+    else hipLaunchKernelGGL(upsample_nearest2x_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)dy, (uint4 *)dx, h, w, c / 8, ldy / 8, ldx / 8, accumulate, total);
+    return check_launch("tedspad_upsample_nearest2x_bwd");
+}
+
+extern "C" int32_t tedspad_add_channels(const void *x, void *y, int64_t npix, int32_t c, int32_t ldx, int32_t ldy, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && npix > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= c && ldy >= c, "tedspad_add_channels: bad arguments");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "tedspad_add_channels: pointers must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_add_channels: bad dtype");
+    const long total = (long)npix * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(add_channels_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
+    else hipLaunchKernelGGL(add_channels_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint4 *)x, (uint4 *)y, c / 8, ldx / 8, ldy / 8, total);
+    return check_launch("tedspad_add_channels");
+}
+
+extern "C" int32_t tedspad_avgpool3d_s1_fwd(const void *x, float *y, int32_t n, int32_t t, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t kt,
+                                            int32_t kh, int32_t kw, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && c % 8 == 0 && ldx % 8 == 0 && ldx >= c && kt > 0 && kh > 0 && kw > 0 && t >= kt && h >= kh && w >= kw,
+               "tedspad_avgpool3d_s1_fwd: bad arguments (the map must be at least as large as the kernel)");
+    TS_REQUIRE(((uintptr_t)x) % 16 == 0, "tedspad_avgpool3d_s1_fwd: x must be 16-byte aligned");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_avgpool3d_s1_fwd: bad dtype");
+    const int to = t - kt + 1, ho = h - kh + 1, wo = w - kw + 1;
+    const long total = (long)n * to * ho * wo * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(avgpool3d_s1_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, t, h, w, c / 8, ldx, kt, kh, kw, to, ho, wo, total);
+    else hipLaunchKernelGGL(avgpool3d_s1_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, s, (const uint16_t *)x, y, t, h, w, c / 8, ldx, kt, kh, kw, to, ho, wo, total);
+    return check_launch("tedspad_avgpool3d_s1_fwd");
+}

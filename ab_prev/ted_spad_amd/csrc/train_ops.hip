@@ -1,0 +1,582 @@
+// HBM-bound kernels of the training step for gfx950 (channels-last 16-bit activations, fp32
+// statistics): train-mode BatchNorm forward/backward around the conv kernels, and the backward
+// of max-pool, global average pool, bilinear x2 upsample and the UNet's sigmoid output.
+// Reference: the autograd of the torch.nn modules of aux_code/models/{large_i3d,unet_parts}.py under
+// `fa_model.train()` / `ft_model.train()` (anonymization_training/train_anonymizer.py:73-75,137-139).
+// Every kernel moves 16 bytes per lane (8 channels of one pixel); per-channel reductions are
+// register partials -> LDS tree -> one float atomic per channel per workgroup.
+#include "common.h"
+
+namespace tedspad {
+namespace {
+
+inline int grid_for(long items) {
+    long g = (items + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    return g < 1 ? 1 : (int)g;
+}
+
+// ---- BatchNorm (train): finalize the batch statistics gathered by the conv epilogue -------------
+__global__ void bn_finalize_kernel(const float *stats, int stats_ld, float count, const float *gamma, const float *beta,
+                                   float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                                   float *shift, float *mean_out, float *invstd_out, int C, const float *conv_bias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c] / count;
+    float var = stats[stats_ld + c] / count - mean * mean;   // biased (normalisation)
+    var = var < 0.f ? 0.f : var;
+    const float invstd = rsqrtf(var + eps);
+    const float s = gamma[c] * invstd;
+    // the conv epilogue accumulated statistics of conv(x) + bias; y = (z - mean) * s + beta with z = conv + bias
+    scale[c] = s;
+    shift[c] = beta[c] - mean * s;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {   // nn.BatchNorm: running stats use the UNBIASED variance
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+    (void)conv_bias;
+}
+
+// y = act(z * scale + shift (+ res))
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *z, const float *scale, const float *shift, const uint16_t *res,
+                                                        uint16_t *y, long pixels, int C8, int ldz, int ldres, int ldy, int relu) {
+    const long total = pixels * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        const long px = idx / C8;
+        float v[8];
+        {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8), b = *reinterpret_cast<const f32x4 *>(z + px * ldz + c8 * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * scale[c8 * 8 + i] + shift[c8 * 8 + i];
+        if (res) {
+            float r[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(res + px * ldres + c8 * 8), r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += r[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8<T>(v);
+    }
+}
+
+// bn_finalize + bn_apply in ONE launch (train-mode BatchNorm forward after the conv that accumulated the statistics): every thread
+// derives scale / shift of its 8 channels from the batch sums itself (2 divisions and an rsqrt per channel: nothing beside the 32 + 16
+// bytes it moves per channel), so the separate per-layer finalize launch (159 per phase-2 iteration of cfg3) disappears; workgroup 0
+// also writes mean / invstd for the backward pass and updates the running statistics.
+// z, the conv output in front of the BatchNorm: fp32, or 16-bit (z16: the dtype of y) -- what the reference's autocast region keeps
+// (train_anonymizer.py:78,151: conv outputs are half tensors there); the batch statistics come from the conv's fp32 accumulators either way.
+template <typename T>
+__device__ __forceinline__ void load_z8(const void *z, bool z16, size_t off, float (&v)[8]) {
+    if (z16) {
+        unpack8<T>(*reinterpret_cast<const uint4 *>((const uint16_t *)z + off), v);
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>((const float *)z + off), b = *reinterpret_cast<const f32x4 *>((const float *)z + off + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int z16, const float *stats, int stats_ld, float count, const float *gamma,
+                                                              const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                                              float *mean_out, float *invstd_out, int C, const uint16_t *res, uint16_t *y, long pixels,
+                                                              int C8, int ldz, int ldres, int ldy, int relu) {
+    // statistics GROUPS (gridDim.y): group g = rows [g * pixels, (g + 1) * pixels) with its own sums, mean and invstd -- the three clips
+    // of a training step normalised separately in one launch (train_anonymizer.py:169-175 calls ft_model three times)
+    const int grp = blockIdx.y;
+    if (blockIdx.x == 0 && grp == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            for (int g = 0; g < (int)gridDim.y; ++g) {                       // the running statistics take the groups' updates in order
+                const float *st = stats + (size_t)g * 2 * stats_ld;
+                const float mean = st[c] / count;
+                float var = st[stats_ld + c] / count - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                mean_out[(size_t)g * C8 * 8 + c] = mean;
+                invstd_out[(size_t)g * C8 * 8 + c] = rsqrtf(var + eps);
+                if (running_mean) {
+                    const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+                }
+            }
+        }
+    }
+    stats += (size_t)grp * 2 * stats_ld;
+    const size_t zbase = (size_t)grp * pixels * ldz;
+    y += (size_t)grp * pixels * ldy;
+    if (res) res += (size_t)grp * pixels * ldres;
+    const long total = pixels * C8;
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration
+    float sc[8], sf[8];
+    int have = -1;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const int c8 = (int)(idx % C8);
+        const long px = idx / C8;
+        if (!fixed || have != c8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c8 * 8 + i;
+                float s = 0.f, b = 0.f;
+                if (c < C) {
+                    const float mean = stats[c] / count;
+                    float var = stats[stats_ld + c] / count - mean * mean;
+                    var = var < 0.f ? 0.f : var;
+                    s = gamma[c] * rsqrtf(var + eps);
+                    b = beta[c] - mean * s;
+                }
+                sc[i] = s; sf[i] = b;
+            }
+            have = c8;
+        }
+        float v[8];
+        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sf[i];
+        if (res) {
+            float r[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(res + px * ldres + c8 * 8), r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += r[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8<T>(v);
+    }
+}
+
+// per-channel sums over pixels:  out[0][c] += sum g,  out[1][c] += sum g * xhat
+//   g = dy * (y > 0 if relu),  xhat = (z - mean) * invstd  (xhat term skipped when z == nullptr)
+// block = 256 threads = (256 / C8L) pixel lanes x C8L channel chunks, C8L = min(C8, 32)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
+                                                             const float *invstd, const float *gamma, const float *beta, float *out, int out_ld, long pixels,
+                                                             int C8, int lddy, int ldy, int ldz, int relu) {
+    __shared__ float red[2][256][8];
+    const int C8L = C8 < 32 ? C8 : 32;
+    const int PL = 256 / C8L;
+    const int cl = threadIdx.x % C8L, pl = threadIdx.x / C8L;
+    const int cgroups = (C8 + C8L - 1) / C8L;
+    const int cg = blockIdx.x % cgroups;
+    const int pb = blockIdx.x / cgroups, pblocks = gridDim.x / cgroups;
+    const int c8 = cg * C8L + cl;
+    {   // statistics group (gridDim.y): rows [grp * pixels, (grp + 1) * pixels), its own mean / invstd / sums
+        const int grp = blockIdx.y;
+        dy += (size_t)grp * pixels * lddy;
+        if (y) y += (size_t)grp * pixels * ldy;
+        if (z) { mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8; }
+        out += (size_t)grp * 2 * out_ld;
+    }
+    const size_t zbase = (size_t)blockIdx.y * pixels * ldz;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    if (c8 < C8 && pl < PL) {
+        // y == NULL with relu (units without a residual input): the ReLU mask is recomputed from z with the forward pass's own scale / shift
+        // (tedspad_bn_train_apply: s = gamma * invstd, b = beta - mean * s, y = relu(z * s + b)) instead of re-reading the 16-bit output
+        const bool remask = relu && !y;
+        float mu[8], is[8], ms[8], mb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = z ? mean[c8 * 8 + i] : 0.f; is[i] = z ? invstd[c8 * 8 + i] : 0.f;
+            ms[i] = remask ? gamma[c8 * 8 + i] * is[i] : 0.f;
+            mb[i] = remask ? beta[c8 * 8 + i] - mu[i] * ms[i] : 0.f;
+        }
+        for (long px = (long)pb * PL + pl; px < pixels; px += (long)pblocks * PL) {
+            float g[8], zz[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
+            if (z) load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, zz);
+            if (remask) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] = zz[i] * ms[i] + mb[i] > 0.f ? g[i] : 0.f;
+            } else if (relu) {
+                float yy[8];
+                unpack8<T>(*reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8), yy);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s0[i] += g[i];
+            if (z) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1[i] += g[i] * (zz[i] - mu[i]) * is[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
+    __syncthreads();
+    // threads 0 .. C8L*8-1 each own one channel of the group and sum over the pixel lanes
+    if (threadIdx.x < C8L * 8) {
+        const int ch = threadIdx.x;   // channel within the group: chunk ch/8, element ch%8
+        const int c = cg * C8L * 8 + ch;
+        if (c < C8 * 8) {
+            float a = 0.f, b = 0.f;
+            for (int q = 0; q < PL; ++q) { a += red[0][q * C8L + ch / 8][ch % 8]; b += red[1][q * C8L + ch / 8][ch % 8]; }
+            atomicAdd(out + c, a);
+            if (z) atomicAdd(out + out_ld + c, b);
+        }
+    }
+}
+
+// dz = k[c] * (g - a[c] - xhat * b[c]),  g = dy * (y > 0 if relu);  optionally dres = g
+//   train BN: k = gamma*invstd, a = dbeta/M, b = dgamma/M
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
+                                                            const float *invstd, const float *gamma, const float *beta, const float *sums, int sums_ld,
+                                                            float inv_count, uint16_t *dz, uint16_t *dres, long pixels, int C8, int lddy,
+                                                            int ldy, int ldz, int lddz, int lddres, int relu) {
+    {   // statistics group (gridDim.y)
+        const int grp = blockIdx.y;
+        dy += (size_t)grp * pixels * lddy;
+        if (y) y += (size_t)grp * pixels * ldy;
+        mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8;
+        sums += (size_t)grp * 2 * sums_ld;
+        dz += (size_t)grp * pixels * lddz;
+        if (dres) dres += (size_t)grp * pixels * lddres;
+    }
+    const long total = pixels * C8;
+    const size_t zbase = (size_t)blockIdx.y * pixels * ldz;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        const long px = idx / C8;
+        float g[8], zz[8], o[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
+        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, zz);
+        if (relu && !y) {             // the forward pass's own expression (see bn_bwd_reduce_kernel)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c8 * 8 + i;
+                const float s_ = gamma[c] * invstd[c];
+                g[i] = zz[i] * s_ + (beta[c] - mean[c] * s_) > 0.f ? g[i] : 0.f;
+            }
+        } else if (relu) {
+            float yy[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8), yy);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
+        }
+        if (dres) *reinterpret_cast<uint4 *>(dres + px * lddres + c8 * 8) = pack8<T>(g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c8 * 8 + i;
+            const float xh = (zz[i] - mean[c]) * invstd[c];
+            o[i] = gamma[c] * invstd[c] * (g[i] - sums[c] * inv_count - xh * sums[sums_ld + c] * inv_count);
+        }
+        *reinterpret_cast<uint4 *>(dz + px * lddz + c8 * 8) = pack8<T>(o);
+    }
+}
+
+// ---- max-pool backward (gather form): dx[i] = sum over windows o containing i of dy[o] * [argmax(o) == i] (+ add[i]),
+//      argmax = the first-maximum index the forward recorded (tedspad_maxpool_fwd_idx): torch's tie rule ----
+struct PoolBKP {
+    const uint16_t *x, *dy, *add;
+    const unsigned char *idx;
+    uint16_t *dx;
+    int Ti, Hi, Wi, C8, ldx, lddy, ldadd, lddx;
+    int To, Ho, Wo;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw;
+    int relu_mask;
+    long total;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolBKP p) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % p.C8);
+        long r = idx / p.C8;
+        const int iw = (int)(r % p.Wi); r /= p.Wi;
+        const int ih = (int)(r % p.Hi); r /= p.Hi;
+        const int it = (int)(r % p.Ti);
+        const long n = r / p.Ti;
+        const size_t xi = (((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw;
+        float xv[8], acc[8];
+        unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + xi * p.ldx + c8 * 8), xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        if (p.add) unpack8<T>(*reinterpret_cast<const uint4 *>(p.add + xi * p.ldadd + c8 * 8), acc);
+        // output windows o with o*s - p <= i < o*s - p + k
+        const int to_lo = max(0, (it + p.pt - p.kt + p.st) / p.st), to_hi = min(p.To - 1, (it + p.pt) / p.st);
+        const int ho_lo = max(0, (ih + p.ph - p.kh + p.sh) / p.sh), ho_hi = min(p.Ho - 1, (ih + p.ph) / p.sh);
+        const int wo_lo = max(0, (iw + p.pw - p.kw + p.sw) / p.sw), wo_hi = min(p.Wo - 1, (iw + p.pw) / p.sw);
+        for (int to = to_lo; to <= to_hi; ++to)
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    const size_t oi = (((size_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+                    // window-local index of this input element in window o
+                    const int li = ((it - (to * p.st - p.pt)) * p.kh + (ih - (ho * p.sh - p.ph))) * p.kw + (iw - (wo * p.sw - p.pw));
+                    const uint2 pk = *reinterpret_cast<const uint2 *>(p.idx + (oi * p.C8 + c8) * 8);
+                    float g[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(p.dy + oi * p.lddy + c8 * 8), g);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int a = (int)(((i < 4 ? pk.x : pk.y) >> (8 * (i & 3))) & 255u);
+                        acc[i] += (a == li) ? g[i] : 0.f;
+                    }
+                }
+        if (p.relu_mask) {   // x is a ReLU output: fold that ReLU's backward in
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = xv[i] > 0.f ? acc[i] : 0.f;
+        }
+        *reinterpret_cast<uint4 *>(p.dx + xi * p.lddx + c8 * 8) = pack8<T>(acc);
+    }
+}
+
+// global average pool backward: dx[n,p,c] = dfeat[n,c] / S
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float *dfeat, const uint16_t *mask, int ldmask, uint16_t *dx, int n, int spatial, int C8, int lddx) {
+    const long total = (long)n * spatial * C8;
+    const float inv = 1.f / (float)spatial;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        const long px = idx / C8;
+        const long b = px / spatial;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = dfeat[b * C8 * 8 + c8 * 8 + i] * inv;
+        if (mask) {
+            float mk[8];
+            unpack8<T>(*reinterpret_cast<const uint4 *>(mask + px * ldmask + c8 * 8), mk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
+        }
+        *reinterpret_cast<uint4 *>(dx + px * lddx + c8 * 8) = pack8<T>(v);
+    }
+}
+
+// bilinear x2 (align_corners=True) backward, gather form over the INPUT pixels; dy lives in a
+// (Ho,Wo) tensor (the concat buffer slice) at offset (py,px).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const uint16_t *dy, uint16_t *dx, int h, int w, int C8, int lddy, int lddx,
+                                                              int Ho, int Wo, int py, int px, long total) {
+    const int oh_sz = 2 * h, ow_sz = 2 * w;
+    const float rh = oh_sz > 1 ? (float)(h - 1) / (float)(oh_sz - 1) : 0.f;
+    const float rw = ow_sz > 1 ? (float)(w - 1) / (float)(ow_sz - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long r = idx / C8;
+        const int iw = (int)(r % w); r /= w;
+        const int ih = (int)(r % h);
+        const long n = r / h;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        // candidate output rows/cols: source index h1r = rh*uh lies in (ih-1, ih+1)
+        const int uh_lo = max(0, 2 * ih - 2), uh_hi = min(oh_sz - 1, 2 * ih + 3);
+        const int uw_lo = max(0, 2 * iw - 2), uw_hi = min(ow_sz - 1, 2 * iw + 3);
+        for (int uh = uh_lo; uh <= uh_hi; ++uh) {
+            const float h1r = rh * uh;
+            const int h1 = (int)h1r;
+            const int h1p = h1 < h - 1 ? 1 : 0;
+            const float hl1 = h1r - h1, hl0 = 1.f - hl1;
+            const float wh = (h1 == ih ? hl0 : 0.f) + (h1 + h1p == ih ? hl1 : 0.f);
+            if (wh == 0.f) continue;
+            for (int uw = uw_lo; uw <= uw_hi; ++uw) {
+                const float w1r = rw * uw;
+                const int w1 = (int)w1r;
+                const int w1p = w1 < w - 1 ? 1 : 0;
+                const float wl1 = w1r - w1, wl0 = 1.f - wl1;
+                const float ww = (w1 == iw ? wl0 : 0.f) + (w1 + w1p == iw ? wl1 : 0.f);
+                if (ww == 0.f) continue;
+                float g[8];
+                unpack8<T>(*reinterpret_cast<const uint4 *>(dy + ((n * Ho + uh + py) * Wo + uw + px) * (long)lddy + c8 * 8), g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += wh * ww * g[i];
+            }
+        }
+        *reinterpret_cast<uint4 *>(dx + ((n * h + ih) * w + iw) * (long)lddx + c8 * 8) = pack8<T>(acc);
+    }
+}
+
+// fp32 NC(T)HW gradient (+ optional sigmoid backward with the module output y) -> 16-bit channels-last, cpad 8
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_grad_to_cl_kernel(const float *dy, const float *y, uint16_t *out, int c, long thw, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long px = idx % thw;
+        const long n = idx / thw;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        for (int ch = 0; ch < c; ++ch) {
+            const long o = (n * c + ch) * thw + px;
+            float g = dy[o];
+            if (y) { const float s = y[o]; g *= s * (1.f - s); }
+            v[ch] = g;
+        }
+        *reinterpret_cast<uint4 *>(out + idx * 8) = pack8<T>(v);
+    }
+}
+
+// 16-bit channels-last (first c of ld channels) -> fp32 NC(T)HW, strided destination allowed
+template <typename T>
+__global__ __launch_bounds__(256) void cl_to_nchw_strided_kernel(const uint16_t *x, float *y, int c, int t, int h, int w, int ldx, long sn,
+                                                                  long sc, long st, long sh, long sw, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int iw = (int)(r % w); r /= w;
+        const int ih = (int)(r % h); r /= h;
+        const int it = (int)(r % t);
+        const long n = r / t;
+        for (int ch = 0; ch < c; ++ch) y[n * sn + ch * sc + it * st + ih * sh + iw * sw] = T::to_f32(x[idx * ldx + ch]);
+    }
+}
+
+}  // namespace
+}  // namespace tedspad
+
+using namespace tedspad;
+
+#define TS_DT(code) ((code) == TEDSPAD_F16 || (code) == TEDSPAD_BF16)
+#define TS_ZDT(zcode, code, ldz) ((zcode) == TEDSPAD_F32 || ((zcode) == (code) && (ldz) % 8 == 0))
+#define LAUNCH_T(dtype, KERN, grid, ...)                                                               \
+    do {                                                                                               \
+        if ((dtype) == TEDSPAD_F16) hipLaunchKernelGGL(KERN<F16>, grid, dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERN<BF16>, grid, dim3(256), 0, s, __VA_ARGS__);                       \
+    } while (0)
+
+namespace tedspad {
+namespace {
+// eval-mode BatchNorm as y = x*scale + shift, folded in fp64 and rounded once (engine.fold_bn; one launch per BN
+// instead of ~6 elementwise torch launches: the frozen network is re-folded after every optimizer step of the other phase)
+__global__ void bn_fold_kernel(const float *gamma, const float *beta, const float *mean, const float *var, const float *conv_bias,
+                               double eps, int C, float *scale, float *shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double inv = (double)gamma[c] / sqrt((double)var[c] + eps);
+    double sh = (double)beta[c] - (double)mean[c] * inv;
+    if (conv_bias) sh += (double)conv_bias[c] * inv;
+    scale[c] = (float)inv;
+    shift[c] = (float)sh;
+}
+}  // namespace
+}  // namespace tedspad
+
+extern "C" int32_t tedspad_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, const float *conv_bias,
+                                   double eps, int32_t C, float *scale, float *shift, void *stream) {
+    TS_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, "tedspad_bn_fold: bad arguments");
+    hipLaunchKernelGGL(tedspad::bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, conv_bias, eps, C,
+                       scale, shift);
+    return tedspad::check_launch("tedspad_bn_fold");
+}
+
+extern "C" int32_t tedspad_bn_finalize(const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+                                       float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                                       float *shift, float *mean, float *invstd, int32_t C, void *stream) {
+    TS_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0 && stats_ld >= C, "tedspad_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, stats_ld, (float)count, gamma, beta,
+                       eps, momentum, running_mean, running_var, scale, shift, mean, invstd, C, (const float *)nullptr);
+    return check_launch("tedspad_bn_finalize");
+}
+
+extern "C" int32_t tedspad_scale_shift_act(const float *z, const float *scale, const float *shift, const void *res, void *y, int64_t pixels,
+                                           int32_t C, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu, int32_t dtype, void *stream) {
+    TS_REQUIRE(z && scale && shift && y && pixels > 0 && C > 0 && C % 8 == 0 && ldz % 4 == 0 && ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0, "tedspad_scale_shift_act: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, bn_apply_kernel, dim3(grid_for(pixels * (C / 8))), z, scale, shift, (const uint16_t *)res, (uint16_t *)y, (long)pixels, C / 8, ldz, ldres, ldy, relu);
+    return check_launch("tedspad_scale_shift_act");
+}
+
+extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
+                                         const float *beta, float *sums,
+                                         int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t relu,
+                                         int32_t groups, int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || (z && gamma && beta)) && (!z || (mean && invstd && TS_ZDT(zdtype, dtype, ldz))) && sums_ld >= C && groups >= 1 && groups < 65536,
+               "tedspad_bn_bwd_reduce: bad arguments (relu needs y, or z + gamma + beta to recompute the mask)");
+    const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
+    long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
+    if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
+    if (pblocks < 1) pblocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z,
+             (int)(zdtype != TEDSPAD_F32), mean, invstd, gamma, beta, sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
+    return check_launch("tedspad_bn_bwd_reduce");
+}
+
+extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
+                                        const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
+                                        int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
+               "tedspad_bn_bwd_apply: bad arguments (relu needs y, or beta to recompute the mask)");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8)), groups), (const uint16_t *)dy, (const uint16_t *)y, z, (int)(zdtype != TEDSPAD_F32), mean,
+             invstd, gamma, beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
+    return check_launch("tedspad_bn_bwd_apply");
+}
+
+extern "C" int32_t tedspad_maxpool_bwd(const tedspad_pool_desc *d, const void *x, const uint8_t *idx, const void *dy, int32_t lddy, const void *add,
+                                       int32_t ldadd, void *dx, int32_t lddx, int32_t relu_mask, void *stream) {
+    TS_REQUIRE(d && x && idx && dy && dx && d->c % 8 == 0 && TS_DT(d->dtype), "tedspad_maxpool_bwd: bad arguments");
+    PoolBKP p;
+    p.x = (const uint16_t *)x; p.idx = idx; p.dy = (const uint16_t *)dy; p.add = (const uint16_t *)add; p.dx = (uint16_t *)dx;
+    p.Ti = d->t; p.Hi = d->h; p.Wi = d->w; p.C8 = d->c / 8; p.ldx = d->ldx; p.lddy = lddy; p.ldadd = ldadd; p.lddx = lddx;
+    p.To = d->to; p.Ho = d->ho; p.Wo = d->wo;
+    p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.st = d->st; p.sh = d->sh; p.sw = d->sw; p.pt = d->pt; p.ph = d->ph; p.pw = d->pw;
+    p.relu_mask = relu_mask;
+    p.total = (long)d->n * d->t * d->h * d->w * p.C8;
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(d->dtype, maxpool_bwd_kernel, dim3(grid_for(p.total)), p);
+    return check_launch("tedspad_maxpool_bwd");
+}
+
+extern "C" int32_t tedspad_global_avgpool_bwd(const float *dfeat, const void *mask, int32_t ldmask, void *dx, int32_t n, int32_t spatial, int32_t c,
+                                              int32_t lddx, int32_t dtype, void *stream) {
+    TS_REQUIRE(dfeat && dx && n > 0 && spatial > 0 && c % 8 == 0 && lddx >= c && TS_DT(dtype), "tedspad_global_avgpool_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, avgpool_bwd_kernel, dim3(grid_for((long)n * spatial * (c / 8))), dfeat, (const uint16_t *)mask, ldmask, (uint16_t *)dx, n, spatial, c / 8, lddx);
+    return check_launch("tedspad_global_avgpool_bwd");
+}
+
+extern "C" int32_t tedspad_upsample_bilinear2x_bwd(const void *dy, void *dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t lddy,
+                                                   int32_t lddx, int32_t ho, int32_t wo, int32_t pad_top, int32_t pad_left, int32_t dtype,
+                                                   void *stream) {
+    TS_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c % 8 == 0 && lddy >= c && lddx >= c && TS_DT(dtype) && ho >= 2 * h + pad_top && wo >= 2 * w + pad_left,
+               "tedspad_upsample_bilinear2x_bwd: bad arguments");
+    const long total = (long)n * h * w * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, upsample2x_bwd_kernel, dim3(grid_for(total)), (const uint16_t *)dy, (uint16_t *)dx, h, w, c / 8, lddy, lddx, ho, wo, pad_top, pad_left, total);
+    return check_launch("tedspad_upsample_bilinear2x_bwd");
+}
+
+extern "C" int32_t tedspad_nchw_grad_to_channels_last(const float *dy, const float *y_sigmoid, void *out, int32_t n, int32_t c, int64_t thw,
+                                                      int32_t dtype, void *stream) {
+    TS_REQUIRE(dy && out && n > 0 && c > 0 && c <= 8 && thw > 0 && TS_DT(dtype), "tedspad_nchw_grad_to_channels_last: bad arguments");
+    const long total = (long)n * thw;
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, nchw_grad_to_cl_kernel, dim3(grid_for(total)), dy, y_sigmoid, (uint16_t *)out, c, (long)thw, total);
+    return check_launch("tedspad_nchw_grad_to_channels_last");
+}
+
+extern "C" int32_t tedspad_channels_last_to_nchw_strided(const void *x, float *y, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int32_t ldx,
+                                                         int64_t sn, int64_t sc, int64_t st_, int64_t sh, int64_t sw, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && n > 0 && c > 0 && ldx >= c && TS_DT(dtype), "tedspad_channels_last_to_nchw_strided: bad arguments");
+    const long total = (long)n * t * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, cl_to_nchw_strided_kernel, dim3(grid_for(total)), (const uint16_t *)x, y, c, t, h, w, ldx, (long)sn, (long)sc, (long)st_, (long)sh, (long)sw, total);
+    return check_launch("tedspad_channels_last_to_nchw_strided");
+}
+
+extern "C" int32_t tedspad_bn_train_apply(const void *z, int32_t zdtype, const float *stats, int32_t stats_ld, int64_t count, const float *gamma, const float *beta,
+                                          float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd, int32_t C,
+                                          const void *res, void *y, int64_t pixels, int32_t Cz, int32_t ldz, int32_t ldres, int32_t ldy, int32_t relu,
+                                          int32_t groups, int32_t dtype, void *stream) {
+    TS_REQUIRE(z && stats && gamma && beta && mean && invstd && y && count > 0 && pixels > 0 && C > 0 && Cz >= C && Cz % 8 == 0 && stats_ld >= C && ldz % 4 == 0 &&
+                   ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0 && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
+               "tedspad_bn_train_apply: bad arguments (z is fp32, or 16-bit of y's dtype with ldz % 8 == 0)");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8)), groups), z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
+             running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
+    return check_launch("tedspad_bn_train_apply");
+}

@@ -1,0 +1,146 @@
+"""Feature-extraction drivers: the build's counterpart of
+`feature_extraction/st_feature_extraction.py:16-37` (extract_features) and of the inline loop
+`feature_extraction/dali_extraction.py:151-182`, batched for MI355X.
+
+Same contract: per video a float64 C-order `(T, F)` `.npy` (np.zeros default dtype,
+st_feature_extraction.py:94), one row per 16-frame clip, file name = video
+basename without extension; the optional anonymizer feed reproduces the reference's
+reshape-not-permute quirk (Q1) by default. `(T, ncrops, F)` is the other layout the MGFN
+loader accepts (anomaly_detection_mgfn/datasets/dataset.py:70-89) and is what the 10-crop
+config writes.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import sharding
+
+
+def _extract_fn(ft_model):
+    # dali_extraction.py:175-178: ft_model.extract_features, else ft_model.i3d.extract_features
+    return ft_model.extract_features if hasattr(ft_model, "extract_features") else ft_model.i3d.extract_features
+
+
+def feature_width(ft_model) -> int:
+    """F of the (n, F) rows `extract_features` returns: 2048 for I3Res50 / wrapper_i3d (large_i3d.py:262), 1024 for InceptionI3d
+    (i3d.py:336-340). Taken from the model, not from a probe forward: an empty shard must not launch anything."""
+    for m in (ft_model, getattr(ft_model, "i3d", None)):
+        f = getattr(m, "feature_dim", None) if m is not None else None
+        if f is not None:
+            return int(f)
+    raise AttributeError("extraction: the feature extractor must expose `feature_dim` (I3Res50 2048, InceptionI3d 1024)")
+
+
+def feed(clips: torch.Tensor, fa_model=None, layout: str = "reference") -> torch.Tensor:
+    """clips: (B, 16, 3, H, W) fp32 in [0,1] as the loaders deliver them -> ft input (B, 3, 16, H, W).
+
+    layout='reference' reproduces st_feature_extraction.py:24-26 / dali_extraction.py:171-173: the
+    frames go through fa as true RGB images (view(-1,3,H,W)), and the result is RESHAPED to
+    (B,3,16,H,W) -- a reinterpretation of (T,C) memory as (C,T). Without fa the
+    reference would hand a 16-channel tensor to a 3-channel conv; the counterpart permutes.
+    layout='permute' is the geometrically meaningful feed.
+    """
+    b, t, c, h, w = clips.shape
+    if fa_model is not None:
+        frames = fa_model(clips.reshape(-1, c, h, w))
+        if layout == "reference":
+            return frames.reshape(b, c, t, h, w)
+        return frames.reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
+    return clips.permute(0, 2, 1, 3, 4)
+
+
+_STREAMS = {}
+
+
+@torch.no_grad()
+def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 75, out: torch.Tensor = None, streams: int = 3) -> torch.Tensor:
+    """clips_cthw: (n, 3, T, H, W) fp32 on the GPU -> (n, F) fp32 on the GPU, `batch` clips per forward.
+    Batches alternate over `streams` HIP streams: the late, small-grid layers of one forward leave CUs idle that the
+    next forward's early layers fill (+3-8 % clips/s measured; results are unchanged; 75 clips per forward quantise best on 256 CUs)."""
+    fx = _extract_fn(ft_model)
+    n = clips_cthw.shape[0]
+    if out is None:
+        out = torch.empty((n, feature_width(ft_model)), dtype=torch.float32, device=clips_cthw.device)
+    if n == 0:                # an empty shard (T < world, sharding.shard_range): nothing to launch, the collective still runs
+        return out
+    dev = clips_cthw.device
+    if dev.type != "cuda":    # host-logic tests drive the sharding with a stub extractor on CPU tensors: no streams there
+        for i in range(0, n, batch):
+            f = fx(clips_cthw[i:i + batch]).flatten(1)
+            out[i:i + f.shape[0]] = f
+        return out
+    pool = _STREAMS.setdefault((dev, streams), [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))])
+    main = torch.cuda.current_stream(dev)
+    for st in pool:
+        st.wait_stream(main)
+    from . import engine as E
+    for j, i in enumerate(range(0, n, batch)):
+        # while the conv tile tuner is still timing candidates, stay on one stream (engine.tuning_pending)
+        with torch.cuda.stream(pool[0 if E.tuning_pending() else j % len(pool)]):
+            f = fx(clips_cthw[i:i + batch]).flatten(1)
+            out[i:i + f.shape[0]] = f
+    for st in pool:
+        main.wait_stream(st)
+    return out
+
+
+@torch.no_grad()
+def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anonymized, segment=False,
+                     batch: int = 75, layout: str = "reference", device="cuda"):
+    """Drop-in for st_feature_extraction.py:16-37. full_vid: sequence of (16,3,H,W) clips;
+    vid_features: preallocated float64 (len(full_vid), F) array that receives the rows;
+    the array is saved to `save_path` with np.save (float64, C order)."""
+    if segment:
+        raise NotImplementedError("segment_features is dead + buggy code in the reference (SURVEY.md Q12)")
+    for i in range(0, len(full_vid), batch):
+        clips = torch.stack([c for c in full_vid[i:i + batch]]).to(device, non_blocking=True)
+        x = feed(clips, fa_model if anonymized else None, layout)
+        f = _extract_fn(ft_model)(x).flatten(1)
+        vid_features[i:i + f.shape[0]] = f.cpu().numpy()
+    np.save(save_path, vid_features)
+    return vid_features
+
+
+@torch.no_grad()
+def extract_video_sharded(ft_model, clips_cthw_local: torch.Tensor, T: int, ncrops: int = 1, batch: int = 75,
+                          group=None) -> torch.Tensor:
+    """Multi-GPU extraction of ONE video. Each rank passes ITS block of clips
+    (sharding.shard_range(T, rank, world) clip times x ncrops crops, crop-minor order,
+    shape (T_r*ncrops, 3, 16, H, W)); returns the full (T, ncrops, F) fp32 tensor on every rank
+    after one RCCL all-gather."""
+    f = extract_clip_features(ft_model, clips_cthw_local, batch)
+    f = f.view(-1, ncrops, f.shape[1])
+    return sharding.gather_video_features(f, T, group)
+
+
+def save_video_features(save_dir: str, video_path: str, feats) -> str:
+    """`<video basename without .mp4/.avi>.npy`, float64 C-order (dali_extraction.py:159,182)."""
+    name = os.path.basename(video_path)
+    for ext in (".mp4", ".avi"):
+        name = name.replace(ext, "")
+    path = os.path.join(save_dir, name + ".npy")
+    arr = feats.detach().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats)
+    if arr.ndim == 3 and arr.shape[1] == 1:
+        arr = arr[:, 0]
+    np.save(path, np.ascontiguousarray(arr, dtype=np.float64))
+    return path
+
+
+def save_features_batched(save_dir: str, items) -> list:
+    """Batched `.npy` writer: items = [(video_path, feats (T,F) or (T,ncrops,F) tensor), ...] of several videos.
+    All features cross PCIe in ONE device-to-host copy (one sync instead of one per clip as in
+    st_feature_extraction.py:31-37), then each video is written with the reference's naming / float64 layout."""
+    items = list(items)
+    if not items:
+        return []
+    flat = torch.cat([f.detach().reshape(-1).to(torch.float32) for _, f in items])
+    host = flat.cpu().numpy()
+    paths, off = [], 0
+    for path, f in items:
+        n = f.numel()
+        paths.append(save_video_features(save_dir, path, host[off:off + n].reshape(tuple(f.shape))))
+        off += n
+    return paths

@@ -1,0 +1,41 @@
+"""Clip sharding of one long video across the GPUs of a node + reassembly of the per-video
+feature tensor with ONE collective (RCCL all-gather over xGMI; `nccl` backend == RCCL on ROCm).
+
+New design, not a translation: the reference's multi-GPU extraction is nn.DataParallel and is
+effectively broken (dali_extraction.py:33,128-133,175-178 -- SURVEY.md §2.1). Clips of a video are
+independent units (dali_extraction.py:62-73: one 16-frame clip per 32 source frames), so rank r
+takes a contiguous block of ceil(T/P) clip times (row order of the .npy stays trivial) and the
+only exchange is the (T_r, ncrops, F) fp32 feature block: ~1.8-18 MB per video.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(T: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of clip times for `rank`; blocks differ by at most `per` rows,
+    trailing ranks may be empty when T < world."""
+    per = -(-T // world)
+    lo = min(rank * per, T)
+    return lo, min(lo + per, T)
+
+
+def gather_video_features(local: torch.Tensor, T: int, group=None) -> torch.Tensor:
+    """local: (T_r, ...) feature rows of this rank's block (shard_range order).
+    Returns the full (T, ...) tensor on every rank. One all_gather_into_tensor of equal-size
+    (padded) blocks: on the full xGMI mesh each rank exchanges its block with all peers at once."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        assert local.shape[0] == T
+        return local
+    rank = dist.get_rank(group)
+    per = -(-T // world)
+    lo, hi = shard_range(T, rank, world)
+    assert local.shape[0] == hi - lo, "rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo)
+    tail = tuple(local.shape[1:])
+    send = local.new_zeros((per,) + tail)
+    send[: hi - lo] = local
+    recv = local.new_empty((world * per,) + tail)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    return recv[:T]

@@ -1,0 +1,45 @@
+"""CPU: bench.py's multi-process control flow (process group, clip sharding, barrier, MAX-reduce of the elapsed time, rank-0-only JSON
+line) rehearsed with 2 gloo ranks and a stub extractor (`--dry-run-cpu`), so that the N > 1 branch has run before the driver's
+8-GPU node runs it over RCCL. No kernel runs here; the numbers mean nothing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_single_process_dry_run():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--steps", "2", "--warmup", "1", "--clip-times", "5",
+                        "--crops", "2", "--batch", "4"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["gather_ok"] and lines[0]["steps"] == 2
+
+
+def test_two_rank_dry_run_prints_one_line_from_rank0():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "3", "--warmup", "1",
+           "--clip-times", "5", "--crops", "2", "--batch", "4"]       # 5 clip times per rank, ragged last batch (10 clips in batches of 4)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout                                  # rank 0 only
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["clips_per_step"] == 2 * 5 * 2
+    assert j["gather_ok"] is True                                     # every rank's rows arrived, in order
+    assert j["value"] > 0 and abs(j["value"] - j["config"]["clips_per_step"] * j["steps"] / (j["ms_per_step"] * j["steps"] / 1e3)) < 1e-2 * j["value"]

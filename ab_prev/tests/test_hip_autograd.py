@@ -1,0 +1,235 @@
+"""-m gpu: the factory's modules inside the REFERENCE'S OWN training-loop statements. The two functions below restate, line for
+line, the bodies of `train_epoch` (anonymization_training/train_anonymizer.py:66-123 phase 1, :137-193 phase 2; only
+`autocast()`, logging and the `.to(device)` copies are dropped) and run them against `ted_spad_amd` objects obtained from
+`model_loaders` -- `fa_model.train()`, `output, feat1 = ft_model(inputs1)`, `loss_fa.backward()`, `optimizer_fa.step()` -- i.e.
+through the torch.autograd bridge (ted_spad_amd/autograd.py), not through `AnonymizerTrainStep`. Checked against the same CPU
+oracle, with the same bounds, as tests/test_hip_train_step.py / test_hip_fb.py check the step driver, plus agreement of the
+two paths with each other."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_tensor, synth_train_video
+from test_hip_fb import _fb
+from test_hip_train_step import _models, _report
+
+pytestmark = pytest.mark.gpu
+
+params = SimpleNamespace(num_frames=16, temporal_loss="trip", loss="ce", temporal_loss_weight=0.1, fb_loss_weight=1.0, ft_loss_weight=0.7,
+                         triplet_loss_margin=1)
+
+
+def _criteria():
+    from ted_spad_amd.losses import CrossEntropyLoss, TripletMarginLoss
+    return CrossEntropyLoss(), TripletMarginLoss(margin=params.triplet_loss_margin)    # train_anonymizer.py:347-350
+
+
+def reference_step1(fa_model, fb_model, ft_model, optimizer_fa, optimizer_fb, optimizer_ft, inputs_vispr, inputs_video, labels_video):
+    """train_anonymizer.py:57,66-123."""
+    from ted_spad_amd.losses import NTXentLoss
+    criterion_ft, criterion_temporal_ft = _criteria()
+    inputs_video = inputs_video.permute(0, 2, 1, 3, 4)
+    optimizer_fa.zero_grad()
+    optimizer_fb.zero_grad()
+    optimizer_ft.zero_grad()
+    fa_model.train()
+    ft_model.eval()
+    fb_model.eval()
+    output1 = [fb_model(fa_model(inputs_vispr[ii])) for ii in range(2)]
+    con_loss_criterion = NTXentLoss(device='cuda', batch_size=output1[0].shape[0], temperature=0.1, use_cosine_similarity=False)
+    loss_fb = con_loss_criterion(output1[0], output1[1])
+    ori_bs, ori_t, ori_c, ori_h, ori_w = inputs_video.shape
+    inputs_video = inputs_video.reshape(-1, inputs_video.shape[1], inputs_video.shape[3], inputs_video.shape[4])
+    anon_input = fa_model(inputs_video).reshape(ori_bs, ori_t, ori_c, ori_h, ori_w)
+    inputs1, inputs2, inputs3 = torch.split(anon_input, [params.num_frames, params.num_frames, params.num_frames], dim=2)
+    output, feat1 = ft_model(inputs1)
+    loss_ft = criterion_ft(output, labels_video)
+    _, feat2 = ft_model(inputs2)
+    _, feat3 = ft_model(inputs3)
+    loss_temporal = criterion_temporal_ft(feat1, feat2, feat3)
+    loss_ft = loss_ft + params.temporal_loss_weight * loss_temporal
+    loss_fa = -params.fb_loss_weight * loss_fb + params.ft_loss_weight * loss_ft
+    loss_fa.backward()
+    grads = {k: p.grad.detach().clone() for k, p in fa_model.named_parameters() if p.grad is not None}
+    optimizer_fa.step()
+    return dict(loss_fa=loss_fa.item(), loss_fb=loss_fb.item(), loss_ft=loss_ft.item(), loss_temporal=loss_temporal.item()), grads
+
+
+def reference_step2(fa_model, fb_model, ft_model, optimizer_fa, optimizer_fb, optimizer_ft, inputs_vispr, inputs_video, labels_video):
+    """train_anonymizer.py:57,66-68,137-193."""
+    from ted_spad_amd.losses import NTXentLoss
+    criterion_ft, criterion_temporal_ft = _criteria()
+    inputs_video = inputs_video.permute(0, 2, 1, 3, 4)
+    optimizer_fa.zero_grad()
+    optimizer_fb.zero_grad()
+    optimizer_ft.zero_grad()
+    fa_model.eval()
+    fb_model.train()
+    ft_model.train()
+    with torch.no_grad():
+        ori_bs, ori_t, ori_c, ori_h, ori_w = inputs_video.shape
+        inputs_video = inputs_video.reshape(-1, inputs_video.shape[1], inputs_video.shape[3], inputs_video.shape[4])
+        input1 = [fa_model(inputs_vispr[ii]) for ii in range(2)]
+        input2 = fa_model(inputs_video).reshape(ori_bs, ori_t, ori_c, ori_h, ori_w)
+    output1 = [fb_model(x) for x in input1]
+    con_loss_criterion = NTXentLoss(device='cuda', batch_size=output1[0].shape[0], temperature=0.1, use_cosine_similarity=False)
+    loss_fb = con_loss_criterion(output1[0], output1[1])
+    inputs1, inputs2, inputs3 = torch.split(input2, [params.num_frames, params.num_frames, params.num_frames], dim=2)
+    output2, feat1 = ft_model(inputs1)
+    loss_ft = criterion_ft(output2, labels_video)
+    _, feat2 = ft_model(inputs2)
+    _, feat3 = ft_model(inputs3)
+    loss_temporal = criterion_temporal_ft(feat1, feat2, feat3)
+    loss_ft = loss_ft + params.temporal_loss_weight * loss_temporal
+    loss_fb.backward()
+    loss_ft.backward()
+    g_fb = {k: p.grad.detach().clone() for k, p in fb_model.named_parameters()}
+    g_ft = {k: p.grad.detach().clone() for k, p in ft_model.named_parameters()}
+    optimizer_fb.step()
+    optimizer_ft.step()
+    return dict(loss_fb=loss_fb.item(), loss_ft=loss_ft.item(), loss_temporal=loss_temporal.item()), g_fb, g_ft
+
+
+def _setup():
+    fa, ft, sd_u, sd_l = _models()
+    fb, sd_b = _fb()
+    opt = [torch.optim.Adam(m.parameters(), lr=lr) for m, lr in ((fa, 0.4e-5), (fb, 1e-5), (ft, 1e-5))]     # train_anonymizer.py:377-380
+    gain = (torch.arange(1, 5).float() / 4).view(4, 1, 1, 1)
+    vispr = [synth_tensor(0, "vispr%d" % i, (4, 3, 128, 128)) * gain for i in range(2)]
+    return fa, fb, ft, opt, vispr, sd_u, sd_l, sd_b
+
+
+def test_reference_phase1_statements_through_autograd():
+    from oracle import train_step_ref
+    fa, fb, ft, opt, vispr, sd_u, sd_l, sd_b = _setup()
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, {k: v.clone() for k, v in sd_u.items()}, sd_l, vispr=vispr, fb_sd=sd_b)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    frozen = {k: v.detach().clone() for m in (fb, ft) for k, v in m.state_dict().items()}
+    out, grads = reference_step1(fa, fb, ft, *opt, [v.cuda() for v in vispr], video.cuda(), labels.cuda())
+    assert abs(out["loss_fb"] - ref_l["loss_fb"]) < 5e-3 * abs(ref_l["loss_fb"])
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 5e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * max(abs(ref_l["loss_fa"]), abs(ref_l["loss_fb"]))
+    errs = _report("autograd phase 1: fa grads", grads, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.3 and max(errs.values()) < 0.5          # the bounds of test_train_step_with_fb_both_phases
+    moved = [float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()]
+    assert 0 < max(moved) <= 1.05 * 0.4e-5                                                    # Adam's first step on fa only
+    now = {k: v for m in (fb, ft) for k, v in m.state_dict().items()}
+    assert all(torch.equal(now[k], v) for k, v in frozen.items())                             # ft, fb untouched (eval mode, no step)
+    assert all(p.grad is None for m in (fb, ft) for p in m.parameters())                      # Q8: the unused gradients are not formed
+    assert int(fa.inc.double_conv[1].num_batches_tracked) == 3                                # Q14
+
+
+def test_reference_phase1_statements_with_the_default_unetpp_anonymizer():
+    """The same statements with `fa_model = load_fa_model()` -- the reference's default arch='unet++' (train_anonymizer.py:331,
+    model_loaders.py:17-30): UnetPlusPlus.forward in train() mode goes through the autograd bridge (UNetPPTrainer underneath)."""
+    from oracle import train_step_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.synth import synth_state_dict
+    _, fb, ft, opt, vispr, _, sd_l, sd_b = _setup()
+    fa = load_fa_model()
+    sd_u = synth_state_dict(fa.state_dict(), 0)
+    fa.load_state_dict(sd_u)
+    fa = fa.cuda()
+    opt[0] = torch.optim.Adam(fa.parameters(), lr=0.4e-5)
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, {k: v.clone() for k, v in sd_u.items()}, sd_l, vispr=vispr, fb_sd=sd_b)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    out, grads = reference_step1(fa, fb, ft, *opt, [v.cuda() for v in vispr], video.cuda(), labels.cuda())
+    assert abs(out["loss_fb"] - ref_l["loss_fb"]) < 1e-2 * abs(ref_l["loss_fb"])
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 1e-2 * abs(ref_l["loss_ft"])
+    assert set(grads) == set(ref_g) and not any(k.startswith("encoder.layer4.") for k in grads)
+    errs = _report("autograd phase 1: unet++ grads", grads, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.3 and max(errs.values()) < 0.45          # measured 0.20 / 0.28, min cosine 0.961
+    moved = {k: float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()}
+    assert all(v == 0.0 for k, v in moved.items() if k.startswith("encoder.layer4.")) and 0 < max(moved.values()) <= 1.05 * 0.4e-5
+    assert int(fa.encoder.bn1.num_batches_tracked) == 3                                       # Q14: two views + the video batch
+
+
+def test_reference_phase2_statements_through_autograd():
+    from oracle import train_step_ref
+    fa, fb, ft, opt, vispr, sd_u, sd_l, sd_b = _setup()
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
+    labels = torch.tensor([5, 77, 101, 1])
+    ref_l, ref_g = train_step_ref.phase2(video, labels, sd_u, sd_l)
+    ref_lfb, ref_gb = train_step_ref.phase2_fb(vispr, sd_u, {k: v.clone() for k, v in sd_b.items()})
+    fa_before = {k: v.detach().clone() for k, v in fa.state_dict().items()}
+    out, g_fb, g_ft = reference_step2(fa, fb, ft, *opt, [v.cuda() for v in vispr], video.cuda(), labels.cuda())
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 8e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 3.5e-2 * abs(ref_l["loss_temporal"])
+    assert abs(out["loss_fb"] - ref_lfb) < 1e-2 * abs(ref_lfb)
+    errs = _report("autograd phase 2: ft grads", g_ft, ref_g, min_cos=0.6, med_cos=0.8)       # bounds of test_phase2_update_ft_vs_oracle
+    # the single worst tensor is the noisiest statistic of this comparison (one full-suite run had mlp.fc1.weight -- behind a BatchNorm1d
+    # over 4 samples -- at 0.95 with cosine 0.75, the usual worst being 0.62-0.72): bound the 90th percentile tightly and the maximum loosely;
+    # the direction of EVERY tensor is held by the cosine bounds inside _report
+    ev = sorted(errs.values())
+    assert float(np.median(ev)) < 0.6 and ev[int(0.9 * (len(ev) - 1))] < 0.75 and ev[-1] < 1.3
+    errs = _report("autograd phase 2: fb grads", g_fb, ref_gb, min_cos=0.5, med_cos=0.75, tiny=1e-3)
+    assert float(np.median(list(errs.values()))) < 0.7
+    assert int(ft.i3d.bn1.num_batches_tracked) == 3 and int(ft.mlp.bn1.num_batches_tracked) == 3 and int(fb[0].bn1.num_batches_tracked) == 2   # Q14
+    assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())
+    moved = max(float((p.detach().cpu() - sd_l[k]).abs().max()) for k, p in ft.named_parameters())
+    assert 0 < moved <= 1.05 * 1e-5
+
+
+def test_autograd_path_agrees_with_the_step_driver():
+    """Same kernels, same order: the autograd bridge and AnonymizerTrainStep run the same launch sequences. Their float-atomic sums
+    (batch statistics, weight gradients) are ordered differently from run to run, and with 16-bit activations under train-mode
+    BatchNorm that alone moves the gradients (the run-to-run spread documented in test_hip_train_step.py), so: losses to 2e-3, and
+    every large gradient tensor in the same direction."""
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64)).cuda()
+    labels = torch.tensor([5, 77, 101, 1]).cuda()
+    fa, ft, _, _ = _models()
+    step = AnonymizerTrainStep(fa, ft)
+    step.opt_ft = torch.optim.SGD(ft.parameters(), lr=0.0)        # keep the gradients, do not move the weights
+    out = step.step_ft(video, labels)
+    g_drv = {k: p.grad.detach().clone() for k, p in ft.named_parameters()}
+    fa2, ft2, _, _ = _models()
+    crit_ce, crit_trip = _criteria()
+    fa2.eval(); ft2.train()
+    with torch.no_grad():
+        v = video.permute(0, 2, 1, 3, 4)
+        b, c, t, h, w = v.shape
+        anon = fa2(v.reshape(-1, c, h, w)).reshape(b, c, t, h, w)
+    c1, c2, c3 = torch.split(anon, [16, 16, 16], dim=2)
+    o, f1 = ft2(c1)
+    _, f2 = ft2(c2)
+    _, f3 = ft2(c3)
+    loss = crit_ce(o, labels) + 0.1 * crit_trip(f1, f2, f3)
+    loss.backward()
+    assert abs(float(loss) - out["loss_ft"]) < 2e-3 * abs(out["loss_ft"])
+    cos = []
+    for k, p in ft2.named_parameters():
+        a_, b_ = p.grad.flatten().double(), g_drv[k].flatten().double()
+        if float(b_.norm()) > 1e-3:
+            cos.append(float(a_ @ b_ / (a_.norm() * b_.norm())))
+    assert float(np.median(cos)) > 0.9 and min(cos) > 0.5, (float(np.median(cos)), min(cos))
+    # a second backward pass into the same parameters accumulates (autograd semantics the reference relies on)
+    g1 = {k: p.grad.detach().clone() for k, p in ft2.named_parameters()}
+    o, f1 = ft2(c1)
+    crit_ce(o, labels).backward()
+    assert any(not torch.equal(p.grad, g1[k]) for k, p in ft2.named_parameters())
+
+
+def test_freeze_bn_flag_and_stale_tape():
+    from ted_spad_amd import autograd
+    fa, ft, _, _ = _models()
+    autograd.freeze_bn(ft)
+    ft.train()
+    x = synth_tensor(0, "fz", (2, 3, 16, 32, 32)).cuda()
+    stats = {k: v.clone() for k, v in ft.state_dict().items() if "running" in k and k.startswith("i3d.")}
+    pred, feat = ft(x)
+    (pred.sum() + feat.sum()).backward()
+    assert all(torch.equal(v, ft.state_dict()[k]) for k, v in stats.items())              # FrozenBN: running statistics untouched
+    assert ft.i3d.bn1.weight.grad is None and ft.i3d.conv1.weight.grad is not None       # gamma / beta are buffers there: no gradient
+    assert ft.mlp.bn1.weight.grad is not None                                             # the head's BatchNorm1d still trains
+    pred, feat = ft(x)
+    keep = pred.sum()
+    ft(x)[0].sum().backward()                # next iteration's forward + backward: the arena is recycled only when no tape is alive ...
+    keep.backward()                          # ... so an older tape can still run

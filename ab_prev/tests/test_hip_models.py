@@ -1,0 +1,187 @@
+"""-m gpu: InceptionI3d, UNet, the wrapper head and the extraction driver on MI355X against
+the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_clips, synth_state_dict, synth_tensor
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _load(m):
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0), strict=True)
+    return m.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def inception():
+    from ted_spad_amd.model_loaders import load_ft_model
+    return _load(load_ft_model("i3d", num_classes=102))
+
+
+@pytest.fixture(scope="module")
+def wrapper():
+    from ted_spad_amd.model_loaders import load_ft_model
+    return _load(load_ft_model("largei3d", num_classes=102))
+
+
+@pytest.fixture(scope="module")
+def unet():
+    from ted_spad_amd.model_loaders import load_fa_model
+    return _load(load_fa_model(arch="unet"))
+
+
+def test_inception_features_224(inception, golden, golden_meta):
+    x = synth_clips(0, 2, (3, 16, 224, 224), device="cuda")
+    taps = {}
+    a = inception._trunk(x, taps=taps)
+    f = inception.extract_features(x).cpu().reshape(2, 1024)
+    for i in range(2):
+        assert rel_l2(f[i], golden["inception_feat_224"][i]) < TOL
+    for name, (mean, l2) in golden_meta["inception_taps_224"].items():
+        assert abs(float(taps[name].buf.double().norm()) - l2) < 2e-3 * l2, name
+
+
+def test_inception_features_on_a_larger_map(inception):
+    """i3d.py:293-295,336-340: AvgPool3d([2,7,7], stride 1) on a Mixed_5c map larger than (2,7,7): a 24 x 256 x 256 clip gives (3,8,8)
+    -> (B,1024,2,2,2), as the reference returns it."""
+    from oracle import inception_i3d_ref
+    x = synth_clips(3, 1, (3, 24, 256, 256))
+    with torch.no_grad():
+        ref = inception_i3d_ref.extract_features(x, {k: v.cpu() for k, v in inception.state_dict().items()})
+    got = inception.extract_features(x.cuda())
+    assert got.shape == ref.shape == (1, 1024, 2, 2, 2)
+    assert rel_l2(got.cpu(), ref) < TOL
+
+
+def test_inception_forward_112_and_q4(inception, golden):
+    x = synth_clips(0, 2, (3, 16, 112, 112), device="cuda")
+    lg = inception(x)
+    assert lg.shape == (2, 102)
+    assert rel_l2(lg.cpu(), golden["inception_logits_112"]) < TOL
+    with pytest.raises(RuntimeError):
+        inception.extract_features(x)
+
+
+def test_wrapper_forward_eval(wrapper, golden):
+    x = synth_clips(0, 2, (3, 16, 112, 112), device="cuda")
+    pred, feat = wrapper(x)
+    assert pred.shape == (2, 102) and feat.shape == (2, 128)
+    assert rel_l2(pred.cpu(), golden["wrapper_eval_pred"]) < TOL
+    assert rel_l2(feat.cpu(), golden["wrapper_eval_feat"]) < TOL
+    assert torch.allclose(feat.norm(dim=1).cpu(), torch.ones(2), atol=1e-5)
+    # Q3: at B=1 I3Res50.forward's feat is squeezed to (2048,) and the mlp refuses it
+    with pytest.raises(ValueError):
+        wrapper(x[:1])
+
+
+def test_unet_eval(unet, golden, golden_meta):
+    frames = synth_tensor(0, "unet_frames", (4, 3, 112, 112)).cuda()
+    y = unet(frames)
+    assert y.shape == (4, 3, 112, 112) and y.dtype == torch.float32
+    y = y.cpu()
+    assert rel_l2(y[0, :, 40:56, 40:56], golden["unet_out_crop"]) < TOL
+    assert rel_l2(y.mean(3), golden["unet_out_rowmeans"]) < TOL
+    assert float(y.min()) > 0 and float(y.max()) < 1
+
+
+@pytest.fixture(scope="module")
+def unetpp():
+    from ted_spad_amd.model_loaders import load_fa_model
+    return _load(load_fa_model())                              # the reference's default: arch='unet++'
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 112, 112), (1, 3, 48, 80)])
+def test_unetpp_eval_vs_oracle(unetpp, shape):
+    """The default anonymizer (smp UnetPlusPlus, resnet18 encoder; model_loaders.py:17-30) against oracle/unetpp_ref.py (restated from
+    the published smp / torchvision sources: parity unpinned, see its header): output and every dense-pathway tensor.
+    Tolerance 2e-3 rel-L2: 16-bit activation storage costs ~3e-4 per conv layer (2^-11 rounding, fp32 accumulation), which adds up in
+    quadrature over the up to 19 conv layers in front of a tensor here; measured 4e-4 (f1) ... 1.06e-3 (x_0_2). The 1e-3 gate of
+    north_star is on the I3D clip feature, checked with this anonymizer in front in test_anonymized_extraction_with_unetpp."""
+    from oracle import unetpp_ref
+    from ted_spad_amd import engine as E
+    frames = synth_tensor(0, "upp_frames%d" % shape[2], shape)
+    sd = {k: v.cpu() for k, v in unetpp.state_dict().items()}
+    rt, gt = {}, {}
+    with torch.no_grad():
+        ref = unetpp_ref.forward(frames, sd, taps=rt)
+    y = unetpp(frames.cuda(), taps=gt)
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    for k in ("f1", "f2", "f3", "f4", "x00", "x11", "x22", "x01", "x12", "x02", "x03"):
+        got = E.act_to_nchw(gt[k]).squeeze(2).cpu()
+        r = rt[k if k.startswith("f") else "x_%s_%s" % (k[1], k[2])]
+        assert rel_l2(got, r) < 2e-3, (k, rel_l2(got, r))
+    assert rel_l2(y.cpu(), ref) < 2e-3
+    with pytest.raises(RuntimeError):
+        unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
+    # train(): batch-statistics BatchNorm (train_anonymizer.py:73 puts fa in train mode), running statistics moved once per call
+    before = {k: v.clone() for k, v in unetpp.state_dict().items()}
+    try:
+        unetpp.train()
+        with torch.no_grad():
+            yt = unetpp(frames.cuda())
+            sd_t = {k: v.clone() for k, v in sd.items()}
+            ref_t = unetpp_ref.forward(frames, sd_t, train=True)
+        # batch statistics over as few as 2 x 14 x 14 values per channel renormalise every layer's 16-bit rounding error: 5e-3 measured at
+        # (2,3,224,224); the backward chain is held to the oracle in tests/test_hip_train_step.py::test_unetpp_backward_chain_tight_on_a_smooth_network
+        assert rel_l2(yt.cpu(), ref_t) < 1.2e-2
+        after = unetpp.state_dict()
+        for k in ("encoder.bn1.running_mean", "encoder.layer3.1.bn2.running_var", "decoder.blocks.x_0_2.conv1.1.running_mean",
+                  "decoder.blocks.x_0_3.conv2.1.running_var"):
+            assert rel_l2(after[k].cpu(), sd_t[k]) < 5e-3, k
+        assert int(after["encoder.bn1.num_batches_tracked"]) == int(before["encoder.bn1.num_batches_tracked"]) + 1
+        assert torch.equal(after["encoder.layer4.0.bn1.running_mean"], before["encoder.layer4.0.bn1.running_mean"])     # not on the path at depth 4
+    finally:
+        unetpp.load_state_dict(before)
+        unetpp.eval()
+
+
+def test_anonymized_extraction_with_unetpp(wrapper, unetpp):
+    """The reference's default extraction chain (st_feature_extraction.py:16-37,72-73: fa = unet++ -> Q1 reshape -> ft.i3d.extract_features)
+    end to end against the oracles: the 2048-d clip feature within the 1e-3 gate."""
+    from oracle import extract_ref, i3res50_ref, unetpp_ref
+    from ted_spad_amd import extraction
+    vid = [synth_tensor(9, "uppvid%d" % i, (16, 3, 64, 64)) for i in range(3)]
+    feats = np.zeros((3, 2048))
+    extraction.extract_features(vid, feats, "/tmp/_upp_feats.npy", unetpp, wrapper, True, False, batch=2)
+    sd_u = {k: v.cpu() for k, v in unetpp.state_dict().items()}
+    sd_i = {k[4:]: v.cpu() for k, v in wrapper.state_dict().items() if k.startswith("i3d.")}
+    with torch.no_grad():
+        ref = extract_ref.extract_video(vid, lambda x: i3res50_ref.extract_features(x, sd_i), fa=lambda x: unetpp_ref.forward(x, sd_u), layout="reference")
+    for t in range(3):
+        assert rel_l2(feats[t], ref[t]) < TOL
+
+
+def test_unet_odd_size_vs_oracle(unet):
+    """Up's pad-to-skip path (unet_parts.py:56-62): 100x92 -> 6x5 at the bottom, skips are odd."""
+    from oracle import unet_ref
+    frames = synth_tensor(0, "unet_odd", (2, 3, 100, 92))
+    with torch.no_grad():
+        ref = unet_ref.forward(frames, {k: v.cpu() for k, v in unet.state_dict().items()})
+    assert rel_l2(unet(frames.cuda()).cpu(), ref) < TOL
+
+
+def test_extraction_driver_q1_and_npy(wrapper, unet, tmp_path):
+    """st_feature_extraction.extract_features counterpart: anonymized feed (Q1), float64 (T,F) .npy,
+    consumed by the restated MGFN loader."""
+    from oracle import extract_ref, i3res50_ref, unet_ref
+    from ted_spad_amd import extraction
+    T = 5
+    vid = [synth_tensor(7, "vid%d" % i, (16, 3, 32, 32)) for i in range(T)]
+    feats = np.zeros((T, 2048))
+    p = str(tmp_path / "Shoplifting033_x264.npy")
+    extraction.extract_features(vid, feats, p, unet, wrapper, True, False, batch=2)
+    arr = np.load(p)
+    assert arr.dtype == np.float64 and arr.shape == (T, 2048) and not np.isfortran(arr)
+    sd_u = {k: v.cpu() for k, v in unet.state_dict().items()}
+    sd_i = {k[4:]: v.cpu() for k, v in wrapper.state_dict().items() if k.startswith("i3d.")}
+    with torch.no_grad():
+        ref = extract_ref.extract_video(vid, lambda x: i3res50_ref.extract_features(x, sd_i),
+                                        fa=lambda x: unet_ref.forward(x, sd_u), layout="reference")
+    for t in range(T):
+        assert rel_l2(arr[t], ref[t]) < TOL
+    assert extract_ref.mgfn_getitem(p).shape == (1, 32, 2049)
+    assert extraction.save_video_features(str(tmp_path), "/x/Abuse001_x264.mp4", torch.zeros(3, 1, 8)).endswith("Abuse001_x264.npy")

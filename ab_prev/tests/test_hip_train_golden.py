@@ -1,0 +1,252 @@
+"""-m gpu: (1) the train-mode golden fixtures captured through the REFERENCE modules (tests/golden/make_golden.py g4, g5, g7) directly
+against the GPU -- forward outputs, running-statistic VALUES (Q14) and per-parameter gradient norms; (2) both training phases at
+cfg3's real per-clip size (112 x 112, BASELINE.json configs[2]) against the fp32 oracle, where train-mode BatchNorm sees hundreds of
+values per channel instead of the 4-32 of the toy sizes in test_hip_train_step.py; (3) the full-size cfg2 batch (225 clips @224^2:
+the tile configurations the tuner picks at M = 225 clips) against the oracle and against single-clip forwards; (4) f16 head-room."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_clips, synth_state_dict, synth_tensor, synth_train_video
+from test_hip_train_step import _models, _report
+
+pytestmark = pytest.mark.gpu
+SEED = 0
+
+
+# ---- (1) golden train-mode fixtures ------------------------------------------------------------------------------------------
+
+def test_wrapper_train_forward_and_running_stats_vs_golden(golden, golden_meta):
+    """wrapper_i3d in train() on the golden clips: (pred, feat) and the running statistics after ONE train-mode forward, values
+    included (not only num_batches_tracked). B = 2 at 112^2: layer4's BatchNorm sees 2 x 2 x 4 x 4 = 64 values per channel."""
+    _, ft, _, _ = _models()
+    ft.train()
+    x = synth_clips(SEED, 2, (3, 16, 112, 112)).cuda()
+    with torch.no_grad():
+        pred, feat = ft(x)
+    e_p, e_f = rel_l2(pred.cpu(), golden["wrapper_train_pred"]), rel_l2(feat.cpu(), golden["wrapper_train_feat"])
+    print("wrapper train forward vs golden: pred %.3e feat %.3e" % (e_p, e_f))
+    assert e_p < 1e-2
+    # `feat` goes through two BatchNorm1d layers over a batch of TWO: (x - mean) / std is +-1 whatever x is, i.e. the feature is a sign
+    # pattern and every pre-activation that the 16-bit trunk moves across the batch mean flips an element (measured 4e-1): only its
+    # unit norm is checkable at this batch size (the B = 4 / B = 8 step tests check it through the triplet loss)
+    assert torch.allclose(feat.norm(dim=1).cpu(), torch.ones(2), atol=1e-4)
+    sd = ft.state_dict()
+    for k, (mean, l2) in golden_meta["wrapper_train_running_stats"].items():
+        t = sd[k].double().cpu()
+        assert abs(float(t.norm()) - l2) <= 2e-3 * l2, (k, float(t.norm()), l2)
+        assert abs(float(t.mean()) - mean) <= 2e-3 * abs(mean) + 2e-3 * l2 / np.sqrt(t.numel()), (k, float(t.mean()), mean)
+    assert int(sd["i3d.bn1.num_batches_tracked"]) == golden_meta["wrapper_train_num_batches_tracked"] == 1
+
+
+def test_unet_train_forward_vs_golden(golden, golden_meta):
+    fa, _, _, _ = _models()
+    fa.train()
+    frames = synth_tensor(SEED, "unet_frames", (4, 3, 112, 112)).cuda()
+    with torch.no_grad():
+        y = fa(frames).cpu()
+    e = rel_l2(y[0, :, 40:56, 40:56], golden["unet_train_out_crop"])
+    print("unet train forward vs golden crop: %.3e" % e)
+    assert e < 4e-3                                   # 18 train-mode BatchNorm layers over 4 frames behind 16-bit activations (measured 1.9e-3)
+    mean, l2 = golden_meta["unet_train_out_cks"]
+    assert abs(float(y.double().norm()) - l2) < 1e-3 * l2 and abs(float(y.double().mean()) - mean) < 1e-3 * abs(mean)
+    assert int(fa.inc.double_conv[1].num_batches_tracked) == 1
+
+
+def test_train_step_gradient_norms_vs_golden(golden_meta):
+    """Loss values and per-parameter gradient L2 norms of both phases as the reference modules produced them (g7), against the GPU step."""
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    g = golden_meta["train_step"]
+    fa, ft, _, _ = _models()
+    step = AnonymizerTrainStep(fa, ft)
+    step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
+    out = step.step_fa(synth_train_video(SEED, "train_video", (2, 48, 3, 32, 32)).cuda(), torch.tensor([5, 77]).cuda())
+    assert abs(out["loss_fa"] - g["phase1"]["loss_fa"]) < 5e-3 * abs(g["phase1"]["loss_fa"])
+    got = {k: float(p.grad.norm()) for k, p in fa.named_parameters()}
+    ratios = [got[k] / ref for k, ref in g["phase1"]["grad_l2"].items() if ref > 1e-3]
+    print("phase 1 |grad| / golden: median %.4f, range %.3f .. %.3f" % (float(np.median(ratios)), min(ratios), max(ratios)))
+    assert 0.9 < float(np.median(ratios)) < 1.1 and min(ratios) > 0.7 and max(ratios) < 1.4
+    fa, ft, _, _ = _models()
+    step = AnonymizerTrainStep(fa, ft)
+    step.opt_ft = torch.optim.SGD(ft.parameters(), lr=0.0)
+    out = step.step_ft(synth_train_video(SEED, "train_video64", (4, 48, 3, 64, 64)).cuda(), torch.tensor([5, 77, 101, 1]).cuda())
+    assert abs(out["loss_ft"] - g["phase2"]["loss_ft"]) < 8e-3 * abs(g["phase2"]["loss_ft"])
+    got = {k: float(p.grad.norm()) for k, p in ft.named_parameters()}
+    ratios = [got[k] / ref for k, ref in g["phase2"]["grad_l2"].items() if ref > 1e-3]
+    print("phase 2 |grad| / golden: median %.4f, range %.3f .. %.3f" % (float(np.median(ratios)), min(ratios), max(ratios)))
+    assert 0.85 < float(np.median(ratios)) < 1.15 and min(ratios) > 0.5 and max(ratios) < 2.0
+    assert int(ft.i3d.bn1.num_batches_tracked) == g["phase2"]["num_batches_tracked"] == 3
+
+
+# ---- (2) cfg3's real clip size ---------------------------------------------------------------------------------------------------
+
+def test_phase2_at_cfg3_shape_vs_oracle():
+    """Phase 2 (update ft) on the cfg3 batch 8 x 48 x 112 x 112 (layer4's train-mode BatchNorm normalises over 8 x 2 x 4 x 4 = 256
+    values per channel, 32 in the 64 x 64 toy test). Measured here (scripts/train_parity_probe.py, independent of the loss scale
+    1 ... 262144, so not a gradient-underflow effect): loss 3e-4, gradient rel-L2 median 0.48 / worst 0.66-0.72, cosine median 0.88 /
+    min 0.75-0.79 -- the SAME as at the toy size: the spread is not a small-batch artefact. It is the conditioning of this randomly
+    initialised train-mode network itself: the fp32 ORACLE's own gradients move by 0.28 (median rel-L2, cosine 0.96) when nothing but
+    its forward activations are rounded to f16 (tests/test_oracle_golden.py::test_gradient_sensitivity_to_f16_activations); the GPU path
+    additionally stores activation gradients in 16 bits and rounds at other points. What IS tight: every kernel on its own
+    (test_hip_train_ops.py), the smooth-network chains (0.4 % / 1.6 %), gradient NORMS against the reference's golden values
+    (median ratio 1.004, test_train_step_gradient_norms_vs_golden), and the losses."""
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(SEED, "train_cfg3", (8, 48, 3, 112, 112))
+    labels = torch.tensor([5, 77, 101, 1, 33, 60, 12, 90])
+    torch.set_num_threads(32)
+    ref_l, ref_g = train_step_ref.phase2(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft)
+    step.opt_ft = torch.optim.SGD(ft.parameters(), lr=0.0)
+    out = step.step_ft(video.cuda(), labels.cuda())
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 5e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 2e-2 * abs(ref_l["loss_temporal"])
+    errs = _report("cfg3 phase 2: ft grads", {k: p.grad for k, p in ft.named_parameters()}, ref_g, min_cos=0.65, med_cos=0.82)
+    med, worst = float(np.median(list(errs.values()))), max(errs.values())
+    print("cfg3 phase 2: median rel-L2 %.3f, worst %.3f" % (med, worst))
+    assert med < 0.6 and worst < 0.9
+
+
+def test_three_clips_as_one_grouped_batch_match_three_passes(monkeypatch):
+    """AnonymizerTrainStep runs the three clips of an iteration through ft as ONE batch of three statistics groups (grouped batch
+    statistics in the conv epilogue, tedspad_bn_train_apply / _bwd_reduce / _bwd_apply with groups = 3; per-group BatchNorm1d in the head;
+    running statistics updated group after group) where the reference calls ft_model three times (train_anonymizer.py:169-175). Same
+    arithmetic: losses, gradients and the running statistics agree with the three-pass path to float-atomic summation order, in phase 2
+    and in phase 1 (frozen ft: plain batching)."""
+    from ted_spad_amd import engine as E
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    monkeypatch.setattr(E, "AUTOTUNE", False)            # only K-order-preserving tiles: no tile-choice differences between the two paths
+    video = synth_train_video(SEED, "train_cfg3", (8, 48, 3, 112, 112)).cuda()
+    labels = torch.tensor([5, 77, 101, 1, 33, 60, 12, 90]).cuda()
+    res = {}
+    for batch in (True, False):
+        fa, ft, _, _ = _models()
+        step = AnonymizerTrainStep(fa, ft)
+        step.batch_clips = batch
+        assert step.ft_tr.min_group_rows((24, 3, 16, 112, 112), 3) == 256
+        step.opt_ft = torch.optim.SGD(ft.parameters(), lr=0.0)
+        step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
+        o2 = step.step_ft(video, labels)
+        g2 = {k: p.grad.detach().cpu() for k, p in ft.named_parameters()}
+        rs = {k: v.detach().cpu() for k, v in ft.state_dict().items() if "running" in k or "num_batches" in k}
+        o1 = step.step_fa(video[:2], labels[:2])
+        g1 = {k: p.grad.detach().cpu() for k, p in fa.named_parameters()}
+        res[batch] = (o2, g2, rs, o1, g1)
+    (a2, ga2, ra, a1, ga1), (b2, gb2, rb, b1, gb1) = res[True], res[False]
+    assert abs(a2["loss_ft"] - b2["loss_ft"]) < 1e-3 * abs(b2["loss_ft"]) and abs(a2["loss_temporal"] - b2["loss_temporal"]) < 6e-3 * abs(b2["loss_temporal"])
+    assert abs(a1["loss_fa"] - b1["loss_fa"]) < 1e-3 * abs(b1["loss_fa"])
+    for k, v in rb.items():
+        if "num_batches" in k:
+            assert int(ra[k]) == int(v) == 3, k                      # Q14: three momentum updates per phase-2 step
+        else:
+            assert rel_l2(ra[k].float(), v.float()) < 1e-2, k      # summation order + other tiles upstream: 1e-4 (stem) ... 2e-3 (mlp.bn2, the last layer) measured
+    # gradients: identical kernels on identical inputs except the summation order inside the statistics / weight-gradient atomics and the
+    # tile configuration the tuner picks for the 3x larger launches; a ReLU-flip-free comparison, so far inside the oracle bounds
+    e2 = [rel_l2(ga2[k], gb2[k]) for k in gb2]
+    e1 = [rel_l2(ga1[k], gb1[k]) for k in gb1 if float(gb1[k].norm()) > 1e-2]
+    print("grouped vs three passes: phase 2 median %.2e worst %.2e; phase 1 median %.2e worst %.2e" % (
+        float(np.median(e2)), max(e2), float(np.median(e1)), max(e1)))
+    # measured 0.25 / 0.19 median with the tuner on AND off: the noise floor between any two runs of this ill-conditioned train-mode
+    # network (float-atomic order of the statistics -> a few 16-bit activations round the other way -> ReLU branch flips); the
+    # arithmetic of the grouped kernels is held tight at op level (test_hip_train_ops.py::test_conv_bn_relu_train_grouped_statistics)
+    # and against the fp32 oracle at this shape (test_phase2_at_cfg3_shape_vs_oracle runs the grouped path)
+    assert float(np.median(e2)) < 0.4 and float(np.median(e1)) < 0.35
+
+
+def test_phase1_at_cfg3_resolution_vs_oracle():
+    """Phase 1 (update fa through the frozen ft) at 112 x 112 with batch 2 (96 pseudo-images through the UNet: the fp32 autograd oracle
+    of the full batch of 8 needs > 20 GB of host memory)."""
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(SEED, "train_cfg3_p1", (2, 48, 3, 112, 112))
+    labels = torch.tensor([5, 77])
+    torch.set_num_threads(32)
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft)
+    step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * abs(ref_l["loss_fa"])
+    errs = _report("cfg3-resolution phase 1: fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g, min_cos=0.85, med_cos=0.95, tiny=1e-2, abs_tol=0.1)   # conv biases in front of a train-mode BN: analytically zero, 96 x 112^2 pixels of rounding noise summed
+    med, worst = float(np.median(list(errs.values()))), max(errs.values())
+    print("cfg3-resolution phase 1: median rel-L2 %.3f, worst %.3f" % (med, worst))
+    assert med < 0.3 and worst < 0.5
+
+
+# ---- (3) the full cfg2 batch ---------------------------------------------------------------------------------------------------
+
+def test_full_size_batch_vs_oracle_and_single_clips():
+    """225 clips @16 x 224 x 224 in ONE forward -- the geometry the bench runs, where the tuner picks the 256 x 256 ping-pong, chunk-major
+    and temporal tiles and the persistent stem walks 344 patches per workgroup: 20 clips spread over the batch against the fp32 CPU
+    oracle (< 1e-3, the north_star gate), and against the same clips forwarded alone (other tile choices, same arithmetic up to fp32
+    summation order)."""
+    from oracle import i3res50_ref
+    from ted_spad_amd import engine as E
+    from ted_spad_amd.model_loaders import load_ft_model
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    ft.load_state_dict(sd)
+    ft = ft.cuda().eval()
+    n = 225
+    clips = torch.cat([synth_clips(0, min(25, n - i), (3, 16, 224, 224), device="cuda", first=i) for i in range(0, n, 25)])
+    with torch.no_grad():
+        for _ in range(60):                                   # let the in-context tuner settle (engine.PackedConv._launch_tuned)
+            f = ft.i3d.extract_features(clips)
+            if not E.tuning_pending():
+                break
+        f = ft.i3d.extract_features(clips).flatten(1).cpu()
+        pick = list(range(0, n, 12))[:19] + [n - 1]
+        torch.set_num_threads(32)
+        sdc = {k[4:]: v for k, v in sd.items() if k.startswith("i3d.")}
+        ref = i3res50_ref.extract_features(clips[pick].cpu(), sdc).flatten(1)
+        rel = [rel_l2(f[i], ref[j]) for j, i in enumerate(pick)]
+        print("full-size batch vs oracle: max rel-L2 %.3e over %d clips" % (max(rel), len(pick)))
+        assert max(rel) < 1e-3
+        alone = torch.cat([ft.i3d.extract_features(clips[i:i + 1]).flatten(1).cpu() for i in pick[:6]])
+        rel1 = [rel_l2(alone[j], f[i]) for j, i in enumerate(pick[:6])]
+        print("batch vs single-clip forwards: max rel-L2 %.3e" % max(rel1))
+        assert max(rel1) < 5e-4
+
+
+# ---- (4) f16 head-room ------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("scale", [64.0, 1.0 / 64.0])
+def test_f16_head_room_of_the_activations(scale):
+    """f16 storage saturates at 65504 (common.h) and flushes below 6e-8. The eval-mode network is positively homogeneous when every
+    BatchNorm shift is scaled along with its input, so scaling the stem's BN (gamma, beta) and every later BN's (running_mean, beta) by s
+    must scale the feature by s: a saturating or flushing activation anywhere breaks that. Checked for s = 64 and 1/64 around the
+    synthetic He-scaled weights (max |activation| ~ 50), with the per-stage maxima reported."""
+    from ted_spad_amd.model_loaders import load_ft_model
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    x = synth_clips(0, 2, (3, 16, 224, 224)).cuda()
+    ft.load_state_dict(sd)
+    ft = ft.cuda().eval()
+    with torch.no_grad():
+        taps = {}
+        ft.i3d._trunk(x, taps=taps)
+        base_max = {k: float(v.buf.float().abs().max()) for k, v in taps.items()}
+        f1 = ft.i3d.extract_features(x).flatten(1).cpu()
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k in sd2:
+        if not k.startswith("i3d.") or not k.endswith((".bias", ".running_mean", ".weight")):
+            continue
+        bn = k.rsplit(".", 1)[0]
+        if bn + ".running_var" not in sd2:
+            continue                                            # not a BatchNorm tensor
+        if bn == "i3d.bn1":
+            if k.endswith((".weight", ".bias")):
+                sd2[k] = sd2[k] * scale                         # the stem: output x s
+        elif k.endswith((".bias", ".running_mean")):
+            sd2[k] = sd2[k] * scale                             # later BNs: input and shift x s, gamma / sigma unchanged
+    ft.load_state_dict(sd2)
+    with torch.no_grad():
+        taps = {}
+        ft.i3d._trunk(x, taps=taps)
+        smax = {k: float(v.buf.float().abs().max()) for k, v in taps.items()}
+        f2 = ft.i3d.extract_features(x).flatten(1).cpu()
+    print("max |activation| per stage, unscaled:", {k: round(v, 2) for k, v in base_max.items()}, " x%g:" % scale, {k: round(v, 3) for k, v in smax.items()})
+    assert max(smax.values()) < 65504 * 0.5
+    assert rel_l2(f2 / scale, f1) < 1e-3

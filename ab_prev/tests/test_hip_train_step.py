@@ -1,0 +1,348 @@
+"""-m gpu: one iteration of each phase of the anonymizer training step on MI355X against the CPU
+oracle (oracle/train_step_ref.py, itself pinned to the reference modules): loss values, the gradient
+handed from ft to fa, and the parameter gradients, then the Adam update."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from ted_spad_amd.synth import synth_state_dict, synth_tensor, synth_train_video
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(beta=None):
+    from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
+    fa, ft = load_fa_model(arch="unet"), load_ft_model("largei3d", num_classes=102)
+    sd_u, sd_l = synth_state_dict(fa.state_dict(), 0), synth_state_dict(ft.state_dict(), 0)
+    if beta is not None:   # push every BatchNorm output far above 0: the ReLUs become (almost) the identity
+        for sd in (sd_u, sd_l):
+            for k in sd:
+                if k.rsplit(".", 1)[0] + ".running_mean" in sd and k.endswith(".bias"):
+                    sd[k] = torch.full_like(sd[k], beta)
+    fa.load_state_dict(sd_u); ft.load_state_dict(sd_l)
+    ft.i3d.drop_p = 0.0       # Q13: dropout is stochastic; parity runs with p = 0
+    return fa.cuda(), ft.cuda(), sd_u, sd_l
+
+
+# Gradient tolerance. Every kernel of the backward chain is checked tightly on its own
+# (tests/test_hip_train_ops.py, 1e-3 .. 5e-3). End to end the comparison is against an fp32 CPU path while
+# the GPU stores activations in 16 bits: a pre-activation within one rounding step of 0 takes the other ReLU
+# branch (about 2.4e-4 of the elements per layer), and each flip is an O(1) difference in that element's
+# gradient, i.e. ~2 % rel-L2 per ReLU layer, sqrt(L) x 2 % over L layers (18 in the UNet, 53 in I3Res50):
+# 10-16 %. (The reference's own fp16-autocast training has the same property w.r.t. its fp32 path.)
+# So: rel-L2 bounds of that size PLUS a direction check (cosine), plus loss parity at 5e-3.
+def _report(name, got, ref, min_cos=0.93, med_cos=0.97, tiny=1e-4, abs_tol=5e-3):
+    """Per-tensor rel-L2 / cosine. Tensors whose reference gradient norm is below `tiny` are (analytically) ~0 --
+    a conv bias or BatchNorm bias in front of a train-mode BN that removes the mean again -- and their direction is
+    rounding noise (it changes from run to run with the float-atomic order): those are held to an ABSOLUTE error
+    norm of `abs_tol` (other gradients have norms of 0.1 .. 10) instead of a cosine."""
+    errs, cos = {}, {}
+    for k in ref:
+        g, r = got[k].detach().cpu().double().flatten(), ref[k].double().flatten()
+        if float(r.norm()) > tiny:
+            errs[k] = rel_l2(g, r)
+            cos[k] = float(g @ r / (g.norm() * r.norm()))
+        else:
+            assert float((g - r).norm()) <= abs_tol, (k, float((g - r).norm()), float(r.norm()))
+    if os.environ.get("TEDSPAD_VERBOSE"):
+        for k in errs:
+            print("   %-50s rel %.3e cos %.5f |g| %.3e" % (k, errs[k], cos[k], float(ref[k].norm())))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print(name, "median rel-L2 %.3e, min cosine %.4f, worst %s" % (float(np.median(list(errs.values()))), min(cos.values()), worst))
+    assert min(cos.values()) > min_cos and float(np.median(list(cos.values()))) > med_cos
+    return errs
+
+
+# loss_scale: the static counterpart of the GradScaler of train_anonymized_action.py:92-94 (AnonymizerTrainStep
+# docstring): gradients x 256 through both networks, divided out before Adam -- the update must not change.
+@pytest.mark.parametrize("loss_scale", [1.0, 256.0])
+def test_phase1_update_fa_vs_oracle(loss_scale):
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, ref_danon = train_step_ref.phase1(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft, loss_scale=loss_scale)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    ft_before = {k: v.detach().clone() for k, v in ft.state_dict().items()}
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert out["phase"] == 1 and out["loss_fb"] is None and out["skipped"] is False
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 5e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * abs(ref_l["loss_fa"])
+    errs = _report("phase1 fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.25 and max(errs.values()) < 0.4
+    # Adam moved every fa parameter by ~lr (first step: |delta| = lr * sign(grad)); ft is untouched in phase 1
+    moved = [float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()]
+    assert 0 < max(moved) <= 1.05 * step.params.learning_rate_fa   # fp32 rounding of p - lr*sign
+    assert all(torch.equal(v, ft_before[k]) for k, v in ft.state_dict().items())
+    assert int(fa.inc.double_conv[1].num_batches_tracked) == 1   # UNet BN saw the B*48 pseudo-images once (Q14)
+
+
+def test_phase1_with_the_default_unetpp_anonymizer_vs_oracle():
+    """Phase 1 (train_anonymizer.py:73-123) with the reference's DEFAULT fa (arch='unet++', model_loaders.py:17-30) in the step driver:
+    losses and the gradients of every on-path unet++ parameter against the oracle (unetpp_ref in train mode -> i3res50_ref eval), the
+    Adam update, `encoder.layer4.*` untouched (no gradient: off the path at encoder_depth 4)."""
+    from oracle import train_step_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    _, ft, _, sd_l = _models()
+    fa = load_fa_model()
+    sd_u = synth_state_dict(fa.state_dict(), 0)
+    fa.load_state_dict(sd_u)
+    fa = fa.cuda()
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, sd_u, sd_l)
+    assert not any(k.startswith("encoder.layer4.") for k in ref_g) and "encoder.layer3.1.conv2.weight" in ref_g
+    step = AnonymizerTrainStep(fa, ft)
+    before = {k: v.detach().clone() for k, v in fa.named_parameters()}
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert out["phase"] == 1 and out["skipped"] is False
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 1e-2 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 1e-2 * abs(ref_l["loss_fa"])
+    errs = _report("phase1 unet++ grads", {k: p.grad for k, p in fa.named_parameters() if p.grad is not None}, ref_g)
+    assert float(np.median(list(errs.values()))) < 0.3 and max(errs.values()) < 0.45      # measured 0.20 / 0.26, min cosine 0.964
+    moved = {k: float((p.detach() - before[k]).abs().max()) for k, p in fa.named_parameters()}
+    assert all(v == 0.0 for k, v in moved.items() if k.startswith("encoder.layer4."))
+    assert 0 < max(moved.values()) <= 1.05 * step.params.learning_rate_fa
+    assert int(fa.encoder.bn1.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("loss_scale", [1.0, 256.0])
+def test_phase2_update_ft_vs_oracle(loss_scale):
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
+    labels = torch.tensor([5, 77, 101, 1])
+    ref_l, ref_g = train_step_ref.phase2(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft, loss_scale=loss_scale)
+    fa_before = {k: v.detach().clone() for k, v in fa.state_dict().items()}
+    out = step.step_ft(video.cuda(), labels.cuda())
+    assert out["phase"] == 2
+    # measured over 8 fresh runs (different tile choices, float-atomic order of the batch statistics): loss_ft is 3.5e-3 .. 4.9e-3
+    # and the triplet term 1.05e-2 .. 2.17e-2 away from the fp32 oracle (16-bit activations under train-mode BN over as few as
+    # 32 values per channel); the bounds leave room for that spread
+    assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 8e-3 * abs(ref_l["loss_ft"])
+    assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 3.5e-2 * abs(ref_l["loss_temporal"])
+    # train-mode BN at this tiny size normalises over as few as 32 values per channel (layer4: 4x2x2x2), which
+    # amplifies the 16-bit storage error ~5x w.r.t. the eval-mode chain of phase 1 -> proportionally more ReLU flips
+    # (run-to-run spread of this comparison from the float-atomic order of the batch statistics alone: median 0.43-0.47,
+    # worst tensor 0.62-0.72, min cosine 0.76-0.80; the bounds leave room for it -- the tight check of the same chain is
+    # test_i3d_backward_chains_tight_on_a_smooth_network)
+    errs = _report("phase2 ft grads", {k: p.grad for k, p in ft.named_parameters()}, ref_g, min_cos=0.6, med_cos=0.8)
+    # the single worst tensor is the noisiest statistic of this comparison (one full-suite run had mlp.fc1.weight -- behind a BatchNorm1d
+    # over 4 samples -- at 0.95 with cosine 0.75, the usual worst being 0.62-0.72): bound the 90th percentile tightly and the maximum loosely;
+    # the direction of EVERY tensor is held by the cosine bounds inside _report
+    ev = sorted(errs.values())
+    assert float(np.median(ev)) < 0.6 and ev[int(0.9 * (len(ev) - 1))] < 0.75 and ev[-1] < 1.3
+    assert int(ft.i3d.bn1.num_batches_tracked) == 3 and int(ft.mlp.bn1.num_batches_tracked) == 3   # Q14
+    assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())                     # fa frozen in phase 2
+
+
+def test_action_training_step_frozen_bn_vs_oracle():
+    """action_training/train_anonymized_action.py:43-94: fa frozen, ft trained with its trunk BatchNorm3d
+    layers frozen (freeze_bn): loss values, conv / fc / mlp gradients against the fp32 oracle, no gradient on the frozen
+    BatchNorm parameters, running statistics of the trunk untouched, the Adam step changes ft only."""
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
+    labels = torch.tensor([5, 77, 101, 1])
+    ref_l, ref_g = train_step_ref.action_step(video, labels, sd_u, sd_l)
+    step = AnonymizerTrainStep(fa, ft)
+    fa_before = {k: v.detach().clone() for k, v in fa.state_dict().items()}
+    ft_before = {k: v.detach().clone() for k, v in ft.state_dict().items()}
+    out = step.step_action(video.cuda(), labels.cuda())
+    assert out["phase"] == "action"
+    assert abs(out["loss"] - ref_l["loss"]) < 5e-3 * abs(ref_l["loss"])
+    assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 2e-2 * abs(ref_l["loss_temporal"])
+    got = {k: p.grad for k, p in ft.named_parameters() if p.grad is not None}
+    frozen = [k for k, _ in ft.named_parameters() if k.startswith("i3d.") and (".bn" in k or ".downsample.1." in k)]
+    assert frozen and all(k not in got for k in frozen), "FrozenBN parameters are buffers in the reference: no gradient"
+    assert set(ref_g) <= set(got), sorted(set(ref_g) - set(got))[:5]
+    errs = _report("action step ft grads", got, ref_g, min_cos=0.9, med_cos=0.97)      # eval-mode BN chain: as tight as phase 1
+    assert float(np.median(list(errs.values()))) < 0.25
+    after = ft.state_dict()
+    assert all(torch.equal(after[k], ft_before[k]) for k in after if k.startswith("i3d.") and ("running_" in k or "num_batches" in k)), \
+        "frozen BatchNorm3d: running statistics untouched"
+    assert any(not torch.equal(after[k], ft_before[k]) for k in after if k.endswith("conv1.weight"))     # Adam moved the conv weights
+    assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())                          # fa is not trained here
+
+
+def _smooth(sd, beta=4.0):
+    """Every BatchNorm bias = +4: almost no pre-activation is near 0, so the ReLUs are (nearly) the identity and
+    the networks are smooth -- the end-to-end gradient error of the tests above (ReLU branch flips) disappears and
+    the WHOLE backward chain must agree with the fp32 oracle to 16-bit rounding accuracy."""
+    for k in sd:
+        if k.rsplit(".", 1)[0] + ".running_mean" in sd and k.endswith(".bias"):
+            sd[k] = torch.full_like(sd[k], beta)
+    return sd
+
+
+def _grad_sd(sd):
+    return {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+
+
+def test_unet_backward_chain_tight_on_a_smooth_network():
+    """UNetTrainer (train-mode BN, skip/concat, max-pool routing, upsample, sigmoid, dgrad + wgrad of all 19 convs)."""
+    from oracle import unet_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.train_nets import UNetTrainer
+    fa = load_fa_model(arch="unet")
+    sd = _smooth(synth_state_dict(fa.state_dict(), 0))
+    fa.load_state_dict(sd)
+    fa = fa.cuda().train()
+    x = synth_tensor(0, "dbgu", (6, 3, 32, 32))
+    sdg = _grad_sd(sd)
+    y = unet_ref.forward(x, sdg, train=True)
+    dy = synth_tensor(0, "dyu", tuple(y.shape), -1, 1)
+    (y * dy).sum().backward()
+    tr = UNetTrainer(fa)
+    yy, tape = tr.forward(x.cuda())
+    assert rel_l2(yy.cpu(), y.detach()) < 2e-3
+    tr.backward(tape, dy.cuda())
+    tr.flush_grads()
+    errs = _report("unet chain (smooth)", {k: p.grad for k, p in fa.named_parameters()}, {k: v.grad for k, v in sdg.items() if v.requires_grad},
+                   min_cos=0.998, med_cos=0.9998)
+    assert max(errs.values()) < 5e-2 and float(np.median(list(errs.values()))) < 8e-3
+
+
+@pytest.mark.parametrize("name,dims", [("layer1.0", (4, 4, 28, 28)), ("layer1.2", (4, 4, 28, 28)), ("layer2.0", (4, 4, 28, 28)), ("layer3.1", (6, 2, 14, 14)),
+                                       ("layer4.0", (8, 2, 8, 8))])
+def test_every_bottleneck_type_backward_on_the_oracles_own_inputs(name, dims):
+    """ONE bottleneck of the real (not smoothed) I3Res50 in train mode, fed the same input and upstream gradient as torch autograd on the
+    oracle's block (oracle.i3res50_ref.bottleneck with batch-statistics BN): block output, input gradient and every parameter gradient of
+    the block. Only the block's own three ReLU layers can flip, so a missing residual / downsample term, a wrong stride or a wrong
+    maxpool2 routing (layer2.0) shows as an O(1) error against a 5e-2 bound -- which the end-to-end comparisons above cannot resolve.
+    Covers: downsample branch at stride 1 (layer1.0) and stride 2 (layer4.0), identity residual with / without a temporal conv1
+    (layer1.2, layer3.1), maxpool2 in front of the block (layer2.0)."""
+    import torch.nn.functional as F
+    from oracle import i3res50_ref
+    from ted_spad_amd import engine as E, train_engine as TE
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.train_nets import BottleneckTrunk, I3DTrainer
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    ft.load_state_dict(sd)
+    ft = ft.cuda().train()
+    tr = I3DTrainer(ft)
+    li, bi = int(name[5]), int(name[7])
+    d = next(b for b in tr.blocks if (b["li"], b["bi"]) == (li, bi))
+    blk = getattr(ft.i3d, "layer%d" % li)[bi]
+    n, t, h, w = dims
+    cin = blk.conv1.weight.shape[1]
+    x = torch.relu(synth_tensor(11, name + "x", (n, cin, t, h, w), -0.6, 1.0)).half().float().requires_grad_()      # a ReLU output, as in the network
+    p = "i3d.%s." % name
+    sdg = {k: (v.clone().requires_grad_() if (k.startswith(p) and v.is_floating_point() and "running" not in k) else v) for k, v in sd.items()}
+    sdb = {k[4:]: v for k, v in sdg.items() if k.startswith("i3d.")}
+    xin = F.max_pool3d(x, (2, 1, 1), (2, 1, 1)) if d["pre_pool"] is not None else x
+    y = i3res50_ref.bottleneck(xin, sdb, name + ".", blk.stride, blk.temp_conv, blk.downsample is not None, bn=i3res50_ref._bn_train)
+    dy = synth_tensor(11, name + "dy", tuple(y.shape), -1, 1).half().float()
+    y.backward(dy)
+    TE.ARENA.reset(torch.device("cuda"))
+    xa = E.Act(x.detach().permute(0, 2, 3, 4, 1).contiguous().half().cuda(), cin)
+    unit = lambda conv, bn, xi, relu=True, residual=None: TE.conv_bn_act_train(conv, bn, xi, relu=relu, residual=residual)
+    ya, rec = BottleneckTrunk.block_forward(d, xa, unit, after_pool=False)
+    got_y = ya.buf.float().cpu().permute(0, 4, 1, 2, 3)
+    assert rel_l2(got_y, y.detach()) < 3e-3
+    dxa = BottleneckTrunk.block_backward_train(rec, E.Act(dy.permute(0, 2, 3, 4, 1).contiguous().half().cuda(), dy.shape[1]))
+    for k in ("c1", "c2", "c3", "cd"):
+        if d[k] is not None:
+            d[k].flush_grad()
+    TE.flush_deferred()
+    assert rel_l2(dxa.buf.float().cpu().permute(0, 4, 1, 2, 3), x.grad) < 5e-2
+    got = {k: q.grad for k, q in ft.named_parameters() if k.startswith(p)}
+    ref = {k: v.grad for k, v in sdg.items() if k.startswith(p) and v.requires_grad}
+    assert set(got) == set(ref) and all(g is not None for g in got.values())
+    errs = _report("block %s on the oracle's inputs" % name, got, ref, min_cos=0.998, med_cos=0.9995)
+    assert max(errs.values()) < 5e-2, max(errs.items(), key=lambda kv: kv[1])
+
+
+def test_unetpp_backward_chain_tight_on_a_smooth_network():
+    """UNetPPTrainer -- the reference's DEFAULT anonymizer (smp UnetPlusPlus, model_loaders.py:17-30) in train mode: train-mode BN,
+    BasicBlock residuals and strided downsample branches, the 3x3/2 max-pool, nearest upsampling, the dense skip pathway (tensors with
+    up to four consumers sum their gradient slices), dgrad + wgrad of all 30 on-path convs. `encoder.layer4.*` is off the path
+    (encoder_depth 4) and gets no gradient on either side."""
+    from oracle import unetpp_ref
+    from ted_spad_amd.model_loaders import load_fa_model
+    from ted_spad_amd.train_nets import UNetPPTrainer
+    fa = load_fa_model()
+    sd = _smooth(synth_state_dict(fa.state_dict(), 0))
+    fa.load_state_dict(sd)
+    fa = fa.cuda().train()
+    x = synth_tensor(0, "dbgupp", (6, 3, 64, 64))
+    sdg = _grad_sd(sd)
+    y = unetpp_ref.forward(x, sdg, train=True)
+    dy = synth_tensor(0, "dyupp", tuple(y.shape), -1, 1)
+    (y * dy).sum().backward()
+    tr = UNetPPTrainer(fa)
+    yy, tape = tr.forward(x.cuda())
+    assert rel_l2(yy.cpu(), y.detach()) < 3e-3
+    tr.backward(tape, dy.cuda())
+    tr.flush_grads()
+    ref = {k: v.grad for k, v in sdg.items() if v.requires_grad and v.grad is not None}
+    got = {k: p.grad for k, p in fa.named_parameters()}
+    assert all((got[k] is None) == (k not in ref) for k in got), [k for k in got if (got[k] is None) != (k not in ref)]
+    assert all(k.startswith("encoder.layer4.") for k in got if got[k] is None)
+    errs = _report("unet++ chain (smooth)", got, ref, min_cos=0.995, med_cos=0.9995)
+    assert max(errs.values()) < 8e-2 and float(np.median(list(errs.values()))) < 1.2e-2
+    after = fa.state_dict()
+    for k in ("encoder.bn1.running_var", "encoder.layer2.0.downsample.1.running_mean", "decoder.blocks.x_1_2.conv2.1.running_var"):
+        assert rel_l2(after[k].cpu(), sdg[k]) < 5e-3, k
+
+
+def test_i3d_backward_chains_tight_on_a_smooth_network():
+    """I3DTrainer: train-mode chain (parameter gradients) and eval-mode chain (gradient w.r.t. the clip)."""
+    from oracle import i3res50_ref
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.train_nets import I3DTrainer
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = _smooth(synth_state_dict(ft.state_dict(), 0))
+    ft.load_state_dict(sd)
+    ft = ft.cuda()
+    ft.i3d.drop_p = 0.0
+    x = synth_tensor(0, "dbgx", (4, 3, 16, 64, 64)) * (torch.arange(1, 5).float() / 4).view(4, 1, 1, 1, 1)
+    dp, dfe = synth_tensor(0, "dp", (4, 102), -1, 1), synth_tensor(0, "df", (4, 128), -1, 1)
+    tr = I3DTrainer(ft)
+    # ---- train mode: parameter gradients ----
+    sdg = _grad_sd(sd)
+    pred, feat = i3res50_ref.wrapper_forward(x, sdg, train=True)
+    ((pred * dp).sum() + (feat * dfe).sum()).backward()
+    ft.train()
+    p, f, tape = tr.forward(x.cuda(), "train")
+    assert rel_l2(p.cpu(), pred.detach()) < 5e-3
+    tr.backward(tape, dp.cuda(), dfe.cuda())
+    tr.flush_grads()
+    errs = _report("i3d train chain (smooth)", {k: q.grad for k, q in ft.named_parameters()}, {k: v.grad for k, v in sdg.items() if v.requires_grad},
+                   min_cos=0.85, med_cos=0.998, tiny=5e-3)   # tiny: BN biases whose gradient is ~0 (|g| ~ 2e-3); layer1 sits behind two max-pools whose
+    assert float(np.median(list(errs.values()))) < 4e-2   # arg-max can differ between 16-bit and fp32 values (2-8 % there, < 2 % elsewhere)
+    # ---- eval mode: gradient w.r.t. the input clip (what phase 1 hands to the anonymizer) ----
+    ft.load_state_dict(sd)      # the train-mode forward above updated the running statistics
+    ft.eval()
+    xg = x.clone().requires_grad_()
+    pred, feat = i3res50_ref.wrapper_forward(xg, sd, train=False)
+    ((pred * dp).sum() + (feat * dfe).sum()).backward()
+    p, f, tape = tr.forward(x.cuda(), "eval")
+    dx = tr.backward(tape, dp.cuda(), dfe.cuda())
+    e = rel_l2(dx.cpu(), xg.grad)
+    print("i3d eval chain: d(clip) rel-L2 %.3e" % e)
+    # eval-mode BN does not re-normalise, so the +4 bias does not keep the deeper pre-activations away from 0: this
+    # chain keeps its ReLU-flip error (53 ReLU layers + 2 max-pools, sqrt(L) x ~2 %); its pieces are checked tightly
+    # in test_hip_train_ops.py (dgrad incl. strided / pixel-pair form, mask + residual epilogue, max-pool routing).
+    assert e < 0.25
+
+
+def test_step_alternates_phases():
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, _, _ = _models()
+    step = AnonymizerTrainStep(fa, ft)
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64)).cuda()
+    labels = torch.tensor([5, 77, 101, 1]).cuda()
+    phases = [step.step(video, labels)["phase"] for _ in range(4)]
+    assert phases == [1, 2, 1, 2]
+

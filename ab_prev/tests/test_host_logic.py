@@ -1,0 +1,208 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tedspad_hip.h declares (no
+compute calls), the host-side packing logic, the loader's checkpoint fallbacks, and that the
+product refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+from ted_spad_amd import _lib, engine as E
+from ted_spad_amd.synth import synth_state_dict, synth_tensor
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tedspad_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tedspad_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libtedspad_hip.so lacks %s" % name
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert _lib.lib().tedspad_abi_version() == 1
+
+
+def test_ktab_and_padding_helpers():
+    d = _lib.ConvDesc(n=1, t=4, h=6, w=5, cin=16, ldx=24, cout=40, ldy=40, ldres=0, kt=3, kh=3, kw=3, st=1, sh=1, sw=1,
+                      pt=1, ph=1, pw=1, to=4, ho=6, wo=5, relu=1, dtype=0, tile_cfg=0)
+    L = _lib.lib()
+    assert L.tedspad_conv_kpad(d) == 448 and L.tedspad_conv_cout_pad(d) == 128 and L.tedspad_conv_ktab_entries(d) == 56
+    buf = (ctypes.c_int32 * 112)()
+    assert L.tedspad_conv_build_ktab(d, buf) == 0
+    tab = np.array(buf).reshape(56, 2)
+    for e in range(54):
+        tap, c8 = divmod(e, 2)
+        dt, dh, dw = tap // 9, (tap // 3) % 3, tap % 3
+        assert tab[e, 0] == ((dt * 6 + dh) * 5 + dw) * 24 + c8 * 8
+        assert tab[e, 1] == dt | ((8 + dh) << 8) | ((16 + dw) << 16)
+    assert (tab[54:, 1] == (31 | 31 << 8 | 31 << 16)).all()      # K padding -> zero page
+    bad = _lib.ConvDesc(n=1, t=1, h=1, w=1, cin=12, ldx=12, cout=8, ldy=8, kt=1, kh=1, kw=1, st=1, sh=1, sw=1, to=1, ho=1, wo=1)
+    assert L.tedspad_conv_kpad(bad) < 0                           # cin not a multiple of 8
+    assert L.tedspad_conv_fwd(ctypes.byref(bad), None, None, None, None, None, None, None, 0, None) < 0
+    assert b"descriptor" in L.tedspad_last_error()
+
+
+@pytest.mark.parametrize("k,pw", [((5, 7, 7), 3), ((7, 7, 7), 2)])
+def test_stem_pair_rewrite_is_the_same_convolution(k, pw):
+    """PackedConv(pair_w=...) turns the Cin=3 stride-2 stem into an 8-channel conv over pixel pairs."""
+    from oracle.conv_ref import conv_cl
+    w = synth_tensor(0, "w", (16, 3) + k, -1, 1)
+    x = synth_tensor(0, "x", (1, 3, 6, 12, 12))
+    pc = E.PackedConv(w, torch.ones(16), torch.zeros(16), stride=(2, 2, 2), dtype="f16", device="cpu", pair_w=pw)
+    kt, kh, kw2 = pc.k
+    w2 = pc.w[:16, :kt * kh * kw2 * 8].float().reshape(16, kt, kh, kw2, 8).permute(0, 4, 1, 2, 3)   # back to (co, ci, kt, kh, kw)
+    xp = torch.zeros(1, 6, 12, 6, 8)
+    xp.view(1, 6, 12, 6, 2, 4)[..., :3] = x.permute(0, 2, 3, 4, 1).reshape(1, 6, 12, 6, 2, 3)
+    pf = (k[0] // 2, 3, pw) if pw == 3 else (2, 2, 2)
+    pb = (k[0] // 2, 3, 3) if pw == 3 else (3, 3, 3)
+    ref = conv_cl(x.permute(0, 2, 3, 4, 1), w.half().float(), torch.ones(16), torch.zeros(16), (2, 2, 2), pf, pb, relu=False)
+    got = conv_cl(xp, w2, torch.ones(16), torch.zeros(16), (2, 2, 1), (pf[0], pf[1], pc.pair_pw),
+                  (pb[0], pb[1], kw2 - 1 - pc.pair_pw), relu=False)
+    assert got.shape == ref.shape and rel_l2(got, ref) < 1e-6
+
+
+def test_fold_bn_matches_torch_batchnorm_eval():
+    bn = torch.nn.BatchNorm3d(8, eps=1e-3).eval()
+    sd = synth_state_dict(bn.state_dict(), 3)
+    bn.load_state_dict(sd)
+    x = synth_tensor(3, "x", (2, 8, 2, 3, 3), -2, 2)
+    s, b = E.fold_bn(sd["weight"], sd["bias"], sd["running_mean"], sd["running_var"], 1e-3)
+    assert torch.allclose(bn(x), x * s.view(1, -1, 1, 1, 1) + b.view(1, -1, 1, 1, 1), atol=1e-6)
+
+
+def test_same_pads_rule():
+    assert E.same_pads(224, 7, 2) == (2, 3) and E.same_pads(16, 7, 2) == (2, 3)
+    assert E.same_pads(112, 3, 2) == (0, 1) and E.same_pads(7, 2, 2) == (0, 1) and E.same_pads(28, 3, 1) == (1, 1)
+
+
+def test_loader_signatures_and_checkpoint_fallbacks(tmp_path, capsys):
+    from ted_spad_amd import model_loaders as ml
+    assert ml.load_ft_model() is None                      # default arch 'r3d' matches no branch (model_loaders.py:65-67)
+    assert "invalid for ft_model" in capsys.readouterr().out
+    assert ml.load_fa_model(arch="nope") is None
+    upp = ml.load_fa_model()                               # default arch 'unet++' (model_loaders.py:17): smp's UnetPlusPlus, restated
+    assert "freshly initialized" in capsys.readouterr().out
+    keys = list(upp.state_dict())
+    assert len(keys) == 206 and sum(p.numel() for p in upp.parameters()) == 13898787
+    for k, shape in (("encoder.conv1.weight", (64, 3, 7, 7)), ("encoder.layer2.0.downsample.0.weight", (128, 64, 1, 1)),
+                     ("encoder.layer4.1.bn2.running_var", (512,)),                      # ResNetEncoder keeps layer4 at depth 4
+                     ("decoder.blocks.x_0_0.conv1.0.weight", (256, 384, 3, 3)), ("decoder.blocks.x_1_1.conv1.0.weight", (64, 192, 3, 3)),
+                     ("decoder.blocks.x_2_2.conv2.1.num_batches_tracked", ()), ("decoder.blocks.x_0_1.conv1.0.weight", (128, 384, 3, 3)),
+                     ("decoder.blocks.x_1_2.conv1.0.weight", (64, 192, 3, 3)), ("decoder.blocks.x_0_2.conv1.0.weight", (64, 320, 3, 3)),
+                     ("decoder.blocks.x_0_3.conv1.0.weight", (32, 64, 3, 3)), ("segmentation_head.0.weight", (3, 32, 3, 3)),
+                     ("segmentation_head.0.bias", (3,))):
+        assert tuple(upp.state_dict()[k].shape) == shape, k
+    assert not any(k.startswith("encoder.fc") or "attention" in k for k in keys)
+    pu = str(tmp_path / "upp.pth")                         # DataParallel-style 'module.' checkpoint (model_loaders.py:38-46)
+    torch.save({"fa_model_state_dict": {"module." + k: v for k, v in upp.state_dict().items()}}, pu)
+    assert ml.load_fa_model(saved_model_file=pu) is not None and "loaded from" in capsys.readouterr().out
+    ft = ml.load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 5)
+    # (1) plain checkpoint dict, as train_anonymizer.py:519-550 writes it
+    p1 = str(tmp_path / "a.pth")
+    torch.save({"epoch": 3, "ft_model_state_dict": sd, "fa_model_state_dict": ml.load_fa_model(arch="unet").state_dict()}, p1)
+    m1 = ml.load_ft_model("largei3d", saved_model_file=p1, num_classes=102)
+    assert torch.equal(m1.state_dict()["i3d.layer3.2.conv2.weight"], sd["i3d.layer3.2.conv2.weight"])
+    # (2) FrozenBN-style keys: `scale` instead of `weight`, no num_batches_tracked (model_loaders.py:76-82)
+    frozen = OrderedDict()
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        is_bn = k.rsplit(".", 1)[0] + ".running_mean" in sd
+        frozen[k.replace(".weight", ".scale") if (is_bn and k.endswith(".weight")) else k] = v
+    p2 = str(tmp_path / "b.pth")
+    torch.save({"ft_model_state_dict": frozen}, p2)
+    m2 = ml.load_ft_model("largei3d", saved_model_file=p2, num_classes=102)
+    assert torch.equal(m2.state_dict()["i3d.bn1.weight"], sd["i3d.bn1.weight"])
+    # (3) bare I3Res50 dict -> ft_model.i3d.load_state_dict (model_loaders.py:84)
+    p3 = str(tmp_path / "c.pth")
+    torch.save({"ft_model_state_dict": OrderedDict((k[4:], v) for k, v in sd.items() if k.startswith("i3d."))}, p3)
+    m3 = ml.load_ft_model("largei3d", saved_model_file=p3, num_classes=102)
+    assert torch.equal(m3.state_dict()["i3d.fc.weight"], sd["i3d.fc.weight"])
+    # (4) fa: DataParallel 'module.' prefix (model_loaders.py:41-46)
+    fa_sd = synth_state_dict(ml.load_fa_model(arch="unet").state_dict(), 5)
+    p4 = str(tmp_path / "d.pth")
+    torch.save({"fa_model_state_dict": OrderedDict(("module." + k, v) for k, v in fa_sd.items())}, p4)
+    fa = ml.load_fa_model(saved_model_file=p4, arch="unet")
+    assert torch.equal(fa.state_dict()["up1.conv.double_conv.0.weight"], fa_sd["up1.conv.double_conv.0.weight"])
+    # the i3d logits are registered first and can be replaced
+    inc = ml.load_ft_model("i3d", num_classes=400)
+    assert list(inc.state_dict())[0] == "logits.conv3d.weight"
+    inc.replace_logits(102)
+    assert inc.state_dict()["logits.conv3d.weight"].shape == (102, 1024, 1, 1, 1)
+
+
+def test_no_cpu_fallback():
+    from ted_spad_amd import model_loaders as ml
+    ft = ml.load_ft_model("largei3d", num_classes=102).eval()
+    with pytest.raises(_lib.TedSpadHipError):
+        ft.i3d.extract_features(torch.zeros(1, 3, 16, 32, 32))
+    fa = ml.load_fa_model(arch="unet").eval()
+    with pytest.raises(_lib.TedSpadHipError):
+        fa(torch.zeros(1, 3, 32, 32))
+    from ted_spad_amd.losses import NTXentLoss
+    with pytest.raises(_lib.TedSpadHipError):
+        NTXentLoss("cpu", 4, 0.1, False)(torch.zeros(4, 8), torch.zeros(4, 8))
+    for holder in (ft.i3d.conv1, ft.i3d.bn1, ft.mlp.fc1):
+        with pytest.raises(RuntimeError):
+            holder(torch.zeros(1))
+
+
+def test_resize_aa_table_matches_torch_antialias_weights():
+    """Host builder of the antialiased-resize weights (tedspad_resize_aa_table, no GPU involved) against the dense
+    resize matrix read off torch.nn.functional.interpolate(antialias=True) itself -- the call behind
+    torchvision F.resize in dali_extraction.py:49. Tolerance: 2e-6 absolute on weights in [0,1] (fp32 rounding)."""
+    from oracle import preprocess_ref
+    from ted_spad_amd import preprocess
+    for n_in, n_out in [(864, 224), (576, 224), (224, 224), (100, 224), (1080, 7), (5, 3), (3, 5)]:
+        tab = preprocess.aa_table_host(n_in, n_out)
+        dense = np.zeros((n_out, n_in), np.float32)
+        for i in range(n_out):
+            lo, cnt = int(tab[i, 0]), int(tab[i, 1])
+            assert 0 <= lo and lo + cnt <= n_in and cnt <= tab.shape[1] - 2
+            dense[i, lo:lo + cnt] = tab[i, 2:2 + cnt].view(np.float32)
+        ref = preprocess_ref.resize_matrix(n_in, n_out).numpy()
+        assert np.abs(dense - ref).max() < 2e-6, (n_in, n_out, np.abs(dense - ref).max())
+        assert np.allclose(dense.sum(1), 1.0, atol=1e-5)
+
+
+def test_crop_boxes():
+    from ted_spad_amd import preprocess
+    assert preprocess.center_crop_box(1080, 1920, 864, 1536) == (108, 192, 864, 1536)
+    assert preprocess.center_crop_box(241, 321, 192, 256) == (24, 32, 192, 256)       # 24.5 -> 24, 32.5 -> 32: half to even
+    boxes = preprocess.ten_crop_boxes(256, 340, 224, 224)
+    assert len(boxes) == 10 and boxes[0] == (0, 0, 224, 224, False) and boxes[4][:2] == (16, 58)
+    assert boxes[5] == (0, 116, 224, 224, True) and boxes[6] == (0, 0, 224, 224, True)  # flipped tl = right edge of the frame
+    with pytest.raises(ValueError):
+        preprocess.center_crop_box(100, 100, 120, 50)
+
+
+def test_save_features_batched(tmp_path):
+    from ted_spad_amd.extraction import save_features_batched
+    a, b = synth_tensor(0, "fa", (5, 16)), synth_tensor(0, "fb", (3, 10, 8))
+    paths = save_features_batched(str(tmp_path), [("/x/y/Abuse001_x264.mp4", a), ("Normal_7.avi", b)])
+    assert [os.path.basename(p) for p in paths] == ["Abuse001_x264.npy", "Normal_7.npy"]
+    la, lb = np.load(paths[0]), np.load(paths[1])
+    assert la.dtype == np.float64 and la.shape == (5, 16) and np.array_equal(la, a.numpy().astype(np.float64))
+    assert lb.shape == (3, 10, 8) and np.array_equal(lb, b.numpy().astype(np.float64))
+
+
+def test_fb_model_has_torchvision_resnet50_keys():
+    """fb = nn.Sequential(resnet50(fc=Identity), MLP) (model_loaders.py:124-153): key names / counts of
+    torchvision.models.resnet50 so `fb_model_state_dict` checkpoints load strict=True (incl. the 'module.' fallback)."""
+    from ted_spad_amd.model_loaders import load_fb_model
+    fb = load_fb_model(arch="r50", ssl=True)
+    sd = fb.state_dict()
+    assert len(sd) == 322 and sum(p.numel() for p in fb.parameters()) == 23508032 + 2048 * 2048 + 2048 + 2048 * 128 + 128
+    for k, shape in {"0.conv1.weight": (64, 3, 7, 7), "0.bn1.running_var": (64,), "0.layer1.0.conv1.weight": (64, 64, 1, 1),
+                     "0.layer1.0.downsample.0.weight": (256, 64, 1, 1), "0.layer2.0.conv2.weight": (128, 128, 3, 3),
+                     "0.layer4.2.bn3.num_batches_tracked": (), "1.fc1.bias": (2048,), "1.fc2.weight": (128, 2048)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert not any(k.startswith("0.fc") for k in sd)                      # fc = nn.Identity()
+    pred = load_fb_model(arch="r50", ssl=False, num_pa=7)
+    assert tuple(pred.state_dict()["fc.weight"].shape) == (7, 2048) and len(pred.state_dict()) == 320

@@ -303,10 +303,13 @@ int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, int3
                               const float *gamma, const float *beta, float *sums, int32_t sums_ld, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy,
                               int32_t ldz, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 
-/* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input); y == NULL with relu as above. */
+/* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input); y == NULL with relu as above.
+ * dbias ([dbias_slots][C] floats, pre-zeroed, may be NULL): the rows together += sum over pixels of dz -- the gradient of the bias of the conv
+ * in front of the BatchNorm (nn.Conv2d(bias=True) + BatchNorm2d in unet_parts.py DoubleConv), gathered here instead of by another pass over dz;
+ * workgroup b adds into row b % dbias_slots (several rows: thousands of atomics on one address serialise), the caller sums the rows. */
 int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd,
                              const float *gamma, const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres,
-                             int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
+                             float *dbias, int32_t dbias_slots, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,
                              int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream);
 
 /* dx[i] = (add ? add[i] : 0) + sum over pooling windows o containing i of dy[o]*[argmax(o) == i]; `d` = forward

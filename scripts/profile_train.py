@@ -9,7 +9,13 @@ fa.load_state_dict(synth_state_dict(fa.state_dict(), 0)); ft.load_state_dict(syn
 fa, ft = fa.cuda(), ft.cuda()
 step = AnonymizerTrainStep(fa, ft)
 video = synth_train_video(0, 'bench_train', (8, 48, 3, 112, 112), device='cuda'); labels = torch.randint(1, 102, (8,), device='cuda')
-for _ in range(30): step.step_fa(video, labels); step.step_ft(video, labels)
+from ted_spad_amd import engine as E
+for fn in (step.step_fa, step.step_ft):            # as bench.py: each phase until the tile tuner has settled every conv geometry
+    for i in range(180):
+        if i >= 45 and not E.tuning_pending():
+            break
+        fn(video, labels)
+for _ in range(5): step.step_fa(video, labels); step.step_ft(video, labels)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 for name, fn in (('phase1', step.step_fa), ('phase2', step.step_ft)):
@@ -22,6 +28,6 @@ for name, fn in (('phase1', step.step_fa), ('phase2', step.step_ft)):
     kern = [e for e in ev if e.device_type == DeviceType.CUDA]
     print(name, 'GPU kernels per step: %d launches, %.2f ms device time' % (sum(e.count for e in kern), sum(e.device_time_total for e in kern) / 1e3))
     print('  -- by device time')
-    for e in sorted(kern, key=lambda e: -e.device_time_total)[:16]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
+    for e in sorted(kern, key=lambda e: -e.device_time_total)[:40]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
     print('  -- by launch count')
     for e in sorted(kern, key=lambda e: -e.count)[:45]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))

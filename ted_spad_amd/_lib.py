@@ -74,7 +74,7 @@ SYMBOLS = {
     "tedspad_bn_train_apply": (_I32, [_P, _I32, _P, _I32, _I64, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _I32, _P, _P, _I64] + [_I32] * 7 + [_P]),
     "tedspad_scale_shift_act": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_bn_bwd_reduce": (_I32, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
-    "tedspad_bn_bwd_apply": (_I32, [_P, _P, _P, _I32] + [_P] * 5 + [_I32, _P, _P, _I64] + [_I32] * 9 + [_P]),
+    "tedspad_bn_bwd_apply": (_I32, [_P, _P, _P, _I32] + [_P] * 5 + [_I32, _P, _P, _P, _I32, _I64] + [_I32] * 9 + [_P]),
     "tedspad_maxpool_bwd": (_I32, [C.POINTER(PoolDesc), _P, _P, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
     "tedspad_global_avgpool_bwd": (_I32, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "tedspad_upsample_bilinear2x_bwd": (_I32, [_P, _P] + [_I32] * 11 + [_P]),

@@ -5,6 +5,8 @@
 // `fa_model.train()` / `ft_model.train()` (anonymization_training/train_anonymizer.py:73-75,137-139).
 // Every kernel moves 16 bytes per lane (8 channels of one pixel); per-channel reductions are
 // register partials -> LDS tree -> one float atomic per channel per workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace tedspad {
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int 
     // statistics GROUPS (gridDim.y): group g = rows [g * pixels, (g + 1) * pixels) with its own sums, mean and invstd -- the three clips
     // of a training step normalised separately in one launch (train_anonymizer.py:169-175 calls ft_model three times)
     const int grp = blockIdx.y;
-    if (blockIdx.x == 0 && grp == 0) {
-        for (int c = threadIdx.x; c < C; c += 256) {
+    if (grp == 0) {     // one channel per thread, spread over the workgroups (a 2048-channel layer in one workgroup was the launch's critical path)
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
             for (int g = 0; g < (int)gridDim.y; ++g) {                       // the running statistics take the groups' updates in order
                 const float *st = stats + (size_t)g * 2 * stats_ld;
                 const float mean = st[c] / count;
@@ -124,6 +126,9 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int 
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
         const int c8 = (int)(idx % C8);
         const long px = idx / C8;
+        float v[8], r[8];                                 // the streaming loads first: the per-channel terms below are fetched while they are in flight
+        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, v);
+        if (res) unpack8<T>(*reinterpret_cast<const uint4 *>(res + px * ldres + c8 * 8), r);
         if (!fixed || have != c8) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -140,13 +145,9 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int 
             }
             have = c8;
         }
-        float v[8];
-        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sf[i];
         if (res) {
-            float r[8];
-            unpack8<T>(*reinterpret_cast<const uint4 *>(res + px * ldres + c8 * 8), r);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += r[i];
         }
@@ -234,11 +235,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 
 // dz = k[c] * (g - a[c] - xhat * b[c]),  g = dy * (y > 0 if relu);  optionally dres = g
 //   train BN: k = gamma*invstd, a = dbeta/M, b = dgamma/M
-template <typename T>
+// DB: also gathers d(conv bias) = sum over pixels of dz (zero up to rounding behind a BatchNorm) in registers -> LDS -> one atomic per channel and
+// workgroup. The per-channel terms are re-read per element (L1 hits) rather than kept in registers: this streaming kernel is bound by the loads in
+// flight, and at 88 VGPRs (5 waves/SIMD) the hoisted version ran 2.4 TB/s against 3.5 TB/s for this one (70 VGPRs).
+template <typename T, bool DB>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
                                                             const float *invstd, const float *gamma, const float *beta, const float *sums, int sums_ld,
-                                                            float inv_count, uint16_t *dz, uint16_t *dres, long pixels, int C8, int lddy,
-                                                            int ldy, int ldz, int lddz, int lddres, int relu) {
+                                                            float inv_count, uint16_t *dz, uint16_t *dres, float *dbias, int db_slots, long pixels, int C8,
+                                                            int lddy, int ldy, int ldz, int lddz, int lddres, int relu) {
+    if (DB) dbias += (size_t)(blockIdx.x % db_slots) * C8 * 8;        // [db_slots][C]: 4096 workgroups adding into ONE row serialise in L2 (~150 us)
     {   // statistics group (gridDim.y)
         const int grp = blockIdx.y;
         dy += (size_t)grp * pixels * lddy;
@@ -250,7 +255,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
     }
     const long total = pixels * C8;
     const size_t zbase = (size_t)blockIdx.y * pixels * ldz;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration
+    float db[DB ? 8 : 1];
+    int mine = -1;
+    if (DB) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) db[i] = 0.f;
+    }
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
         const int c8 = (int)(idx % C8);
         const long px = idx / C8;
         float g[8], zz[8], o[8];
@@ -277,6 +290,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
             o[i] = gamma[c] * invstd[c] * (g[i] - sums[c] * inv_count - xh * sums[sums_ld + c] * inv_count);
         }
         *reinterpret_cast<uint4 *>(dz + px * lddz + c8 * 8) = pack8<T>(o);
+        if (DB) {
+            if (fixed) {
+                mine = c8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) db[i] += o[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) atomicAdd(dbias + c8 * 8 + i, o[i]);
+            }
+        }
+    }
+    if (DB) {
+        __shared__ float red[256][9];
+        if (fixed && 256 % C8 == 0) {                     // thread t owns chunk t % C8 in every workgroup
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = db[i];
+            __syncthreads();
+            const int t = threadIdx.x;
+            if (t < C8 * 8) {
+                const int c8 = t >> 3, i = t & 7;
+                float a = 0.f;
+                for (int u = c8; u < 256; u += C8) a += red[u][i];
+                atomicAdd(dbias + c8 * 8 + i, a);
+            }
+        } else if (fixed && mine >= 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(dbias + mine * 8 + i, db[i]);
+        }
     }
 }
 
@@ -506,13 +547,18 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
 }
 
 extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
-                                        const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, int64_t pixels, int32_t C, int32_t lddy,
+                                        const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, float *dbias, int32_t dbias_slots, int64_t pixels, int32_t C, int32_t lddy,
                                         int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz) && (!dbias || dbias_slots >= 1),
                "tedspad_bn_bwd_apply: bad arguments (relu needs y, or beta to recompute the mask)");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 8)), groups), (const uint16_t *)dy, (const uint16_t *)y, z, (int)(zdtype != TEDSPAD_F32), mean,
-             invstd, gamma, beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu);
+#define BWD_APPLY(TT, DD)                                                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, DD>), dim3(grid_for(pixels * (C / 8)), groups), dim3(256), 0, s, (const uint16_t *)dy, (const uint16_t *)y, z, \
+                       (int)(zdtype != TEDSPAD_F32), mean, invstd, gamma, beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, dbias,      \
+                       dbias_slots, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu)
+    if (dtype == TEDSPAD_F16) { if (dbias) BWD_APPLY(F16, true); else BWD_APPLY(F16, false); }
+    else { if (dbias) BWD_APPLY(BF16, true); else BWD_APPLY(BF16, false); }
+#undef BWD_APPLY
     return check_launch("tedspad_bn_bwd_apply");
 }
 

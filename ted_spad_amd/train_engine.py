@@ -73,6 +73,7 @@ ARENA = ZeroArena()
 # the conv output in front of a train-mode BatchNorm (re-read by the BN apply and twice by the backward) kept in the 16-bit activation dtype, as
 # the reference's autocast region holds it (train_anonymizer.py:78,151), instead of fp32: 2 of the 6-8 bytes per element each of those passes moves
 TRAIN_Z16 = os.environ.get("TEDSPAD_TRAIN_Z16", "1") != "0"
+DB_SLOTS = 64           # rows of the conv-bias gradient accumulator of tedspad_bn_bwd_apply
 REFRESH_IN_PLACE = os.environ.get("TEDSPAD_WEIGHT_REFRESH", "1") != "0"     # 0: every stale image rebuilt by the lazy path (A/B timing)
 IMAGES_GEN = 0          # bumped whenever a ConvLayer builds a NEW kernel-form image (WeightRefresh then rebuilds its job tables)
 _PENDING_COUNT = {}     # id(tensor) -> [tensor, increments]
@@ -265,7 +266,7 @@ class ConvLayer:
             IMAGES_GEN += 1
         return plan[1].run(dy, residual=residual, mask=mask, out=out)
 
-    def wgrad(self, x: Act, dy: Act):
+    def wgrad(self, x: Act, dy: Act, db: Optional[torch.Tensor] = None):
         """Accumulates d(weight) in the packed [cout_pad][kpad] fp32 layout (float atomics); several calls per step
         (the three clips) add into the same matrix. `flush_grad()` converts it to the parameter layout once."""
         pc = self.geom_conv()
@@ -285,7 +286,8 @@ class ConvLayer:
             d = pc._desc(n1 - n0, t, h, w, xs.ld, pk, dy.dims[1:], ds.ld, 0, False)
             check(_lib.lib().tedspad_conv_wgrad(C.byref(d), xs.ptr, ds.ptr, pc._ktab(d).data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
         if self.bias is not None:
-            db = channel_sums(dy)[0]
+            if db is None:                                     # (tedspad_bn_bwd_apply gathers it while it writes dy when a BatchNorm follows the conv)
+                db = channel_sums(dy)[0]
             self._db = db if self._db is None else self._db + db
 
     def flush_grad(self):
@@ -543,14 +545,16 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
     sums = channel_sums(dy, ymask, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G, gamma=gam, beta=bet, zcode=ctx.zcode)
     dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
     dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
+    dbias = ARENA.take((DB_SLOTS, cz), z.device) if ctx.conv.bias is not None else None
     check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ymask.ptr if ymask is not None else None, z.data_ptr(), ctx.zcode, ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
-                                          bet.data_ptr(), sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None, n * t * h * w // G, cz,
+                                          bet.data_ptr(), sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None,
+                                          dbias.data_ptr() if dbias is not None else None, DB_SLOTS, n * t * h * w // G, cz,
                                           dy.ld, y.ld, cz, dz.ld, dres.ld if dres is not None else 0, int(ctx.relu), G,
                                           _code(y.buf), _stream_ptr()), "tedspad_bn_bwd_apply")
     for sg in (sums.unbind(0) if G > 1 else (sums,)):                # d(beta), d(gamma): the groups' sums add up
         defer_grad(bn.bias, sg[0, :c])
         defer_grad(bn.weight, sg[1, :c])
-    ctx.conv.wgrad(ctx.x, dz)
+    ctx.conv.wgrad(ctx.x, dz, db=dbias.sum(0) if dbias is not None else None)
     dx = None
     if need_dx:
         dx = ctx.conv.dgrad(dz, ctx.x.dims[1:] if x_dims is None else x_dims, residual=dx_residual, mask=dx_mask)

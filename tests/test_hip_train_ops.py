@@ -116,12 +116,24 @@ def test_conv_bn_relu_train_fwd_bwd(with_res):
     assert rel_l2(bn.running_mean.cpu(), rm_ref) < 1e-3 and rel_l2(bn.running_var.cpu(), rv_ref) < 1e-3
     TE.flush_deferred()      # counters / BN gradients are applied in multi-tensor batches
     assert int(bn.num_batches_tracked) == 1
+    seen, wgrad = {}, layer.wgrad
+
+    def spy(xa, dza, db=None):
+        seen["dz"], seen["db"] = dza, db
+        return wgrad(xa, dza, db=db)
+    layer.wgrad = spy
     dx, dres = TE.conv_bn_act_train_bwd(ctx, cl(dy))
     layer.flush_grad()
     assert rel_l2(nc(dx), x.grad) < 5e-3
     assert rel_l2(wp.grad.cpu(), w.grad) < 5e-3
     assert rel_l2(bn.weight.grad.cpu(), g.grad) < 5e-3 and rel_l2(bn.bias.grad.cpu(), be.grad) < 5e-3
     assert float(bp.grad.abs().max()) < 2e-2 * float(dy.abs().sum()) ** 0.5   # analytically 0 (BN removes the mean)
+    # the conv-bias gradient is gathered by the BatchNorm backward while it writes dz: == the per-channel sum of dz up to dz's 16-bit rounding
+    dz = nc(seen["dz"])
+    assert seen["db"] is not None
+    npx = dz.numel() // cout
+    tol = 4 * npx ** 0.5 * float(dz.pow(2).mean().sqrt()) * 2.0 ** -11 + 1e-6
+    assert float((bp.grad.cpu() - dz.sum(dim=(0, 2, 3, 4))).abs().max()) < tol
     if with_res:
         assert rel_l2(nc(dres), res.grad) < 1e-3
 
