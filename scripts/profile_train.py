@@ -29,5 +29,9 @@ for name, fn in (('phase1', step.step_fa), ('phase2', step.step_ft)):
     print(name, 'GPU kernels per step: %d launches, %.2f ms device time' % (sum(e.count for e in kern), sum(e.device_time_total for e in kern) / 1e3))
     print('  -- by device time')
     for e in sorted(kern, key=lambda e: -e.device_time_total)[:40]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
+    pat = os.environ.get('PROFILE_KERNEL')           # every launch of the kernels whose name contains this, in launch order
+    if pat:
+        evs = sorted((e for e in prof.events() if e.device_type == DeviceType.CUDA and pat in e.name), key=lambda e: e.time_range.start)
+        print('  -- %s: %d launches (us): %s' % (pat, len(evs), ' '.join('%.0f' % e.device_time for e in evs)))
     print('  -- by launch count')
     for e in sorted(kern, key=lambda e: -e.count)[:45]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))

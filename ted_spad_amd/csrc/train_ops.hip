@@ -18,6 +18,16 @@ inline int grid_for(long items) {
     return g < 1 ? 1 : (int)g;
 }
 
+// grid for kernels that set up per-channel terms once per thread (bn_train_apply: 8 divisions, 8 rsqrt and 32 loads for 8 channels): `iters`
+// items per thread where the tensor allows it, but never fewer than ~2 workgroups per CU
+inline int grid_for_iters(long items, int iters) {
+    long g = (items + 256L * iters - 1) / (256L * iters);
+    const long full = (items + 255) / 256;
+    if (g < 512) g = full < 512 ? full : 512;
+    if (g > 256 * 16) g = 256 * 16;
+    return g < 1 ? 1 : (int)g;
+}
+
 // ---- BatchNorm (train): finalize the batch statistics gathered by the conv epilogue -------------
 __global__ void bn_finalize_kernel(const float *stats, int stats_ld, float count, const float *gamma, const float *beta,
                                    float eps, float momentum, float *running_mean, float *running_var, float *scale,
@@ -235,28 +245,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
 
 // dz = k[c] * (g - a[c] - xhat * b[c]),  g = dy * (y > 0 if relu);  optionally dres = g
 //   train BN: k = gamma*invstd, a = dbeta/M, b = dgamma/M
-// DB: also gathers d(conv bias) = sum over pixels of dz (zero up to rounding behind a BatchNorm) in registers -> LDS -> one atomic per channel and
-// workgroup. The per-channel terms are re-read per element (L1 hits) rather than kept in registers: this streaming kernel is bound by the loads in
-// flight, and at 88 VGPRs (5 waves/SIMD) the hoisted version ran 2.4 TB/s against 3.5 TB/s for this one (70 VGPRs).
+// dz = gamma*invstd*(g - S0/M - xhat*S1/M) with xhat = (z - mean)*invstd, written as dz = ks*g + A*z + B with three per-channel terms
+//   ks = gamma*invstd,  A = -ks*invstd*S1/M,  B = -ks*(S0/M) - A*mean
+// (+ the forward's shift mb = beta - mean*ks when the ReLU mask is recomputed from z), set up once per workgroup in LDS ([4][C] floats) and read
+// back as 16-byte vectors per element: the version that re-read 6 global arrays x 8 channels per element was TA-bound (3.1 TB/s at 70 VGPRs), one
+// that kept the terms in registers needed 88-100 VGPRs and ran at 2.4 TB/s (5 waves / SIMD).
+// DB: also gathers d(conv bias) = sum over pixels of dz (zero up to rounding behind a BatchNorm): registers -> LDS -> one atomic per channel
+// and workgroup, into row blockIdx.x % db_slots of the accumulator.
 template <typename T, bool DB>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
                                                             const float *invstd, const float *gamma, const float *beta, const float *sums, int sums_ld,
                                                             float inv_count, uint16_t *dz, uint16_t *dres, float *dbias, int db_slots, long pixels, int C8,
                                                             int lddy, int ldy, int ldz, int lddz, int lddres, int relu) {
-    if (DB) dbias += (size_t)(blockIdx.x % db_slots) * C8 * 8;        // [db_slots][C]: 4096 workgroups adding into ONE row serialise in L2 (~150 us)
+    extern __shared__ __attribute__((aligned(16))) float bn_terms[];      // [4][C]: ks, A, B, mb
+    const int C = C8 * 8;
+    if (DB) dbias += (size_t)(blockIdx.x % db_slots) * C;              // [db_slots][C]: 4096 workgroups adding into ONE row serialise in L2 (~150 us)
     {   // statistics group (gridDim.y)
         const int grp = blockIdx.y;
         dy += (size_t)grp * pixels * lddy;
         if (y) y += (size_t)grp * pixels * ldy;
-        mean += (size_t)grp * C8 * 8; invstd += (size_t)grp * C8 * 8;
+        mean += (size_t)grp * C; invstd += (size_t)grp * C;
         sums += (size_t)grp * 2 * sums_ld;
         dz += (size_t)grp * pixels * lddz;
         if (dres) dres += (size_t)grp * pixels * lddres;
     }
+    const bool remask = relu && !y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float is = invstd[c], mu = mean[c];
+        const float ks = gamma[c] * is;
+        const float a = -ks * is * sums[sums_ld + c] * inv_count;
+        bn_terms[c] = ks;
+        bn_terms[C + c] = a;
+        bn_terms[2 * C + c] = -ks * sums[c] * inv_count - a * mu;
+        bn_terms[3 * C + c] = remask ? beta[c] - mu * ks : 0.f;        // the forward pass's own shift (its scale is ks; see bn_bwd_reduce_kernel)
+    }
+    __syncthreads();
     const long total = pixels * C8;
     const size_t zbase = (size_t)blockIdx.y * pixels * ldz;
     const long stride = (long)gridDim.x * 256;
-    const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration
+    const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration (DB: sums kept in registers)
     float db[DB ? 8 : 1];
     int mine = -1;
     if (DB) {
@@ -266,16 +293,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
         const int c8 = (int)(idx % C8);
         const long px = idx / C8;
-        float g[8], zz[8], o[8];
+        float g[8], zz[8];
         unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
         load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, zz);
-        if (relu && !y) {             // the forward pass's own expression (see bn_bwd_reduce_kernel)
+        const float *kt = bn_terms + c8 * 8;
+        float ks[8];
+        *reinterpret_cast<f32x4 *>(ks) = *reinterpret_cast<const f32x4 *>(kt);
+        *reinterpret_cast<f32x4 *>(ks + 4) = *reinterpret_cast<const f32x4 *>(kt + 4);
+        if (remask) {
+            float mb[8];
+            *reinterpret_cast<f32x4 *>(mb) = *reinterpret_cast<const f32x4 *>(kt + 3 * C);
+            *reinterpret_cast<f32x4 *>(mb + 4) = *reinterpret_cast<const f32x4 *>(kt + 3 * C + 4);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = c8 * 8 + i;
-                const float s_ = gamma[c] * invstd[c];
-                g[i] = zz[i] * s_ + (beta[c] - mean[c] * s_) > 0.f ? g[i] : 0.f;
-            }
+            for (int i = 0; i < 8; ++i) g[i] = zz[i] * ks[i] + mb[i] > 0.f ? g[i] : 0.f;
         } else if (relu) {
             float yy[8];
             unpack8<T>(*reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8), yy);
@@ -283,21 +313,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
             for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
         }
         if (dres) *reinterpret_cast<uint4 *>(dres + px * lddres + c8 * 8) = pack8<T>(g);
+        {
+            float ka[8], kb[8];
+            *reinterpret_cast<f32x4 *>(ka) = *reinterpret_cast<const f32x4 *>(kt + C);
+            *reinterpret_cast<f32x4 *>(ka + 4) = *reinterpret_cast<const f32x4 *>(kt + C + 4);
+            *reinterpret_cast<f32x4 *>(kb) = *reinterpret_cast<const f32x4 *>(kt + 2 * C);
+            *reinterpret_cast<f32x4 *>(kb + 4) = *reinterpret_cast<const f32x4 *>(kt + 2 * C + 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = c8 * 8 + i;
-            const float xh = (zz[i] - mean[c]) * invstd[c];
-            o[i] = gamma[c] * invstd[c] * (g[i] - sums[c] * inv_count - xh * sums[sums_ld + c] * inv_count);
+            for (int i = 0; i < 8; ++i) g[i] = ks[i] * g[i] + (ka[i] * zz[i] + kb[i]);
         }
-        *reinterpret_cast<uint4 *>(dz + px * lddz + c8 * 8) = pack8<T>(o);
+        *reinterpret_cast<uint4 *>(dz + px * lddz + c8 * 8) = pack8<T>(g);
         if (DB) {
             if (fixed) {
                 mine = c8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) db[i] += o[i];
+                for (int i = 0; i < 8; ++i) db[i] += g[i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) atomicAdd(dbias + c8 * 8 + i, o[i]);
+                for (int i = 0; i < 8; ++i) atomicAdd(dbias + c8 * 8 + i, g[i]);
             }
         }
     }
@@ -549,11 +582,11 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
 extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
                                         const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, float *dbias, int32_t dbias_slots, int64_t pixels, int32_t C, int32_t lddy,
                                         int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz) && (!dbias || dbias_slots >= 1),
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz) && (!dbias || dbias_slots >= 1) && C <= 8192,
                "tedspad_bn_bwd_apply: bad arguments (relu needs y, or beta to recompute the mask)");
     hipStream_t s = (hipStream_t)stream;
 #define BWD_APPLY(TT, DD)                                                                                                                            \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, DD>), dim3(grid_for(pixels * (C / 8)), groups), dim3(256), 0, s, (const uint16_t *)dy, (const uint16_t *)y, z, \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, DD>), dim3(grid_for_iters(pixels * (C / 8), 8), groups), dim3(256), (size_t)C * 16, s, (const uint16_t *)dy, (const uint16_t *)y, z, \
                        (int)(zdtype != TEDSPAD_F32), mean, invstd, gamma, beta, sums, sums_ld, 1.f / (float)pixels, (uint16_t *)dz, (uint16_t *)dres, dbias,      \
                        dbias_slots, (long)pixels, C / 8, lddy, ldy, ldz, lddz, lddres, relu)
     if (dtype == TEDSPAD_F16) { if (dbias) BWD_APPLY(F16, true); else BWD_APPLY(F16, false); }
@@ -622,7 +655,7 @@ extern "C" int32_t tedspad_bn_train_apply(const void *z, int32_t zdtype, const f
                    ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0 && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
                "tedspad_bn_train_apply: bad arguments (z is fp32, or 16-bit of y's dtype with ldz % 8 == 0)");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for(pixels * (Cz / 8)), groups), z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
+    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for_iters(pixels * (Cz / 8), 8), groups), z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
              running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
     return check_launch("tedspad_bn_train_apply");
 }
