@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolBKP p) {
         const long n = r / p.Ti;
         const size_t xi = (((size_t)n * p.Ti + it) * p.Hi + ih) * p.Wi + iw;
         float xv[8], acc[8];
-        unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + xi * p.ldx + c8 * 8), xv);
+        if (p.relu_mask) unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + xi * p.ldx + c8 * 8), xv);    // only the mask needs the forward input
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
         if (p.add) unpack8<T>(*reinterpret_cast<const uint4 *>(p.add + xi * p.ldadd + c8 * 8), acc);

@@ -16,6 +16,7 @@ Backward of the reference's torch.nn modules inside `loss.backward()`
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import List, Optional, Tuple
@@ -96,8 +97,33 @@ def flush_counters():
         torch._foreach_add_([e[0] for e in ent], [e[1] for e in ent])
 
 
+_SIDE = {}              # device -> [stream, busy]
+WGRAD_STREAM = os.environ.get("TEDSPAD_WGRAD_STREAM", "1") != "0"
+
+
+def side_stream(device):
+    """The stream the weight-gradient kernels run on, or None: while the tile tuner is timing launches (a candidate measured with another
+    stream's kernels on the chip can lose to a slower one), during stream capture, or with TEDSPAD_WGRAD_STREAM=0."""
+    if not WGRAD_STREAM or E.tuning_pending() or torch.cuda.is_current_stream_capturing():
+        return None
+    ent = _SIDE.get(device)
+    if ent is None:
+        ent = _SIDE[device] = [torch.cuda.Stream(device=device), False]       # (priority range here is (0, -1): 0 is already the lowest)
+    ent[1] = True
+    return ent[0]
+
+
+def join_side_stream():
+    """The current stream waits for the weight-gradient kernels launched so far (before their accumulators are read, or the arena is reset)."""
+    for ent in _SIDE.values():
+        if ent[1]:
+            torch.cuda.current_stream().wait_stream(ent[0])
+            ent[1] = False
+
+
 def flush_deferred():
     """Apply the collected counter increments and BN parameter gradients (must run before the arena is reset)."""
+    join_side_stream()
     flush_counters()
     if not _PENDING_GRAD:
         return
@@ -280,11 +306,21 @@ class ConvLayer:
         nc = n
         if n * max(t * h * w * x.ld, to * ho * wo * dy.ld) >= E.MAX_ELEMS or n * to * ho * wo >= E.MAX_WGRAD_PIXELS:
             nc = min(E.batch_chunk(n, [t * h * w * x.ld, to * ho * wo * dy.ld], E.MAX_ELEMS), E.batch_chunk(n, [to * ho * wo], E.MAX_WGRAD_PIXELS))
+        # The weight gradient is off the backward pass's critical path (nothing reads it before the flush): it goes to a side stream, where
+        # this L2->LDS-feed-bound kernel runs beside the HBM-bound BatchNorm passes and the data-gradient convs of the layers in front.
+        side = side_stream(x.buf.device)
+        launches = []
         for n0 in range(0, n, nc):                      # chunks of whole samples accumulate into the same matrix
             n1 = min(n, n0 + nc)
             xs, ds = (Act(x.buf[n0:n1], x.c, x.coff), Act(dy.buf[n0:n1], dy.c, dy.coff)) if nc < n else (x, dy)
             d = pc._desc(n1 - n0, t, h, w, xs.ld, pk, dy.dims[1:], ds.ld, 0, False)
-            check(_lib.lib().tedspad_conv_wgrad(C.byref(d), xs.ptr, ds.ptr, pc._ktab(d).data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
+            launches.append((d, xs, ds, pc._ktab(d)))
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())          # x, dy and the zeroed accumulator are ready
+            x.buf.record_stream(side); dy.buf.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            for d, xs, ds, ktab in launches:
+                check(_lib.lib().tedspad_conv_wgrad(C.byref(d), xs.ptr, ds.ptr, ktab.data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
         if self.bias is not None:
             if db is None:                                     # (tedspad_bn_bwd_apply gathers it while it writes dy when a BatchNorm follows the conv)
                 db = channel_sums(dy)[0]
