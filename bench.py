@@ -48,8 +48,9 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def bench_train(dev, steps=10, warmup=45):
-    """cfg3 on this GPU: ms per phase-1 / phase-2 iteration, algorithmic TFLOP/s, kernel launches per iteration."""
+def bench_train(dev, steps=10, warmup=45, hw=112):
+    """cfg3 on this GPU: ms per phase-1 / phase-2 iteration, algorithmic TFLOP/s, kernel launches per iteration.
+    hw = 224: the per-rank batch of cfg5 (8 x 48 x 224^2; its FLOP are 4x cfg3's, every conv scales with the pixels)."""
     from ted_spad_amd import engine as E
     from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
     from ted_spad_amd.synth import synth_state_dict, synth_train_video
@@ -60,10 +61,11 @@ def bench_train(dev, steps=10, warmup=45):
     ft.load_state_dict(synth_state_dict(ft.state_dict(), 0))
     fa, ft = fa.to(dev), ft.to(dev)
     step = AnonymizerTrainStep(fa, ft)
-    video = synth_train_video(0, "bench_train", (8, 48, 3, 112, 112), device=dev)
+    video = synth_train_video(0, "bench_train", (8, 48, 3, hw, hw), device=dev)
+    fl = (hw / 112.0) ** 2
     labels = torch.randint(1, 102, (8,), device=dev)
-    out = {"config": "cfg3 train_anonymizer.py iteration: UNet anonymizer + I3Res50 + CE + 0.1 x triplet, batch 8 x 48 x 112^2, f16 "
-                     "activations / fp32 accumulate, fb branch excluded, Adam step included", "steps": steps}
+    out = {"config": "%s train_anonymizer.py iteration: UNet anonymizer + I3Res50 + CE + 0.1 x triplet, batch 8 x 48 x %d^2, f16 "
+                     "activations / fp32 accumulate, fb branch excluded, Adam step included" % ("cfg3" if hw == 112 else "cfg5 per-rank", hw), "steps": steps}
     for name, fn in (("phase1", step.step_fa), ("phase2", step.step_ft)):
         for i in range(4 * warmup):              # until the tile tuner has settled every conv geometry of this phase
             if i >= warmup and not E.tuning_pending():
@@ -76,8 +78,8 @@ def bench_train(dev, steps=10, warmup=45):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         out[name + "_ms"] = round(ms, 3)
-        out[name + "_tflops"] = round(TRAIN_TFLOP[name] / ms * 1e3, 1)
-        out[name + "_mfma_frac"] = round(TRAIN_TFLOP[name] / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
+        out[name + "_tflops"] = round(fl * TRAIN_TFLOP[name] / ms * 1e3, 1)
+        out[name + "_mfma_frac"] = round(fl * TRAIN_TFLOP[name] / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
         out[name + "_loss"] = round(r["loss_ft"], 5)
     # the reference's loop runs BOTH phases per batch (train_anonymizer.py:87-123 then :137-191): each phase then starts from the
     # other network's fresh weights (frozen-BN folds and 16-bit weight images rebuilt), which the per-phase loops above never pay
@@ -106,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the cfg3 training-iteration timing appended at N = 1")
     ap.add_argument("--train", action="store_true", help="only the cfg3 training-iteration timing (one JSON line)")
+    ap.add_argument("--train-hw", type=int, default=112, help="with --train: frame size (112: cfg3; 224: the per-rank batch of cfg5)")
     ap.add_argument("--act-range", action="store_true", help="add the per-stage max |activation| of one forward (f16 head-room) to the line")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on CPU/gloo with a stub extractor")
     args = ap.parse_args()
@@ -132,7 +135,7 @@ def main():
     if args.train:
         assert world == 1 and not dry, "--train is a single-GPU measurement"
         print(json.dumps({"metric": "cfg3 training iteration", "unit": "ms", "n_gpus": 1, "higher_is_better": False, "dtype": args.dtype,
-                          "data": "synthetic", "train_cfg3": bench_train(dev, steps=max(args.steps, 5))}))
+                          "data": "synthetic", ("train_cfg3" if args.train_hw == 112 else "train_cfg5_rank"): bench_train(dev, steps=max(args.steps, 5), hw=args.train_hw)}))
         return
 
     from ted_spad_amd import sharding
