@@ -29,6 +29,7 @@ struct WgradKP {
     int To, Ho, Wo, ldy;
     int st, sh, sw, pt, ph, pw;
     int k_tiles, co_tiles, rows_per_split;
+    int cc_tiles;                       // conv_wgrad3_kernel: Cin / 64
     unsigned long long mWo, mHo, mTo;   // ceil(2^40 / d): n / d == (n * m) >> 40 for n < 2^23, d < 2^12
 };
 
@@ -39,6 +40,12 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned long long m) { return (unsigned)(((unsigned long long)n * m) >> 40); }
 
 constexpr int WG_SUB = 64 * 64 * 2;      // one [64 px][64 ch] sub-tile
+
+// LDS row r (one pixel, 64 channels = 8 chunks of 16 bytes) holds channel chunk c at chunk position c ^ wg_swz(r). A `ds_read_b64_tr_b16`
+// banks over each 32-lane half: 4 rows x 64 bytes, and rows r, r + 2 of a 128-byte pitch start on the same bank -- the swizzle moves every second
+// row PAIR to the other 64-byte half of the row. (The first version XOR-ed (r >> 1) & 7, which only permutes chunks inside the same half for
+// rows r, r + 2: every transposing read was a 2-way conflict, 128 instead of 256 B/clk, and that, not the L2 -> LDS stream, capped these kernels.)
+__device__ __forceinline__ int wg_swz(int row) { return ((row >> 1) & 1) << 2; }
 constexpr int WG_S = 3;
 
 // NY x NX waves (4 or 8): the workgroup's dW tile is [64*NY co] x [64*NX k], one 64x64 block per wave. (2,2) is the
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(64 * NY * NX) void conv_wgrad_kernel(const WgradKP 
 
     // ---- DMA roles ---------------------------------------------------------------------------
     const int rsub = wave * 8 + (lane >> 3);
-    const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);   // source chunk (swizzle on the source)
+    const int kc = (lane & 7) ^ wg_swz(lane >> 3);                       // source chunk (swizzle on the source; rows of a DMA instruction start at a multiple of 8)
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16w);
     // this thread's chunk of the two X sub-tiles: tap offsets are fixed for the whole kernel
     int xoff[NX], xdt[NX], xdh[NX], xdw[NX];
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(64 * NY * NX) void conv_wgrad_kernel(const WgradKP 
         for (int rd = 0; rd < 2; ++rd) {
             const int row = 8 * h + 4 * rd + q;
             const int c = 32 * a + 16 * (g & 1) + 4 * pp;
-            off[a][rd] = row * 128 + ((((c >> 3) ^ ((row >> 1) & 7))) << 4) + (c & 7) * 2;
+            off[a][rd] = row * 128 + ((((c >> 3) ^ wg_swz(row))) << 4) + (c & 7) * 2;
         }
     f32x16 acc[2][2];
 #pragma unroll
@@ -180,6 +187,178 @@ __global__ __launch_bounds__(64 * NY * NX) void conv_wgrad_kernel(const WgradKP 
         }
 }
 
+// ---- 1 x 3 x 3, stride 1, pad 1, Cin % 64 == 0: the nine taps from THREE activation tiles -------------------------------------
+// The kernel above gathers a [64 px][64 ch] activation tile per (tap, channel chunk): for a 3 x 3 conv that is nine tiles per 64 pixels,
+// 120 KB of L2 -> LDS traffic with dY re-read by each K tile -- the stream this kernel family is bound by (the UNet's 64-channel
+// full-resolution layers ran at ~330 TFLOP/s). Here a workgroup owns ALL nine taps of a [64 co] x [64 ci] block: per 64 consecutive
+// output pixels it loads dY once and, per kernel row dh, ONE tile of 66 consecutive input pixels (m-1 .. m+64 of the row above / the same
+// row / the row below in flat (n,h,w) order); the taps dw = -1, 0, +1 are that tile read at row offsets 0, 1, 2. 33 KB per 64 pixels.
+//   * pixels of rows outside the image come from the zero page (decided per slot from its own (h + dh - 1));
+//   * dw = +-1 at the left / right image edge would read the neighbouring ROW's end pixel: the waves that own those taps zero the
+//     dY elements of the edge pixels in their A fragments instead (a 64-bit mask per step, built on the scalar unit);
+//   * 6 waves = (dw) x (32-channel half of ci): a wave's A fragments (dY, masked for its dw) serve its three dh taps; accumulators
+//     3 dh x 2 co halves x 16; two-slot LDS ring (70 KB: two workgroups per CU), one barrier per 64 pixels.
+constexpr int W3_XROWS = 72;                       // 66 used
+constexpr int W3_STAGE = WG_SUB + 3 * W3_XROWS * 128;
+
+template <typename T>
+__global__ __launch_bounds__(384) void conv_wgrad3_kernel(const WgradKP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * W3_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cc = b % p.cc_tiles; b /= p.cc_tiles;
+    const int cot = b % p.co_tiles;
+    const int ms = b / p.co_tiles;
+    const int m_begin = ms * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    const int W = p.Wi, H = p.Hi;
+    const unsigned long long mH = p.mHo;
+
+    // ---- DMA roles: a wave moves 8 rows x 128 bytes per instruction; rows 48.. of a tile by the first waves ----------------------
+    const int kc = (lane & 7) ^ wg_swz(lane >> 3);                          // source chunk (swizzle on the source: LDS row r holds chunk c at c ^ wg_swz(r))
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16w);
+    const bool yok = cot * 64 + kc * 8 < p.Cout;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    const uint16_t *xc = p.x + cc * 64 + kc * 8;
+    const uint16_t *yc = p.dy + cot * 64 + kc * 8;
+
+    // Per-lane state of the two rows (ps = 0, 1) this lane moves per tile, advanced by 64 pixels per step: the address arithmetic of a step
+    // (pixel -> (row, column), three validity tests, four 64-bit addresses) was as long as its MFMA work when redone from the pixel index.
+    int qs[2], wq[2], hq[2];
+    const uint16_t *px[2], *py[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int row = ps * 48 + wave * 8 + (lane >> 3);
+        const int q = m_begin + row - 1;                                    // the flat pixel of X slot `row`; dY row `row` is pixel q + 1
+        const int qc = q < 0 ? 0 : q;
+        const unsigned qr = fdiv(qc, p.mWo);
+        qs[ps] = q;
+        wq[ps] = qc - (int)qr * W;
+        hq[ps] = (int)(qr - fdiv(qr, mH) * H);
+        px[ps] = xc + (ptrdiff_t)q * p.ldx;
+        py[ps] = yc + (ptrdiff_t)(q + 1) * p.ldy;
+    }
+    const ptrdiff_t xrow = (ptrdiff_t)W * p.ldx;
+
+    auto issue = [&](int slot) {                        // the tiles of the NEXT step not issued yet
+        const unsigned stage = lds0 + slot * W3_STAGE;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int r0 = ps * 48 + wave * 8;                              // wave-uniform
+            const int row = r0 + (lane >> 3);
+            const int q = qs[ps];
+            if (r0 < 64) {
+                const uint16_t *src = (q + 1 < m_end && yok) ? py[ps] : zero;
+                lds_dma16(src, stage + r0 * 128);
+            }
+            if (r0 < W3_XROWS) {
+                const bool qok = row < 66 && q >= 0 && q < p.M;
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    const bool ok = qok && (unsigned)(hq[ps] + dh - 1) < (unsigned)H;
+                    const uint16_t *src = ok ? px[ps] + (dh - 1) * xrow : zero;
+                    lds_dma16(src, stage + WG_SUB + dh * (W3_XROWS * 128) + r0 * 128);
+                }
+            }
+            // advance to the next step
+            qs[ps] = q + 64;
+            px[ps] += (ptrdiff_t)64 * p.ldx;
+            py[ps] += (ptrdiff_t)64 * p.ldy;
+            int wn = wq[ps] + (q < 0 ? 63 : 64), hn = hq[ps];               // (slot 0 of the first split starts at pixel -1, set up as pixel 0)
+            while (wn >= W) { wn -= W; hn = hn + 1 == H ? 0 : hn + 1; }
+            wq[ps] = wn; hq[ps] = hn;
+        }
+    };
+
+    // ---- MFMA roles ----------------------------------------------------------------------------------------------------------------
+    const int dw = wave % 3, cih = wave / 3;            // tap column (shift dw: rows +0, +1, +2 of the X tiles), ci half
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
+    int offa[2][2], offb[2];                            // dY: [co half][rd]; X: [rd]
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int row = 8 * h + 4 * rd + q4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int c = 32 * a + 16 * (g & 1) + 4 * pp;
+            offa[a][rd] = row * 128 + ((((c >> 3) ^ wg_swz(row))) << 4) + (c & 7) * 2;
+        }
+        const int rb = row + dw, cb = 32 * cih + 16 * (g & 1) + 4 * pp;
+        offb[rd] = rb * 128 + ((((cb >> 3) ^ wg_swz(rb))) << 4) + (cb & 7) * 2;
+    }
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][a][r] = 0.f;
+    auto tr = [&](const unsigned char *base) -> uint2 {
+        const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(base));
+        return __builtin_bit_cast(uint2, v);
+    };
+
+    if (nsteps > 0) issue(0);
+    int wbase = m_begin % W;                            // column of the step's first pixel
+    for (int step = 0; step < nsteps; ++step) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 1 < nsteps) issue((step + 1) & 1);
+        // edge pixels of this step for the wave's tap column: dw = 0 (shift -1) must not see w == 0, dw = 2 (shift +1) not w == W - 1
+        unsigned long long edge = 0;
+        if (dw != 1) {
+            int p0 = dw == 0 ? W - wbase : W - 1 - wbase;
+            if (p0 >= W) p0 -= W;
+            for (; p0 < 64; p0 += W) edge |= 1ull << p0;
+        }
+        wbase = (wbase + 64) % W;
+        const unsigned char *Y = smem + (step & 1) * W3_STAGE;
+        const unsigned char *X = Y + WG_SUB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const uint2 lo = tr(Y + ks * 16 * 128 + offa[a][0]), hi = tr(Y + ks * 16 * 128 + offa[a][1]);
+                fa[a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            const unsigned bits = (unsigned)(edge >> (16 * ks + 8 * h)) & 0xffu;      // element j of the fragment = pixel 16 ks + 8 h + j
+            if (bits) {
+                unsigned mk[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) mk[d] = ((bits >> (2 * d)) & 1u ? 0u : 0xffffu) | ((bits >> (2 * d + 1)) & 1u ? 0u : 0xffff0000u);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) { fa[a].x &= mk[0]; fa[a].y &= mk[1]; fa[a].z &= mk[2]; fa[a].w &= mk[3]; }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const unsigned char *Xd = X + d * (W3_XROWS * 128) + ks * 16 * 128;
+                const uint2 lo = tr(Xd + offb[0]), hi = tr(Xd + offb[1]);
+                const uint4 fb = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[d][a] = T::mfma(fa[a], fb, acc[d][a]);
+            }
+        }
+    }
+
+    // ---- partial tile -> fp32 dW with float atomics: k = ((dh * 3 + dw) * Cin + cc * 64 + cih * 32 + lane % 32) -----------------------
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int Cin = p.cc_tiles * 64;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int k = (d * 3 + dw) * Cin + cc * 64 + cih * 32 + l31;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.Kpad + k, acc[d][a][r]);
+            }
+    }
+}
+
 }  // namespace
 }  // namespace tedspad
 
@@ -211,6 +390,27 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
     p.co_tiles = narrow ? (d->cout + 63) / 64 : (d->cout + 127) / 128;
     auto magic = [](unsigned dv) { return ((1ULL << 40) + dv - 1) / dv; };
     p.mWo = magic(d->wo); p.mHo = magic(d->ho); p.mTo = magic(d->to);
+    hipStream_t s = (hipStream_t)stream;
+    // 1 x 3 x 3 / stride 1 / pad 1 over whole 64-channel chunks: the three-tile kernel (frames are independent images: t folds into n)
+    static const bool allow_rows = getenv("TEDSPAD_WGRAD_NO_ROWS") == nullptr;        // A/B knob
+    if (allow_rows && d->kt == 1 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 1 && d->pw == 1 &&
+        d->to == d->t && d->ho == d->h && d->wo == d->w && d->cin % 64 == 0 && 9 * d->cin <= kpad) {
+        p.cc_tiles = d->cin / 64;
+        p.co_tiles = (d->cout + 63) / 64;
+        const long tiles3 = (long)p.cc_tiles * p.co_tiles;
+        long splits3 = (1024 + tiles3 - 1) / tiles3;
+        const long max_splits3 = (M + 511) / 512;
+        if (splits3 > max_splits3) splits3 = max_splits3;
+        if (splits3 < 1) splits3 = 1;
+        long rows3 = (M + splits3 - 1) / splits3;
+        rows3 = (rows3 + 63) / 64 * 64;
+        splits3 = (M + rows3 - 1) / rows3;
+        p.rows_per_split = (int)rows3;
+        const dim3 grid3((unsigned)(tiles3 * splits3));
+        if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL((conv_wgrad3_kernel<F16>), grid3, dim3(384), 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad3_kernel<BF16>), grid3, dim3(384), 0, s, p);
+        return check_launch("tedspad_conv_wgrad");
+    }
     // split the pixels so the grid covers the chip ~4x, each split a whole number of 64-pixel steps (>= 8 steps)
     const long tiles = (long)p.k_tiles * p.co_tiles;
     long splits = (1024 + tiles - 1) / tiles;
@@ -221,7 +421,6 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
     rows = (rows + 63) / 64 * 64;
     splits = (M + rows - 1) / rows;
     p.rows_per_split = (int)rows;
-    hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(tiles * splits));
     if (narrow) {
         if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL((conv_wgrad_kernel<F16, 1, 4>), grid, dim3(256), 0, s, p);
