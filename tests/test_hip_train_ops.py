@@ -32,8 +32,10 @@ CONVS = [
     ("1x1_s2_odd", 64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 15, 15)),
     ("1x1_s2_even", 64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 14, 14)),
     ("unet3x3", 128, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 28, 28)),
-    # the three-tile weight-gradient kernel (conv_wgrad3_kernel): rows wider than a 64-pixel step, a partial 64-channel co tile, two ci chunks
+    # the three-tile weight-gradient kernel (conv_wgrad3_kernel, rows of >= 66 pixels) and the gather kernel on 3 x 3 layers it does not take:
+    # a partial 64-channel co tile, two ci chunks, frames as independent images
     ("3x3_w72", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 9, 72)),
+    ("3x3_w80_frames_co96_c128", 128, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 5, 80)),       # six 5-row images: rows above / below missing often
     ("3x3_co96_w7", 64, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 7, 7)),
     ("3x3_c128_co192", 128, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 10, 20)),
 ]
