@@ -404,7 +404,10 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
         p.cc_tiles = d->cin / 64;
         p.co_tiles = (d->cout + 63) / 64;
         const long tiles3 = (long)p.cc_tiles * p.co_tiles;
-        long splits3 = (1024 + tiles3 - 1) / tiles3;
+        // workgroups to aim for: one per CU. The kernel runs on the training step's side stream: at 256 it leaves the main stream's kernels
+        // the second workgroup slot of every CU (cfg3 phase 1: 36.4 ms at 1024 / 512, 35.2-36.3 at 256, 41.5 at 128 where it no longer finishes in time)
+        static const long wgs3 = getenv("TEDSPAD_WGRAD3_WGS") ? atol(getenv("TEDSPAD_WGRAD3_WGS")) : 256;
+        long splits3 = (wgs3 + tiles3 - 1) / tiles3;
         const long max_splits3 = (M + 511) / 512;
         if (splits3 > max_splits3) splits3 = max_splits3;
         if (splits3 < 1) splits3 = 1;
