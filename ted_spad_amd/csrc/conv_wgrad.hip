@@ -422,7 +422,7 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
     }
     // split the pixels so the grid covers the chip ~4x, each split a whole number of 64-pixel steps (>= 8 steps)
     const long tiles = (long)p.k_tiles * p.co_tiles;
-    long splits = (1024 + tiles - 1) / tiles;
+    long splits = (1024 + tiles - 1) / tiles;              // (512 / 256 measured the same in the training step)
     const long max_splits = (M + 511) / 512;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
