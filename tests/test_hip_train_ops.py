@@ -89,9 +89,11 @@ def test_stem_pair_form_backward():
     assert rel_l2(wp.grad.cpu(), w.grad) < 1e-3
 
 
+@pytest.mark.parametrize("z16", [True, False], ids=["z16", "z32"])
 @pytest.mark.parametrize("with_res", [False, True])
-def test_conv_bn_relu_train_fwd_bwd(with_res):
+def test_conv_bn_relu_train_fwd_bwd(with_res, z16, monkeypatch):
     from ted_spad_amd import train_engine as TE
+    monkeypatch.setattr(TE, "TRAIN_Z16", z16)       # the conv output in front of the BatchNorm in the 16-bit activation dtype (default) or fp32
     from ted_spad_amd.params import BNParams
     cin, cout, thw = 64, 128, (2, 9, 10)
     x = synth_tensor(3, "x", (3, cin) + thw, -1, 1).to(H).float().requires_grad_()
