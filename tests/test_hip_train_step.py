@@ -346,3 +346,52 @@ def test_step_alternates_phases():
     phases = [step.step(video, labels)["phase"] for _ in range(4)]
     assert phases == [1, 2, 1, 2]
 
+
+
+def test_alternating_iterations_train_and_the_in_place_refresh_matches_rebuilt_images(monkeypatch):
+    """Six iterations of the reference's loop (phase 1 then phase 2 on a fixed batch): every phase after the first starts from parameters the
+    other phase's optimizer step changed, so it runs on weight images / BatchNorm folds that `WeightRefresh` / `PackedRefresh` rewrote in place.
+    (i) the losses go down (stale images would freeze or derail them); (ii) the same six iterations with the refresh switched off -- every
+    stale image rebuilt from scratch by the lazy path -- give the same losses up to the run-to-run noise of the atomically accumulated
+    gradients; (iii) at the end every image the trainers hold equals a fresh pack of the current parameters bit for bit."""
+    from ted_spad_amd import engine as E, train_engine as TE
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    monkeypatch.setattr(E, "AUTOTUNE", False)                 # one tile per conv: the two runs execute the same launches
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64)).cuda()
+    labels = torch.tensor([5, 77, 101, 1]).cuda()
+
+    def run(refresh):
+        monkeypatch.setattr(TE, "REFRESH_IN_PLACE", refresh)
+        fa, ft, _, _ = _models()
+        step = AnonymizerTrainStep(fa, ft)
+        out = []
+        for _ in range(6):
+            r1 = step.step_fa(video, labels)
+            r2 = step.step_ft(video, labels)
+            out.append((r1["loss_ft"], r2["loss_ft"]))
+        return out, step
+
+    a, step = run(True)
+    assert all(np.isfinite(v) for pair in a for v in pair)
+    assert a[-1][1] < 0.97 * a[0][1] and a[-1][0] < a[1][0], a  # both phases' utility loss falls on the fixed batch (ln 102 = 4.62 at the start; Adam at 1e-3)
+    # (iii) before anything else touches the images: trainers' images vs fresh packs of the parameters as they are now
+    checked = 0
+    for tr in (step.fa_tr, step.ft_tr):
+        tr.refresh.run() if hasattr(tr, "refresh") else tr.trunk.refresh.run()
+        torch.cuda.synchronize()
+        for L in tr.conv_layers():
+            w5 = L._w5()
+            for (_, _), (_, pc, sc, sh) in L._fwd.items():
+                fresh = E.PackedConv(w5, sc, (L.bias.detach() if L.bias is not None else None) if sh is None else sh, stride=L.stride, dtype=L.dtype, pair_w=L.pair_w)
+                assert torch.equal(pc.w, fresh.w) and torch.equal(pc.shift, fresh.shift)
+                checked += 1
+            for (x_dims, dy_dims, _), (_, plan, sc) in L._dgrad.items():
+                pk, _ = L._pads_k(L.geom_conv())
+                fresh = TE.DgradPlan(w5.float(), sc, L.geom_conv().stride, pk, x_dims, dy_dims, L.dtype, pair_w=L.pair_w)
+                for (_, p_old, _, _), (_, p_new, _, _) in zip(plan.subs, fresh.subs):
+                    assert torch.equal(p_old.w, p_new.w)
+                    checked += 1
+    assert checked > 150
+    b, _ = run(False)
+    for (a1, a2), (b1, b2) in zip(a, b):
+        assert abs(a1 - b1) <= 0.05 * abs(b1) + 1e-3 and abs(a2 - b2) <= 0.05 * abs(b2) + 1e-3, (a, b)
