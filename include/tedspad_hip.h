@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TEDSPAD_ABI_VERSION 1
+#define TEDSPAD_ABI_VERSION 2   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2) */
 
 enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };

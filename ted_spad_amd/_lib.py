@@ -10,6 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtedspad_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
+ABI_VERSION = 2          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
 
 
 class ConvDesc(C.Structure):
@@ -132,7 +133,7 @@ def lib():
             f = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
             f.restype = res
             f.argtypes = args
-        if l.tedspad_abi_version() != 1:
+        if l.tedspad_abi_version() != ABI_VERSION:
             raise TedSpadHipError("libtedspad_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libtedspad_hip.so lacks %s" % name
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().tedspad_abi_version() == 1
+    assert _lib.lib().tedspad_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_ktab_and_padding_helpers():
