@@ -103,9 +103,9 @@ WGRAD_STREAM = os.environ.get("TEDSPAD_WGRAD_STREAM", "1") != "0"
 
 def side_stream(device):
     """The stream the weight-gradient kernels run on, or None: while the tile tuner is timing launches (a candidate measured with another
-    stream's kernels on the chip can lose to a slower one), during stream capture, or with TEDSPAD_WGRAD_STREAM=0."""
-    if not WGRAD_STREAM or E.tuning_pending() or torch.cuda.is_current_stream_capturing():
-        return None
+    stream's kernels on the chip can lose to a slower one), or with TEDSPAD_WGRAD_STREAM=0."""
+    if not WGRAD_STREAM or E.tuning_pending():
+        return None                                     # (inside a stream capture the side stream joins the capture: a parallel branch of the graph)
     ent = _SIDE.get(device)
     if ent is None:
         ent = _SIDE[device] = [torch.cuda.Stream(device=device), False]       # (priority range here is (0, -1): 0 is already the lowest)
@@ -317,7 +317,8 @@ class ConvLayer:
             launches.append((d, xs, ds, pc._ktab(d)))
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())          # x, dy and the zeroed accumulator are ready
-            x.buf.record_stream(side); dy.buf.record_stream(side)
+            if not torch.cuda.is_current_stream_capturing():       # (a graph's pool keeps its tensors alive by itself)
+                x.buf.record_stream(side); dy.buf.record_stream(side)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             for d, xs, ds, ktab in launches:
                 check(_lib.lib().tedspad_conv_wgrad(C.byref(d), xs.ptr, ds.ptr, ktab.data_ptr(), self._dwp.data_ptr(), _stream_ptr()), "tedspad_conv_wgrad")
