@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().tedspad_abi_version() == _lib.ABI_VERSION == 2
 
 
+def test_job_structs_mirror_the_header():
+    """The multi-job launches take arrays of plain C structs (include/tedspad_hip.h: tedspad_pack_job / _fold_job / _wgrad_unpack_job); the ctypes
+    mirrors must have the sizes csrc/pack.hip static_asserts and the header's field order. No GPU: a null job list is refused by the host check."""
+    assert (ctypes.sizeof(_lib.PackJob), ctypes.sizeof(_lib.FoldJob), ctypes.sizeof(_lib.WgradUnpackJob)) == (120, 96, 64)
+    hdr = open(os.path.join(ROOT, "include", "tedspad_hip.h")).read()
+    for cls, cname in ((_lib.PackJob, "tedspad_pack_job"), (_lib.FoldJob, "tedspad_fold_job"), (_lib.WgradUnpackJob, "tedspad_wgrad_unpack_job")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            for piece in decl.split(","):               # "const float *w", " *scale", "int32_t geo[9]", " nblocks"
+                ids = re.findall(r"[A-Za-z_][A-Za-z0-9_]*", re.sub(r"\[\d+\]", "", piece))
+                if ids:
+                    names.append(ids[-1])
+        assert names == [f[0] for f in cls._fields_], (cname, names, [f[0] for f in cls._fields_])
+    L = _lib.lib()
+    assert L.tedspad_pack_multi(None, 0, None, 0, None) != 0 and b"tedspad_pack_multi" in L.tedspad_last_error()
+
+
 def test_ktab_and_padding_helpers():
     d = _lib.ConvDesc(n=1, t=4, h=6, w=5, cin=16, ldx=24, cout=40, ldy=40, ldres=0, kt=3, kh=3, kw=3, st=1, sh=1, sw=1,
                       pt=1, ph=1, pw=1, to=4, ho=6, wo=5, relu=1, dtype=0, tile_cfg=0)
