@@ -264,6 +264,7 @@ def test_phase2_ft_pass_replayed_as_a_hipgraph_matches_the_eager_launches(monkey
     from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
     from ted_spad_amd.train_step import AnonymizerTrainStep
     monkeypatch.setattr(E, "AUTOTUNE", False)
+    monkeypatch.setattr(E, "_TUNING", {})                     # tuning jobs other tests of this process left unfinished would keep the step eager
     video = synth_train_video(0, "graph_video", (8, 48, 3, 112, 112), device="cuda")
     labels = torch.tensor([5, 77, 101, 1, 9, 33, 60, 2]).cuda()
 
