@@ -58,6 +58,8 @@ class _Cfgs(dict):
 
 
 _TUNING = {}            # (id(_Cfgs), geometry key) -> weakref to the _Cfgs whose configurations are still taking turns
+_CLOCK = [0]            # conv launches so far (a tuning job that has not been touched for TUNE_STALE launches no longer holds anybody up)
+TUNE_STALE = 20000
 
 
 def tuning_pending() -> bool:
@@ -65,11 +67,15 @@ def tuning_pending() -> bool:
     streams stay on ONE stream until this is False: a candidate timed while other streams' kernels share the CUs
     is measured with their interference and can lose to a slower configuration. Jobs whose convolution was dropped
     (a model re-packed from scratch) or already decided are pruned here."""
+    pending = False
     for k, ref in list(_TUNING.items()):
         cfgs = ref()
-        if cfgs is None or not isinstance(cfgs.get(k[1]), dict):
+        st = cfgs.get(k[1]) if cfgs is not None else None
+        if not isinstance(st, dict):
             del _TUNING[k]
-    return bool(_TUNING)
+        elif _CLOCK[0] - st.get("tick", 0) <= TUNE_STALE:      # a geometry that stopped coming (a one-off batch size): its job waits, nobody waits for it
+            pending = True
+    return pending
 
 
 def _stream_ptr():
@@ -390,6 +396,7 @@ class PackedConv:
     def _launch_tuned(self, key, d, args):
         L = _lib.lib()
         stream = _stream_ptr()
+        _CLOCK[0] += 1
         if FORCE_TILE_CFG is not None:
             d.tile_cfg = FORCE_TILE_CFG
             check(L.tedspad_conv_fwd_ex(*args, stream), "tedspad_conv_fwd(cfg %d)" % FORCE_TILE_CFG)
@@ -412,6 +419,7 @@ class PackedConv:
             st = {"cands": [c for c in range(0, L.tedspad_conv_num_tile_cfgs() + 1) if c not in SKIP_TILE_CFGS], "pos": 0, "rep": 0, "rec": {}}
             self._cfgs[key] = st
             _TUNING[(id(self._cfgs), key)] = weakref.ref(self._cfgs)
+        st["tick"] = _CLOCK[0]
         while True:
             cfg = st["cands"][st["pos"]]
             d.tile_cfg = cfg

@@ -676,3 +676,21 @@ def test_hand_counted_waits_are_race_free_over_many_launches():
         repeat(lambda: spt.conv(xtp, variant=variant).buf, n=30)
     for variant in (2, 6):                               # ... with the whole pool fused, on 32x32x16 and on 16x16x32 MFMAs
         repeat(lambda: spt.conv_pool(xtp, variant=variant).buf, n=30)
+
+
+def test_a_tuning_job_that_stopped_coming_no_longer_holds_the_streams(monkeypatch):
+    """`engine.tuning_pending()` keeps multi-stream callers (bench.py's forwards, the weight-gradient side stream) on one stream while a tile
+    is being timed. A geometry that is seen once and never again (a one-off batch size) would hold them there for the rest of the run: its job
+    stops counting once TUNE_STALE further conv launches went by without it."""
+    from ted_spad_amd import engine as E
+    monkeypatch.setattr(E, "_TUNING", {})
+    monkeypatch.setattr(E, "AUTOTUNE", True)
+    wgt = synth_tensor(41, "tw", (64, 64, 1, 3, 3), -0.1, 0.1)
+    pc = E.PackedConv(wgt, torch.ones(64), torch.zeros(64), dtype="f16", device="cuda")
+    x = E.Act(synth_tensor(41, "tx", (1, 1, 9, 13, 64), -1, 1).to(torch.float16).cuda(), 64)
+    pc(x, pads=(0, 1, 1))
+    assert E.tuning_pending()
+    monkeypatch.setattr(E, "_CLOCK", [E._CLOCK[0] + E.TUNE_STALE + 1])
+    assert not E.tuning_pending()
+    pc(x, pads=(0, 1, 1))                                     # it comes again: counted again
+    assert E.tuning_pending()
