@@ -586,19 +586,23 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
     }
     const int cc = tid & 7, r0 = tid >> 3;     // 8 chunks of 8 channels per pixel, NT/8 pixels per pass
     const int nch = cc * 8;
-    if (nch >= p.Cout) return;
-    float sc[8], sf[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
+    const bool chan_ok = nch < p.Cout;
+    float sc[8], sf[8], s1[8], s2[8];          // s1 / s2: batch statistics of the pre-activation (train-mode BatchNorm behind the stem: the UNet's first conv,
+#pragma unroll                                 // I3Res50's stem), as the generic epilogue gathers them; a tile lies inside one sample, hence inside one statistics group
+    for (int i = 0; i < 8; ++i) { sc[i] = chan_ok ? p.scale[nch + i] : 0.f; sf[i] = chan_ok ? p.shift[nch + i] : 0.f; s1[i] = 0.f; s2[i] = 0.f; }
     for (int r = r0; r < 256 * FR; r += NT / 8) {
         const int tf = to + (r >> 8), ho = ho0 + (r & 255) / TW, wo = wo0 + (r & 255) % TW;
-        if (tf >= p.To || ho >= p.Ho || wo >= p.Wo) continue;
+        if (!chan_ok || tf >= p.To || ho >= p.Ho || wo >= p.Wo) continue;
         const size_t m = (((size_t)n * p.To + tf) * p.Ho + ho) * p.Wo + wo;
         const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch);
         const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + nch + 4);
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+        if (p.stats) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+        }
         if (p.res) {
             float rr[8];
             unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + m * p.ldres + nch), rr);
@@ -610,6 +614,26 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
         }
         *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+    }
+    if (p.stats) {   // block-level reduction over the NT / 8 row groups, then one atomic per channel (workgroup-uniform branch)
+        constexpr int RG = NT / 8;
+        __syncthreads();
+        float *red = stg;   // [2][RG][64]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[r0 * 64 + cc * 8 + i] = s1[i];
+            red[(RG + r0) * 64 + cc * 8 + i] = s2[i];
+        }
+        __syncthreads();
+        const size_t mfirst = ((size_t)n * p.To + to) * p.Ho * p.Wo;
+        const size_t sgrp = p.stats_rows ? mfirst / (size_t)p.stats_rows : 0;
+        float *so = p.stats + sgrp * 2 * p.stats_ld;
+        if (tid < 64 && tid < p.Cout) {
+            float sa = 0.f, sb = 0.f;
+            for (int r = 0; r < RG; ++r) { sa += red[r * 64 + tid]; sb += red[(RG + r) * 64 + tid]; }
+            atomicAdd(so + tid, sa);
+            atomicAdd(so + p.stats_ld + tid, sb);
+        }
     }
 }
 
@@ -903,7 +927,9 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     }
     if (cfg == 9 || cfg == 20 || cfg == 21 || (cfg >= 29 && cfg <= 31)) {
         TS_REQUIRE(d->cin == 8, "tedspad_conv_fwd: tile_cfg 9 (halo-direct) needs cin == 8");
-        TS_REQUIRE(!extras, "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask/stats/strided-output epilogue");
+        TS_REQUIRE(!(p.mask || p.ostrided || p.y32), "tedspad_conv_fwd_ex: tile_cfg 9 (halo-direct) has no mask / strided-output / fp32-output epilogue (batch statistics: yes)");
+        TS_REQUIRE(!p.stats || !p.stats_rows || ((long)d->to * d->ho * d->wo > 0 && p.stats_rows % ((long)d->to * d->ho * d->wo) == 0),
+                   "tedspad_conv_fwd_ex: halo-direct tiles need statistics groups of whole samples");
     }
     return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, d->cin, s) : launch_cfg<BF16>(cfg, p, d->n, d->cin, s);
 }

@@ -262,3 +262,43 @@ def test_batch_chunking_matches_single_launch(monkeypatch):
     with pytest.raises(Exception):
         E.batch_chunk(2, [1 << 31], E.MAX_ELEMS)          # a single sample that does not fit fails loudly
 
+
+
+@pytest.mark.parametrize("k,pads,pair", [((1, 3, 3), (0, 1, 1), False), ((5, 7, 7), (2, 3, 3), True)])
+def test_stem_halo_tiles_gather_batch_statistics(k, pads, pair):
+    """The halo-direct stem tiles (tile_cfg 9 / 20 / 21 / 29-31: cin = 8 records) with the batch-statistics epilogue a train-mode BatchNorm
+    behind them needs -- the UNet's first conv (3 -> 64, 3 x 3) and I3Res50's stem in pixel-pair form -- against a generic tile on the same
+    launch: outputs, plain sums and sums per statistics group (three groups of two samples)."""
+    from ted_spad_amd import _lib, engine as E
+    n, t, h, w = 6, (4 if pair else 1), 20, 24
+    wgt = (synth_tensor(51, "shw", (64, 3) + k, -1, 1) * 0.1).to(H).float()
+    if pair:
+        pc = E.PackedConv(wgt, None, None, stride=(2, 2, 2), dtype="f16", device="cuda", pair_w=3)
+        x = E.clip_to_act(synth_tensor(51, "shx", (n, 3, t, h, w), -1, 1).cuda(), cpad=4, dtype="f16")
+        kw = dict(pads=(2, 3, pc.pair_pw), pads_back=(2, 3, 1))
+    else:
+        pc = E.PackedConv(wgt, None, None, dtype="f16", device="cuda")
+        xb = torch.zeros((n, t, h, w, 8), dtype=H, device="cuda")
+        xb[..., :3] = synth_tensor(51, "shx", (n, t, h, w, 3), -1, 1).to(H).cuda()
+        x = E.Act(xb, 8)
+        kw = dict(pads=pads)
+    got = {}
+    try:
+        for cfg in (5, 9, 20, 21, 29, 30, 31):
+            E.FORCE_TILE_CFG = cfg
+            try:
+                st, sg = torch.zeros((2, pc.cpad), device="cuda"), torch.zeros((3, 2, pc.cpad), device="cuda")
+                y = pc(x, stats=st, **kw)
+                pc(x, stats=sg, **kw)                          # (G, 2, ld): three groups of two samples
+                got[cfg] = (y.buf.float().cpu(), st.cpu(), sg.cpu())
+            except _lib.TedSpadHipError:
+                continue
+    finally:
+        E.FORCE_TILE_CFG = None
+    assert 5 in got and len(got) >= 3, sorted(got)
+    ref = got[5]
+    for cfg, (y, st, sg) in got.items():
+        assert bool(((y - ref[0]).abs() <= 2.0 ** -10 * ref[0].abs() + 1e-4).all()), cfg
+        assert rel_l2(st, ref[1]) < 1e-5, cfg
+        assert rel_l2(sg, ref[2]) < 1e-5, cfg
+        assert rel_l2(sg.sum(0), st) < 1e-5, cfg
