@@ -35,7 +35,7 @@ for name, fn in (('phase1', step.step_fa), ('phase2', step.step_ft)):
         print('  -- %s: %d launches (us): %s' % (pat, len(evs), ' '.join('%.0f' % e.device_time for e in evs)))
         if os.environ.get('PROFILE_NAMES'):
             import re
-            for e in evs[:int(os.environ['PROFILE_NAMES'])]:
+            for e in [e for e in evs if e.device_time >= float(os.environ.get('PROFILE_MIN_US', '0'))][:int(os.environ['PROFILE_NAMES'])]:
                 print('     %6.0f us  %s' % (e.device_time, re.sub(r'tedspad::|\(anonymous namespace\)::|void ', '', e.name)[:110]))
     print('  -- by launch count')
     for e in sorted(kern, key=lambda e: -e.count)[:45]: print('   %-90s n=%4d  %8.2f ms' % (e.key[:90], e.count, e.device_time_total/1e3))
