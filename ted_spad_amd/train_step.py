@@ -75,6 +75,7 @@ class AnonymizerTrainStep:
         # nothing in that sequence moves any more -- weight images are rewritten in place, the arena hands out the same slices, gradients are bucket views
         self.use_graph = os.environ.get("TEDSPAD_TRAIN_GRAPH", "0") == "1"
         self._g2, self._g2_warm = None, 0
+        self.lazy_losses = os.environ.get("TEDSPAD_TRAIN_LAZY_LOSSES", "0") == "1"
         from .unetpp import UnetPlusPlus
         self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
         self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
@@ -107,6 +108,11 @@ class AnonymizerTrainStep:
         loss_ce = self.ce(heads[0][0], labels)                        # :107
         loss_trip = self.trip(heads[0][1], heads[1][1], heads[2][1])  # :115
         return loss_ce + p.temporal_loss_weight * loss_trip, loss_ce, loss_trip
+
+    def _val(self, t):
+        """A loss for the returned dict: a Python float (one device sync per step, as the reference's `loss.item()` logging has), or -- `lazy_losses` --
+        the detached 0-d tensor: the caller converts when it logs, and the next step's launches are queued behind this step's without a bubble."""
+        return t.detach() if self.lazy_losses else float(t.detach())
 
     def _scaled(self, g):
         return g if (g is None or self.loss_scale == 1.0) else g * self.loss_scale
@@ -187,8 +193,8 @@ class AnonymizerTrainStep:
         if ok:
             self.opt_fa.step()                                        # :123
         self.iteration += 1
-        return dict(phase=1, loss_fa=float(loss_fa.detach()), loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
-                    loss_fb=None if loss_fb is None else float(loss_fb.detach()), skipped=not ok)
+        return dict(phase=1, loss_fa=self._val(loss_fa), loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
+                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=not ok)
 
     def _three_clips(self, clips, labels, mode, drop_masks):
         """Forward + loss + backward of ft ('train' / 'frozen') on the three clips of an iteration (:169-175 / action :64-84). The reference
@@ -284,8 +290,8 @@ class AnonymizerTrainStep:
         if ok:
             self.opt_ft.step()                                        # :193
         self.iteration += 1
-        return dict(phase=2, loss_ft=float(loss_ft.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
-                    loss_fb=None if loss_fb is None else float(loss_fb.detach()), skipped=not ok)
+        return dict(phase=2, loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
+                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=not ok)
 
     def step_action(self, inputs_video, labels, drop_masks=None):
         """One iteration of action_training/train_anonymized_action.py:43-94 (`--temporal_loss trip`, cross-entropy): the
@@ -309,7 +315,7 @@ class AnonymizerTrainStep:
         if ok:
             self.opt_ft.step()                                        # :87
         self.iteration += 1
-        return dict(phase="action", loss=float(loss.detach()), loss_ce=float(loss_ce.detach()), loss_temporal=float(loss_trip.detach()),
+        return dict(phase="action", loss=self._val(loss), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
                     skipped=not ok)
 
     def step(self, inputs_video, labels, inputs_vispr=None):

@@ -395,3 +395,24 @@ def test_alternating_iterations_train_and_the_in_place_refresh_matches_rebuilt_i
     b, _ = run(False)
     for (a1, a2), (b1, b2) in zip(a, b):
         assert abs(a1 - b1) <= 0.05 * abs(b1) + 1e-3 and abs(a2 - b2) <= 0.05 * abs(b2) + 1e-3, (a, b)
+
+
+def test_lazy_losses_are_the_same_numbers_without_the_sync(monkeypatch):
+    """`lazy_losses`: the step hands back 0-d device tensors instead of Python floats (no device sync per phase); same values (phase 2 runs after
+    phase 1's Adam step: equal up to the run-to-run noise of the atomically accumulated gradients)."""
+    from ted_spad_amd import engine as E
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    monkeypatch.setattr(E, "AUTOTUNE", False)
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64)).cuda()
+    labels = torch.tensor([5, 77, 101, 1]).cuda()
+    outs = []
+    for lazy in (False, True):
+        fa, ft, _, _ = _models()
+        step = AnonymizerTrainStep(fa, ft)
+        step.lazy_losses = lazy
+        r1, r2 = step.step_fa(video, labels), step.step_ft(video, labels)
+        if lazy:
+            assert all(torch.is_tensor(r[k]) and r[k].dim() == 0 and r[k].is_cuda for r in (r1, r2) for k in ("loss_ft", "loss_ce", "loss_temporal"))
+        outs.append([float(r1["loss_fa"]), float(r1["loss_ft"]), float(r2["loss_ft"]), float(r2["loss_temporal"])])
+    for a, b in zip(*outs):
+        assert abs(a - b) <= 5e-2 * abs(a) + 1e-3, outs
