@@ -54,7 +54,7 @@ class ZeroArena:
         for d in shape:
             n *= int(d)
         n4 = (n + 3) // 4 * 4                                   # keep 16-byte alignment
-        if os.environ.get('TEDSPAD_NO_ARENA'):
+        if NO_ARENA:
             return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
         if self.buf is None or self.buf.device != torch.device(device):
             self.reset(device)
@@ -75,6 +75,7 @@ ARENA = ZeroArena()
 # the reference's autocast region holds it (train_anonymizer.py:78,151), instead of fp32: 2 of the 6-8 bytes per element each of those passes moves
 TRAIN_Z16 = os.environ.get("TEDSPAD_TRAIN_Z16", "1") != "0"
 DB_SLOTS = 64           # rows of the conv-bias gradient accumulator of tedspad_bn_bwd_apply
+NO_ARENA = bool(os.environ.get("TEDSPAD_NO_ARENA"))       # every request its own torch.zeros (debugging)
 REFRESH_IN_PLACE = os.environ.get("TEDSPAD_WEIGHT_REFRESH", "1") != "0"     # 0: every stale image rebuilt by the lazy path (A/B timing)
 IMAGES_GEN = 0          # bumped whenever a ConvLayer builds a NEW kernel-form image (WeightRefresh then rebuilds its job tables)
 _PENDING_COUNT = {}     # id(tensor) -> [tensor, increments]
