@@ -1,6 +1,7 @@
 """-m gpu: the training-path kernels (data gradient, weight gradient, train-mode BatchNorm, pooling /
 upsample backward) against torch CPU autograd of the reference's own ops (fp32/fp64) on seeded inputs
 pre-rounded to f16, so only summation order and output rounding differ."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -302,3 +303,26 @@ def test_stem_halo_tiles_gather_batch_statistics(k, pads, pair):
         assert rel_l2(st, ref[1]) < 1e-5, cfg
         assert rel_l2(sg, ref[2]) < 1e-5, cfg
         assert rel_l2(sg.sum(0), st) < 1e-5, cfg
+
+
+def test_three_tile_weight_gradient_on_seeded_random_geometries():
+    """conv_wgrad3_kernel (every 1 x 3 x 3 stride-1 'same' conv with whole 64-channel chunks) against torch autograd on seeded random shapes: rows
+    narrower and wider than a 64-pixel step, single rows and columns, several frames per sample (independent images), ragged cout, 1-3 ci chunks,
+    pixel counts that end inside a step and inside a split."""
+    from ted_spad_amd import train_engine as TE
+    rng = np.random.RandomState(4321)
+    for case in range(8):
+        n, t = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+        h, w = int(rng.choice([1, 2, 5, 9, 17])), int(rng.choice([1, 3, 7, 20, 63, 64, 65, 70, 130]))
+        cin, cout = 64 * int(rng.randint(1, 4)), int(rng.choice([8, 24, 64, 72, 136]))
+        x = synth_tensor(60 + case, "fx", (n, cin, t, h, w), -1, 1).to(H).float().requires_grad_()
+        wt = (synth_tensor(60 + case, "fw", (cout, cin, 1, 3, 3), -1, 1) * (1.0 / (9 * cin)) ** 0.5).to(H).float().requires_grad_()
+        y = F.conv3d(x, wt, padding=(0, 1, 1))
+        dy = synth_tensor(60 + case, "fdy", tuple(y.shape), -1, 1).to(H).float()
+        y.backward(dy)
+        wp = torch.nn.Parameter(wt.detach().clone().cuda())
+        layer = TE.ConvLayer(wp, None, (1, 1, 1), (0, 1, 1))
+        TE.ARENA.reset("cuda")
+        layer.wgrad(cl(x.detach()), cl(dy))
+        layer.flush_grad()
+        assert rel_l2(wp.grad.cpu(), wt.grad) < 1e-3, (case, n, t, h, w, cin, cout)
