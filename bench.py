@@ -146,8 +146,14 @@ def main():
 
     if args.train:
         assert world == 1 and not dry, "--train is a single-GPU measurement"
-        print(json.dumps({"metric": "cfg3 training iteration", "unit": "ms", "n_gpus": 1, "higher_is_better": False, "dtype": args.dtype,
-                          "data": "synthetic", ("train_cfg3" if args.train_hw == 112 else "train_cfg5_rank"): bench_train(dev, steps=max(args.steps, 5), hw=args.train_hw)}))
+        tr = bench_train(dev, steps=max(args.steps, 5), hw=args.train_hw)
+        fl = (args.train_hw / 112.0) ** 2 * (TRAIN_TFLOP["phase1"] + TRAIN_TFLOP["phase2"])       # algorithmic TFLOP of one iteration (both phases)
+        ach = fl / tr["iteration_ms"] * 1e3
+        print(json.dumps({"metric": "cfg3 training iteration" if args.train_hw == 112 else "cfg5 per-rank training iteration", "value": tr["iteration_ms"], "unit": "ms",
+                          "n_gpus": 1, "higher_is_better": False, "dtype": args.dtype, "data": "synthetic",
+                          "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                       "kernel": "both phases of one iteration, alternating (conv / linear MACs x 2 of BASELINE.md section 2 over iteration_ms)"},
+                          ("train_cfg3" if args.train_hw == 112 else "train_cfg5_rank"): tr}))
         return
 
     from ted_spad_amd import sharding
