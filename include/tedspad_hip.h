@@ -163,6 +163,28 @@ int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const
                                const void *w3p, const float *scale3, const float *shift3, int32_t cout3, const void *residual, int32_t ldres,
                                const void *x2, int32_t ldx2, const float *scale_d, void *y, int32_t ldy, int32_t relu, int32_t variant, void *stream);
 
+/* WHOLE bottleneck of a plain I3Res50 layer3 block (csrc/conv_bneck_frame.hip) -- replaces the `Bottleneck.forward` of
+ * aux_code/models/large_i3d.py:61-84 for blocks without `downsample` on 14 x 14 frames (cin = 1024, cmid = 256):
+ *     y = act( bn3(conv3( relu(bn2(conv2( relu(bn1(conv1(x))) ))) )) + x )
+ * conv1 1x1x1 (steps1 = cin / 32) or 3x1x1 'same' on TWO-frame clips in its folded form (steps1 = 2 * cin / 32, t == 2: output frame f =
+ * Wa . x[frame 0] + Wb . x[frame 1] with (Wa, Wb) = (W[:,:,1], W[:,:,2]) for f = 0 and (W[:,:,0], W[:,:,1]) for f = 1); conv2 1x3x3 stride 1 pad 1;
+ * conv3 1x1x1. One workgroup owns a whole frame; both cmid-channel tensors stay in LDS. x / y: (n, t, h, w, cin) 16-bit channels-last with pixel
+ * strides ldx / ldy (y must not alias x).
+ * Weights are streams of 16 KB SLOT IMAGES, one per 32-deep K step and 256 output channels: for a matrix Wm[rows][K], row block rb, K step ks
+ *     img[wc 0..3][j 0..3][lane 0..63][kk 0..7] = Wm[256 rb + 64 wc + r(j, lane & 15)][32 ks + 8 (lane >> 4) + kk]
+ * (lane-linear v_mfma_f32_16x16x32 fragments) with r(j, i) = 16 (i >> 2) + 4 j + (i & 3) for conv1 / conv2 (a lane ends with 16 consecutive channels of a pixel:
+ * the LDS rows of the mid tensors) and r(j, i) = 4 i + j for conv3 (weights as the B operand: consecutive lanes end with consecutive channels, so residual
+ * loads and stores are fully coalesced).
+ *   w1_even / w1_odd: steps1 images of conv1 for even / odd frames (the same buffer twice for the 1x1x1 form), K = ci (folded form: frame * cin + ci);
+ *   w23: 72 images of conv2 (K = (dh*3 + dw) * cmid + ci), 4 x 8 images of conv3 (row block = 256 output channels, K = ci) and 2 padding images (the ring
+ *        fetches two steps past the end).
+ * scale / shift: the three folded BatchNorms (cmid, cmid, cin floats, 16-byte aligned). ldy must equal ldx; relu must be non-zero (large_i3d.py:84). */
+int32_t tedspad_bneck_frame_fwd(const void *x, int32_t ldx, void *y, int32_t ldy, int32_t n, int32_t t, int32_t h, int32_t w, int32_t cin, int32_t cmid,
+                                const void *w1_even, const void *w1_odd, int32_t steps1, const void *w23, const float *scale1, const float *shift1,
+                                const float *scale2, const float *shift2, const float *scale3, const float *shift3, int32_t relu, int32_t dtype,
+                                void *stream);
+int32_t tedspad_bneck_frame_lds_bytes(void);   /* dynamic LDS of the kernel above (one workgroup per CU) */
+
 /* Persistent Cin = 3 stem (csrc/conv_stem_pt.hip): conv1 5x7x7 / stride 2 / pad (2,3,3) + bn1 + ReLU of large_i3d.py:133-137,229-231
  * with the temporal half of maxpool1 (MaxPool3d((2,3,3), 2), large_i3d.py:138,232) fused: y[n][to/2][ho][wo][64] =
  * max over the output frame pair (to, to+1) of act(conv * scale + shift); the spatial 3x3 / 2 half of the pool is a
@@ -306,7 +328,8 @@ int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const void *z, int3
 /* dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M); optionally dres = g (gradient of a fused residual input); y == NULL with relu as above.
  * dbias ([dbias_slots][C] floats, pre-zeroed, may be NULL): the rows together += sum over pixels of dz -- the gradient of the bias of the conv
  * in front of the BatchNorm (nn.Conv2d(bias=True) + BatchNorm2d in unet_parts.py DoubleConv), gathered here instead of by another pass over dz;
- * workgroup b adds into row b % dbias_slots (several rows: thousands of atomics on one address serialise), the caller sums the rows. */
+ * workgroup b adds into row b % dbias_slots (several rows: thousands of atomics on one address serialise), the caller sums the rows.
+ * C <= 3520 (the kernel keeps 16 bytes of folded terms per channel in LDS). */
 int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd,
                              const float *gamma, const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres,
                              float *dbias, int32_t dbias_slots, int64_t pixels, int32_t C, int32_t lddy, int32_t ldy, int32_t ldz, int32_t lddz,

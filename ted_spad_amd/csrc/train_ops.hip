@@ -340,9 +340,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
 #pragma unroll
             for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = db[i];
             __syncthreads();
-            const int t = threadIdx.x;
-            if (t < C8 * 8) {
-                const int c8 = t >> 3, i = t & 7;
+            for (int ch = threadIdx.x; ch < C8 * 8; ch += 256) {      // C8 * 8 can exceed the 256 threads (C = 512 ... 2048): every channel gets its turn
+                const int c8 = ch >> 3, i = ch & 7;
                 float a = 0.f;
                 for (int u = c8; u < 256; u += C8) a += red[u][i];
                 atomicAdd(dbias + c8 * 8 + i, a);
@@ -582,7 +581,7 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
 extern "C" int32_t tedspad_bn_bwd_apply(const void *dy, const void *y, const void *z, int32_t zdtype, const float *mean, const float *invstd, const float *gamma,
                                         const float *beta, const float *sums, int32_t sums_ld, void *dz, void *dres, float *dbias, int32_t dbias_slots, int64_t pixels, int32_t C, int32_t lddy,
                                         int32_t ldy, int32_t ldz, int32_t lddz, int32_t lddres, int32_t relu, int32_t groups, int32_t dtype, void *stream) {
-    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz) && (!dbias || dbias_slots >= 1) && C <= 8192,
+    TS_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || beta) && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz) && (!dbias || dbias_slots >= 1) && (size_t)C * 16 + 9216 <= 65536,   // [4][C] fp32 terms + the 9 KB reduction image: the default 64 KB dynamic-LDS limit (C <= 3520)
                "tedspad_bn_bwd_apply: bad arguments (relu needs y, or beta to recompute the mask)");
     hipStream_t s = (hipStream_t)stream;
 #define BWD_APPLY(TT, DD)                                                                                                                            \

@@ -25,6 +25,7 @@ DEFAULT_DTYPE = "f16"  # DESIGN.md "precision": bf16 operands cannot meet the 1e
 # calls of a conv on a new geometry the tile configurations of the kernel take turns, timed in context with
 # HIP events, and the fastest is kept (PackedConv._launch_tuned). Same arithmetic for every configuration
 # (K order per output is fixed), so results do not depend on the choice. Off inside hipGraph capture.
+BNECK_FRAME = os.environ.get("TEDSPAD_BNECK_FRAME", "1") != "0"   # layer3's plain blocks as one launch per block, a workgroup per 14 x 14 frame (BneckFrame); 0: three launches (A/B)
 BNECK_TAIL = os.environ.get("TEDSPAD_BNECK_TAIL", "1") != "0"   # layer1: conv2 -> conv3 (+ residual / downsample) in one launch (BneckTail); 0: separate launches (A/B)
 BNECK_TAIL128 = os.environ.get("TEDSPAD_BNECK_TAIL128", "1") != "0"   # layer2's plain blocks (128 mid channels) on the fused tail as well; 0: conv2 + conv3 launches (A/B)
 BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # layer1's last block: the fused tail with maxpool2 inside; 0: conv2 + (conv3 + pool) launches (A/B)
@@ -713,6 +714,73 @@ class BneckTail:
                                                 self.scale_d.data_ptr() if self.dual else None, out.ptr, out.ld, int(relu),
                                                 self.VARIANT | (4 if pool_t2 else 0), _stream_ptr()),
               "tedspad_bneck_tail_fwd")
+        return out
+
+
+class BneckFrame:
+    """A whole plain bottleneck of I3Res50's layer3 -- conv1 (1x1x1 | 3x1x1) + bn1 + ReLU -> conv2 (1x3x3) + bn2 + ReLU -> conv3 (1x1x1) + bn3 + residual +
+    ReLU (large_i3d.py:61-84, blocks without `downsample`) -- as ONE launch (csrc/conv_bneck_frame.hip): a workgroup owns a whole 14 x 14 frame, both
+    256-channel tensors between the convolutions stay in LDS. The weights are packed here into the kernel's stream of 16 KB slot images
+    (include/tedspad_hip.h, tedspad_bneck_frame_fwd)."""
+
+    def __init__(self, w1: torch.Tensor, s1, b1, w2: torch.Tensor, s2, b2, w3: torch.Tensor, s3, b3, dtype: str = DEFAULT_DTYPE, device="cuda"):
+        assert self.supported(w1, w2, w3)
+        dev = torch.device(device)
+        self.torch_dtype, self.dtype_code = DTYPES[dtype]
+        self.cin, self.cmid = int(w1.shape[1]), int(w1.shape[0])
+        f = lambda w: w.detach().to(dev, torch.float32)
+        w1, w2, w3 = f(w1), f(w2), f(w3)
+        self.temporal = w1.shape[2] == 3
+        if self.temporal:       # folded two-frame form (TPairConv): frame 0 = W1 . x0 + W2 . x1, frame 1 = W0 . x0 + W1 . x1
+            m1 = [torch.cat([w1[:, :, 1, 0, 0], w1[:, :, 2, 0, 0]], dim=1), torch.cat([w1[:, :, 0, 0, 0], w1[:, :, 1, 0, 0]], dim=1)]
+        else:
+            m1 = [w1[:, :, 0, 0, 0]]
+        self.w1 = [self.slot_images(m).to(self.torch_dtype).contiguous() for m in m1]
+        m2 = w2[:, :, 0].permute(0, 2, 3, 1).reshape(self.cmid, 9 * self.cmid)          # K = (dh*3 + dw) * cmid + ci
+        pad = torch.zeros(2, 4, 4, 64, 8, device=dev)         # the kernel's ring keeps fetching two steps past the end
+        self.w23 = torch.cat([self.slot_images(m2), self.slot_images(w3[:, :, 0, 0, 0], cols=True), pad]).to(self.torch_dtype).contiguous()
+        self.steps1 = self.w1[0].shape[0]
+        vec = lambda v: v.detach().to(dev, torch.float32).contiguous().clone()
+        self.bn = [vec(v) for v in (s1, b1, s2, b2, s3, b3)]
+
+    @staticmethod
+    def slot_images(wm: torch.Tensor, cols: bool = False) -> torch.Tensor:
+        """(rows, K) matrix -> (rows / 256 * K / 32, 4, 4, 64, 8): slot image of (row block rb, K step ks) at index rb * (K / 32) + ks;
+        img[wc][j][lane][kk] = wm[256 rb + 64 wc + r(j, lane & 15)][32 ks + 8 (lane >> 4) + kk] with r(j, i) = 16 (i >> 2) + 4 j + (i & 3) (weights as the MFMA A
+        operand: a lane ends with 16 consecutive channels of one pixel) or, cols=True, r(j, i) = 4 i + j (weights as the B operand, stage 3: a lane ends with 4
+        consecutive channels of 4 pixels, consecutive lanes with consecutive channels)."""
+        rows, K = wm.shape
+        assert rows % 256 == 0 and K % 32 == 0
+        dev = wm.device
+        lane = torch.arange(64, device=dev)
+        i, kg = lane & 15, lane >> 4
+        j = torch.arange(4, device=dev).view(1, 4, 1)
+        rin = (4 * i).view(1, 1, 64) + j if cols else 4 * j + (16 * (i >> 2) + (i & 3)).view(1, 1, 64)
+        r = 64 * torch.arange(4, device=dev).view(4, 1, 1) + rin                          # (4,4,64)
+        kk = 8 * kg.view(64, 1) + torch.arange(8, device=dev).view(1, 8)                  # (64,8)
+        w4 = wm.reshape(rows // 256, 256, K // 32, 32).permute(0, 2, 1, 3)              # (rb, ks, 256, 32)
+        g = w4[:, :, r]                                                                  # (rb, ks, 4, 4, 64, 32)
+        img = torch.gather(g, 5, kk.view(1, 1, 1, 1, 64, 8).expand(g.shape[0], g.shape[1], 4, 4, 64, 8))
+        return img.reshape(-1, 4, 4, 64, 8)
+
+    @staticmethod
+    def supported(w1, w2, w3) -> bool:
+        return (tuple(w1.shape[:2]) == (256, 1024) and tuple(w1.shape[2:]) in ((1, 1, 1), (3, 1, 1)) and tuple(w2.shape) == (256, 256, 1, 3, 3) and
+                tuple(w3.shape) == (1024, 256, 1, 1, 1))
+
+    def applies(self, x: Act) -> bool:
+        n, t, h, w = x.dims
+        return (BNECK_FRAME and (h, w) == (14, 14) and x.c == self.cin and x.coff == 0 and x.ld == self.cin and (not self.temporal or t == 2) and x.buf.dtype == self.torch_dtype and
+                n * t * h * w * x.ld < MAX_ELEMS)
+
+    def __call__(self, x: Act, relu=True) -> Act:
+        assert self.applies(x)
+        n, t, h, w = x.dims
+        out = Act.empty(n, t, h, w, self.cin, self.torch_dtype, x.buf.device)
+        w1e, w1o = self.w1[0], self.w1[-1]
+        check(_lib.lib().tedspad_bneck_frame_fwd(x.ptr, x.ld, out.ptr, out.ld, n, t, h, w, self.cin, self.cmid, w1e.data_ptr(), w1o.data_ptr(), self.steps1,
+                                                 self.w23.data_ptr(), *[v.data_ptr() for v in self.bn], int(relu), self.dtype_code, _stream_ptr()),
+              "tedspad_bneck_frame_fwd")
         return out
 
 

@@ -88,6 +88,10 @@ class I3Res50(nn.Module):
                         s, b = self._bn_fold(blk.downsample[1])
                         P[p + "down"] = E.PackedConv(blk.downsample[0].weight, s, b, stride=(1, blk.stride, blk.stride),
                                                      dtype=self.compute_dtype, device=dev)
+                    if blk.downsample is None and E.BneckFrame.supported(blk.conv1.weight, blk.conv2.weight, blk.conv3.weight):
+                        # layer3's plain blocks: the whole bottleneck in one launch, a workgroup per 14 x 14 frame
+                        P[p + "frame"] = E.BneckFrame(blk.conv1.weight, *self._bn_fold(blk.bn1), blk.conv2.weight, *self._bn_fold(blk.bn2),
+                                                      blk.conv3.weight, *self._bn_fold(blk.bn3), dtype=self.compute_dtype, device=dev)
                     if li in (1, 2) and E.BneckTail.supported(P[p + "conv2"], blk.conv3.weight, blk.downsample[0].weight if blk.downsample is not None else None):
                         s3, b3 = self._bn_fold(blk.bn3)
                         if blk.downsample is not None and blk.stride == 1:
@@ -138,6 +142,10 @@ class I3Res50(nn.Module):
             layer = getattr(self, "layer%d" % li)
             for i, blk in enumerate(layer):
                 p = "layer%d.%d." % (li, i)
+                bf = P.get(p + "frame") if taps is None else None
+                if bf is not None and bf.applies(a):
+                    a = bf(a)                                             # conv1 -> conv2 -> conv3 + residual: only the block input and output touch HBM
+                    continue
                 tp = P.get(p + "conv1_tp") if taps is None else None
                 if tp is not None and tp.applies(a, (blk.temp_conv, 0, 0)):
                     h = tp(a)                                             # two frames: both outputs from ONE K = 2*cin GEMM, no products on zero padding

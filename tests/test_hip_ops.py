@@ -694,3 +694,60 @@ def test_a_tuning_job_that_stopped_coming_no_longer_holds_the_streams(monkeypatc
     assert not E.tuning_pending()
     pc(x, pads=(0, 1, 1))                                     # it comes again: counted again
     assert E.tuning_pending()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("temporal,n,t", [(False, 3, 2), (True, 3, 2), (False, 1, 5), (True, 1, 2)])
+def test_whole_bottleneck_per_frame_vs_oracle_and_unfused(temporal, n, t, dtype, monkeypatch):
+    """engine.BneckFrame (csrc/conv_bneck_frame.hip): conv1 (1x1x1 | 3x1x1) + bn1 + ReLU -> conv2 1x3x3 + bn2 + ReLU -> conv3 + bn3 + residual + ReLU of a plain
+    layer3 bottleneck (large_i3d.py:61-84 without `downsample`; 14 x 14 frames, 1024 -> 256 -> 1024) in ONE launch, one workgroup per frame --
+    against the oracle's three convolutions with both 256-channel tensors rounded where the unfused path stores them, and against the three
+    launches it replaces (conv1 in its folded two-frame form for the temporal block)."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    name = "bf%d%d%d" % (temporal, n, t)
+    kt = 3 if temporal else 1
+    x = _round(synth_tensor(11, name + "x", (n, t, 14, 14, 1024), -1, 1), tdt)
+    w1 = _round(synth_tensor(11, name + "w1", (256, 1024, kt, 1, 1), -1, 1) * (2.0 / (1024 * (2 if temporal else 1))) ** 0.5, tdt)
+    w2 = _round(synth_tensor(11, name + "w2", (256, 256, 1, 3, 3), -1, 1) * (2.0 / 2304) ** 0.5, tdt)
+    w3 = _round(synth_tensor(11, name + "w3", (1024, 256, 1, 1, 1), -1, 1) * (2.0 / 256) ** 0.5, tdt)
+    bn = [synth_tensor(11, name + "bn%d" % i, (c,), lo, hi) for i, (c, lo, hi) in enumerate(
+        [(256, 0.5, 1.5), (256, -0.3, 0.3), (256, 0.5, 1.5), (256, -0.3, 0.3), (1024, 0.5, 1.5), (1024, -0.3, 0.3)])]
+    pt = 1 if temporal else 0
+    m1 = _round(conv_cl(x, w1, bn[0], bn[1], (1, 1, 1), (pt, 0, 0), (pt, 0, 0), None, relu=True), tdt)
+    m2 = _round(conv_cl(m1, w2, bn[2], bn[3], (1, 1, 1), (0, 1, 1), (0, 1, 1), None, relu=True), tdt)
+    ref = conv_cl(m2, w3, bn[4], bn[5], (1, 1, 1), (0, 0, 0), (0, 0, 0), x, relu=True)
+    bf = E.BneckFrame(w1, bn[0], bn[1], w2, bn[2], bn[3], w3, bn[4], bn[5], dtype=dtype, device="cuda")
+    xa = E.Act(x.to(tdt).cuda(), 1024)
+    assert bf.applies(xa) and bf.temporal == temporal
+    got = bf(xa).buf.float().cpu()
+    assert got.shape == ref.shape
+    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
+    err = (got - ref).abs()
+    # a 16-bit intermediate that lands on the other side of a rounding boundary moves the output by more than its own rounding step
+    assert rel_l2(got, ref) < (5e-4 if dtype == "f16" else 4e-3), rel_l2(got, ref)
+    assert float(err.max()) < (0.02 if dtype == "f16" else 0.15), "max err %g" % float(err.max())
+    assert float((err <= ulp * ref.abs() + 2e-3).float().mean()) > (0.97 if dtype == "f16" else 0.5)
+    # ... and the three launches it replaces
+    monkeypatch.setattr(E, "FORCE_TILE_CFG", None)
+    cuda = lambda v: v.cuda()
+    if temporal:
+        h1 = E.TPairConv(w1, bn[0], bn[1], dtype=dtype, device="cuda")(xa)
+    else:
+        h1 = E.PackedConv(w1, cuda(bn[0]), cuda(bn[1]), dtype=dtype, device="cuda")(xa, pads=(0, 0, 0))
+    h2 = E.PackedConv(w2, cuda(bn[2]), cuda(bn[3]), dtype=dtype, device="cuda")(h1, pads=(0, 1, 1))
+    old = E.PackedConv(w3, cuda(bn[4]), cuda(bn[5]), dtype=dtype, device="cuda")(h2, residual=xa, relu=True).buf.float().cpu()
+    assert rel_l2(got, old) < (6e-4 if dtype == "f16" else 5e-3), rel_l2(got, old)
+    # a second launch gives the same bits (no race between the DMA rings and the fragment reads)
+    assert torch.equal(bf(xa).buf, bf(xa).buf)
+
+
+def test_whole_bottleneck_refuses_other_geometries():
+    from ted_spad_amd import engine as E
+    w1, w2, w3 = torch.zeros(256, 1024, 1, 1, 1), torch.zeros(256, 256, 1, 3, 3), torch.zeros(1024, 256, 1, 1, 1)
+    assert E.BneckFrame.supported(w1, w2, w3) and not E.BneckFrame.supported(torch.zeros(128, 512, 1, 1, 1), w2, w3)
+    one = torch.ones(256)
+    bf = E.BneckFrame(w1, one, one, w2, one, one, w3, torch.ones(1024), torch.ones(1024))
+    assert not bf.applies(E.Act(torch.zeros(1, 2, 7, 7, 1024, dtype=torch.float16, device="cuda"), 1024))
+    assert not bf.applies(E.Act(torch.zeros(1, 2, 14, 14, 512, dtype=torch.float16, device="cuda"), 512))

@@ -326,3 +326,51 @@ def test_three_tile_weight_gradient_on_seeded_random_geometries():
         layer.wgrad(cl(x.detach()), cl(dy))
         layer.flush_grad()
         assert rel_l2(wp.grad.cpu(), wt.grad) < 1e-3, (case, n, t, h, w, cin, cout)
+
+
+@pytest.mark.parametrize("C", [64, 256, 512, 1024, 2048, 2560])
+def test_bn_bwd_apply_bias_gradient_covers_every_channel(C):
+    """tedspad_bn_bwd_apply's `dbias` rows must add up to the plain per-channel sum of the dz it writes, for every channel -- including
+    C >= 512, where one workgroup's 256 threads own more than 256 (chunk, element) pairs (round-2 advisor finding: channels >= 256 were
+    dropped; the true bias gradient in front of a train-mode BatchNorm is ~0, so network-level tests could not see it). dz here is made
+    non-centred on purpose: sums[] are NOT the real channel sums, so sum(dz) is far from 0."""
+    import ctypes as Ct
+    from ted_spad_amd import _lib
+    L = _lib.lib()
+    px, slots = 777, 4
+    g = torch.Generator().manual_seed(C)
+    dy = torch.randn(px, C, generator=g).to(H).cuda()
+    z = torch.randn(px, C, generator=g).cuda()
+    mean = (0.1 * torch.randn(C, generator=g)).cuda()
+    invstd = (1.0 + 0.1 * torch.rand(C, generator=g)).cuda()
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = torch.zeros(C).cuda()
+    sums = torch.randn(2, C, generator=g).cuda() * 3.0
+    dz = torch.empty(px, C, dtype=H, device="cuda")
+    dbias = torch.zeros(slots, C, device="cuda")
+    stream = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.tedspad_bn_bwd_apply(dy.data_ptr(), None, z.data_ptr(), _lib.F32, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                sums.data_ptr(), C, dz.data_ptr(), None, dbias.data_ptr(), slots, px, C, C, C, C, C, 0, 0, 1, _lib.F16, stream)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    # the kernel's own formula in fp64 (include/tedspad_hip.h): dz = gamma*invstd*(g - sums[0]/M - xhat*sums[1]/M)
+    gd, zd = dy.double().cpu(), z.double().cpu()
+    ks = (gamma * invstd).double().cpu()
+    xhat = (zd - mean.double().cpu()) * invstd.double().cpu()
+    ref = ks * (gd - sums[0].double().cpu() / px - xhat * sums[1].double().cpu() / px)
+    assert rel_l2(dz.float().cpu().numpy(), ref.numpy()) < 2e-3
+    got = dbias.sum(0).double().cpu()
+    want = ref.sum(0)
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-3, "dbias misses channels: worst %s" % int((got - want).abs().argmax())
+    assert int((got == 0).sum()) == 0
+
+
+def test_bn_bwd_apply_rejects_channel_counts_beyond_its_lds():
+    import ctypes as Ct
+    from ted_spad_amd import _lib
+    t = torch.zeros(8, 4096, device="cuda")
+    h = t.to(H)
+    rc = _lib.lib().tedspad_bn_bwd_apply(h.data_ptr(), None, t.data_ptr(), _lib.F32, t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 4096,
+                                         h.data_ptr(), None, None, 1, 8, 4096, 4096, 4096, 4096, 4096, 0, 0, 1, _lib.F16,
+                                         Ct.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0
