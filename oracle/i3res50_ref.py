@@ -17,9 +17,10 @@ Everything is a function of a `state_dict` with the reference's key names
 (`conv1.weight`, `layer1.0.bn1.running_var`, ...), so the same weights drive the
 reference, this oracle and the HIP path.
 
-`q` is an optional rounding hook `q(tensor, kind)` used only by the precision-budget
-simulation (tests/test_precision_budget.py): kind in {"w", "act", "res"}; the default is
-the identity, i.e. the exact fp32 path.
+`q` is an optional rounding hook `q(tensor, kind)`, kind in {"w", "act", "res"}, used by the
+precision tests (tests/test_oracle_golden.py::test_gradient_sensitivity_to_f16_activations,
+tests/test_hip_ops.py bottleneck cases) to round where the device rounds; the default is the
+identity, i.e. the exact fp32 path.
 """
 import torch
 import torch.nn.functional as F

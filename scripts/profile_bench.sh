@@ -17,9 +17,9 @@ echo "write done"
 T=$(find $O/main -name '*kernel_trace.csv' | head -1); T1=$(find $O/one -name '*kernel_trace.csv' | head -1)
 F=$(find $O/fetch -name '*counter_collection.csv' | head -1); W=$(find $O/write -name '*counter_collection.csv' | head -1)
 python3 scripts/summarize_rocprof.py $T --fetch $F --write $W --batch 225 --forwards 20 --streams 2 --out $O/kernels.md \
-  --title "${ROUND:-r02}: bench.py cfg2 (largei3d, 225 clips/forward, 2 streams, f16) - the default bench command: kernel time and HBM traffic" > $O/summary.json
+  --title "${ROUND:-r03}: bench.py cfg2 (largei3d, 225 clips/forward, 2 streams, f16) - the default bench command: kernel time and HBM traffic" > $O/summary.json
 python3 scripts/summarize_rocprof.py $T1 --batch 225 --forwards 20 --streams 1 --out $O/kernels_1stream.md \
-  --title "${ROUND:-r02}: bench.py cfg2 --streams 1 (largei3d, 225 clips/forward, f16) - undisturbed per-kernel durations" > $O/summary_1stream.json
+  --title "${ROUND:-r03}: bench.py cfg2 --streams 1 (largei3d, 225 clips/forward, f16) - undisturbed per-kernel durations" > $O/summary_1stream.json
 cp $(find $O/main -name '*kernel_stats.csv' | head -1) $O/main_kernel_stats.csv
 cp $(find $O/one -name '*kernel_stats.csv' | head -1) $O/one_kernel_stats.csv
 # keep the merged scratch small: the raw traces are not needed once summarised

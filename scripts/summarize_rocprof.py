@@ -10,11 +10,14 @@ ap.add_argument('trace')
 ap.add_argument('--fetch'); ap.add_argument('--write')
 ap.add_argument('--batch', type=int, default=50)
 ap.add_argument('--forwards', type=int, default=45, help='forwards in the last step')
-ap.add_argument('--gflop-per-clip', type=float, default=32.829145088)
+ap.add_argument('--arch', default='largei3d', choices=['largei3d', 'i3d'], help='network of the run: sets the algorithmic GFLOP per clip (BASELINE.md §2)')
+ap.add_argument('--gflop-per-clip', type=float, default=None, help='override (default: by --arch)')
 ap.add_argument('--out', required=True)
 ap.add_argument('--title', default='bench.py cfg2, last timed step')
 ap.add_argument('--streams', type=int, default=1, help='HIP streams the bench used (kernels of different forwards overlap when > 1)')
 a = ap.parse_args()
+if a.gflop_per_clip is None:
+    a.gflop_per_clip = {'largei3d': 32.829145088, 'i3d': 55.575138304}[a.arch]      # conv MACs x 2 per 16 x 224^2 clip
 
 def short(n):
     n = re.sub(r'tedspad::\(anonymous namespace\)::', '', n)
@@ -22,7 +25,7 @@ def short(n):
     return n[:90]
 
 rows = [r for r in csv.DictReader(open(a.trace)) if 'tedspad' in r['Kernel_Name']]
-FIRST = ('to_channels_last', 'clip_to_tp')      # the first kernel of a forward (layout pass)
+FIRST = ('clip_to_channels_last', 'to_channels_last', 'clip_to_tp')      # the first kernel of a forward (layout pass)
 starts = [i for i, r in enumerate(rows) if any(f in r['Kernel_Name'] for f in FIRST)]
 first = starts[-a.forwards] if len(starts) >= a.forwards else starts[0]
 sel = rows[first:]

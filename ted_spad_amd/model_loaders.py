@@ -8,7 +8,7 @@ the networks running on MI355X HIP kernels (libtedspad_hip.so).
     mlp, wrapper_i3d                                                          model_loaders.py:235-268
 
 In scope: arch 'largei3d' and 'i3d' for ft, 'unet' for fa (the architectures whose source is part of the reference), 'unet++' for
-fa (segmentation_models_pytorch's UnetPlusPlus, the reference's default, restated: unetpp.py; inference) and 'r50' for fb
+fa (segmentation_models_pytorch's UnetPlusPlus, the reference's default, restated: unetpp.py; inference and training) and 'r50' for fb
 (torchvision's ResNet-50, restated: resnet50.py). 'r3d_18' and 'mvitv2' are third-party torchvision video models that are out of
 scope: they raise NotImplementedError rather than silently falling back.
 """

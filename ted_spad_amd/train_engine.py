@@ -454,27 +454,40 @@ class WeightRefresh:
         self.fold_tab, self.pack_tab = E.JobTable(fj, keep), E.JobTable(pj)
         self.gen, self.nfolds = IMAGES_GEN, len(self.folds)
 
-    def stale(self, layers) -> bool:
+    @staticmethod
+    def _ptrs(sig):
+        return tuple(None if v is None else v[0] for v in sig)
+
+    def _changes(self, layers):
+        """(anything stale, any tensor MOVED): a signature holds (data_ptr, version[, rev]) per tensor; a changed data_ptr (`p.data = ...`, `.to()`, a dtype cast,
+        an EMA swap) means the job tables' source addresses are dead, not just that the values changed."""
+        stale = moved = False
         for L in layers:
-            for ent in L._fwd.values():
-                if ent[0] != L._sig(ent[2], ent[3]):
-                    return True
-            for ent in L._dgrad.values():
-                if ent[0] != L._sig(ent[2], None):
-                    return True
+            for ent, new in [(e, L._sig(e[2], e[3])) for e in L._fwd.values()] + [(e, L._sig(e[2], None)) for e in L._dgrad.values()]:
+                if ent[0] != new:
+                    stale = True
+                    moved = moved or self._ptrs(ent[0]) != self._ptrs(new)
         for ent in self.folds.values():
-            if ent[0] != fold_sig(ent[3], ent[4]):
-                return True
-        return False
+            new = fold_sig(ent[3], ent[4])
+            if ent[0] != new:
+                stale = True
+                moved = moved or self._ptrs(ent[0]) != self._ptrs(new)
+        return stale, moved
+
+    def stale(self, layers) -> bool:
+        return self._changes(layers)[0]
 
     def run(self):
         if not REFRESH_IN_PLACE:
             return False
         layers = self.layers_fn()
-        if not layers or not self.stale(layers):
+        if not layers:
             return False
-        if self.gen != IMAGES_GEN or self.nfolds != len(self.folds) or self.pack_tab is None:
-            self._build(layers)
+        stale, moved = self._changes(layers)
+        if not stale:
+            return False
+        if moved or self.gen != IMAGES_GEN or self.nfolds != len(self.folds) or self.pack_tab is None:
+            self._build(layers)                 # (a moved parameter / BatchNorm tensor: the cached tables point at its old storage)
         dev = layers[0].weight.device
         self.fold_tab.launch(dev)
         self.pack_tab.launch(dev)
@@ -489,7 +502,12 @@ class WeightRefresh:
 
 
 def fold_sig(bn, conv_bias=None):
-    return tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((conv_bias,) if conv_bias is not None else ()))
+    """(data_ptr, version) of every tensor a fold reads. The running statistics are written by tedspad_bn_train_apply through raw pointers, which torch's version
+    counter does not see: `num_batches_tracked` (bumped once per train-mode forward, train_engine.bump_counter) stands in for them, so a frozen-flavour forward after
+    a train-mode one without an optimizer step (a skipped step under loss scaling, a no_grad train() pass) re-folds."""
+    sig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((conv_bias,) if conv_bias is not None else ()))
+    nbt = getattr(bn, "num_batches_tracked", None)
+    return sig + ((nbt.data_ptr(), nbt._version + int(getattr(nbt, "_tedspad_rev", 0))),) if nbt is not None else sig
 
 
 def cached_fold(folds: dict, bn, conv_bias=None):

@@ -1,17 +1,17 @@
 """state_dict templates (key names + shapes) of the three in-scope reference networks,
-taken from this package's own parameter-holder modules. CPU only."""
+taken from the package's parameter-holder modules. Test helper, CPU only."""
 
 
 def wrapper_i3d_template(num_classes=102):
-    from .model_loaders import wrapper_i3d
+    from ted_spad_amd.model_loaders import wrapper_i3d
     return wrapper_i3d(num_classes=num_classes).state_dict()
 
 
 def inception_i3d_template(num_classes=102):
-    from .inception_i3d import InceptionI3d
+    from ted_spad_amd.inception_i3d import InceptionI3d
     return InceptionI3d(num_classes=num_classes).state_dict()
 
 
 def unet_template():
-    from .unet import UNet
+    from ted_spad_amd.unet import UNet
     return UNet(3, 3).state_dict()

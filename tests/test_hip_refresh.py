@@ -106,6 +106,63 @@ def test_refreshed_images_equal_a_fresh_pack():
     assert TE.IMAGES_GEN == gen and R.run() is False           # the lazy path found every image fresh
 
 
+def test_refresh_follows_parameters_whose_storage_moved():
+    """A parameter or BatchNorm tensor that MOVED (`p.data = ...`, a `.to()` / dtype round trip, an EMA swap) since the job tables were built: the refresh must
+    read the new storage -- the cached tables hold the old addresses (possibly freed memory) -- and the images must equal a fresh pack of the new values
+    (round-2 advisor finding: the tables were reused and the stale images then stamped as fresh)."""
+    from ted_spad_amd import engine as E, train_engine as TE
+    items = _layers()[1:4]
+    folds = {}
+    layers = [L for L, _, _ in items]
+    for L, bn, xd in items:
+        x, dy = _acts(L, xd)
+        s, b = TE.cached_fold(folds, bn, L.bias)
+        L.forward(x); L.forward(x, scale=s, shift=b); L.dgrad(dy, x.dims[1:]); L.dgrad(dy, x.dims[1:], scale=s)
+    R = TE.WeightRefresh(lambda: layers, folds)
+    with torch.no_grad():
+        for L, _, _ in items:
+            L.weight.mul_(1.1)
+    assert R.run() is True                                    # tables built on the original storage
+    old = [(L.weight.data, bn.running_var.data) for L, bn, _ in items]
+    with torch.no_grad():
+        for i, (L, bn, _) in enumerate(items):
+            L.weight.data = (L.weight.data * 0.5 + 0.02 * (i + 1)).clone()       # new storage, new values
+            bn.running_var.data = (bn.running_var.data * 1.3).clone()
+    for w_old, v_old in old:                                   # what a stale table would read
+        w_old.fill_(float("nan")); v_old.fill_(float("nan"))
+    assert R.run() is True
+    torch.cuda.synchronize()
+    for L, bn, xd in items:
+        s_new, b_new = E.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, conv_bias=L.bias)
+        s, b = TE.cached_fold(folds, bn, L.bias)
+        assert torch.equal(s, s_new) and torch.equal(b, b_new)
+        w5 = L._w5()
+        for (s_none, b_none), (_, pc, sc, sh) in L._fwd.items():
+            fresh = E.PackedConv(w5, sc, (L.bias.detach() if L.bias is not None else None) if sh is None else sh, stride=L.stride, dtype=L.dtype, pair_w=L.pair_w)
+            assert torch.equal(pc.w, fresh.w) and not bool(torch.isnan(pc.w.float()).any()), "forward image read the old storage"
+        for (x_dims, dy_dims, s_none), (_, plan, sc) in L._dgrad.items():
+            pk, _ = L._pads_k(L.geom_conv())
+            fresh = TE.DgradPlan(w5.float(), sc, L.geom_conv().stride, pk, x_dims, dy_dims, L.dtype, pair_w=L.pair_w)
+            for (_, a, _, _), (_, f, _, _) in zip(plan.subs, fresh.subs):
+                assert torch.equal(a.w, f.w), "data-gradient image read the old storage"
+    assert R.run() is False
+
+
+def test_running_statistics_written_by_the_kernel_refold_the_frozen_flavour():
+    """tedspad_bn_train_apply updates running_mean / running_var through raw pointers (no version bump): the fold signature follows
+    num_batches_tracked instead, so an eval-flavour forward after a train-mode forward WITHOUT an optimizer step sees the new statistics."""
+    from ted_spad_amd import train_engine as TE
+    L, bn, xd = _layers()[1]
+    folds = {}
+    x, _ = _acts(L, xd)
+    s0 = TE.cached_fold(folds, bn)[0].clone()
+    TE.conv_bn_act_train(L, bn, x)
+    TE.flush_deferred()
+    torch.cuda.synchronize()
+    s1 = TE.cached_fold(folds, bn)[0]
+    assert not torch.equal(s0, s1), "the fold still holds the statistics from before the train-mode forward"
+
+
 def test_stale_fold_alone_marks_the_images_stale():
     """Only a BatchNorm changed (weights untouched): cached_fold re-folds into the same vectors and the data-gradient image that has the old
     scale folded in is rebuilt."""

@@ -9,7 +9,7 @@ import torch
 
 from conftest import rel_l2
 from oracle import extract_ref, i3res50_ref, inception_i3d_ref, losses_ref, unet_ref
-from ted_spad_amd import reference_shapes as RS
+import reference_shapes as RS
 from ted_spad_amd.synth import synth_clips, synth_state_dict, synth_tensor, synth_train_video
 
 SEED = 0
