@@ -106,6 +106,119 @@ def bench_train(dev, steps=10, warmup=45, hw=112):
     return out
 
 
+def bench_train_main(args, dev, world, rank, dry):
+    """`--train` at any N (cfg3 at N = 1 / 112^2, cfg5 at N = 8 / --train-hw 224): one process per GPU, per-rank batch 8 x 48 frames, the gradients of the network
+    being updated all-reduced over RCCL in per-stage buckets from inside the backward pass (grad_reduce.GradBucketReducer). Reports the iteration time (MAX over
+    ranks, barrier on both sides) with the exchange and -- same loop, `exchange = False` -- without it: their difference is the all-reduce's exposed share
+    (BASELINE.md section 4, row 4). `--dry-run-cpu`: the same control flow on gloo with a stand-in step that drives the REAL reducer (no kernels)."""
+    from ted_spad_amd.grad_reduce import GradBucketReducer
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    def timed_loop(fn, steps):
+        sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()) / steps * 1e3
+
+    steps = max(args.steps, 5)
+    hw = args.train_hw
+    if dry:
+        # stand-in step: three "stages" whose gradients become final one after the other; every rank contributes rank + 1 so the mean is known
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 50, 7, 300, 11)]
+        red = GradBucketReducer([params[3:], params[1:3], params[:1]], all_params=params)
+        ok = [True]
+
+        def it():
+            red.prepare()
+            for i in range(len(red.buckets)):
+                for p in red.buckets[i]:
+                    p.grad.add_(float(rank + 1))
+                red.bucket_ready(i)
+            red.finish()
+            want = (world + 1) / 2.0 if red.exchange else float(rank + 1)
+            ok[0] = ok[0] and all(bool((p.grad == want).all()) for p in params) and red.issued == list(range(len(red.buckets)))
+        reducers, nbytes = [red], red.nbytes()
+        losses = {}
+    else:
+        from ted_spad_amd import engine as E
+        from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
+        from ted_spad_amd.synth import synth_state_dict, synth_train_video
+        from ted_spad_amd.train_step import AnonymizerTrainStep
+        with contextlib.redirect_stdout(io.StringIO()):
+            fa, ft = load_fa_model(arch="unet"), load_ft_model("largei3d", num_classes=102)
+        fa.load_state_dict(synth_state_dict(fa.state_dict(), 0))            # the same initial replica on every rank (the reference's DataParallel broadcast)
+        ft.load_state_dict(synth_state_dict(ft.state_dict(), 0))
+        fa, ft = fa.to(dev), ft.to(dev)
+        step = AnonymizerTrainStep(fa, ft, group=dist.group.WORLD if world > 1 else None)
+        video = synth_train_video(rank, "bench_train", (8, 48, 3, hw, hw), device=dev)      # a different shard of the batch per rank
+        labels = torch.randint(1, 102, (8,), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+        losses = {}
+
+        def it():
+            r1 = step.step_fa(video, labels)
+            r2 = step.step_ft(video, labels)
+            losses["phase1_loss"], losses["phase2_loss"] = float(r1["loss_ft"]), float(r2["loss_ft"])
+        for i in range(4 * 45):                   # until the tile tuner has settled every conv geometry of both phases
+            if i >= 45 and not E.tuning_pending():
+                break
+            it()
+        reducers = [step.red_fa, step.red_ft]
+        nbytes = sum(r.nbytes() for r in reducers)
+        ok = [True]
+    for _ in range(2):
+        it()
+    with_x = timed_loop(it, steps)
+    for r in reducers:
+        r.exchange = False
+    for _ in range(2):
+        it()
+    without_x = timed_loop(it, steps)
+    for r in reducers:
+        r.exchange = True
+    if rank == 0:
+        fl = (hw / 112.0) ** 2 * (TRAIN_TFLOP["phase1"] + TRAIN_TFLOP["phase2"]) * world      # algorithmic TFLOP of one iteration of the whole job
+        ach = fl / with_x * 1e3
+        cfg = "cfg3" if (hw == 112 and world == 1) else ("cfg5" if hw == 224 else "cfg3-shape, DDP")
+        res = {"metric": "%s training iteration" % cfg, "value": round(with_x, 3), "unit": "ms", "n_gpus": world, "steps": steps, "higher_is_better": False,
+               "scaling": "weak", "dtype": args.dtype, "data": "synthetic", "samples_per_s": round(8 * world / with_x * 1e3, 2),
+               "config": {"workload": ("DRY RUN (CPU, stand-in step, no kernels): " if dry else "") +
+                                      "train_anonymizer.py iteration (phase 1 + phase 2, Adam steps included), per-rank batch 8 x 48 x %d^2, global batch %d x 48 x %d^2" % (hw, 8 * world, hw),
+                          "parallelism": "data-parallel x%d, RCCL all-reduce of fp32 gradient buckets (per stage, from inside the backward pass)" % world},
+               "allreduce": {"bytes_per_rank_per_iteration": nbytes, "iteration_ms_without_exchange": round(without_x, 3),
+                             "exposed_ms": round(with_x - without_x, 3), "exposed_frac": round(max(0.0, with_x - without_x) / with_x, 4)}}
+        if dry:
+            res["dry_run"] = True
+        else:
+            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": round(ach / (MFMA_PEAK_TFLOPS * world), 4),
+                               "traffic": None, "kernel": "both phases of one iteration on every rank (conv / linear MACs x 2 of BASELINE.md section 2 over the iteration time)"}
+            res.update(losses)
+    if world > 1:
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok[0]))
+        if rank == 0:
+            res["allreduce_ok"] = all(flags)
+    elif rank == 0 and dry:
+        res["allreduce_ok"] = bool(ok[0])
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +236,9 @@ def main():
     ap.add_argument("--train-hw", type=int, default=112, help="with --train: frame size (112: cfg3; 224: the per-rank batch of cfg5)")
     ap.add_argument("--act-range", action="store_true", help="add the per-stage max |activation| of one forward (f16 head-room) to the line")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on CPU/gloo with a stub extractor")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank keeps --clip-times clip times (the video grows with N); strong: ONE video of --clip-times clip times split over the N ranks "
+                         "(BASELINE.json north_star: 'clips of a long video shard across the 8 GPUs'; ragged shards and a ragged last batch per rank)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,15 +261,7 @@ def main():
             torch.cuda.synchronize()
 
     if args.train:
-        assert world == 1 and not dry, "--train is a single-GPU measurement"
-        tr = bench_train(dev, steps=max(args.steps, 5), hw=args.train_hw)
-        fl = (args.train_hw / 112.0) ** 2 * (TRAIN_TFLOP["phase1"] + TRAIN_TFLOP["phase2"])       # algorithmic TFLOP of one iteration (both phases)
-        ach = fl / tr["iteration_ms"] * 1e3
-        print(json.dumps({"metric": "cfg3 training iteration" if args.train_hw == 112 else "cfg5 per-rank training iteration", "value": tr["iteration_ms"], "unit": "ms",
-                          "n_gpus": 1, "higher_is_better": False, "dtype": args.dtype, "data": "synthetic",
-                          "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                       "kernel": "both phases of one iteration, alternating (conv / linear MACs x 2 of BASELINE.md section 2 over iteration_ms)"},
-                          ("train_cfg3" if args.train_hw == 112 else "train_cfg5_rank"): tr}))
+        bench_train_main(args, dev, world, rank, dry)
         return
 
     from ted_spad_amd import sharding
@@ -180,7 +288,7 @@ def main():
         fx = ft.extract_features if hasattr(ft, "extract_features") else ft.i3d.extract_features
 
     # ---- this rank's shard of the synthetic video, resident in HBM -------------------------------
-    T_total = args.clip_times * world
+    T_total = args.clip_times * world if args.scaling == "weak" else args.clip_times
     lo, hi = sharding.shard_range(T_total, rank, world)
     n_local = (hi - lo) * args.crops
     clips = torch.empty((n_local,) + shape, dtype=torch.float32, device=dev)
@@ -236,21 +344,51 @@ def main():
         return full
 
     with torch.no_grad():
+        # batch sizes (= conv geometries) any rank will run: the full batch and every rank's ragged last batch
+        sizes = sorted({min(args.batch, (h_ - l_) * args.crops) for l_, h_ in (sharding.shard_range(T_total, r, world) for r in range(world)) if h_ > l_} |
+                       {((h_ - l_) * args.crops) % args.batch for l_, h_ in (sharding.shard_range(T_total, r, world) for r in range(world))} - {0}, reverse=True)
         if not dry:
-            # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are
-            # chosen in context during the first ~45 forwards of every conv geometry; do that before the counted warm-up
+            # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are chosen in context during the
+            # first ~45 forwards of every conv geometry; do that before the counted warm-up. At N > 1 only rank 0 tunes; its table is broadcast so that
+            # every rank runs the same tiles (identical features for identical clips, no start-up skew from N tuning passes).
             from ted_spad_amd import engine as _E
-            for i in range(0, args.batch * 96, args.batch):   # > number of tile configurations + TUNE_REPS pruned passes
-                if not _E.AUTOTUNE:
-                    break
-                multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
-                with torch.cuda.stream(streams[(i // args.batch) % len(streams) if multi and i else 0]):
-                    fx(clips[:args.batch])
-            rem = n_local % args.batch              # a ragged last batch is its own conv geometry: tune it too
-            for i in range(96 if (rem and _E.AUTOTUNE) else 0):
-                multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
-                with torch.cuda.stream(streams[i % len(streams) if multi and i else 0]):
-                    fx(clips[:rem])
+            packed_of = lambda: (ft.i3d if hasattr(ft, "i3d") else ft).packed()
+            if rank == 0 or world == 1:
+                for size in sizes:
+                    if not _E.AUTOTUNE or size > n_local:
+                        continue
+                    for i in range(96):                       # > number of tile configurations + TUNE_REPS pruned passes
+                        multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
+                        with torch.cuda.stream(streams[i % len(streams) if multi and i else 0]):
+                            fx(clips[:size])
+                        if i >= 48 and not _E.tuning_pending():
+                            break
+            if world > 1:
+                sync()
+                box = [_E.export_tile_table(packed_of()) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                if rank != 0:
+                    res_tiles = _E.import_tile_table(packed_of(), box[0])
+        elif world > 1:
+            # rehearsal of the tile-table hand-off with stand-in objects (no kernels): rank 0 "decides", every rank must end with the same table
+            from ted_spad_amd import engine as _E
+
+            class _Tuned:
+                def __init__(self):
+                    self._cfgs = _E._Cfgs()
+            fake = {"layer%d.conv" % i: _Tuned() for i in range(3)}
+            if rank == 0:
+                for i, o in enumerate(fake.values()):
+                    for size in sizes:
+                        o._cfgs[(size, 2, 14, 14, 1024, (0, 1, 1), True, None)] = 17 + i
+            box = [_E.export_tile_table(fake) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                _E.import_tile_table(fake, box[0])
+            mine = _E.export_tile_table(fake)
+            flags = [None] * world
+            dist.all_gather_object(flags, mine == box[0] and all(len(v) == len(sizes) for v in mine.values()))
+            tiles_ok = all(flags)
         sync()
         for _ in range(args.warmup):
             step(False)
@@ -274,15 +412,18 @@ def main():
 
     if rank != 0:
         if world > 1:
+            dist.barrier()              # rank 0 checks its first clips against the CPU oracle after the timed region (below)
             dist.destroy_process_group()
         return
 
     res = {"metric": "clips/sec (16x224^2 I3D features)", "value": round(value, 2), "unit": "clips/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": ("DRY RUN (CPU, stub extractor, no kernels): " if dry else "") +
                                   "cfg2 dali_extraction path: %s extract_features, %d clip times x %d crops = %d clip-forwards of "
-                                  "3x16x224x224 per GPU per step, random-init weights" % (args.arch, args.clip_times, args.crops, n_local),
+                                  "3x16x224x224 %s per step, random-init weights" % (args.arch, T_total if args.scaling == "strong" else args.clip_times, args.crops,
+                                                                                     T_total * args.crops if args.scaling == "strong" else n_local,
+                                                                                     "in total (split over the ranks)" if args.scaling == "strong" else "per GPU"),
                       "global_batch": args.batch * world, "clips_per_step": T_total * args.crops,
                       "parallelism": "clip-sharded x%d + RCCL all-gather of (T,10,F) features" % world}}
 
@@ -291,8 +432,11 @@ def main():
         want = torch.cat([synth_clips(0, min(25, T_total * args.crops - i), shape, first=i).flatten(1).mean(1, keepdim=True) for i in range(0, T_total * args.crops, 25)])
         res["dry_run"] = True
         res["gather_ok"] = bool(torch.allclose(out.reshape(-1, F), want * proj))
+        if world > 1:
+            res["tile_table_ok"] = bool(tiles_ok)
         print(json.dumps(res))
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -316,7 +460,7 @@ def main():
                        "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}
 
     # ---- CPU baseline + parity on a bounded sample: the oracle on this box's host cores ------------
-    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: at N > 1 the other ranks must not wait for it
+    if not args.no_cpu_baseline:      # the parity check runs at every N (the other ranks wait at the final barrier); the CPU extractor is TIMED at N = 1 only
         from oracle import i3res50_ref, inception_i3d_ref
         ncpu = os.cpu_count() or 1
         cores = min(ncpu, 32)  # measured on the GPU box's host (128 hardware threads): 8/16/32/64/128 threads -> 6.6/9.2/10.2/7.7/4.0 clips/s
@@ -329,16 +473,18 @@ def main():
             cpu_fx = lambda x: inception_i3d_ref.extract_features(x, sd)
         with torch.no_grad():
             ref = cpu_fx(xs)  # warm-up (also the parity reference)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                cpu_fx(xs)
-            cdt = time.perf_counter() - t0
+            if world == 1:
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    cpu_fx(xs)
+                cdt = time.perf_counter() - t0
         ref = ref.flatten(1)
         got = out.reshape(-1, F)[:10]
         rel = ((got.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1))
-        res["cpu_baseline"] = {"value": round(30.0 / cdt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-                               "sample": "oracle (fp32 torch CPU restatement) on the first 10 clips (one 10-crop group), 1 warm-up + 3 timed passes; "
-                                         "%d of the host's %d hardware threads (the fastest thread count measured on this host type)" % (cores, ncpu)}
+        if world == 1:
+            res["cpu_baseline"] = {"value": round(30.0 / cdt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+                                   "sample": "oracle (fp32 torch CPU restatement) on the first 10 clips (one 10-crop group), 1 warm-up + 3 timed passes; "
+                                             "%d of the host's %d hardware threads (the fastest thread count measured on this host type)" % (cores, ncpu)}
         res["feature_rel_l2_max"] = float(rel.max())
         res["feature_rel_l2_tol"] = 1e-3
     if args.act_range and args.arch == "largei3d":
@@ -352,6 +498,7 @@ def main():
         res["train_cfg3"] = bench_train(dev)
     print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -79,6 +79,33 @@ def tuning_pending() -> bool:
     return pending
 
 
+def _tuned_objects(packed: dict):
+    """(name, object holding a `_cfgs` table) for every tunable launch of a network's `packed()` dict."""
+    for name, obj in packed.items():
+        for suffix, o in (("", obj), (".pc", getattr(obj, "pc", None)), (".conv2", getattr(obj, "conv2", None))):
+            if o is not None and isinstance(getattr(o, "_cfgs", None), _Cfgs):
+                yield name + suffix, o
+
+
+def export_tile_table(packed: dict) -> dict:
+    """{launch name: {geometry key: tile configuration}} of every DECIDED choice of a packed network -- what rank 0 broadcasts after its tuning
+    pass so that every rank of a multi-GPU job runs the same tiles (bench.py, extraction.extract_video_sharded): tiles that re-associate the K sum
+    differ in the last bit, so ranks that tuned on their own would not produce bit-identical features for the same clip."""
+    return {name: {k: v for k, v in o._cfgs.items() if isinstance(v, int)} for name, o in _tuned_objects(packed)}
+
+
+def import_tile_table(packed: dict, table: dict) -> int:
+    """Adopt the choices of `export_tile_table` (same network, same geometries); pending tuning jobs for those geometries are dropped.
+    Returns the number of choices taken over."""
+    n = 0
+    for name, o in _tuned_objects(packed):
+        for k, v in table.get(name, {}).items():
+            o._cfgs[k] = int(v)
+            _TUNING.pop((id(o._cfgs), k), None)
+            n += 1
+    return n
+
+
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -39,6 +39,11 @@ class GradBucketReducer:
         self.pending = []           # (bucket index, work handle)
         self.issued: List[int] = [] # bucket indices in launch order of the current step (tests, logging)
         self.ready = set()
+        self.exchange = True        # False: the buckets are not all-reduced (bench.py times a step with and without the exchange: its share)
+
+    def nbytes(self) -> int:
+        """Bytes one step's all-reduce moves per rank (fp32 gradients of every bucket)."""
+        return 4 * sum(p.numel() for b in self.buckets for p in b)
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -81,7 +86,7 @@ class GradBucketReducer:
                     v.copy_(p.grad)
                 p.grad = v
         self.issued.append(i)
-        if self.world() > 1:
+        if self.exchange and self.world() > 1:
             self.pending.append((i, dist.all_reduce(self.flats[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def finish(self):
@@ -91,6 +96,6 @@ class GradBucketReducer:
         w = self.world()
         for _, work in self.pending:
             work.wait()
-        if w > 1:
+        if w > 1 and self.exchange:
             torch._foreach_div_(self.flats, float(w))
         self.pending = []

@@ -43,3 +43,53 @@ def test_two_rank_dry_run_prints_one_line_from_rank0():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["clips_per_step"] == 2 * 5 * 2
     assert j["gather_ok"] is True                                     # every rank's rows arrived, in order
     assert j["value"] > 0 and abs(j["value"] - j["config"]["clips_per_step"] * j["steps"] / (j["ms_per_step"] * j["steps"] / 1e3)) < 1e-2 * j["value"]
+    assert j["tile_table_ok"] is True                                 # rank 0's tile choices reached every rank unchanged (engine.export / import_tile_table)
+
+
+def test_two_rank_strong_scaling_dry_run_splits_one_video():
+    """`--scaling strong`: ONE video of --clip-times clip times split over the ranks (ragged: 7 clip times over 2 ranks = 4 + 3), the gathered block complete."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1",
+           "--clip-times", "7", "--crops", "2", "--batch", "4", "--scaling", "strong"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_lines(r.stdout)
+    assert len(j) == 1
+    j = j[0]
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["clips_per_step"] == 7 * 2
+    assert j["gather_ok"] is True and j["tile_table_ok"] is True
+
+
+def test_two_rank_training_dry_run_drives_the_real_reducer():
+    """`bench.py --train --gpus 2 --dry-run-cpu`: the distributed training entry (cfg5's launch line) with a stand-in step around the REAL GradBucketReducer:
+    buckets all-reduced in the order they become final, means correct on every rank, one JSON line with the exchange's exposed share."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--train", "--train-hw", "224", "--dry-run-cpu", "--steps", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_lines(r.stdout)
+    assert len(j) == 1
+    j = j[0]
+    assert j["n_gpus"] == 2 and j["dry_run"] and j["allreduce_ok"] is True and j["higher_is_better"] is False
+    assert j["allreduce"]["bytes_per_rank_per_iteration"] > 0 and "exposed_ms" in j["allreduce"] and j["metric"].startswith("cfg5")
+
+
+def test_tile_table_export_import_roundtrip():
+    from ted_spad_amd import engine as E
+
+    class T:
+        def __init__(self):
+            self._cfgs = E._Cfgs()
+
+    class Pair:
+        def __init__(self):
+            self.pc = T()
+    a, b = {"x": T(), "y": Pair()}, {"x": T(), "y": Pair()}
+    a["x"]._cfgs[(1, 2, "k")] = 25
+    a["x"]._cfgs[(3,)] = {"cands": [1, 2]}          # still tuning: not exported
+    a["y"].pc._cfgs[(9, 9)] = 33
+    tab = E.export_tile_table(a)
+    assert tab == {"x": {(1, 2, "k"): 25}, "y.pc": {(9, 9): 33}}
+    assert E.import_tile_table(b, tab) == 2 and E.export_tile_table(b) == tab
