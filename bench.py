@@ -352,7 +352,6 @@ def main():
             # first ~45 forwards of every conv geometry; do that before the counted warm-up. At N > 1 only rank 0 tunes; its table is broadcast so that
             # every rank runs the same tiles (identical features for identical clips, no start-up skew from N tuning passes).
             from ted_spad_amd import engine as _E
-            packed_of = lambda: (ft.i3d if hasattr(ft, "i3d") else ft).packed()
             if rank == 0 or world == 1:
                 for size in sizes:
                     if not _E.AUTOTUNE or size > n_local:
@@ -365,10 +364,8 @@ def main():
                             break
             if world > 1:
                 sync()
-                box = [_E.export_tile_table(packed_of()) if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                if rank != 0:
-                    res_tiles = _E.import_tile_table(packed_of(), box[0])
+                from ted_spad_amd.extraction import share_tile_choices
+                share_tile_choices(ft)
         elif world > 1:
             # rehearsal of the tile-table hand-off with stand-in objects (no kernels): rank 0 "decides", every rank must end with the same table
             from ted_spad_amd import engine as _E

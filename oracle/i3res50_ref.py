@@ -56,6 +56,37 @@ def _bn_train(x, sd, p, eps=BN_EPS):
     return (x - mean) / torch.sqrt(var + eps) * sd[p + "weight"].view(shape) + sd[p + "bias"].view(shape)
 
 
+def device_rounding(dtype=torch.float16):
+    """(q, bn_train) that round where the HIP training path rounds (ted_spad_amd/train_engine.conv_bn_act_train and its backward), for the matched-rounding parity
+    test of the training gradients: tests/test_hip_train_golden.py::test_phase2_at_cfg3_shape_vs_matched_rounding_oracle.
+      forward : weights, the clip, every pre-BatchNorm conv output z and every stored activation y are 16-bit values (straight-through: the fp32 master keeps the
+                gradient path); the batch statistics come from the fp32 accumulators, i.e. from the UNROUNDED z, the normalisation reads the rounded one;
+      backward: the gradient arriving at every stored activation (d y: the sum over its consumers, rounded once) and at every z (d z) is a 16-bit value;
+                parameter gradients are fp32 sums of products of those 16-bit values (the device accumulates them in fp32).
+    The head (fc, mlp, both BatchNorm1d) and the losses are exact fp32 on the device: untouched here."""
+    def r(t):
+        return t.to(dtype).float()
+
+    def q(t, kind):
+        if kind == "w":
+            return t + (r(t) - t).detach() if t.requires_grad else r(t)
+        if getattr(t, "_q16", False):
+            return t
+        y = t + (r(t) - t).detach() if t.requires_grad else r(t)
+        if y.requires_grad:
+            y.register_hook(r)
+        y._q16 = True
+        return y
+
+    def bn_train(x, sd, p, eps=BN_EPS):
+        dims = [0] + list(range(2, x.dim()))
+        mean = x.mean(dims, keepdim=True)
+        var = x.var(dims, unbiased=False, keepdim=True)
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        return (q(x, "z") - mean) / torch.sqrt(var + eps) * sd[p + "weight"].view(shape) + sd[p + "bias"].view(shape)
+    return q, bn_train
+
+
 def bottleneck(x, sd, p, stride, temp_conv, has_down, q=_id, bn=_bn_eval):
     """large_i3d.py:61-84. `x` is the (possibly higher-precision) residual stream."""
     xin = q(x, "act")
@@ -98,12 +129,12 @@ def extract_features(x, sd, q=_id, taps=None):
     return x.mean(dim=(2, 3, 4), keepdim=True)
 
 
-def forward(x, sd, train=False, frozen_bn=False):
+def forward(x, sd, train=False, frozen_bn=False, q=_id, bn_train=None):
     """I3Res50.forward, large_i3d.py:228-246 -> (logits (B,nc), feat = avgpool.squeeze()).
     frozen_bn: the trunk's BatchNorm3d layers replaced by FrozenBN (large_i3d.py:8-38, `freeze_bn` :30-38): running statistics.
     Dropout(0.5) before fc is stochastic in train mode; the oracle omits it (p -> 0),
     SURVEY.md Q13. `feat` is taken BEFORE dropout, so it is unaffected."""
-    x = trunk(x, sd, bn=_bn_train if (train and not frozen_bn) else _bn_eval)
+    x = trunk(x, sd, q=q, bn=(bn_train or _bn_train) if (train and not frozen_bn) else _bn_eval)
     x = x.mean(dim=(2, 3, 4), keepdim=True)
     feat = x.squeeze()
     logits = F.linear(x.flatten(1), sd["fc.weight"], sd["fc.bias"])
@@ -118,8 +149,8 @@ def mlp(feat, sd, p="mlp.", train=False):
     return F.normalize(h, p=2, dim=1)
 
 
-def wrapper_forward(x, sd, train=False, frozen_bn=False):
+def wrapper_forward(x, sd, train=False, frozen_bn=False, q=_id, bn_train=None):
     """wrapper_i3d.forward, model_loaders.py:265-268; sd keys prefixed `i3d.` / `mlp.`."""
     i3d = {k[4:]: v for k, v in sd.items() if k.startswith("i3d.")}
-    pred, feat = forward(x, i3d, train=train, frozen_bn=frozen_bn)
+    pred, feat = forward(x, i3d, train=train, frozen_bn=frozen_bn, q=q, bn_train=bn_train)
     return pred, mlp(feat, sd, "mlp.", train=train)

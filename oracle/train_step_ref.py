@@ -30,8 +30,13 @@ def _grad_sd(sd):
             for k, v in sd.items()}
 
 
-def _utility(ft_sd, clips, labels, train, tlw=0.1, frozen_bn=False):
-    heads = [i3res50_ref.wrapper_forward(c, ft_sd, train=train, frozen_bn=frozen_bn) for c in clips]
+def _utility(ft_sd, clips, labels, train, tlw=0.1, frozen_bn=False, rounding=None):
+    def kw(k):      # rounding: None | (q, bn_train) | a callable clip index -> (q, bn_train)
+        if rounding is None:
+            return {}
+        q, bn_train = rounding(k) if callable(rounding) else rounding
+        return dict(q=q, bn_train=bn_train)
+    heads = [i3res50_ref.wrapper_forward(c, ft_sd, train=train, frozen_bn=frozen_bn, **kw(k)) for k, c in enumerate(clips)]
     ce = losses_ref.cross_entropy_torch(heads[0][0], labels)
     trip = losses_ref.triplet_torch(heads[0][1], heads[1][1], heads[2][1])
     return ce + tlw * trip, ce, trip
@@ -73,14 +78,18 @@ def phase2_fb(vispr, fa_sd, fb_sd):
     return loss_fb.item(), {k: p.grad for k, p in fb.items() if p.requires_grad and p.grad is not None}
 
 
-def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
+def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16, ft_rounding=None, anon=None):
+    """ft_rounding: `i3res50_ref.device_rounding(dtype)` -- ft's trunk rounds its forward values and activation gradients to 16 bits where the HIP training path
+    does (matched-rounding parity); None: the exact fp32 path of the reference. anon: the (B,3,48,H,W) anonymised video to feed ft instead of this
+    oracle's own fa output (the matched test hands over the device's, so that ft sees the same input on both sides)."""
     ft = _grad_sd(ft_sd)
     v = video_b48.permute(0, 2, 1, 3, 4)
     b, c, t, h, w = v.shape
-    with torch.no_grad():
-        anon = _fa(v.reshape(-1, c, h, w), fa_sd, False).reshape(b, c, t, h, w)
+    if anon is None:
+        with torch.no_grad():
+            anon = _fa(v.reshape(-1, c, h, w), fa_sd, False).reshape(b, c, t, h, w)
     clips = torch.split(anon, [num_frames] * 3, dim=2)
-    loss_ft, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw)
+    loss_ft, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw, rounding=ft_rounding)
     loss_ft.backward()
     grads = {k: p.grad for k, p in ft.items() if p.requires_grad and p.grad is not None}
     return dict(loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads

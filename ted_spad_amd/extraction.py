@@ -116,6 +116,20 @@ def extract_video_sharded(ft_model, clips_cthw_local: torch.Tensor, T: int, ncro
     return sharding.gather_video_features(f, T, group)
 
 
+def share_tile_choices(ft_model, group=None, src: int = 0) -> int:
+    """Multi-GPU jobs: broadcast rank `src`'s decided conv tile configurations (engine.export_tile_table of the packed network) to every rank, so that all
+    ranks run the same tiles -- identical clips then give bit-identical features on every GPU and no rank spends its first forwards tuning. Call it once
+    after rank `src` has run a few dozen forwards of the batch sizes in use (bench.py does). Returns the number of choices this rank took over."""
+    import torch.distributed as dist
+    from . import engine as E
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    net = ft_model.i3d if hasattr(ft_model, "i3d") else ft_model
+    box = [E.export_tile_table(net.packed()) if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return E.import_tile_table(net.packed(), box[0]) if dist.get_rank(group) != src else 0
+
+
 def save_video_features(save_dir: str, video_path: str, feats) -> str:
     """`<video basename without .mp4/.avi>.npy`, float64 C-order (dali_extraction.py:159,182)."""
     name = os.path.basename(video_path)
