@@ -48,10 +48,25 @@ def _bn_eval(x, sd, p, eps=BN_EPS):
     return x * inv.view(shape) + sh.view(shape)
 
 
+def update_running(sd, p, mean, var, count):
+    """nn.BatchNorm's train-mode side effect (momentum 0.1, UNBIASED variance into running_var, num_batches_tracked += 1), applied in place to the state dict
+    when it carries `_track_running` = True: multi-iteration trajectories (three updates per ft step, one per fa step) need it, single-step
+    parity does not."""
+    if not sd.get("_track_running"):
+        return
+    with torch.no_grad():
+        m = 0.1
+        sd[p + "running_mean"].mul_(1 - m).add_(m * mean.detach().flatten())
+        sd[p + "running_var"].mul_(1 - m).add_(m * var.detach().flatten() * (count / max(count - 1, 1)))
+        if p + "num_batches_tracked" in sd:
+            sd[p + "num_batches_tracked"] += 1
+
+
 def _bn_train(x, sd, p, eps=BN_EPS):
     dims = [0] + list(range(2, x.dim()))
     mean = x.mean(dims, keepdim=True)
     var = x.var(dims, unbiased=False, keepdim=True)
+    update_running(sd, p, mean, var, x.numel() // x.shape[1])
     shape = [1, -1] + [1] * (x.dim() - 2)
     return (x - mean) / torch.sqrt(var + eps) * sd[p + "weight"].view(shape) + sd[p + "bias"].view(shape)
 
@@ -152,5 +167,7 @@ def mlp(feat, sd, p="mlp.", train=False):
 def wrapper_forward(x, sd, train=False, frozen_bn=False, q=_id, bn_train=None):
     """wrapper_i3d.forward, model_loaders.py:265-268; sd keys prefixed `i3d.` / `mlp.`."""
     i3d = {k[4:]: v for k, v in sd.items() if k.startswith("i3d.")}
+    if sd.get("_track_running"):
+        i3d["_track_running"] = True
     pred, feat = forward(x, i3d, train=train, frozen_bn=frozen_bn, q=q, bn_train=bn_train)
     return pred, mlp(feat, sd, "mlp.", train=train)

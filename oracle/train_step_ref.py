@@ -26,7 +26,9 @@ def _fa(x, sd, train):
 
 
 def _grad_sd(sd):
-    return {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+    """Leaf copies of the trainable tensors; buffers (running statistics, counters) and the `_track_running` flag are passed through BY REFERENCE, so that a
+    tracked train-mode forward updates the caller's state dict in place (i3res50_ref.update_running)."""
+    return {k: (v.clone().requires_grad_() if torch.is_tensor(v) and v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
             for k, v in sd.items()}
 
 
@@ -61,7 +63,7 @@ def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_fra
     if loss_fb is not None:
         loss_fa = -fb_loss_weight * loss_fb + loss_fa
     loss_fa.backward()
-    grads = {k: p.grad for k, p in fa.items() if p.requires_grad and p.grad is not None}
+    grads = {k: p.grad for k, p in fa.items() if torch.is_tensor(p) and p.requires_grad and p.grad is not None}
     return dict(loss_fa=loss_fa.item(), loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item(),
                 loss_fb=None if loss_fb is None else loss_fb.item()), grads, anon.grad
 
@@ -75,7 +77,7 @@ def phase2_fb(vispr, fa_sd, fb_sd):
     z = [resnet50_ref.forward(xi, fb, train=True) for xi in x]
     loss_fb = losses_ref.nt_xent_torch(z[0], z[1], 0.1)
     loss_fb.backward()
-    return loss_fb.item(), {k: p.grad for k, p in fb.items() if p.requires_grad and p.grad is not None}
+    return loss_fb.item(), {k: p.grad for k, p in fb.items() if torch.is_tensor(p) and p.requires_grad and p.grad is not None}
 
 
 def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16, ft_rounding=None, anon=None):
@@ -91,7 +93,7 @@ def phase2(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16, ft_rounding=
     clips = torch.split(anon, [num_frames] * 3, dim=2)
     loss_ft, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw, rounding=ft_rounding)
     loss_ft.backward()
-    grads = {k: p.grad for k, p in ft.items() if p.requires_grad and p.grad is not None}
+    grads = {k: p.grad for k, p in ft.items() if torch.is_tensor(p) and p.requires_grad and p.grad is not None}
     return dict(loss_ft=loss_ft.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads
 
 
@@ -109,5 +111,5 @@ def action_step(video_b48, labels, fa_sd, ft_sd, tlw=0.1, num_frames=16):
     loss, ce, trip = _utility(ft, clips, labels, train=True, tlw=tlw, frozen_bn=True)
     loss.backward()
     frozen = {k for k in ft if k.startswith("i3d.") and (".bn" in k or k.startswith("i3d.bn") or ".downsample.1." in k)}
-    grads = {k: p.grad for k, p in ft.items() if p.requires_grad and p.grad is not None and k not in frozen}
+    grads = {k: p.grad for k, p in ft.items() if torch.is_tensor(p) and p.requires_grad and p.grad is not None and k not in frozen}
     return dict(loss=loss.item(), loss_ce=ce.item(), loss_temporal=trip.item()), grads

@@ -27,6 +27,8 @@ def _bn2d(x, sd, p, train):
     if train:
         mean = x.mean((0, 2, 3), keepdim=True)
         var = x.var((0, 2, 3), unbiased=False, keepdim=True)
+        from .i3res50_ref import update_running
+        update_running(sd, p, mean, var, x.numel() // x.shape[1])       # only when the state dict carries `_track_running`
         return (x - mean) / torch.sqrt(var + BN_EPS) * sd[p + "weight"].view(1, -1, 1, 1) + sd[p + "bias"].view(1, -1, 1, 1)
     inv = sd[p + "weight"] / torch.sqrt(sd[p + "running_var"] + BN_EPS)
     sh = sd[p + "bias"] - sd[p + "running_mean"] * inv
