@@ -106,8 +106,13 @@ def import_tile_table(packed: dict, table: dict) -> int:
     return n
 
 
+_raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current HIP stream on the current device: `torch.cuda.current_stream().cuda_stream` builds a Stream object and resolves the device
+    # through three Python layers (9 us a call under the profiler, 500 calls per training step: a third of phase 2's host time)
+    return C.c_void_p(_raw_stream(_cur_device()))
 
 
 def require_cuda(t: torch.Tensor, what: str):
