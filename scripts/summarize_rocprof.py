@@ -37,7 +37,7 @@ for r in sel:
     c = agg.setdefault(k, [0, 0.0]); c[0] += 1; c[1] += d
 tot = sum(v[1] for v in agg.values())
 span = (max(int(r['End_Timestamp']) for r in sel) - min(int(r['Start_Timestamp']) for r in sel)) / 1e3   # us, wall clock of the step
-conv = sum(v[1] for k, v in agg.items() if k.startswith('conv_'))
+conv = sum(v[1] for k, v in agg.items() if k.startswith(('conv_', 'bneck_')))
 lines = ['# %s' % a.title, '',
          'Source: `rocprofv3 --kernel-trace --stats -- python3 bench.py ...` on MI355X; %d forwards of %d clips.' % (nf, a.batch), '',
          '| kernel | launches / forward | avg µs | µs / forward | share |', '|---|---|---|---|---|']
@@ -77,7 +77,7 @@ if a.fetch and a.write:
     for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
         fm = 2 * f[k] * 1024 / 1e6; wm = w.get(k, 0) * 1024 / 1e6
         lines.append('| `%s` | %d | %.1f | %.1f | %.1f |' % (k, fn[k], fm, wm, fm + wm))
-    conv_bytes = sum((2 * f[k] + w.get(k, 0)) * 1024 for k in f if k.startswith('conv_'))
+    conv_bytes = sum((2 * f[k] + w.get(k, 0)) * 1024 for k in f if k.startswith(('conv_', 'bneck_')))
     all_bytes = sum((2 * f[k] + w.get(k, 0)) * 1024 for k in f)
     summary['conv_traffic_bytes_per_forward'] = conv_bytes
     summary['all_traffic_bytes_per_forward'] = all_bytes

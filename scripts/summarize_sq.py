@@ -43,7 +43,7 @@ for k, g in sorted(agg.items(), key=lambda kv: -kv[1]['GRBM_GUI_ACTIVE']):
     lines.append('| `%s` | %d | %.2f | %.1f %% | %.0f %% | %.0f %% | %.0f %% |' % (
         k, g['n'], g['GRBM_GUI_ACTIVE'] / 8e6, 100 * g['SQ_VALU_MFMA_BUSY_CYCLES'] / (g['GRBM_GUI_ACTIVE'] / 8 * 1024),
         100 * g['SQ_WAIT_ANY'] / wc, 100 * g['SQ_WAIT_INST_ANY'] / wc, 100 * g['SQ_ACTIVE_INST_ANY'] / wc))
-    if k.startswith('conv_'):
+    if k.startswith(('conv_', 'bneck_')):
         tot.update(g)
 lines += ['', '* conv kernels together: MFMA utilisation **%.1f %%** of the GPU-active cycles (%.1f Mcycles per forward)'
           % (100 * tot['SQ_VALU_MFMA_BUSY_CYCLES'] / (tot['GRBM_GUI_ACTIVE'] / 8 * 1024), tot['GRBM_GUI_ACTIVE'] / 8e6),
