@@ -450,8 +450,23 @@ def main():
         if (tj.get("arch") == args.arch and tj.get("batch") == args.batch and tj.get("dtype") == args.dtype and
                 tj.get("kernel_sources_sha") == kernel_sources_sha()):
             traffic = tj["conv_traffic_bytes_per_forward"]
+    # sustained shader clock of THIS box under matrix load (DVFS lowers it below the 2.4 GHz the nominal peak assumes): reported beside the nominal peak, never instead
+    clock_mhz = None
+    try:
+        import ctypes as _C
+        from ted_spad_amd import _lib as _L
+        tbuf = torch.zeros(2 * 1024, dtype=torch.int64, device=dev)
+        for _ in range(2):      # ~20 ms each at 1024 workgroups x 4 waves x 4 x 60000 MFMAs; the second one is read
+            _L.check(_L.lib().tedspad_clock_probe(60000, 1024, tbuf.data_ptr(), _C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tedspad_clock_probe")
+        torch.cuda.synchronize()
+        t = tbuf.view(-1, 2).double().cpu()
+        clock_mhz = float((100.0 * t[:, 0] / t[:, 1]).median())
+    except Exception as e:          # a measurement aid only
+        print("clock probe failed: %s" % e, file=sys.stderr)
     res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                       "clock_mhz_under_mfma_load": None if clock_mhz is None else round(clock_mhz, 1),
+                       "peak_at_clock": None if clock_mhz is None else round(MFMA_PEAK_TFLOPS * clock_mhz / 2400.0, 1),
                        "kernel": "conv stack of one batch forward (conv_stem_pt_kernel + conv_p8 / conv_patch / conv_flat / conv_igemm / conv_pw "
                                  "launches; layout, max-pool and average-pool passes included in the time)",
                        "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}

@@ -185,6 +185,11 @@ int32_t tedspad_bneck_frame_fwd(const void *x, int32_t ldx, void *y, int32_t ldy
                                 void *stream);
 int32_t tedspad_bneck_frame_lds_bytes(void);   /* dynamic LDS of the kernel above (one workgroup per CU) */
 
+/* Measurement aid (bench.py `roofline.peak_at_clock`): `workgroups` x 256 threads run 4 x iters v_mfma_f32_32x32x16_f16 per wave; workgroup b writes
+ * out[2b] = elapsed shader cycles (s_memtime) and out[2b+1] = elapsed 100 MHz ticks (s_memrealtime): the sustained clock under matrix load is
+ * 100 MHz x out[2b] / out[2b+1]. out: 2 x workgroups uint64. */
+int32_t tedspad_clock_probe(int32_t iters, int32_t workgroups, void *out, void *stream);
+
 /* Persistent Cin = 3 stem (csrc/conv_stem_pt.hip): conv1 5x7x7 / stride 2 / pad (2,3,3) + bn1 + ReLU of large_i3d.py:133-137,229-231
  * with the temporal half of maxpool1 (MaxPool3d((2,3,3), 2), large_i3d.py:138,232) fused: y[n][to/2][ho][wo][64] =
  * max over the output frame pair (to, to+1) of act(conv * scale + shift); the spatial 3x3 / 2 half of the pool is a

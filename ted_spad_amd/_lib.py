@@ -93,6 +93,7 @@ SYMBOLS = {
     "tedspad_conv_p8_dual_fwd": (_I32, [C.POINTER(ConvDesc), _P, _P] + [_I32] * 6 + [_P, _P, _P, _P, _P]),
     "tedspad_bneck_frame_fwd": (_I32, [_P, _I32, _P, _I32] + [_I32] * 6 + [_P, _P, _I32, _P] + [_P] * 6 + [_I32, _I32, _P]),
     "tedspad_bneck_frame_lds_bytes": (_I32, []),
+    "tedspad_clock_probe": (_I32, [_I32, _I32, _P, _P]),
     "tedspad_bneck_tail_fwd": (_I32, [C.POINTER(ConvDesc)] + [_P] * 7 + [_I32, _P, _I32, _P, _I32, _P, _P, _I32, _I32, _I32, _P]),
     "tedspad_clip_to_tp": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 4 + [_P]),
     "tedspad_stem_pt_wimg_bytes": (_I32, []),

@@ -87,6 +87,18 @@ __device__ int g_bf_ablate;
 #else
 #define BF_ABL(bit) 0
 #endif
+#ifdef TEDSPAD_BF_STAGE_STAMPS
+// Diagnostic build only (scripts/bneck_frame_cycles.py): s_memtime / s_memrealtime at the stage boundaries of every workgroup and pixel half -- 5 stamps per workgroup,
+// no measurable cost: cycles per stage and the shader clock the kernel really runs at.
+__device__ long long *g_bf_stage_ts;
+#define BF_STAGE_DECL() long long st_[5], sr_[2]; st_[0] = __builtin_amdgcn_s_memtime(); sr_[0] = __builtin_amdgcn_s_memrealtime()
+#define BF_STAGE(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define BF_STAGE_FLUSH() { sr_[1] = __builtin_amdgcn_s_memrealtime(); if (lane == 0 && (wave & 3) == 0 && g_bf_stage_ts) { long long *o_ = g_bf_stage_ts + ((size_t)blockIdx.x * 2 + hp) * 8; for (int i_ = 0; i_ < 5; ++i_) o_[i_] = st_[i_]; o_[5] = sr_[0]; o_[6] = sr_[1]; } }
+#else
+#define BF_STAGE_DECL()
+#define BF_STAGE(i)
+#define BF_STAGE_FLUSH()
+#endif
 #ifdef TEDSPAD_BF_STAMPS
 // Diagnostic build only: per workgroup and pixel half, cycles spent in the LOAD / COMPUTE phases of each stage split into work, counted-wait and barrier
 // time. The stamps go to a buffer of their own; no output value depends on them. (They cost a third of the kernel's time: read them as proportions.)
@@ -111,6 +123,8 @@ __device__ long long *g_bf_ts;
 // behind waves 0-3, so that on every SIMD one wave multiplies while its partner loads (the ping-pong of conv_p8.hip). A slot of step s is
 // first read by waves 0-3; every wave therefore waits for ITS pieces of step s + 1 at the end of the phase in which waves 0-3 compute step s:
 // waves 0-3 at the end of their COMPUTE(s), waves 4-7 at the end of their LOAD(s).
+// (A version with the pixel half as a template parameter -- two copies of the body, no `if (hp)` / `if (t < ntl)` branch inside a K step -- was SLOWER: 57 KB of
+// code for the two halves against 29 KB, stage 2 went from 1120 to 1500 cycles per step. The loops are instruction-fetch sensitive: keep the code small.)
 template <typename T>
 __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -197,8 +211,12 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
                 if (t + NB < 7 && t + NB < ntl && !BF_ABL(128)) b[t + NB] = BF_LDS16(baddr(t + NB));
             }
     };
-    typedef std::integral_constant<int, 7> NB7;
-    typedef std::integral_constant<int, 4> NB4;
+#ifndef TEDSPAD_BF_NB12
+#define TEDSPAD_BF_NB12 7
+#endif
+    typedef std::integral_constant<int, TEDSPAD_BF_NB12> NB7;      // stages 1 and 2: pixel fragments read in the LOAD phase
+    constexpr int NB3V = 4;                                  // stage 3: pixel fragments read in LOAD (the rest three tiles ahead of their MFMAs in COMPUTE: registers)
+    typedef std::integral_constant<int, NB3V> NB4;
     // relu(bn(.)) of the accumulators -> M rows (16 consecutive channels per lane and tile: two 16-byte chunks)
     auto write_mid = [&](const float *scale, const float *shift) {
 #pragma unroll
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
     BF_BARRIER();
     if (hp) BF_BARRIER();                                    // waves 4-7: one phase behind
     BF_TS_DECL();
+    BF_STAGE_DECL();
 
     // ================================ stage 1: conv1, both operands streamed ================================
     for (int s = 0; s < S1; ++s) {
@@ -257,6 +276,7 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
         BF_BARRIER();
         BF_TS(5);
     }
+    BF_STAGE(1);
     // every wave is done with the pixel slots (waves 4-7 read their last one a phase ago): the conv1 tensor lands there
     write_mid(p.scale1, p.shift1);
     zero_acc();
@@ -307,11 +327,13 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
             }
         }
     }
+    BF_STAGE(2);
     write_mid(p.scale2, p.shift2);                           // every wave has read the conv1 tensor: the conv2 tensor replaces it
     zero_acc();
     BF_BARRIER();
     BF_BARRIER();
 
+    BF_STAGE(3);
     // ================================ stage 3: conv3 + residual, four passes of 256 channels ================================
     // Operand roles SWAPPED: pixels are the MFMA A operand, weights the B operand, so D[pixel 4 g + e][channel column l15]: a lane ends with four
     // pixels x one column per channel tile, and the host orders the rows of the stage-3 images so that tile j's column l15 is channel 4 l15 + j of the wave's
@@ -337,34 +359,27 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
             BF_TS(12);
             // counted waits of waves 4-7 (24 residual loads at step 5, 2 bn loads at step 7, 24 stores): the slot of step kc + 1 and what this wave issued after it
             if (hp) { if (kc == 6 || (kc == 0 && n > 0)) wait_vmcnt<26>(); else wait_vmcnt<2>(); }
-            if (kc == BF_RES_STEP) {
-                // residual rows + bn3 of this pass, two K steps ahead of their use (vector memory completes in order: a weight slot issued after them
-                // cannot be waited for before they have arrived, so they cannot be requested earlier than the ring is deep)
-                unsigned rl = rlane, rr2 = rrow;
-                asm volatile("" : "+v"(rl), "+s"(rr2));     // offsets are built here (hoisted out of the loop they spilled)
-                rl += (unsigned)(256 * n) * 2u;
-#pragma unroll
-                for (int t = 0; t < 7; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (t < ntl && hb + 16 * t + 4 * g + e < BF_HW && !BF_ABL(4)) {
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            const u32x2 r = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(xres_b + (rl + (unsigned)(16 * t + e) * rr2)));
-                            res[t][e] = make_uint2(r.x, r.y);
-                        } else {
-                            res[t][e] = make_uint2(0u, 0u);
-                        }
-                    }
-            }
-            if (kc == 7) {                                   // bn3 of the lane's four channels (L2 hits; a phase ahead is enough, and 8 registers fewer for two K steps)
-                sc3 = *reinterpret_cast<const f32x4 *>(p.scale3 + 256 * n + 64 * wc + 4 * l15);
-                sh3 = *reinterpret_cast<const f32x4 *>(p.shift3 + 256 * n + 64 * wc + 4 * l15);
-            }
+            auto load_bn3 = [&]() {                          // bn3 of the lane's four channels (L2 hits)
+                unsigned bo = (unsigned)(64 * wc + 4 * l15) * 4u;
+                asm volatile("" : "+v"(bo));                 // (a 32-bit lane offset built here: kept as a 64-bit pointer across the pass it spilled)
+                bo += (unsigned)(256 * n) * 4u;
+                sc3 = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(p.scale3) + bo);
+                sh3 = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(p.shift3) + bo);
+            };
+            if (kc == 7) load_bn3();                         // a phase ahead of the epilogue
             BF_TS(13);
             BF_BARRIER();
             BF_TS(14);
-            // (pixels, weights): the accumulator tile is D[pixel][channel]
+            // (pixels, weights): the accumulator tile is D[pixel][channel]. At step BF_RES_STEP the residual rows of the pass are requested from inside this MFMA
+            // stream, a tile's four rows behind that tile's MFMAs (a burst of 28 loads in the LOAD phase held the wave ~1.1 k cycles at the address unit, with the
+            // partner waiting at the barrier): two K steps ahead of their use -- vector memory completes in order, a weight slot issued after them cannot be waited
+            // for before they have arrived, so they cannot be requested earlier than the ring is deep.
             {
+                unsigned rl = rlane, rr2 = rrow;
+                if (kc == BF_RES_STEP) {
+                    asm volatile("" : "+v"(rl), "+s"(rr2));  // offsets are built here (hoisted out of the loop they spilled)
+                    rl += (unsigned)(256 * n) * 2u;
+                }
 #pragma unroll
                 for (int t = 0; t < 7; ++t)
                     if (t < ntl) {
@@ -372,10 +387,28 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[j][t] = T::mfma16(b[t], a[j], acc[j][t]);
                         }
-                        if (t + 4 < 7 && t + 4 < ntl && !BF_ABL(128)) b[t + 4] = BF_LDS16(maddr(t + 4));
+                        if (t + NB3V < 7 && t + NB3V < ntl && !BF_ABL(128)) b[t + NB3V] = BF_LDS16(maddr(t + NB3V));
+                        if (kc == BF_RES_STEP) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (hb + 16 * t + 4 * g + e < BF_HW && !BF_ABL(4)) {
+                                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                    const u32x2 r = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(xres_b + (rl + (unsigned)(16 * t + e) * rr2)));
+                                    res[t][e] = make_uint2(r.x, r.y);
+                                } else {
+                                    res[t][e] = make_uint2(0u, 0u);
+                                }
+                            }
+                        }
+                    } else if (kc == BF_RES_STEP) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res[t][e] = make_uint2(0u, 0u);
                     }
             }
             if (kc == 7) {
+                // waves 0-3 run their epilogue one phase later, BESIDE the last compute + epilogue of waves 4-7 (which then idle one phase while waves 0-3 load the
+                // next pass's first step): the two epilogues (~5 k cycles each, no MFMA) share one phase instead of stretching two
+                if (!hp) BF_BARRIER();
                 // epilogue in two sweeps: every result first (the packed 4 channels replace the residual registers), THEN the stores back to back -- hipcc
                 // drains vmcnt(0) before the first use of a loaded register that follows an asm store (seen in the ISA: serialised store round trips)
                 asm volatile("" ::: "memory");
@@ -389,13 +422,25 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
 #pragma unroll
                             for (int q = 0; q < 2; ++q) {
                                 float v[2];
+                                if constexpr (T::kDtype == TEDSPAD_F16) {
+                                    // 3.5 vector instructions per value instead of 5.5 (the epilogue is ~5 k cycles of VALU per pass with no MFMA beside it):
+                                    // shift + residual in ONE v_fma_mix_f32 that reads the f16 half directly, one fma, one med3 (ReLU + saturation), and a
+                                    // packed round-to-nearest conversion of both values (v_cvt_pk_f16_f32, gfx950)
+                                    float t0, t1;
+                                    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(rw[q]), "v"(sh3[2 * q]));
+                                    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(rw[q]), "v"(sh3[2 * q + 1]));
+                                    v[0] = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(acc[2 * q][t][e], sc3[2 * q], t0), 0.f), 65504.f);
+                                    v[1] = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(acc[2 * q + 1][t][e], sc3[2 * q + 1], t1), 0.f), 65504.f);
+                                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[q]) : "v"(v[0]), "v"(v[1]));
+                                } else {
 #pragma unroll
-                                for (int i = 0; i < 2; ++i) {
-                                    const int j = 2 * q + i;
-                                    const float r = T::to_f32((uint16_t)(i ? rw[q] >> 16 : rw[q] & 0xffffu));
-                                    v[i] = __builtin_fmaxf(acc[j][t][e] * sc3[j] + sh3[j] + r, 0.f);
+                                    for (int i = 0; i < 2; ++i) {
+                                        const int j = 2 * q + i;
+                                        const float r = T::to_f32((uint16_t)(i ? rw[q] >> 16 : rw[q] & 0xffffu));
+                                        v[i] = __builtin_fmaxf(acc[j][t][e] * sc3[j] + sh3[j] + r, 0.f);
+                                    }
+                                    pk[q] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
                                 }
-                                pk[q] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
                             }
                             res[t][e] = make_uint2(pk[0], pk[1]);
                         }
@@ -425,13 +470,16 @@ __global__ __launch_bounds__(512) void bneck_frame_kernel(const BneckFrameKP p) 
             if (!hp) { if (kc >= 5 || (kc == 0 && n > 0)) wait_vmcnt<30>(); else wait_vmcnt<2>(); }
             BF_TS(16);
             BF_BARRIER();
+            if (kc == 7 && hp) BF_BARRIER();                 // (the idle phase of waves 4-7)
             BF_TS(17);
         }
     }
-    if (!hp) BF_BARRIER();                                   // the phase in which waves 4-7 finish
-    wait_vmcnt<0>();
+    wait_vmcnt<0>();                                         // (both halves leave stage 3 in the same phase: no closing barrier for waves 0-3)
+    BF_STAGE(4);
+    BF_STAGE_FLUSH();
     BF_TS_FLUSH();
 }
+
 
 }  // namespace
 }  // namespace tedspad
@@ -443,6 +491,11 @@ extern "C" int32_t tedspad_bneck_frame_lds_bytes(void) { return BF_LDS; }
 #ifdef TEDSPAD_BF_STAMPS
 extern "C" int32_t tedspad_debug_set_bf_ts(void *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_bf_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef TEDSPAD_BF_STAGE_STAMPS
+extern "C" int32_t tedspad_debug_set_bf_stage_ts(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bf_stage_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef TEDSPAD_BF_ABLATE
