@@ -76,7 +76,7 @@ def stage_report(tag, flags, ablations):
         w1 = synth_tensor(1, 'w1%d' % kt, (256, 1024, kt, 1, 1), -0.03, 0.03); w2 = synth_tensor(1, 'w2', (256, 256, 1, 3, 3), -0.03, 0.03); w3 = synth_tensor(1, 'w3', (1024, 256, 1, 1, 1), -0.06, 0.06)
         bfk = E.BneckFrame(w1, one(256), zero(256), w2, one(256), zero(256), w3, one(1024), zero(1024), dtype='f16', device=dev)
         for bits, what in ablations:
-            if bits is not None:
+            if bits is not None and hasattr(LS, 'tedspad_debug_set_bf_ablate'):
                 LS.tedspad_debug_set_bf_ablate.restype = C.c_int32; LS.tedspad_debug_set_bf_ablate.argtypes = [C.c_int32]
                 assert LS.tedspad_debug_set_bf_ablate(bits) == 0
             for _ in range(20): go(bfk)
@@ -95,6 +95,9 @@ def stage_report(tag, flags, ablations):
 
 
 stage_report('st', ['-DTEDSPAD_BF_STAGE_STAMPS'], [(None, 'release + stage stamps')])
+for bits, what in ((4, 'no residual loads'), (8, 'no stores'), (12, 'no residual loads, no stores'), (32, 'no epilogue arithmetic'), (44, 'no residual, stores, epilogue arithmetic'),
+                   (1, 'no weight DMA'), (2, 'no pixel DMA'), (16, 'no MFMAs')):
+    stage_report('ct%d' % bits, ['-DTEDSPAD_BF_STAGE_STAMPS', '-DTEDSPAD_BF_CT_ABLATE=%d' % bits], [(None, 'compile-time ablation: ' + what)])
 stage_report('sta', ['-DTEDSPAD_BF_STAGE_STAMPS', '-DTEDSPAD_BF_ABLATE'],
              [(0, 'ablate build, nothing off'), (32, 'no epilogue arithmetic'), (12, 'no residual loads, no stores'), (44, 'neither'), (1, 'no weight DMA'), (3, 'no DMA')])
 # ---- how many pixel fragments of stages 1 / 2 the LOAD phase reads (the rest goes into the COMPUTE phase, three tiles ahead of its MFMAs) ----

@@ -84,6 +84,8 @@ __device__ __forceinline__ void gstore8f(const void *base, unsigned off, uint2 v
 // 16 no MFMAs, 32 no epilogue arithmetic, 64 no barriers, 128 no LDS fragment reads. Results are garbage; only the time is meaningful.
 __device__ int g_bf_ablate;
 #define BF_ABL(bit) (ablate & (bit))
+#elif defined(TEDSPAD_BF_CT_ABLATE)
+#define BF_ABL(bit) ((TEDSPAD_BF_CT_ABLATE) & (bit))      // the same switches decided at compile time: no extra branch in the loops (the runtime form costs 700 cycles per K step)
 #else
 #define BF_ABL(bit) 0
 #endif
