@@ -24,7 +24,7 @@ def short(n):
     n = re.sub(r'\(tedspad.*$', '', n).replace('void ', '')
     return n[:90]
 
-rows = [r for r in csv.DictReader(open(a.trace)) if 'tedspad' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(a.trace)) if 'tedspad' in r['Kernel_Name'] and 'clock_probe' not in r['Kernel_Name']]      # (bench.py's clock probe runs after the timed region)
 FIRST = ('clip_to_channels_last', 'to_channels_last', 'clip_to_tp')      # the first kernel of a forward (layout pass)
 starts = [i for i, r in enumerate(rows) if any(f in r['Kernel_Name'] for f in FIRST)]
 first = starts[-a.forwards] if len(starts) >= a.forwards else starts[0]
@@ -58,7 +58,7 @@ summary = {'ms_per_forward_all': tot / nf / 1e3, 'ms_per_forward_conv': conv / n
 
 def counter(path, name):
     """per-kernel sums over the LAST forward of the pass (earlier launches include the tile autotuner)."""
-    rows = [r for r in csv.DictReader(open(path)) if r.get('Counter_Name') == name and 'tedspad' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(path)) if r.get('Counter_Name') == name and 'tedspad' in r['Kernel_Name'] and 'clock_probe' not in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     st = [i for i, r in enumerate(rows) if any(f in r['Kernel_Name'] for f in FIRST)]
     rows = rows[st[-1]:]

@@ -17,7 +17,7 @@ def short(n):
     n = re.sub(r'tedspad::\(anonymous namespace\)::', '', n)
     return re.sub(r'\(tedspad.*$', '', n).replace('void ', '')[:80]
 
-rows = [r for r in csv.DictReader(open(a.csv)) if 'tedspad' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(a.csv)) if 'tedspad' in r['Kernel_Name'] and 'clock_probe' not in r['Kernel_Name']]
 disp = collections.OrderedDict()
 for r in rows:
     d = disp.setdefault(int(r['Dispatch_Id']), {'name': short(r['Kernel_Name']), 'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
