@@ -35,6 +35,38 @@ __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: the store reads its data registers late, hipcc pads nothing after an asm statement
 }
 
+// bn3 (+ residual) + ReLU + saturation of two neighbouring output channels -> one packed pair. `b0`, `b1` carry the shift (and the second branch's
+// product, when there is one); `res` = the residual pair (16-bit halves), `lo` = 0 with ReLU, else the most negative finite value.
+// F16: 3.5 vector instructions per value -- v_fma_mix_f32 adds the f16 half to the shift without a conversion, one fma, one v_med3_f32 (ReLU and
+// saturation together), v_cvt_pk_f16_f32 rounds both (gfx950) -- where the generic form below took 8.5 with `relu` / `res != NULL` as run-time selects
+// (the tails issue vector instructions 45 % of their wave-cycles: profiles/r03_bench_cfg2_mfma_util.md).
+template <typename T, bool RES>
+__device__ __forceinline__ unsigned tail_pair(float a0, float a1, float s0, float s1, float b0, float b1, unsigned res, float lo) {
+    if constexpr (T::kDtype == TEDSPAD_F16) {
+        unsigned pk;
+        if (RES) {
+            float t0, t1;
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(res), "v"(b0));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(res), "v"(b1));
+            b0 = t0;
+            b1 = t1;
+        }
+        const float v0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(a0, s0, b0), lo, 65504.f);
+        const float v1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(a1, s1, b1), lo, 65504.f);
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(v0), "v"(v1));
+        return pk;
+    } else {
+        float o0 = __builtin_fmaf(a0, s0, b0), o1 = __builtin_fmaf(a1, s1, b1);
+        if (RES) {
+            o0 += T::to_f32((uint16_t)(res & 0xffffu));
+            o1 += T::to_f32((uint16_t)(res >> 16));
+        }
+        return (unsigned)T::from_f32(__builtin_fmaxf(o0, lo)) | ((unsigned)T::from_f32(__builtin_fmaxf(o1, lo)) << 16);
+    }
+}
+template <typename T>
+__device__ __forceinline__ float tail_lo(int relu) { return relu ? 0.f : (T::kDtype == TEDSPAD_F16 ? -65504.f : -3.3e38f); }
+
 struct BneckKP {
     const uint16_t *x;          // conv2 input (n,t,h,w,64+) 16-bit, pixel stride ldx
     const uint16_t *w2;         // conv2 weights, packed [>=64][Kpad] (K = (dh, dw, ci))
@@ -242,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     unsigned char *wbuf = dsm + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
     const unsigned wbuf_lds = lds0 + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
     const bool has_res = !DUAL && p.res != nullptr;
+    const float lo = tail_lo<T>(p.relu);
     // row-layout role of this lane in instruction k: pixel row k*8 + (lane >> 3) of the wave, physical chunk lane & 7
     const int rrow = lane >> 3, rch = lane & 7;
     // row k*8 + rrow: chunk swizzle (row >> 1) & 7 = (rrow >> 1) ^ 4 (k & 1); the addresses are rebuilt from ONE base per call (an opaque
@@ -329,16 +362,19 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            float v[2];
+                            const int r = 4 * q + 2 * h;
+                            if (DUAL) {
+                                float v[2];
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int r = 4 * q + 2 * h + e;
-                                float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
-                                if (DUAL) o += ad[b][r] * sd[q][2 * h + e];
-                                if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
-                                v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                                for (int e = 0; e < 2; ++e) {
+                                    const float o = a3[b][r + e] * s3[q][2 * h + e] + b3[q][2 * h + e] + ad[b][r + e] * sd[q][2 * h + e];
+                                    v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
+                                }
+                                d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                            } else {
+                                // without a residual pointer rs is zero: the add stays (no select per value)
+                                d[tt][b][q][h] = tail_pair<T, true>(a3[b][r], a3[b][r + 1], s3[q][2 * h], s3[q][2 * h + 1], b3[q][2 * h], b3[q][2 * h + 1], rs[q][h], lo);
                             }
-                            d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
                         }
 #pragma unroll
                     for (int q = 0; q < 4; q += 2)
@@ -569,6 +605,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
     unsigned char *wbuf = dsm + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
     const unsigned wbuf_lds = lds0 + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
     const bool has_res = p.res != nullptr;
+    const float lo = tail_lo<T>(p.relu);
     const int rrow = lane >> 3, rch = lane & 7;
     const int c0 = rch ^ (rrow >> 1);
     const int limw = lim - wave * 64;
@@ -636,15 +673,8 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        float v[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int r = 4 * q + 2 * h + e;
-                            float o = a3[b][r] * s3[q][2 * h + e] + b3[q][2 * h + e];
-                            if (has_res) o += T::to_f32((uint16_t)(e ? rs[q][h] >> 16 : rs[q][h] & 0xffffu));
-                            v[e] = p.relu ? __builtin_fmaxf(o, 0.f) : o;
-                        }
-                        d[tt][b][q][h] = (unsigned)T::from_f32(v[0]) | ((unsigned)T::from_f32(v[1]) << 16);
+                        const int r = 4 * q + 2 * h;
+                        d[tt][b][q][h] = tail_pair<T, true>(a3[b][r], a3[b][r + 1], s3[q][2 * h], s3[q][2 * h + 1], b3[q][2 * h], b3[q][2 * h + 1], rs[q][h], lo);
                     }
 #pragma unroll
                 for (int q = 0; q < 4; q += 2)
