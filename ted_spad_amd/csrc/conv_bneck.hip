@@ -67,6 +67,23 @@ __device__ __forceinline__ unsigned tail_pair(float a0, float a1, float s0, floa
 template <typename T>
 __device__ __forceinline__ float tail_lo(int relu) { return relu ? 0.f : (T::kDtype == TEDSPAD_F16 ? -65504.f : -3.3e38f); }
 
+#ifdef TEDSPAD_BT_ABLATE      // diagnostic builds (wrong results): bit 1 = no residual loads, 2 = no result stores, 8 = every conv2 weight stage re-reads tap 0's 8 KB (always an L2 / L1 hit), 16 = no conv3 weight image load, 32 / 64 = halo source chunks unswizzled / swizzled by whole quads only
+#define BT_ABL(bit) ((TEDSPAD_BT_ABLATE) & (bit))
+#else
+#define BT_ABL(bit) 0
+#endif
+#ifdef TEDSPAD_BT_STAGE_STAMPS
+// Diagnostic build only (scripts/bneck_tail_cycles.py): s_memtime at the stage boundaries of every workgroup (wave 0) of the 64-channel tail.
+__device__ long long *g_bt_stage_ts;
+#define BT_STAGE_DECL() long long st_[13], sr_[2]; for (int i_ = 0; i_ < 13; ++i_) st_[i_] = 0; st_[0] = __builtin_amdgcn_s_memtime(); sr_[0] = __builtin_amdgcn_s_memrealtime()
+#define BT_STAGE(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define BT_STAGE_FLUSH() { sr_[1] = __builtin_amdgcn_s_memrealtime(); if (tid == 0 && g_bt_stage_ts) { long long *o_ = g_bt_stage_ts + (size_t)blockIdx.x * 16; for (int i_ = 0; i_ < 13; ++i_) o_[i_] = st_[i_]; o_[14] = sr_[0]; o_[15] = sr_[1]; } }
+#else
+#define BT_STAGE_DECL()
+#define BT_STAGE(i)
+#define BT_STAGE_FLUSH()
+#endif
+
 struct BneckKP {
     const uint16_t *x;          // conv2 input (n,t,h,w,64+) 16-bit, pixel stride ldx
     const uint16_t *w2;         // conv2 weights, packed [>=64][Kpad] (K = (dh, dw, ci))
@@ -79,6 +96,7 @@ struct BneckKP {
     int M, Kpad, W, H, kh, kw, ph, pw, ldx, ldres, ldx2, ldy, cout3, relu;
     int R, NP, ntaps;           // flat-halo geometry (conv_flat.hip)
     int HW, tpf;                // POOLT: pixels / tiles per frame
+    unsigned winv, hinv;        // ceil(2^20 / W), ceil(2^20 / H): (t * inv) >> 20 == t / W for the small t the kernels divide (t < W + 256; t * W < 2^20)
 };
 
 // STAGED: residual rows in / result rows out through wave-private LDS images (whole 128-byte lines per access); otherwise 16-byte
@@ -94,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    BT_STAGE_DECL();
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int q0f[NF];                                        // first pixel of the tile (in each of the two frames)
     int lim;                                            // valid pixels of the tile
@@ -128,38 +147,113 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
     const int NH = (Sr + NT - 1) / NT;
+    // ---- stage B's LDS images and loads, set up here because they are ISSUED right after stage A's last barrier (under the bn2 / ReLU arithmetic) -------------
+    // conv3 weight image: tiles of [64 co'][64 k] (the swizzled image of every weight tile of stage A), HG output-channel groups of 64 resident at a time: all of
+    // them for the plain block (32 KB), two at a time with the second source (2 x 2 x 8 KB), so that weight image + BatchNorm vectors + the waves' row images
+    // stay below the 80 KB that let two workgroups share a CU
+    const int n3 = p.cout3 / 64;                           // 64-channel groups of the output
+    const int HG = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    auto load_w3 = [&](int g0) {                           // groups g0 .. g0 + HG - 1: slot kb * HG + (g - g0)
+        for (int i = wave; i < KB * HG * 8; i += 4) {      // 8 wave-instructions (8 rows x 128 B) per tile
+            const int tl = i >> 3, sub = i & 7;
+            const int kb = tl / HG, g = g0 + tl - kb * HG;
+            if (g >= n3) continue;
+            const int row = sub * 8 + (lane >> 3);         // row of the tile
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            lds_dma16(p.w3p + (size_t)(g * 64 + row) * (KB * 64) + kb * 64 + ch * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
+        }
+    };
+    // BatchNorm vectors [3][CP] fp32 (scale3, shift3, scale of the second branch), CP = cout3 rounded up to 256: one 1 KB LDS-DMA instruction per 256 channels
+    // (every load of this phase is an asm DMA, so the counted wait below can leave the residual rows in flight: hipcc's own wait for a plain load would drain them)
+    const int CP = (p.cout3 + 255) & ~255;
+    const int bnv_off = KB * HG * BT_WSTAGE;
+    float *bnv = reinterpret_cast<float *>(dsm + bnv_off);
+    auto load_bnv = [&]() {
+        const int nck = CP >> 8;
+        for (int i = wave; i < (DUAL ? 3 : 2) * nck; i += 4) {
+            const int v = i / nck, ck = i - v * nck;
+            const float *vec = v == 0 ? p.scale3 : v == 1 ? p.shift3 : p.scaled;
+            const int c = min(ck * 256 + lane * 4, p.cout3 - 4);
+            lds_dma16(vec + c, lds0 + bnv_off + (v * CP + ck * 256) * 4);
+        }
+    };
+    const int wb_off = bnv_off + 3 * CP * 4;
+    unsigned char *wbuf = dsm + wb_off + wave * 8192;
+    const unsigned wbuf_lds = lds0 + wb_off + wave * 8192;
+    const bool has_res = !DUAL && p.res != nullptr;
+    const float lo = tail_lo<T>(p.relu);
+    // row-layout role of this lane in instruction k: pixel row k*8 + (lane >> 3) of the wave, physical chunk lane & 7
+    const int rrow = lane >> 3, rch = lane & 7;
+    // row k*8 + rrow: chunk swizzle (row >> 1) & 7 = (rrow >> 1) ^ 4 (k & 1); the addresses are rebuilt from ONE base per call (an opaque
+    // zero keeps hipcc from carrying 8 row pointers per frame across the loop -- the pooled variant spilled them, and every reload drained
+    // the DMA queue)
+    const int c0 = rch ^ (rrow >> 1);
+    const int limw = lim - wave * 64;                   // valid rows of this wave
+    auto issue_res = [&](int g, int f) {
+        if (BT_ABL(1)) return;
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const uint16_t *base = p.res + (size_t)(q0f[f] + wave * 64 + rrow + opq) * p.ldres + 64 * g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
+            lds_dma16(src, wbuf_lds + k * 1024);
+        }
+    };
+    // bn2's scale / shift ([2][64] fp32) go through LDS too, past everything else: read as 4-channel vectors after stage A (64 scalar global loads per lane
+    // sat between stage A and stage B before)
+    const int main_end = halo_bytes + WS * BT_WSTAGE, tail_end = wb_off + (STAGED ? 4 * 8192 : 0);
+    float *bn2v = reinterpret_cast<float *>(dsm + (main_end > tail_end ? main_end : tail_end));
+    f32x4 bn2reg = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 32) bn2reg = reinterpret_cast<const f32x4 *>(tid < 16 ? p.scale2 : p.shift2)[tid & 15];
     uint4 y2[NF][4][2];       // relu(bn2(conv2)) packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel half a
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int q0 = q0f[f];
+        if (f == 0) BT_STAGE(9);
         issue_w(0, 0);                                       // issue order w(0), halo, w(1): the counted waits below rely on it
-        for (int i = 0; i < NH; ++i) {
-            if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
-            const int s = i * NT + tid;
-            const int pos = s >> 3, cs = s & 7;
-            const int q = q0 - p.R + pos;
-            const bool ok = pos < p.NP && (unsigned)q < (unsigned)p.M;
-            const uint16_t *src = ok ? p.x + (size_t)q * p.ldx + ((cs ^ ((pos >> 1) & 7)) << 3) : zero;
-            lds_dma16(src, lds0 + (i * NT + wave * 64) * 16);
+        {
+            // lane: 16-byte chunk cs of halo position pos0 + 32 i; its swizzle term ((pos >> 1) & 7) does not depend on i, the source advances 32 pixels per
+            // instruction (one 64-bit add; the first version recomputed every address and took 4.4 k cycles to ISSUE the 12 instructions, scripts/bneck_tail_cycles.py)
+            const int pos0 = tid >> 3, cs = tid & 7;
+            const int qa = q0 - p.R + pos0;
+            const uint16_t *src = p.x + (long)qa * p.ldx + ((BT_ABL(32) ? cs : BT_ABL(64) ? (cs ^ ((pos0 >> 1) & 4)) : (cs ^ ((pos0 >> 1) & 7))) << 3);
+            const long step = (long)32 * p.ldx;
+            for (int i = 0; i < NH; ++i) {
+                if (i * NT + wave * 64 >= Sr) break;             // wave-uniform
+                const bool ok = pos0 + 32 * i < p.NP && (unsigned)(qa + 32 * i) < (unsigned)p.M;
+                if (BT_ABL(128)) {     // timing only: M0 left alone (every piece lands on the same 1 KB)
+                    if (i == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds0 + wave * 64 * 16) : "memory");
+                    asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(ok ? src : zero) : "memory");
+                } else
+                lds_dma16(ok ? src : zero, lds0 + (i * NT + wave * 64) * 16);
+                src += step;
+            }
         }
         if (p.ntaps > 1) issue_w(1, 1);
+        if (f == 0) BT_STAGE(10);
 
+        // Which taps of a pixel lie inside its frame: bit dh of rb / bit dw of cb (3 + 3 compares per pixel instead of a division, a modulo and kh x kw tests:
+        // that prologue took 4.3 k cycles). The tile starts at row h0, column w0 of its frame (uniform); a lane's pixel is < 256 further on.
         int pj[2];
-        unsigned vmask[2];        // bit (dh*kw + dw): the tap lies inside the frame
+        unsigned rb[2], cb[2];
+        {
+            const int r0 = q0 / p.W, w0 = q0 - r0 * p.W, h0 = r0 % p.H;      // uniform
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int j = wave * 64 + b * 32 + l31;
-            pj[b] = j;
-            const int q = q0 + j;
-            unsigned mk = 0;
-            if (q < p.M) {
-                const int r1 = q / p.W, w = q - r1 * p.W;
-                const int h = r1 % p.H;
-                for (int dh = 0; dh < p.kh; ++dh)
-                    for (int dw = 0; dw < p.kw; ++dw)
-                        if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+            for (int b = 0; b < 2; ++b) {
+                const int j = wave * 64 + b * 32 + l31;
+                pj[b] = j;
+                const unsigned t = (unsigned)(w0 + j);
+                const unsigned dr = (t * p.winv) >> 20;
+                const int w = (int)(t - dr * p.W);
+                const unsigned hh = (unsigned)h0 + dr;
+                const int h = (int)(hh - ((hh * p.hinv) >> 20) * p.H);
+                unsigned r = 0, c = 0;
+                for (int dh = 0; dh < p.kh; ++dh) r |= ((unsigned)(h + dh - p.ph) < (unsigned)p.H ? 1u : 0u) << dh;
+                for (int dw = 0; dw < p.kw; ++dw) c |= ((unsigned)(w + dw - p.pw) < (unsigned)p.W ? 1u : 0u) << dw;
+                rb[b] = q0 + j < p.M ? r : 0u;
+                cb[b] = c;
             }
-            vmask[b] = mk;
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -169,23 +263,27 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+        if (f == 0) BT_STAGE(11);
+        if (f == 0 && tid < 32) *reinterpret_cast<f32x4 *>(bn2v + tid * 4) = bn2reg;
         if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
+        if (f == 0) BT_STAGE(12);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (f == 0) BT_STAGE(1);
         int dh = 0, dw = 0;
         for (int kt = 0; kt < p.ntaps; ++kt) {
             const int delta = dh * p.W + dw;
             unsigned xoff[2], xswz[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+                const int pos = ((rb[b] >> dh) & (cb[b] >> dw) & 1u) ? pj[b] + delta : p.NP;
                 xoff[b] = (unsigned)pos * 128u;
                 xswz[b] = (unsigned)(pos >> 1) & 7u;
             }
             if (kt + 1 < p.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
             __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
             asm volatile("" ::: "memory");
-            if (kt + 2 < p.ntaps) issue_w(kt + 2, (kt + 2) % WS);
+            if (kt + 2 < p.ntaps) { if (!BT_ABL(8)) issue_w(kt + 2, (kt + 2) % WS); else { issue_w(0, 0); } }
             const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * BT_WSTAGE) + l31 * BK;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -203,15 +301,23 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
             if (++dw == p.kw) { dw = 0; ++dh; }
         }
         __syncthreads();          // every wave is done with the halo and the weight ring: the next frame's halo / the conv3 weight image lands there
+        if (f == NF - 1) {
+            // stage A's LDS is free: stage B's weight image, BatchNorm vectors and the first residual rows land under the arithmetic below
+            BT_STAGE(2);
+            if (!BT_ABL(16)) load_w3(0);
+            load_bnv();
+            if (STAGED && has_res) issue_res(0, 0);
+        }
         // ---- relu(bn2(.)) of the conv2 tile, packed to 16 bits ---------------------------------------------------------------------
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float sc[16], sf[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                sc[r] = p.scale2[c];
-                sf[r] = p.shift2[c];
+            for (int rq = 0; rq < 4; ++rq) {
+                const int c = a * 32 + 8 * rq + 4 * lh;           // register 4 rq + i <-> channel c + i
+                const f32x4 vs = *reinterpret_cast<const f32x4 *>(bn2v + c), vf = *reinterpret_cast<const f32x4 *>(bn2v + 64 + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { sc[4 * rq + i] = vs[i]; sf[4 * rq + i] = vf[i]; }
             }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -226,28 +332,6 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     }
 
     // ================================ stage B: conv3 (+ downsample branch) on the register tile ================================
-    // ---- conv3 weight image: tiles of [64 co'][64 k] (the swizzled image of every weight tile above), HG output-channel groups of 64
-    // resident at a time: all of them for the plain block (32 KB), two at a time with the second source (2 x 2 x 8 KB), so that weight image
-    // + BatchNorm vectors + the waves' row images stay below the 80 KB that let two workgroups share a CU -------------------------------
-    const int n3 = p.cout3 / 64;                           // 64-channel groups of the output
-    const int HG = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
-    auto load_w3 = [&](int g0) {                           // groups g0 .. g0 + HG - 1: slot kb * HG + (g - g0)
-        for (int i = wave; i < KB * HG * 8; i += 4) {      // 8 wave-instructions (8 rows x 128 B) per tile
-            const int tl = i >> 3, sub = i & 7;
-            const int kb = tl / HG, g = g0 + tl - kb * HG;
-            if (g >= n3) continue;
-            const int row = sub * 8 + (lane >> 3);         // row of the tile
-            const int ch = (lane & 7) ^ ((row >> 1) & 7);
-            lds_dma16(p.w3p + (size_t)(g * 64 + row) * (KB * 64) + kb * 64 + ch * 8, lds0 + tl * BT_WSTAGE + sub * 1024);
-        }
-    };
-    load_w3(0);
-    float *bnv = reinterpret_cast<float *>(dsm + KB * HG * BT_WSTAGE);     // [3][cout3]: scale3, shift3, scale of the second branch
-    for (int i = tid; i < p.cout3; i += NT) {
-        bnv[i] = p.scale3[i];
-        bnv[p.cout3 + i] = p.shift3[i];
-        bnv[2 * p.cout3 + i] = DUAL ? p.scaled[i] : 0.f;
-    }
     // ---- this wave's pixels; the second source's pixel fragments (natural k order) straight from global memory --------------------------
     size_t mpx[2];
     bool inb[2];
@@ -264,35 +348,14 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 #pragma unroll
             for (int b = 0; b < 2; ++b) xin[ks][b] = *reinterpret_cast<const uint4 *>(p.x2 + mpx[b] * p.ldx2 + (ks * 2 + lh) * 8);
     }
-    wait_vmcnt<0>();
-    __syncthreads();           // weight image + BN vectors visible
+    if (STAGED && has_res) wait_vmcnt<8>(); else wait_vmcnt<0>();      // weight image + BatchNorm vectors landed; the 8 residual rows of step 0 may still fly
+    __syncthreads();           // ... of every wave
+    BT_STAGE(3);
 
     // ---- 64 output channels per step. Every global access of the step moves whole 128-byte lines: the residual rows arrive by LDS-DMA
     // into a wave-private [64 px][64 ch] image (8 lanes per pixel row; the chunk swizzle of every other image here), the results leave
     // through the same image and are stored 8 lanes per row. (First version: 16-byte loads / stores straight from the accumulator layout,
     // one 32-byte piece per pixel and instruction -- 32 lines touched per instruction: 935 us for the plain block against 860 us unfused.)
-    unsigned char *wbuf = dsm + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
-    const unsigned wbuf_lds = lds0 + KB * HG * BT_WSTAGE + 3 * p.cout3 * 4 + wave * 8192;
-    const bool has_res = !DUAL && p.res != nullptr;
-    const float lo = tail_lo<T>(p.relu);
-    // row-layout role of this lane in instruction k: pixel row k*8 + (lane >> 3) of the wave, physical chunk lane & 7
-    const int rrow = lane >> 3, rch = lane & 7;
-    // row k*8 + rrow: chunk swizzle (row >> 1) & 7 = (rrow >> 1) ^ 4 (k & 1); the addresses are rebuilt from ONE base per call (an opaque
-    // zero keeps hipcc from carrying 8 row pointers per frame across the loop -- the pooled variant spilled them, and every reload drained
-    // the DMA queue)
-    const int c0 = rch ^ (rrow >> 1);
-    const int limw = lim - wave * 64;                   // valid rows of this wave
-    auto issue_res = [&](int g, int f) {
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
-        const uint16_t *base = p.res + (size_t)(q0f[f] + wave * 64 + rrow + opq) * p.ldres + 64 * g;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
-            lds_dma16(src, wbuf_lds + k * 1024);
-        }
-    };
-    if (STAGED && has_res) issue_res(0, 0);
     const int ng = p.cout3 / 64;
     for (int g = 0; g < ng; ++g) {
         if (g && g % HG == 0) {                  // the next HG groups of the weight image (second-source variant only)
@@ -338,8 +401,8 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
                 for (int q = 0; q < 4; ++q) {
                     const int c = 32 * t + 8 * q + 4 * lh;
                     s3[q] = *reinterpret_cast<const f32x4 *>(bnv + c);
-                    b3[q] = *reinterpret_cast<const f32x4 *>(bnv + p.cout3 + c);
-                    if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * p.cout3 + c);
+                    b3[q] = *reinterpret_cast<const f32x4 *>(bnv + CP + c);
+                    if (DUAL) sd[q] = *reinterpret_cast<const f32x4 *>(bnv + 2 * CP + c);
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
@@ -445,9 +508,12 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
             const int j = wave * 64 + row;
             uint16_t *dst = j < lim ? p.y + (obase + j) * p.ldy + 64 * g + ((rch ^ ((row >> 1) & 7)) << 3)
                                     : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;      // rows past the tile: a scratch line, so that every wave issues 8 stores
-            gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
+            if (!BT_ABL(2)) gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
         }
+        if (g < 4) BT_STAGE(4 + g);
     }
+    BT_STAGE(8);
+    BT_STAGE_FLUSH();
 }
 
 // The same tail for 128 mid channels (layer2's plain bottlenecks: conv2 1 x 3 x 3 128 -> 128, conv3 128 -> 512 + residual; large_i3d.py:69-84).
@@ -740,8 +806,9 @@ int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
     const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * BT_WSTAGE;
     const int n3 = p.cout3 / 64, hg = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
-    const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * p.cout3 * 4 + (STAGED ? 4 * 8192 : 0);     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)
-    const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
+    const int cp = (p.cout3 + 255) & ~255;
+    const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * cp * 4 + (STAGED ? 4 * 8192 : 0);     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)
+    const int lds = (main_bytes > tail_bytes ? main_bytes : tail_bytes) + 512;                          // + bn2's scale / shift
     if (lds > 160 * 1024) {
         set_error("tedspad_bneck_tail_fwd: halo / conv3 weight image does not fit LDS (%d bytes)", lds);
         return TEDSPAD_EINVAL;
@@ -780,7 +847,8 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     TS_REQUIRE(!(residual && x2), "tedspad_bneck_tail_fwd: either a residual tensor or the second (downsample) source, not both");
     TS_REQUIRE(!residual || (ldres >= cout3 && ldres % 8 == 0), "tedspad_bneck_tail_fwd: bad ldres");
     TS_REQUIRE(!x2 || (scale_d && ldx2 >= 64 && ldx2 % 8 == 0), "tedspad_bneck_tail_fwd: second source needs its BatchNorm scale and ldx2 >= 64");
-    TS_REQUIRE(((uintptr_t)x | (uintptr_t)w2_packed | (uintptr_t)w3p | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)x2 | (uintptr_t)scale3 | (uintptr_t)shift3) % 16 == 0,
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)w2_packed | (uintptr_t)w3p | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)x2 | (uintptr_t)scale3 | (uintptr_t)shift3 |
+                (uintptr_t)scale2 | (uintptr_t)shift2 | (uintptr_t)scale_d) % 16 == 0,
                "tedspad_bneck_tail_fwd: pointers must be 16-byte aligned");
     TS_REQUIRE(d2->dtype == TEDSPAD_F16 || d2->dtype == TEDSPAD_BF16, "tedspad_bneck_tail_fwd: bad dtype");
     const long M = (long)d2->n * d2->t * d2->h * d2->w;
@@ -791,6 +859,7 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     p.res = (const uint16_t *)residual; p.x2 = (const uint16_t *)x2; p.y = (uint16_t *)y;
     p.M = (int)M; p.Kpad = tedspad_conv_kpad(d2); p.W = d2->w; p.H = d2->h; p.kh = d2->kh; p.kw = d2->kw; p.ph = d2->ph; p.pw = d2->pw;
     p.ldx = d2->ldx; p.ldres = ldres; p.ldx2 = ldx2; p.ldy = ldy; p.cout3 = cout3; p.relu = relu;
+    p.winv = ((1u << 20) + d2->w - 1) / d2->w; p.hinv = ((1u << 20) + d2->h - 1) / d2->h;
     p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
     TS_REQUIRE(p.Kpad == p.ntaps * d2->cin, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");
     if (c128) return d2->dtype == TEDSPAD_F16 ? launch_bneck128<F16>(p, (hipStream_t)stream) : launch_bneck128<BF16>(p, (hipStream_t)stream);
@@ -809,3 +878,9 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     if (staged) return f16 ? launch_bneck<F16, false, true>(p, s) : launch_bneck<BF16, false, true>(p, s);
     return f16 ? launch_bneck<F16, false, false>(p, s) : launch_bneck<BF16, false, false>(p, s);
 }
+
+#ifdef TEDSPAD_BT_STAGE_STAMPS
+extern "C" int32_t tedspad_debug_set_bt_stage_ts(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(tedspad::g_bt_stage_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif

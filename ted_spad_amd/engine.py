@@ -724,12 +724,15 @@ class BneckTail:
         return (x.c == self.cmid and pads[0] == 0 and pads[1] < kh and pads[2] < kw and 2 * pads[1] == kh - 1 and 2 * pads[2] == kw - 1 and
                 flat_halo <= 80 * 1024 and n * t * h * w * max(x.ld, self.cout3) < MAX_ELEMS)
 
-    def __call__(self, x: Act, pads=(0, 1, 1), residual: Optional[Act] = None, x2: Optional[Act] = None, relu=True, pool_t2=False) -> Act:
+    def __call__(self, x: Act, pads=(0, 1, 1), residual: Optional[Act] = None, x2: Optional[Act] = None, relu=True, pool_t2=False, out: Optional[Act] = None) -> Act:
         """pool_t2: MaxPool3d((2,1,1), (2,1,1)) of the block's output fused (large_i3d.py:139): result (n, t // 2, h, w, cout3)."""
         n, t, h, w = x.dims
         assert self.applies(x, pads) and (x2 is not None) == self.dual and not (self.dual and residual is not None)
         assert not pool_t2 or (not self.dual and t % 2 == 0 and self.cmid == 64), "BneckTail: the temporal pool goes with the plain 64-channel block and an even frame count"
-        out = Act.empty(n, t // 2 if pool_t2 else t, h, w, self.cout3, self.conv2.torch_dtype, x.buf.device)
+        odims = (n, t // 2 if pool_t2 else t, h, w)
+        if out is None:
+            out = Act.empty(*odims, self.cout3, self.conv2.torch_dtype, x.buf.device)
+        assert out.dims == odims and out.c == self.cout3 and out.coff == 0
         for o in (residual, x2):
             if o is not None:
                 assert o.dims == x.dims
