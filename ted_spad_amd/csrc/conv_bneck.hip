@@ -19,6 +19,7 @@
 // the residual (whole rows by LDS-DMA into a wave-private image, read in the store layout and brought into the accumulator layout by
 // v_permlane32_swap, which is its own inverse), ReLU, and the results leave through the same image as whole 128-byte rows.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace tedspad {
 namespace {
@@ -108,7 +109,7 @@ struct BneckKP {
 template <typename T, bool DUAL, bool STAGED, bool POOLT>
 __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p) {
     static_assert(!POOLT || (!DUAL && STAGED), "the pooled variant is the plain block with staged rows");
-    constexpr int NT = 256, WS = 3, KB = DUAL ? 2 : 1, NF = POOLT ? 2 : 1;
+    constexpr int NT = 256, WS = 4, KB = DUAL ? 2 : 1, NF = POOLT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
             }
         }
         if (p.ntaps > 1) issue_w(1, 1);
+        if (p.ntaps > 2) issue_w(2, 2);
         if (f == 0) BT_STAGE(10);
 
         // Which taps of a pixel lie inside its frame: bit dh of rb / bit dw of cb (3 + 3 compares per pixel instead of a division, a modulo and kh x kw tests:
@@ -265,41 +267,79 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 
         if (f == 0) BT_STAGE(11);
         if (f == 0 && tid < 32) *reinterpret_cast<f32x4 *>(bn2v + tid * 4) = bn2reg;
-        if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stage 1 may still fly)
+        if (p.ntaps > 2) wait_vmcnt<4>(); else if (p.ntaps > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();   // halo + weight stage 0 of this wave have landed (stages 1, 2 may still fly)
         if (f == 0) BT_STAGE(12);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (f == 0) BT_STAGE(1);
-        int dh = 0, dw = 0;
-        for (int kt = 0; kt < p.ntaps; ++kt) {
-            const int delta = dh * p.W + dw;
-            unsigned xoff[2], xswz[2];
+        // The fragments of tap kt + 1 are REQUESTED during tap kt: k-step ks of the next tap right after the four MFMAs of k-step ks of this one, into the
+        // registers those MFMAs have just read (a whole tap = 512 MFMA cycles between an LDS request and its use; the first version asked for a k-step's
+        // fragments one k-step ahead, 128 cycles, and a tap took 1 500 - 1 800 cycles: scripts/bneck_tail_cycles.py). That needs weight stage kt + 1 landed when
+        // tap kt starts, hence four ring slots with stages kt + 1, kt + 2 in flight; the DMA of stage kt + 3 is issued behind the first MFMAs of the tap, where
+        // its issue cost hides.
+        u32x4 fa[4][2], fw[4][2];
+        auto tap_pos = [&](int dh_, int dw_, unsigned (&xo)[2], unsigned (&xs)[2]) {
+            const int delta = dh_ * p.W + dw_;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int pos = ((rb[b] >> dh) & (cb[b] >> dw) & 1u) ? pj[b] + delta : p.NP;
-                xoff[b] = (unsigned)pos * 128u;
-                xswz[b] = (unsigned)(pos >> 1) & 7u;
+                const int pos = ((rb[b] >> dh_) & (cb[b] >> dw_) & 1u) ? pj[b] + delta : p.NP;
+                xo[b] = (unsigned)pos * 128u;
+                xs[b] = (unsigned)(pos >> 1) & 7u;
             }
-            if (kt + 1 < p.ntaps) wait_vmcnt<2>(); else wait_vmcnt<0>();   // stage kt landed; stage kt+1 (2 instructions) may stay in flight
-            __builtin_amdgcn_s_barrier();   // ... of every wave; the slot of stage kt-1 is free
-            asm volatile("" ::: "memory");
-            if (kt + 2 < p.ntaps) { if (!BT_ABL(8)) issue_w(kt + 2, (kt + 2) % WS); else { issue_w(0, 0); } }
-            const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * BT_WSTAGE) + l31 * BK;
+        };
+        // The requests are asm, not C++ loads: hipcc drains every outstanding LDS request at the loop header (s_waitcnt lgkmcnt(0)) when they are carried
+        // around the loop, which would undo the pipeline; here a k-step waits for exactly its own four fragments (the 12 younger requests stay in flight).
+        // The counted wait relies on LDS requests completing in order and on NO scalar memory load inside the tap loop (they share lgkmcnt and complete out
+        // of order): tests/test_host_logic.py checks the compiled loop for that.
+        auto read_frags = [&](int ks, int slot, const unsigned (&xo)[2], const unsigned (&xs)[2]) {
+            const unsigned c = (unsigned)((ks << 1) | lh);
+            const unsigned wt = lds0 + halo_bytes + slot * BT_WSTAGE + l31 * (BK * 2) + ((c ^ swz) << 4);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][b]) : "v"(lds0 + xo[b] + ((c ^ xs[b]) << 4)));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fw[ks][0]) : "v"(wt));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fw[ks][1]) : "v"(wt));
+        };
+        static_assert(32 * BK * 2 == 4096, "second weight fragment: 32 rows further");
+        int dh = 0, dw = 0;
+        unsigned xoff[2], xswz[2];
+        tap_pos(0, 0, xoff, xswz);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) read_frags(ks, 0, xoff, xswz);
+        // One tap; straight-line code (the counted DMA wait, the barrier, the DMA issue and the requests for the next tap are decided by the caller at compile time)
+        auto tap = [&](int kt, auto waitn, auto issue, auto more) {
+            if (++dw == p.kw) { dw = 0; ++dh; }          // (dh, dw) of tap kt + 1
+            if constexpr (decltype(more)::value) tap_pos(dh, dw, xoff, xswz);
+            if constexpr (decltype(waitn)::value >= 0) {
+                wait_vmcnt<decltype(waitn)::value>();    // stage kt + 1 landed; stage kt + 2 (2 instructions) may stay in flight
+                __builtin_amdgcn_s_barrier();            // ... of every wave; nobody reads the slot of stage kt - 1 any more
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const unsigned c = (unsigned)((ks << 1) | lh);
-                uint4 fa[2], fw[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) fa[b] = *reinterpret_cast<const uint4 *>(dsm + xoff[b] + ((c ^ xswz[b]) << 4));
-#pragma unroll
-                for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[a][b] = T::mfma(fw[a], fa[b], acc[a][b]);
+                // this k-step's four fragments have arrived: with the next tap's requests behind them 12 stay outstanding, on the last tap 4 (3 - ks)
+                u32x4 x0 = fa[ks][0], x1 = fa[ks][1], w0 = fw[ks][0], w1 = fw[ks][1];      // (locals: the asm cannot tie elements of a captured array)
+                if (decltype(more)::value || ks == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(x0), "+v"(x1), "+v"(w0), "+v"(w1));
+                else if (ks == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x0), "+v"(x1), "+v"(w0), "+v"(w1));
+                else if (ks == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0), "+v"(x1), "+v"(w0), "+v"(w1));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(w0), "+v"(w1));
+                acc[0][0] = T::mfma(__builtin_bit_cast(uint4, w0), __builtin_bit_cast(uint4, x0), acc[0][0]);
+                acc[0][1] = T::mfma(__builtin_bit_cast(uint4, w0), __builtin_bit_cast(uint4, x1), acc[0][1]);
+                acc[1][0] = T::mfma(__builtin_bit_cast(uint4, w1), __builtin_bit_cast(uint4, x0), acc[1][0]);
+                acc[1][1] = T::mfma(__builtin_bit_cast(uint4, w1), __builtin_bit_cast(uint4, x1), acc[1][1]);
+                if constexpr (decltype(more)::value) read_frags(ks, (kt + 1) & 3, xoff, xswz);
+                if constexpr (decltype(issue)::value) {
+                    if (ks == 0) { if (!BT_ABL(8)) issue_w(kt + 3, (kt + 3) & 3); else issue_w(0, 0); }
+                }
             }
-            if (++dw == p.kw) { dw = 0; ++dh; }
-        }
+        };
+        using std::integral_constant;
+        typedef integral_constant<bool, true> yes;
+        typedef integral_constant<bool, false> no;
+        int kt = 0;
+        for (; kt + 3 < p.ntaps; ++kt) tap(kt, integral_constant<int, 2>{}, yes{}, yes{});
+        if (kt + 2 < p.ntaps) { tap(kt, integral_constant<int, 2>{}, no{}, yes{}); ++kt; }
+        if (kt + 1 < p.ntaps) { tap(kt, integral_constant<int, 0>{}, no{}, yes{}); ++kt; }
+        tap(kt, integral_constant<int, -1>{}, no{}, no{});
         __syncthreads();          // every wave is done with the halo and the weight ring: the next frame's halo / the conv3 weight image lands there
         if (f == NF - 1) {
             // stage A's LDS is free: stage B's weight image, BatchNorm vectors and the first residual rows land under the arithmetic below
@@ -804,7 +844,7 @@ int32_t launch_bneck128(const BneckKP &p, hipStream_t s) {
 template <typename T, bool DUAL, bool STAGED, bool POOLT = false>
 int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
-    const int main_bytes = (S + 63) / 64 * 64 * 16 + 3 * BT_WSTAGE;
+    const int main_bytes = (S + 63) / 64 * 64 * 16 + 4 * BT_WSTAGE;         // halo + the four-slot weight ring
     const int n3 = p.cout3 / 64, hg = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
     const int cp = (p.cout3 + 255) & ~255;
     const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * cp * 4 + (STAGED ? 4 * 8192 : 0);     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)

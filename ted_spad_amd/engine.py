@@ -720,7 +720,7 @@ class BneckTail:
     def applies(self, x: Act, pads) -> bool:
         n, t, h, w = x.dims
         kt, kh, kw = self.conv2.k
-        flat_halo = (256 + (kh - 1) * w + (kw - 1) + 1) * 128 + (3 * 8192 if self.cmid == 64 else 2 * 16384)
+        flat_halo = (256 + (kh - 1) * w + (kw - 1) + 1 + 8) * 128 + (4 * 8192 + 512 if self.cmid == 64 else 2 * 16384)   # halo (rounded up to 1 KB) + weight ring (+ bn2 vectors)
         return (x.c == self.cmid and pads[0] == 0 and pads[1] < kh and pads[2] < kw and 2 * pads[1] == kh - 1 and 2 * pads[2] == kw - 1 and
                 flat_halo <= 80 * 1024 and n * t * h * w * max(x.ld, self.cout3) < MAX_ELEMS)
 
