@@ -591,22 +591,27 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
     const int NH = (Sr + NT - 1) / NT;
+    // which taps of a pixel lie inside its frame: bit dh of rb / bit dw of cb, from the tile's (uniform) first row / column -- no division per lane (see the
+    // 64-channel kernel above)
     int pj[2];
-    unsigned vmask[2];
+    unsigned rb[2], cb[2];
+    {
+        const int r0 = q0 / p.W, w0 = q0 - r0 * p.W, h0 = r0 % p.H;      // uniform
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int j = wave * 64 + b * 32 + l31;
-        pj[b] = j;
-        const int q = q0 + j;
-        unsigned mk = 0;
-        if (q < p.M) {
-            const int r1 = q / p.W, w = q - r1 * p.W;
-            const int h = r1 % p.H;
-            for (int dh = 0; dh < p.kh; ++dh)
-                for (int dw = 0; dw < p.kw; ++dw)
-                    if ((unsigned)(h + dh - p.ph) < (unsigned)p.H && (unsigned)(w + dw - p.pw) < (unsigned)p.W) mk |= 1u << (dh * p.kw + dw);
+        for (int b = 0; b < 2; ++b) {
+            const int j = wave * 64 + b * 32 + l31;
+            pj[b] = j;
+            const unsigned t = (unsigned)(w0 + j);
+            const unsigned dr = (t * p.winv) >> 20;
+            const int w = (int)(t - dr * p.W);
+            const unsigned hh = (unsigned)h0 + dr;
+            const int h = (int)(hh - ((hh * p.hinv) >> 20) * p.H);
+            unsigned r = 0, c = 0;
+            for (int dh = 0; dh < p.kh; ++dh) r |= ((unsigned)(h + dh - p.ph) < (unsigned)p.H ? 1u : 0u) << dh;
+            for (int dw = 0; dw < p.kw; ++dw) c |= ((unsigned)(w + dw - p.pw) < (unsigned)p.W ? 1u : 0u) << dw;
+            rb[b] = q0 + j < p.M ? r : 0u;
+            cb[b] = c;
         }
-        vmask[b] = mk;
     }
     f32x16 acc[4][2];
 #pragma unroll
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
             unsigned xoff[2], xswz[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int pos = ((vmask[b] >> kt) & 1u) ? pj[b] + delta : p.NP;
+                const int pos = ((rb[b] >> dh) & (cb[b] >> dw) & 1u) ? pj[b] + delta : p.NP;
                 xoff[b] = (unsigned)pos * 128u;
                 xswz[b] = (unsigned)(pos >> 1) & 7u;
             }
