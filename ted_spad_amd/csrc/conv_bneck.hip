@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
         };
         // The requests are asm, not C++ loads: hipcc drains every outstanding LDS request at the loop header (s_waitcnt lgkmcnt(0)) when they are carried
         // around the loop, which would undo the pipeline; here a k-step waits for exactly its own four fragments (the 12 younger requests stay in flight).
-        // The counted wait relies on LDS requests completing in order and on NO scalar memory load inside the tap loop (they share lgkmcnt and complete out
-        // of order): tests/test_host_logic.py checks the compiled loop for that.
+        // The counted wait relies on LDS requests completing in order. A scalar load in flight (same counter, out of order) can only make the wait longer:
+        // it counts as outstanding, so "at most 12 outstanding" still means that at most 12 LDS requests are, i.e. the four oldest have completed.
         auto read_frags = [&](int ks, int slot, const unsigned (&xo)[2], const unsigned (&xs)[2]) {
             const unsigned c = (unsigned)((ks << 1) | lh);
             const unsigned wt = lds0 + halo_bytes + slot * BT_WSTAGE + l31 * (BK * 2) + ((c ^ swz) << 4);
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
         int dh = 0, dw = 0;
         unsigned xoff[2], xswz[2];
         tap_pos(0, 0, xoff, xswz);
+        asm volatile("; BT_COUNTED_LGKM_BEGIN" ::: "memory");      // (markers for the structure check of tests/test_host_logic.py)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) read_frags(ks, 0, xoff, xswz);
         // One tap; straight-line code (the counted DMA wait, the barrier, the DMA issue and the requests for the next tap are decided by the caller at compile time)
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
         if (kt + 2 < p.ntaps) { tap(kt, integral_constant<int, 2>{}, no{}, yes{}); ++kt; }
         if (kt + 1 < p.ntaps) { tap(kt, integral_constant<int, 0>{}, no{}, yes{}); ++kt; }
         tap(kt, integral_constant<int, -1>{}, no{}, no{});
+        asm volatile("; BT_COUNTED_LGKM_END" ::: "memory");
         __syncthreads();          // every wave is done with the halo and the weight ring: the next frame's halo / the conv3 weight image lands there
         if (f == NF - 1) {
             // stage A's LDS is free: stage B's weight image, BatchNorm vectors and the first residual rows land under the arithmetic below

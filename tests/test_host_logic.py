@@ -74,6 +74,42 @@ def test_no_kernel_spills_registers():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_tail_stage_a_keeps_its_counted_lds_waits():
+    """csrc/conv_bneck.hip's stage A requests its MFMA fragments one tap ahead with asm ds_read_b128 and waits with COUNTED s_waitcnt lgkmcnt(12) (hipcc's own
+    bookkeeping drained every request at the loop header). Compiles the file to assembly and checks, between the markers the kernel emits, that every
+    instantiation still has the requests, the counted waits, and no full drain (lgkmcnt(0)) in front of the MFMAs of the pipelined taps."""
+    import subprocess
+    import tempfile
+    from ted_spad_amd import build as B
+    if not os.path.exists(B.HIPCC):
+        pytest.skip("hipcc not installed")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "conv_bneck.s")
+        flags = [f for f in B.FLAGS if f != "-fPIC"]
+        subprocess.run([B.HIPCC] + flags + ["-S", "--cuda-device-only", os.path.join(B.CSRC, "conv_bneck.hip"), "-o", out], check=True, capture_output=True)
+        text = open(out).read()
+    regions = re.findall(r"; BT_COUNTED_LGKM_BEGIN(.*?); BT_COUNTED_LGKM_END", text, flags=re.S)
+    assert len(regions) >= 12, "expected the marked region in every instantiation of the 64-channel tail, found %d" % len(regions)
+    for r in regions:
+        assert r.count("ds_read_b128") >= 16 * 4 and r.count("s_waitcnt lgkmcnt(12)") >= 4 * 3 + 1
+        loop = re.search(r"=>This Inner Loop Header.*?s_cbranch_scc\d \.LBB", r, flags=re.S)      # the steady-state taps
+        assert loop and loop.group(0).count("v_mfma") == 16 and "lgkmcnt(0)" not in loop.group(0)
+        # hipcc believes an asm request's destination is written when the statement ends: it must not spill or copy such a register inside the region
+        # (the bytes land later); the fragments stay put because they are live from the request to the MFMA
+        frag = set()
+        for a, b in re.findall(r"ds_read_b128 v\[(\d+):(\d+)\]", r):
+            frag.update(range(int(a), int(b) + 1))
+        moved = []
+        for l in r.splitlines():
+            code = l.split(";")[0]
+            if re.match(r"\s*(scratch_store|v_accvgpr_write|v_mov_b32)", code):
+                ops = code.split(None, 1)[1].split(",")
+                srcs = re.findall(r"\bv(\d+)\b", ",".join(ops[1:]))          # everything after the first operand (destination / 'off')
+                if any(int(v) in frag for v in srcs):
+                    moved.append(code.strip())
+        assert not moved, "fragment registers spilled / copied inside the counted-wait region: %s" % moved[:4]
+
+
 def test_job_structs_mirror_the_header():
     """The multi-job launches take arrays of plain C structs (include/tedspad_hip.h: tedspad_pack_job / _fold_job / _wgrad_unpack_job); the ctypes
     mirrors must have the sizes csrc/pack.hip static_asserts and the header's field order. No GPU: a null job list is refused by the host check."""
