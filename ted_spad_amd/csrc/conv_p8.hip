@@ -312,6 +312,77 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     __syncthreads();   // ring free: reused as the fp32 staging tile
     P8_STAMP(2);
 
+    // ---- epilogue without a residual: scale / shift / ReLU / rounding in the accumulator layout, ONE pass of 16-bit rows through LDS ([256 px][256 ch], 528-byte
+    // rows), then whole 512-byte rows out. (The fp32 two-pass form below moved 2 x 128 KB in and out of LDS behind three barriers: 15 k cycles per workgroup,
+    // as long as 4.6 K tiles of the loop -- scripts/p8_cycles.py; it stays for the residual case, whose sum must be formed in fp32 in the row layout.)
+    if (!p.res) {
+        constexpr int S16 = 256 + 8;                        // 16-bit elements per staged row
+        static_assert(BM * S16 * 2 <= LDS_BYTES, "16-bit staging tile");
+        uint16_t *stg16 = reinterpret_cast<uint16_t *>(smem);
+        const float lo = p.relu ? 0.f : (T::kDtype == TEDSPAD_F16 ? -65504.f : -3.3e38f);
+        auto pack2 = [&](float a, float b) -> unsigned {
+            if constexpr (T::kDtype == TEDSPAD_F16) {
+                unsigned pk;
+                const float x = __builtin_amdgcn_fmed3f(a, lo, 65504.f), y = __builtin_amdgcn_fmed3f(b, lo, 65504.f);
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(x), "v"(y));
+                return pk;
+            } else {
+                return (unsigned)T::from_f32(__builtin_fmaxf(a, lo)) | ((unsigned)T::from_f32(__builtin_fmaxf(b, lo)) << 16);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int nb = n0 + 128 * j;                          // folded output frames: scale / shift are indexed inside the frame
+            if (p.fold_hw) nb -= (nb / p.fold_c) * p.fold_c;
+            constexpr int NG = MF == 32 ? 4 : NWF;          // 4-channel groups of this lane per accumulator set
+            f32x4 sc[NG], sh[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int cb = nb + 32 * wn + (MF == 32 ? 8 * g + 4 * lh : 16 * g + 4 * lq);
+                sc[g] = *reinterpret_cast<const f32x4 *>(p.scale + cb);
+                sh[g] = *reinterpret_cast<const f32x4 *>(p.shift + cb);
+            }
+#pragma unroll
+            for (int b = 0; b < 2 * NXF; ++b) {
+                const int ml = (b / NXF) * 128 + 64 * grp + (b % NXF) * FR + frow;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float a;
+                        if constexpr (MF == 32) a = acc[j][b][0][4 * g + i]; else a = acc[j][b][g][i];
+                        v[i] = __builtin_fmaf(a, sc[g][i], sh[g][i]);
+                    }
+                    const int ch = 128 * j + 32 * wn + (MF == 32 ? 8 * g + 4 * lh : 16 * g + 4 * lq);
+                    *reinterpret_cast<uint2 *>(stg16 + ml * S16 + ch) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                }
+            }
+        }
+        __syncthreads();
+        P8_STAMP(3);
+        const int cc = tid & 31, r0 = tid >> 5;             // 32 chunks of 8 channels per row, 16 rows per sweep
+        int nsel = 0, nloc = n0 + cc * 8;
+        if (p.fold_hw) { nsel = nloc / p.fold_c; nloc -= nsel * p.fold_c; }
+#pragma unroll 4
+        for (int it = 0; it < BM / 16; ++it) {
+            const int r = r0 + it * 16;
+            const int m = m0 + r;
+            if (m < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(stg16 + r * S16 + cc * 8);
+                size_t orow = (size_t)m;
+                if (p.fold_hw) orow += (size_t)(m / p.fold_hw) * (size_t)((p.fold_f - 1) * p.fold_hw) + (size_t)nsel * p.fold_hw;
+                *reinterpret_cast<uint4 *>(p.y + orow * p.ldy + nloc) = v;
+            }
+        }
+        P8_STAMP(4);
+#ifdef TEDSPAD_P8_ABLATIONS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P8_STAMP(5);
+#endif
+        return;
+    }
+
     // ---- epilogue: two passes of 256 pixels x 128 channels: fp32 -> LDS -> coalesced 16-byte rows ------------------------
     // The residual rows of both passes are requested BEFORE the staging writes (the fragment registers are dead by now):
     // their L2 / HBM round trip runs under the staging traffic instead of once per row inside the store loop.
