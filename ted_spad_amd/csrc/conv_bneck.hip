@@ -570,6 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    BT_STAGE_DECL();
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int q0 = tile * BT_BM;
     const int lim = min(BT_BM, p.M - q0);
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     for (int ch = 0; ch < 2; ++ch) {
-        if (ch) __builtin_amdgcn_s_barrier();              // every wave has read the previous chunk's halo and weight slots
+        if (ch) { BT_STAGE(9); __builtin_amdgcn_s_barrier(); }              // every wave has read the previous chunk's halo and weight slots
         asm volatile("" ::: "memory");
         issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
         for (int i = 0; i < NH; ++i) {
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
             if (kt + 1 < p.ntaps) wait_vmcnt<4>(); else wait_vmcnt<0>();   // stage kt (and, on kt = 0, the halo) landed; stage kt+1 (4 instructions) may stay in flight
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (kt == 0) { if (ch == 0) BT_STAGE(1); else BT_STAGE(10); }
             const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt & 1) * WSTAGE) + l31 * BK;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
         }
     }
     __syncthreads();          // every wave is done with the halo and the weight ring
+    BT_STAGE(2);
 
     // ================================ stage B: conv3 + residual on the register tile ================================
     const int n3 = p.cout3 / 64;
@@ -714,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
     }
     wait_vmcnt<0>();
     __syncthreads();           // weight image + BN vectors visible
+    BT_STAGE(3);
 
     unsigned char *wbuf = dsm + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
     const unsigned wbuf_lds = lds0 + 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + wave * 8192;
@@ -822,7 +826,10 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
                                     : reinterpret_cast<uint16_t *>(g_sink16b) + lane * 8;
             gstore16(dst, u32x4{rowv[k].x, rowv[k].y, rowv[k].z, rowv[k].w});
         }
+        if (g < 4) BT_STAGE(4 + g);
     }
+    BT_STAGE(8);
+    BT_STAGE_FLUSH();
 }
 
 template <typename T>
