@@ -23,13 +23,15 @@ def _id(t, kind):
     return t
 
 
-def _bn2d(x, sd, p, train):
+def _bn2d(x, sd, p, train, q=_id):
     if train:
         mean = x.mean((0, 2, 3), keepdim=True)
         var = x.var((0, 2, 3), unbiased=False, keepdim=True)
         from .i3res50_ref import update_running
         update_running(sd, p, mean, var, x.numel() // x.shape[1])       # only when the state dict carries `_track_running`
-        return (x - mean) / torch.sqrt(var + BN_EPS) * sd[p + "weight"].view(1, -1, 1, 1) + sd[p + "bias"].view(1, -1, 1, 1)
+        # q(., "z"): the precision tests round / adopt the conv output the normalisation READS (the batch statistics come from the unrounded one, as the
+        # device's come from its fp32 accumulators); the default hook is the identity
+        return (q(x, "z") - mean) / torch.sqrt(var + BN_EPS) * sd[p + "weight"].view(1, -1, 1, 1) + sd[p + "bias"].view(1, -1, 1, 1)
     inv = sd[p + "weight"] / torch.sqrt(sd[p + "running_var"] + BN_EPS)
     sh = sd[p + "bias"] - sd[p + "running_mean"] * inv
     return x * inv.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
@@ -38,7 +40,7 @@ def _bn2d(x, sd, p, train):
 def double_conv(x, sd, p, q=_id, train=False):
     for c, b in (("0.", "1."), ("3.", "4.")):
         x = F.conv2d(q(x, "act"), q(sd[p + c + "weight"], "w"), sd[p + c + "bias"], padding=1)
-        x = q(F.relu(_bn2d(x, sd, p + b, train)), "act")
+        x = q(F.relu(_bn2d(x, sd, p + b, train, q)), "act")
     return x
 
 
@@ -62,4 +64,4 @@ def forward(x, sd, q=_id, train=False, taps=None):
         if taps is not None:
             taps["up%d" % i] = h
     logits = F.conv2d(q(h, "act"), q(sd["outc.conv.weight"], "w"), sd["outc.conv.bias"])
-    return torch.sigmoid(logits)
+    return q(torch.sigmoid(logits), "out")

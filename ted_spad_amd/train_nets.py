@@ -173,6 +173,7 @@ class BottleneckTrunk:
         h2, rec["u2"] = unit(d["c2"], d["bn2"], h1)
         if d["cd"] is not None:
             r, rec["ud"] = unit(d["cd"], d["bnd"], a, relu=False)
+            rec["r"] = r
         else:
             r = a
         a, rec["u3"] = unit(d["c3"], d["bn3"], h2, relu=True, residual=r)

@@ -17,9 +17,14 @@ optimises the utility term alone and says so in its result (`loss_fb` None).
 
 Gradient range: activations AND activation gradients are stored in f16 (fp32 accumulate). The reference's
 train_anonymizer.py back-propagates its fp16-autocast graph without a GradScaler; its action-training scripts use one
-(train_anonymized_action.py:92-94). `loss_scale` (default 1 = the reference's behaviour) multiplies the loss gradients
-entering the networks and is divided out of every parameter gradient before the optimizer step; a step whose gradients
-are not finite is skipped and reported (`skipped: True`), like `GradScaler.step`.
+(train_anonymized_action.py:92-94). `loss_scale` multiplies the loss gradients entering the networks and is divided out of
+every parameter gradient before the optimizer step (powers of two: the same arithmetic); a step whose gradients are not
+finite is skipped and reported (`skipped: True`), like `GradScaler.step`. The default is 256, not 1: gfx950's matrix cores
+flush f16 SUBNORMAL operands, and the per-pixel activation gradients of the UNet's 112 x 112 / 224 x 224 levels are below
+6e-5 at the reference's scale -- the data- and weight-gradient MFMAs dropped them (3-7 % error in the neighbouring
+parameter gradients against autograd at the same forward point, 0.5-0.8 % with the scale;
+tests/test_hip_train_golden.py::test_phase1_backward_at_the_devices_forward_point_vs_autograd). `loss_scale=1.0` is the
+reference's literal behaviour.
 
 Data parallel: one process per GPU, per-rank BatchNorm statistics (what nn.DataParallel does in the
 reference). The gradients of the network being updated live in flat buckets (grad_reduce.GradBucketReducer): on
@@ -67,7 +72,7 @@ def ntxent_from_embeddings(z0, z1, temperature=0.1):
 
 
 class AnonymizerTrainStep:
-    def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 1.0):
+    def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 256.0):
         self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
         self.loss_scale = float(loss_scale)
         self.batch_clips = os.environ.get("TEDSPAD_TRAIN_BATCH_CLIPS", "1") != "0"   # the three clips of an iteration as one ft batch (0: three passes, A/B)

@@ -4,6 +4,7 @@ cfg3's real per-clip size (112 x 112, BASELINE.json configs[2]) against the fp32
 values per channel instead of the 4-32 of the toy sizes in test_hip_train_step.py; (3) the full-size cfg2 batch (225 clips @224^2:
 the tile configurations the tuner picks at M = 225 clips) against the oracle and against single-clip forwards; (4) f16 head-room."""
 import contextlib
+import os
 import io
 
 import numpy as np
@@ -127,9 +128,9 @@ def _adopting_rounding(values, dtype=torch.float16):
             return t + (r(t) - t).detach() if t.requires_grad else r(t)
         if getattr(t, "_q16", False):
             return t
-        if first[0] and kind == "act":          # the clip itself (the same fp32 tensor on both sides)
+        if first[0] and kind == "act":          # the clip itself (the same fp32 tensor on both sides; phase 1: the anonymizer's output, which carries the gradient)
             first[0] = False
-            y = r(t)
+            y = t + (r(t) - t).detach() if t.requires_grad else r(t)
         else:
             dv = next(it)
             assert dv.shape == t.shape, (dv.shape, t.shape, kind)
@@ -192,11 +193,88 @@ def test_phase2_backward_at_the_devices_forward_point_vs_autograd():
     per_clip = [values_of_clip(k) for k in range(3)]
     torch.set_num_threads(32)
     ref_l, ref_g = train_step_ref.phase2(video, labels, sd_u, sd_l, ft_rounding=lambda k: _adopting_rounding(per_clip[k]), anon=anon)
+    print("cfg3 phase 2 at the device's forward point: loss_ft %.6f vs %.6f (%.2e)" % (out["loss_ft"], ref_l["loss_ft"], abs(out["loss_ft"] / ref_l["loss_ft"] - 1)))
     assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 1e-3 * abs(ref_l["loss_ft"])
     errs = _report("cfg3 phase 2 backward at the device's forward point: ft grads", {k: p.grad for k, p in ft.named_parameters()}, ref_g, min_cos=0.9995, med_cos=0.9999)
     med, worst = float(np.median(list(errs.values()))), max(errs.values())
     print("cfg3 phase 2 backward at the device's forward point: median rel-L2 %.4f, worst %.4f" % (med, worst))
     assert med < 1e-2 and worst < 3e-2          # measured 2.3e-3 / 5.2e-3, cosine 1.0000 (round 3): 16-bit activation gradients and summation order are all that is left
+
+
+@pytest.mark.parametrize("loss_scale", [256.0, 1.0])
+def test_phase1_backward_at_the_devices_forward_point_vs_autograd(loss_scale):
+    """Phase 1 (update fa through the frozen ft, train_anonymizer.py:66-123) the same way: the oracle's UNet (train mode) and I3Res50 (eval mode) adopt every tensor
+    of the device's two tapes -- conv outputs in front of the UNet's BatchNorms, every stored activation, pool outputs, the skip | upsample concatenations, the
+    sigmoid output, and ft's activations clip by clip -- and autograd's gradients of fa's parameters are compared with the device's. 2 x 48 frames at 112 x 112
+    (the CPU oracle's memory bounds the batch). What this pins beyond the fp32-oracle test below (median 0.3): the UNet's BatchNorm / max-pool / bilinear-upsample /
+    concat backward, the data gradient through all of eval-mode ft (strided convs, the fused tails' masks, the three clips' gradients meeting in one video).
+    What it FOUND (round 3): with the gradients at the reference's scale (loss_scale 1) the tensors next to the 112 x 112 concatenation -- inc's and up3's second
+    BatchNorm, up4's first conv -- were 3-7 % off while everything else sat at 0.3 %; with the loss gradient scaled by 256 (and divided out of the parameter
+    gradients) they are at 0.5-0.8 % too. The matrix cores flush f16 SUBNORMAL inputs, and per-pixel activation gradients of a 96 x 112 x 112 tensor are below
+    6e-5: the data- and weight-gradient MFMAs dropped them, which the reference's autocast backward on its hardware does not. AnonymizerTrainStep therefore
+    scales by 256 by default now (the same arithmetic, exact powers of two); both scales stay under test."""
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(SEED, "train_cfg3_p1", (2, 48, 3, 112, 112))
+    labels = torch.tensor([5, 77])
+    step = AnonymizerTrainStep(fa, ft, loss_scale=loss_scale)
+    step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
+    tapes_fa, tapes_ft, o_fa, o_ft = [], [], step.fa_tr.forward, step.ft_tr.forward
+
+    def rec_fa(*a, **k):
+        out = o_fa(*a, **k)
+        tapes_fa.append(out[1])
+        return out
+
+    def rec_ft(*a, **k):
+        out = o_ft(*a, **k)
+        tapes_ft.append(out[2])
+        return out
+    step.fa_tr.forward, step.ft_tr.forward = rec_fa, rec_ft
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert len(tapes_fa) == 1 and len(tapes_ft) == 1, "one anonymizer pass, the three clips as one eval batch"
+    tu, t3, nb = tapes_fa[0], tapes_ft[0], 2
+
+    def nchw(t, c=None):        # (n,1,h,w,c') 16-bit tensor or Act -> (n,c,h,w) fp32 on the host
+        if hasattr(t, "buf"):
+            t, c = t.buf[..., t.coff:t.coff + t.c], None
+        t = t[:, 0].float().permute(0, 3, 1, 2)
+        return (t if c is None else t[:, :c]).contiguous().cpu()
+
+    def dc_vals(rec, with_input):
+        v = [nchw(rec["u1"].x)] if with_input else []
+        return v + [nchw(rec["u1"].z, rec["u1"].y.c), nchw(rec["u1"].y), nchw(rec["u2"].z, rec["u2"].y.c), nchw(rec["u2"].y)]
+    fa_vals = dc_vals(tu["enc"][0], False)                  # inc: its input is the video itself (rounded, not adopted)
+    for rec in tu["enc"][1:] + [tu["bottom"]]:
+        fa_vals += dc_vals(rec, True)                       # a max-pool output in front
+    for rec in tu["dec"]:
+        fa_vals += dc_vals(rec, True)                       # the [skip | upsampled] concatenation in front
+    fa_vals.append(tu["y"].float().cpu())                   # the sigmoid output, as the device rounded it
+
+    def ft_vals(k):
+        nct = lambda t: (t.buf if hasattr(t, "buf") else t)[k * nb:(k + 1) * nb].float().permute(0, 4, 1, 2, 3).contiguous().cpu()
+        vals = [nct(t3["stem_y"])]
+        for rec in t3["units"]:
+            if rec["after_pool"]:
+                vals.append(nct(rec["a_in"]))
+            vals += [nct(rec["h1"]), nct(rec["h2"])]
+            if "r" in rec:
+                vals.append(nct(rec["r"]))
+            vals.append(nct(rec["out"]))
+        return vals
+    per_clip = [ft_vals(k) for k in range(3)]
+    torch.set_num_threads(32)
+    q_fa, _ = _adopting_rounding(fa_vals)
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, sd_u, sd_l, fa_rounding=q_fa, ft_rounding=lambda k: _adopting_rounding(per_clip[k]))
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 1e-3 * abs(ref_l["loss_fa"])
+    errs = _report("phase 1 backward at the device's forward point: fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g, min_cos=0.995, med_cos=0.9995, tiny=1e-2, abs_tol=0.1)
+    med, worst = float(np.median(list(errs.values()))), max(errs.values())
+    print("phase 1 backward at the device's forward point: median rel-L2 %.4f, worst %.4f" % (med, worst))
+    if loss_scale > 1:
+        assert med < 1e-2 and worst < 3e-2      # measured 2.6e-3 / 8.0e-3, cosine 1.0000
+    else:
+        assert med < 2e-2 and worst < 1.5e-1    # measured 4.2e-3 / 7.1e-2 (subnormal activation gradients flushed by the MFMAs, see above)
 
 
 def test_cfg5_per_rank_batch_properties():

@@ -212,7 +212,7 @@ def test_pool_and_upsample_backward():
     got = nc(TE.global_avgpool_bwd(df.cuda(), like, mask=cl(m)))
     assert rel_l2(got, (df.view(3, 128, 1, 1, 1) / 18).expand(3, 128, 2, 3, 3) * (m.to(H).float() > 0)) < 1e-3
     # bilinear x2 align_corners=True into a padded, wider buffer (odd skip size)
-    for h, w, ho, wo in ((7, 7, 14, 14), (6, 5, 13, 11), (1, 3, 2, 6)):
+    for h, w, ho, wo in ((7, 7, 14, 14), (6, 5, 13, 11), (1, 3, 2, 6), (28, 28, 56, 56), (56, 56, 112, 112)):
         u = synth_tensor(4, "ux%d" % h, (2, 16, h, w), -1, 1).to(H).float().requires_grad_()
         up = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=True)
         dyy, dxx = ho - 2 * h, wo - 2 * w
