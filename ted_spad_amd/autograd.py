@@ -68,6 +68,21 @@ def _capture_grads(params, fn):
     return out, new
 
 
+def _up(g):
+    """A gradient entering a network: scaled up (TE.GRAD_SCALE, see there)."""
+    return None if g is None else g.contiguous().float() * TE.GRAD_SCALE
+
+
+def _down(gs):
+    """Gradients leaving a network (fresh tensors): the scale divided out again."""
+    if gs is None or TE.GRAD_SCALE == 1.0:
+        return gs
+    inv = 1.0 / TE.GRAD_SCALE
+    if torch.is_tensor(gs):
+        return gs * inv
+    return [None if g is None else g.mul_(inv) for g in gs]
+
+
 def _trainer(module, cls):
     tr = module.__dict__.get("_hip_trainer")
     if tr is None:
@@ -96,12 +111,12 @@ class _UNetFn(torch.autograd.Function):
         ctx.tape_guard.check()
 
         def run():
-            tr.backward(ctx.tape, dy.contiguous().float())
+            tr.backward(ctx.tape, _up(dy))
             tr.flush_grads()
 
         _, grads = _capture_grads(params, run)
         ctx.tape = None
-        return (None, None) + tuple(grads)
+        return (None, None) + tuple(_down(grads))
 
 
 def unet_forward(module, x):
@@ -143,17 +158,17 @@ class _I3DFn(torch.autograd.Function):
             return none + (None,) + (None,) * len(params)
         ctx.tape_guard.check()
         if mode == "eval":
-            dx = tr.backward(ctx.tape, dpred, dfeat)
+            dx = tr.backward(ctx.tape, _up(dpred), _up(dfeat))
             ctx.tape = None
-            return none + (dx,)
+            return none + (_down(dx),)
 
         def run():
-            tr.backward(ctx.tape, dpred, dfeat)
+            tr.backward(ctx.tape, _up(dpred), _up(dfeat))
             tr.flush_grads()
 
         _, grads = _capture_grads(params, run)
         ctx.tape = None
-        return none + (None,) + tuple(grads)
+        return none + (None,) + tuple(_down(grads))
 
 
 def wrapper_forward(module, x, drop_mask=None):
@@ -185,17 +200,17 @@ class _FBFn(torch.autograd.Function):
             return (None, None, None) + (None,) * len(params)
         ctx.tape_guard.check()
         if mode == "eval":
-            dx = tr.backward(ctx.tape, demb.contiguous().float())
+            dx = tr.backward(ctx.tape, _up(demb))
             ctx.tape = None
-            return (None, None, dx)
+            return (None, None, _down(dx))
 
         def run():
-            tr.backward(ctx.tape, demb.contiguous().float())
+            tr.backward(ctx.tape, _up(demb))
             tr.flush_grads()
 
         _, grads = _capture_grads(params, run)
         ctx.tape = None
-        return (None, None, None) + tuple(grads)
+        return (None, None, None) + tuple(_down(grads))
 
 
 def fb_forward(module, x):

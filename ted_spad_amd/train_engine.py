@@ -74,6 +74,11 @@ ARENA = ZeroArena()
 # the conv output in front of a train-mode BatchNorm (re-read by the BN apply and twice by the backward) kept in the 16-bit activation dtype, as
 # the reference's autocast region holds it (train_anonymizer.py:78,151), instead of fp32: 2 of the 6-8 bytes per element each of those passes moves
 TRAIN_Z16 = os.environ.get("TEDSPAD_TRAIN_Z16", "1") != "0"
+# Gradients entering the networks through the autograd bridge (autograd.py: the reference's own training loop) are multiplied by this power of two and every
+# gradient leaving them is divided by it again: gfx950's matrix cores flush f16 SUBNORMAL operands, and the per-pixel activation gradients of the anonymizer's
+# high-resolution levels are below 6e-5 at the reference's scale. 1: the reference's literal arithmetic. (AnonymizerTrainStep has its own
+# `loss_scale`, with the non-finite check of a GradScaler; the bridge cannot skip a step, an overflow shows as non-finite gradients exactly as in the reference's fp16 run.)
+GRAD_SCALE = float(os.environ.get("TEDSPAD_GRAD_SCALE", "256"))
 DB_SLOTS = 64           # rows of the conv-bias gradient accumulator of tedspad_bn_bwd_apply
 NO_ARENA = bool(os.environ.get("TEDSPAD_NO_ARENA"))       # every request its own torch.zeros (debugging)
 REFRESH_IN_PLACE = os.environ.get("TEDSPAD_WEIGHT_REFRESH", "1") != "0"     # 0: every stale image rebuilt by the lazy path (A/B timing)

