@@ -506,11 +506,20 @@ class WeightRefresh:
         return True
 
 
+def mark_updated(params):
+    """Tell the weight images / BatchNorm folds built from `params` that the parameters changed. Needed after an optimizer whose step() writes the parameters WITHOUT
+    bumping their version counters -- torch's `fused=True` implementations do (measured: `_version` stays 0 across `torch.optim.Adam(fused=True).step()`) -- since
+    `WeightRefresh` recognises a change by (data_ptr, version, this revision). AnonymizerTrainStep calls it after its own fused steps; a caller that drives the
+    modules through autograd.py with a fused optimizer must too."""
+    for p in params:
+        p._tedspad_rev = getattr(p, "_tedspad_rev", 0) + 1
+
+
 def fold_sig(bn, conv_bias=None):
     """(data_ptr, version) of every tensor a fold reads. The running statistics are written by tedspad_bn_train_apply through raw pointers, which torch's version
     counter does not see: `num_batches_tracked` (bumped once per train-mode forward, train_engine.bump_counter) stands in for them, so a frozen-flavour forward after
     a train-mode one without an optimizer step (a skipped step under loss scaling, a no_grad train() pass) re-folds."""
-    sig = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((conv_bias,) if conv_bias is not None else ()))
+    sig = tuple((t.data_ptr(), t._version + int(getattr(t, "_tedspad_rev", 0))) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((conv_bias,) if conv_bias is not None else ()))
     nbt = getattr(bn, "num_batches_tracked", None)
     return sig + ((nbt.data_ptr(), nbt._version + int(getattr(nbt, "_tedspad_rev", 0))),) if nbt is not None else sig
 

@@ -85,9 +85,14 @@ class AnonymizerTrainStep:
         self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
         self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
         self._fa_off_path = self.fa_tr.off_path_params() if hasattr(self.fa_tr, "off_path_params") else []   # unet++: encoder.layer4 (never run)
-        self.opt_fa = torch.optim.Adam(fa_model.parameters(), lr=params.learning_rate_fa)     # train_anonymizer.py:377-380
-        self.opt_ft = torch.optim.Adam(ft_model.parameters(), lr=params.learning_rate_ft)
-        self.opt_fb = torch.optim.Adam(fb_model.parameters(), lr=params.learning_rate_fb) if fb_model is not None else None
+        def adam(m, lr):          # torch.optim.Adam as train_anonymizer.py:377-380 builds it; the fused implementation where it exists (same update, one launch per
+            try:                  # parameter group, and it takes the loss scale's non-finite flag on the device: no host sync before the step)
+                return torch.optim.Adam(m.parameters(), lr=lr, fused=True)
+            except (RuntimeError, TypeError, ValueError):
+                return torch.optim.Adam(m.parameters(), lr=lr)
+        self.opt_fa = adam(fa_model, params.learning_rate_fa)
+        self.opt_ft = adam(ft_model, params.learning_rate_ft)
+        self.opt_fb = adam(fb_model, params.learning_rate_fb) if fb_model is not None else None
         self.ce = CrossEntropyLoss()
         self.trip = TripletMarginLoss(margin=params.triplet_loss_margin)
         self.iteration = 0
@@ -122,16 +127,39 @@ class AnonymizerTrainStep:
     def _scaled(self, g):
         return g if (g is None or self.loss_scale == 1.0) else g * self.loss_scale
 
-    def _unscale(self, module) -> bool:
-        """Divide the loss scale out of `module`'s gradients; False if they are not finite (the step is skipped).
+    def _unscale(self, module):
+        """Divide the loss scale out of `module`'s gradients. Returns the 0-d device flag "some gradient was not finite" (None without a loss scale).
         Called on the ALL-REDUCED gradients: an overflow on any rank makes the sum non-finite on every rank, so all
         ranks take the same step / skip decision (replicas and Adam step counts stay in lock-step)."""
         if self.loss_scale == 1.0:
-            return True
+            return None
         grads = [p.grad for p in module.parameters() if p.grad is not None]
-        found_inf = torch.zeros(1, device=grads[0].device)
-        torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, torch.full((1,), 1.0 / self.loss_scale, device=grads[0].device))
-        return float(found_inf) == 0.0
+        found_inf = torch.zeros((), device=grads[0].device)          # 0-d, as torch.amp.GradScaler's (the fused optimizer subtracts it from its 0-d step counters)
+        torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, torch.full((), 1.0 / self.loss_scale, device=grads[0].device))
+        return found_inf
+
+    def _opt_step(self, opt, found_inf, module):
+        """optimizer.step(), skipped when `found_inf` is set. With a fused optimizer (the default Adam here) the skip is decided ON THE DEVICE, as torch.amp.GradScaler
+        does it: no host sync between the backward pass and the next phase's launches. Returns what goes into the result's `skipped`."""
+        fused = getattr(opt, "_step_supports_amp_scaling", False)
+        try:
+            if found_inf is None:
+                opt.step()
+                return False
+            if fused:
+                opt.grad_scale, opt.found_inf = None, found_inf
+                try:
+                    opt.step()
+                finally:
+                    del opt.grad_scale, opt.found_inf
+                return found_inf != 0 if self.lazy_losses else bool(found_inf.item() != 0)
+            if float(found_inf) != 0.0:
+                return True
+            opt.step()
+            return False
+        finally:
+            if fused:       # a fused step leaves the parameters' version counters alone: say that they changed (TE.mark_updated)
+                TE.mark_updated(module.parameters())
 
     def _opts(self):
         return [o for o in (self.opt_fa, self.opt_fb, self.opt_ft) if o is not None]
@@ -194,12 +222,10 @@ class AnonymizerTrainStep:
         self.fa_tr.backward(tape_fa, danon.reshape(anon_flat.shape), on_bucket_done=self.red_fa.bucket_ready)   # fa's last backward pass of the step
         self.fa_tr.flush_grads()
         self.red_fa.finish()
-        ok = self._unscale(self.fa)
-        if ok:
-            self.opt_fa.step()                                        # :123
+        skipped = self._opt_step(self.opt_fa, self._unscale(self.fa), self.fa)     # :123
         self.iteration += 1
         return dict(phase=1, loss_fa=self._val(loss_fa), loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
-                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=not ok)
+                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=skipped)
 
     def _three_clips(self, clips, labels, mode, drop_masks):
         """Forward + loss + backward of ft ('train' / 'frozen') on the three clips of an iteration (:169-175 / action :64-84). The reference
@@ -284,19 +310,15 @@ class AnonymizerTrainStep:
                 self.fb_tr.backward(tape_b, self._scaled(z.grad), on_bucket_done=self.red_fb.bucket_ready if j == len(ctx) - 1 else None)
             self.fb_tr.flush_grads()
             self.red_fb.finish()
-            ok_fb = self._unscale(self.fb)
-            if ok_fb:
-                self.opt_fb.step()
+            self._opt_step(self.opt_fb, self._unscale(self.fb), self.fb)
         clips = torch.split(anon, [p.num_frames] * 3, dim=2)
         loss_ft, loss_ce, loss_trip = self._three_clips(clips, labels, "train", drop_masks)             # :169-175,191
         self.ft_tr.flush_grads()
         self.red_ft.finish()
-        ok = self._unscale(self.ft)
-        if ok:
-            self.opt_ft.step()                                        # :193
+        skipped = self._opt_step(self.opt_ft, self._unscale(self.ft), self.ft)     # :193
         self.iteration += 1
         return dict(phase=2, loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
-                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=not ok)
+                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=skipped)
 
     def step_action(self, inputs_video, labels, drop_masks=None):
         """One iteration of action_training/train_anonymized_action.py:43-94 (`--temporal_loss trip`, cross-entropy): the
@@ -316,12 +338,10 @@ class AnonymizerTrainStep:
         loss, loss_ce, loss_trip = self._three_clips(clips, labels, "frozen", drop_masks)
         self.ft_tr.flush_grads()
         self.red_ft.finish()
-        ok = self._unscale(self.ft)
-        if ok:
-            self.opt_ft.step()                                        # :87
+        skipped = self._opt_step(self.opt_ft, self._unscale(self.ft), self.ft)     # :87
         self.iteration += 1
         return dict(phase="action", loss=self._val(loss), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
-                    skipped=not ok)
+                    skipped=skipped)
 
     def step(self, inputs_video, labels, inputs_vispr=None):
         """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft (and fb)."""
