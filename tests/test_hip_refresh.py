@@ -263,3 +263,30 @@ def test_eval_networks_refresh_in_place_after_an_in_place_update(monkeypatch):
             m2.load_state_dict(m.state_dict())
             y2 = m2.cuda().eval()(x)
         assert torch.equal(y, y2), arch
+
+
+def test_fused_optimizer_steps_need_mark_updated():
+    """torch's fused optimizers write the parameters without bumping their version counters (pinned here: if a later torch does bump them this test says so and the
+    helper becomes a no-op): the refresh cannot see such a step until `train_engine.mark_updated` says the parameters changed; then the rewritten image equals a
+    fresh pack."""
+    from ted_spad_amd import engine as E, train_engine as TE
+    L, bn, xd = _layers()[1]
+    x, _ = _acts(L, xd)
+    pc = L.fwd_conv()
+    refresh = TE.WeightRefresh(lambda: [L])
+    refresh.run()
+    assert not refresh.stale([L])
+    opt = torch.optim.Adam([L.weight], lr=0.05, fused=True)
+    L.weight.grad = torch.ones_like(L.weight)
+    v0, w0 = L.weight._version, L.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(L.weight.detach(), w0)
+    if L.weight._version == v0:
+        assert not refresh.stale([L])                      # the step is invisible to the version counter ...
+        TE.mark_updated([L.weight])
+    assert refresh.stale([L])                              # ... and visible once marked
+    refresh.run()
+    torch.cuda.synchronize()
+    fresh = E.PackedConv(L._w5(), None, None, stride=L.stride, dtype=L.dtype, pair_w=L.pair_w)
+    assert torch.equal(L.fwd_conv().w, fresh.w) and L.fwd_conv() is pc
+
