@@ -190,6 +190,16 @@ int32_t tedspad_bneck_frame_lds_bytes(void);   /* dynamic LDS of the kernel abov
  * 100 MHz x out[2b] / out[2b+1]. out: 2 x workgroups uint64. */
 int32_t tedspad_clock_probe(int32_t iters, int32_t workgroups, void *out, void *stream);
 
+/* Deterministic mode for the training kernels (the reference has no such switch: torch's convolution backward is non-deterministic too unless
+ * torch.use_deterministic_algorithms is set). on != 0: the workgroups of a launch pass through their float-atomic sections -- BatchNorm batch statistics in
+ * the conv epilogues (tedspad_conv_fwd_ex with `stats`), the channel sums of tedspad_bn_bwd_reduce, the weight-gradient flush of tedspad_conv_wgrad -- one at a
+ * time, in blockIdx order (csrc/det_gate.h): bit-identical sums from run to run, at the price of serialising those sections. The caller must keep such
+ * launches of one kernel family off concurrent streams, use fixed tile configurations, and form a conv bias gradient with tedspad_bn_bwd_reduce instead of
+ * tedspad_bn_bwd_apply's fused one (ted_spad_amd.engine.set_deterministic does all of it). Synchronises the device. tedspad_deterministic_giveups: how many
+ * workgroups stopped waiting for their turn since the mode was set (0 unless something is wrong; results are then not reproducible, nothing hangs). */
+int32_t tedspad_set_deterministic(int32_t on);
+int32_t tedspad_deterministic_giveups(void);
+
 /* Persistent Cin = 3 stem (csrc/conv_stem_pt.hip): conv1 5x7x7 / stride 2 / pad (2,3,3) + bn1 + ReLU of large_i3d.py:133-137,229-231
  * with the temporal half of maxpool1 (MaxPool3d((2,3,3), 2), large_i3d.py:138,232) fused: y[n][to/2][ho][wo][64] =
  * max over the output frame pair (to, to+1) of act(conv * scale + shift); the spatial 3x3 / 2 half of the pool is a

@@ -94,6 +94,8 @@ SYMBOLS = {
     "tedspad_bneck_frame_fwd": (_I32, [_P, _I32, _P, _I32] + [_I32] * 6 + [_P, _P, _I32, _P] + [_P] * 6 + [_I32, _I32, _P]),
     "tedspad_bneck_frame_lds_bytes": (_I32, []),
     "tedspad_clock_probe": (_I32, [_I32, _I32, _P, _P]),
+    "tedspad_set_deterministic": (_I32, [_I32]),
+    "tedspad_deterministic_giveups": (_I32, []),
     "tedspad_bneck_tail_fwd": (_I32, [C.POINTER(ConvDesc)] + [_P] * 7 + [_I32, _P, _I32, _P, _I32, _P, _P, _I32, _I32, _I32, _P]),
     "tedspad_clip_to_tp": (_I32, [_P, _P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 4 + [_P]),
     "tedspad_stem_pt_wimg_bytes": (_I32, []),

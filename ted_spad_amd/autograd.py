@@ -26,6 +26,7 @@ import weakref
 
 import torch
 
+from . import engine as E
 from . import train_engine as TE
 
 _LIVE = [0]      # tapes alive (autograd nodes whose backward has not run / been freed)
@@ -86,6 +87,7 @@ def _down(gs):
 def _trainer(module, cls):
     tr = module.__dict__.get("_hip_trainer")
     if tr is None:
+        E.apply_env_determinism()
         tr = cls(module)
         module.__dict__["_hip_trainer"] = tr
     return tr

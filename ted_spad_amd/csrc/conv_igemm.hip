@@ -25,6 +25,7 @@
 //   * the fp32 tile is staged through LDS so the final stores (and the residual loads)
 //     are full 16-byte-per-lane coalesced rows of the NTHWC tensor.
 #include "conv_common.h"
+#include "det_gate.h"
 
 namespace tedspad {
 namespace {
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         }
         __syncthreads();
         float *so = p.stats + (size_t)sgrp * 2 * p.stats_ld;
+        const bool det = det_enter();            // deterministic mode: one workgroup at a time, in blockIdx order (det_gate.h)
         if (tid < BN && n0 + tid < p.Cout) {
             float a = 0.f, b = 0.f;
             for (int r = 0; r < RPP; ++r) { a += red[r * BN + tid]; b += red[(RPP + r) * BN + tid]; }
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
                 atomicAdd(so + 3 * p.stats_ld + n0 + tid, b);
             }
         }
+        det_exit(det);
     }
 }
 
@@ -628,12 +631,14 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
         const size_t mfirst = ((size_t)n * p.To + to) * p.Ho * p.Wo;
         const size_t sgrp = p.stats_rows ? mfirst / (size_t)p.stats_rows : 0;
         float *so = p.stats + sgrp * 2 * p.stats_ld;
+        const bool det = det_enter();
         if (tid < 64 && tid < p.Cout) {
             float sa = 0.f, sb = 0.f;
             for (int r = 0; r < RG; ++r) { sa += red[r * 64 + tid]; sb += red[(RG + r) * 64 + tid]; }
             atomicAdd(so + tid, sa);
             atomicAdd(so + p.stats_ld + tid, sb);
         }
+        det_exit(det);
     }
 }
 
@@ -984,3 +989,6 @@ extern "C" int32_t tedspad_debug_set_igemm_ts(void *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(tedspad::g_dbg_ts_ig), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
+namespace tedspad {
+int32_t det_ctl_igemm(int op, int on) { return det_ctl(op, on); }
+}  // namespace tedspad

@@ -11,6 +11,7 @@
 // fp32 sums re-associated, like tiles 15 / 16 / 28. The epilogue also carries the training extras (batch statistics, fp32 output, ReLU-backward
 // mask): the UNet's train-mode forward and its data gradients run on it too.
 #include "conv_common.h"
+#include "det_gate.h"
 
 namespace tedspad {
 namespace {
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             }
             __syncthreads();
             float *so = p.stats + sgrp * 2 * p.stats_ld;
+            const bool det = det_enter(pass, BN / 64);       // deterministic mode (det_gate.h): passage `pass` of this workgroup
             if (tid < 64 && n0 + pass * 64 + tid < p.Cout) {
                 float sa = 0.f, sb = 0.f;
                 for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                     atomicAdd(so + 3 * p.stats_ld + n0 + pass * 64 + tid, sb);
                 }
             }
+            det_exit(det, pass, BN / 64);
         }
     }
 }
@@ -377,4 +380,7 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
     return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128>(p, frames, cin, s) : launch_patch_t<BF16, 128>(p, frames, cin, s);
 }
 
+}  // namespace tedspad
+namespace tedspad {
+int32_t det_ctl_patch(int op, int on) { return det_ctl(op, on); }
 }  // namespace tedspad

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "det_gate.h"
 
 namespace tedspad {
 namespace {
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(64 * NY * NX) void conv_wgrad_kernel(const WgradKP 
     }
 
     // ---- partial tile -> fp32 dW with float atomics (lanes 0-31 / 32-63: two 128-byte row segments) ---
+    const bool det = det_enter();                 // deterministic mode (det_gate.h): the workgroups flush one at a time, in blockIdx order
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(64 * NY * NX) void conv_wgrad_kernel(const WgradKP 
                 if (co < p.Cout && k < p.Kpad) atomicAdd(p.dw + (size_t)co * p.Kpad + k, acc[a][c][r]);
             }
         }
+    det_exit(det);
 }
 
 // ---- 1 x 3 x 3, stride 1, pad 1, Cin % 64 == 0: the nine taps from THREE activation tiles -------------------------------------
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(384) void conv_wgrad3_kernel(const WgradKP p) {
     }
 
     // ---- partial tile -> fp32 dW with float atomics: k = ((dh * 3 + dw) * Cin + cc * 64 + cih * 32 + lane % 32) -----------------------
+    const bool det = det_enter();
     const int l31 = lane & 31, lh = lane >> 5;
     const int Cin = p.cc_tiles * 64;
 #pragma unroll
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(384) void conv_wgrad3_kernel(const WgradKP p) {
                 if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.Kpad + k, acc[d][a][r]);
             }
     }
+    det_exit(det);
 }
 
 }  // namespace
@@ -443,3 +448,6 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
     }
     return check_launch("tedspad_conv_wgrad");
 }
+namespace tedspad {
+int32_t det_ctl_wgrad(int op, int on) { return det_ctl(op, on); }
+}  // namespace tedspad

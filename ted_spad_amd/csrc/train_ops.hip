@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "det_gate.h"
 
 namespace tedspad {
 namespace {
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
     for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
     __syncthreads();
     // threads 0 .. C8L*8-1 each own one channel of the group and sum over the pixel lanes
+    const bool det = det_enter();                 // deterministic mode (det_gate.h): one workgroup at a time, in blockIdx order
     if (threadIdx.x < C8L * 8) {
         const int ch = threadIdx.x;   // channel within the group: chunk ch/8, element ch%8
         const int c = cg * C8L * 8 + ch;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
             if (z) atomicAdd(out + out_ld + c, b);
         }
     }
+    det_exit(det);
 }
 
 // dz = k[c] * (g - a[c] - xhat * b[c]),  g = dy * (y > 0 if relu);  optionally dres = g
@@ -657,4 +660,22 @@ extern "C" int32_t tedspad_bn_train_apply(const void *z, int32_t zdtype, const f
     LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for_iters(pixels * (Cz / 8), 8), groups), z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
              running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
     return check_launch("tedspad_bn_train_apply");
+}
+
+namespace tedspad {
+int32_t det_ctl_train_ops(int op, int on) { return det_ctl(op, on); }
+}  // namespace tedspad
+
+extern "C" int32_t tedspad_set_deterministic(int32_t on) {
+    TS_REQUIRE(hipDeviceSynchronize() == hipSuccess, "tedspad_set_deterministic: device error pending");      // no launch may be in its gate while the state is rewritten
+    const int o = on ? 1 : 0;
+    TS_REQUIRE(tedspad::det_ctl_igemm(0, o) == 0 && tedspad::det_ctl_patch(0, o) == 0 && tedspad::det_ctl_wgrad(0, o) == 0 && tedspad::det_ctl_train_ops(0, o) == 0,
+               "tedspad_set_deterministic: cannot write the device state");
+    return TEDSPAD_OK;
+}
+
+extern "C" int32_t tedspad_deterministic_giveups(void) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const int32_t a = tedspad::det_ctl_igemm(1, 0), b = tedspad::det_ctl_patch(1, 0), c = tedspad::det_ctl_wgrad(1, 0), d = tedspad::det_ctl_train_ops(1, 0);
+    return (a < 0 || b < 0 || c < 0 || d < 0) ? -1 : a + b + c + d;
 }

@@ -35,6 +35,37 @@ STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
+DETERMINISTIC = False        # set_deterministic() below; TEDSPAD_DETERMINISTIC=1 switches it on when the first training object is built
+_DET_SAVED = None
+
+
+def set_deterministic(on: bool) -> None:
+    """Bit-identical training from run to run (the reference has no such switch; round-2 review item 4 ii). On: the library's float-atomic sections
+    (BatchNorm batch statistics, channel sums, the weight-gradient flush) are passed by one workgroup at a time in blockIdx order (csrc/det_gate.h); the tile tuner
+    is off (one K-order-preserving tile per conv); the weight gradients stay on the main stream; conv bias gradients come from the channel-sum kernel instead of
+    tedspad_bn_bwd_apply's fused accumulation (train_engine reads `DETERMINISTIC`). Slower -- those sections are serialised -- and meant for tests and debugging.
+    `deterministic_giveups()` must stay 0."""
+    global DETERMINISTIC, AUTOTUNE, _DET_SAVED
+    from . import _lib
+    _lib.check(_lib.lib().tedspad_set_deterministic(1 if on else 0), "tedspad_set_deterministic")
+    if on and not DETERMINISTIC:
+        _DET_SAVED = AUTOTUNE
+        AUTOTUNE = False
+    elif not on and DETERMINISTIC and _DET_SAVED is not None:
+        AUTOTUNE = _DET_SAVED
+    DETERMINISTIC = bool(on)
+
+
+def deterministic_giveups() -> int:
+    from . import _lib
+    return int(_lib.lib().tedspad_deterministic_giveups())
+
+
+def apply_env_determinism() -> None:
+    """TEDSPAD_DETERMINISTIC=1: called where training objects are built (the library is loaded and a GPU is present by then)."""
+    if os.environ.get("TEDSPAD_DETERMINISTIC", "0") == "1" and not DETERMINISTIC:
+        set_deterministic(True)
+
 PREFER_TILE_CFG = int(os.environ.get("TEDSPAD_PREFER_CFG", "0"))
 FORCE_TILE_CFG = None   # tests: run every conv with this tile configuration (error if it does not apply)
 # The kernels index with 32-bit element offsets (and the weight gradient decodes < 2^23 pixels): larger tensors

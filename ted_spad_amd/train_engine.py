@@ -110,7 +110,7 @@ WGRAD_STREAM = os.environ.get("TEDSPAD_WGRAD_STREAM", "1") != "0"
 def side_stream(device):
     """The stream the weight-gradient kernels run on, or None: while the tile tuner is timing launches (a candidate measured with another
     stream's kernels on the chip can lose to a slower one), or with TEDSPAD_WGRAD_STREAM=0."""
-    if not WGRAD_STREAM or E.tuning_pending():
+    if not WGRAD_STREAM or E.tuning_pending() or E.DETERMINISTIC:           # (deterministic mode: one launch of a kernel family at a time, csrc/det_gate.h)
         return None                                     # (inside a stream capture the side stream joins the capture: a parallel branch of the graph)
     ent = _SIDE.get(device)
     if ent is None:
@@ -615,7 +615,8 @@ def conv_bn_act_train_bwd(ctx: BNTrainCtx, dy: Act, need_dx=True, dx_residual: O
     sums = channel_sums(dy, ymask, z, ctx.mean, ctx.invstd, relu=ctx.relu, groups=G, gamma=gam, beta=bet, zcode=ctx.zcode)
     dz = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device)
     dres = Act.empty(n, t, h, w, cz, y.buf.dtype, z.device) if ctx.has_res else None
-    dbias = ARENA.take((DB_SLOTS, cz), z.device) if ctx.conv.bias is not None else None
+    # (deterministic mode: the fused bias-gradient accumulation adds from many threads per address; ConvLayer.wgrad then forms it with the channel-sum kernel)
+    dbias = ARENA.take((DB_SLOTS, cz), z.device) if (ctx.conv.bias is not None and not E.DETERMINISTIC) else None
     check(_lib.lib().tedspad_bn_bwd_apply(dy.ptr, ymask.ptr if ymask is not None else None, z.data_ptr(), ctx.zcode, ctx.mean.data_ptr(), ctx.invstd.data_ptr(), gam.data_ptr(),
                                           bet.data_ptr(), sums.data_ptr(), cz, dz.ptr, dres.ptr if dres is not None else None,
                                           dbias.data_ptr() if dbias is not None else None, DB_SLOTS, n * t * h * w // G, cz,

@@ -42,6 +42,7 @@ import torch.distributed as dist
 
 from .grad_reduce import GradBucketReducer
 from .losses import CrossEntropyLoss, NTXentLoss, TripletMarginLoss
+from . import engine as E
 from . import train_engine as TE
 from .train_nets import FBTrainer, I3DTrainer, UNetPPTrainer, UNetTrainer
 
@@ -75,6 +76,7 @@ class AnonymizerTrainStep:
     def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 256.0):
         self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
         self.loss_scale = float(loss_scale)
+        E.apply_env_determinism()
         self.batch_clips = os.environ.get("TEDSPAD_TRAIN_BATCH_CLIPS", "1") != "0"   # the three clips of an iteration as one ft batch (0: three passes, A/B)
         # phase 2's ft forward + losses + backward (~350 of its 530 launches, 5-40 us each) captured once as a hipGraph and replayed: possible because
         # nothing in that sequence moves any more -- weight images are rewritten in place, the arena hands out the same slices, gradients are bucket views

@@ -231,8 +231,11 @@ def test_bridge_gradient_scale_is_divided_out_again(monkeypatch):
         out, grads = reference_step1(fa, fb, ft, *opt, [v.cuda() for v in vispr], video, labels)
         got[scale] = {k: g.detach().double().flatten().cpu() for k, g in grads.items()}
     ratios, cos = [], []
+    import re
     for k, a_ in got[1.0].items():
         b_ = got[256.0][k]
+        if re.search(r"double_conv\.[03]\.bias$", k):      # a conv bias in front of a train-mode BatchNorm: analytically zero, its value is rounding noise of whatever forms it
+            continue
         if float(a_.norm()) > 1e-3:
             ratios.append(float(b_.norm() / a_.norm()))
             cos.append(float(a_ @ b_ / (a_.norm() * b_.norm())))

@@ -418,3 +418,36 @@ def test_lazy_losses_are_the_same_numbers_without_the_sync(monkeypatch):
     # four: two identical runs differed by 6.3 % once in three full-suite runs (round 3), the other three by < 0.1 %
     for a, b, tol in zip(outs[0], outs[1], (5e-2, 5e-2, 5e-2, 2e-1)):
         assert abs(a - b) <= tol * abs(a) + 1e-3, outs
+
+
+def test_deterministic_mode_repeats_bit_for_bit():
+    """engine.set_deterministic(True) (round-2 review item 4 ii): two runs of phase 1 + phase 2 from the same weights on the same batch give the SAME BITS -- losses,
+    every parameter gradient of both networks (read before the optimizer steps via zero learning rates), the running statistics; nobody gave up waiting at a gate.
+    The same two runs with the mode off differ (float atomics, tile tuner) -- which is what every other bound in these files allows for."""
+    from ted_spad_amd import engine as E
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64)).cuda()
+    labels = torch.tensor([5, 77, 101, 1]).cuda()
+
+    def run():
+        fa, ft, _, _ = _models()
+        step = AnonymizerTrainStep(fa, ft)
+        step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
+        step.opt_ft = torch.optim.SGD(ft.parameters(), lr=0.0)
+        r1 = step.step_fa(video, labels)
+        g_fa = {k: p.grad.detach().clone() for k, p in fa.named_parameters()}
+        r2 = step.step_ft(video, labels)
+        g_ft = {k: p.grad.detach().clone() for k, p in ft.named_parameters()}
+        stats = {k: v.detach().clone() for m in (fa, ft) for k, v in m.state_dict().items() if "running" in k}
+        return (r1["loss_fa"], r2["loss_ft"], r2["loss_temporal"]), g_fa, g_ft, stats
+    E.set_deterministic(True)
+    try:
+        a, b = run(), run()
+        assert E.deterministic_giveups() == 0
+    finally:
+        E.set_deterministic(False)
+    assert a[0] == b[0], (a[0], b[0])
+    for da, db in zip(a[1:], b[1:]):
+        bad = [k for k in da if not torch.equal(da[k], db[k])]
+        assert not bad, "tensors that differ between two deterministic runs: %s" % bad[:5]
+
