@@ -30,3 +30,17 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture
+def deterministic():
+    """GPU tests whose bounds should carry no run-to-run slack: the training kernels' float-atomic sections in a fixed workgroup order, tuner off
+    (ted_spad_amd.engine.set_deterministic); the test also checks that no workgroup gave up waiting at a gate."""
+    from ted_spad_amd import engine as E
+    E.set_deterministic(True)
+    try:
+        yield
+        assert E.deterministic_giveups() == 0
+    finally:
+        E.set_deterministic(False)
+

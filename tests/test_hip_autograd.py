@@ -151,7 +151,7 @@ def test_reference_phase1_statements_with_the_default_unetpp_anonymizer():
     assert int(fa.encoder.bn1.num_batches_tracked) == 3                                       # Q14: two views + the video batch
 
 
-def test_reference_phase2_statements_through_autograd():
+def test_reference_phase2_statements_through_autograd(deterministic):
     from oracle import train_step_ref
     fa, fb, ft, opt, vispr, sd_u, sd_l, sd_b = _setup()
     video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
@@ -164,11 +164,10 @@ def test_reference_phase2_statements_through_autograd():
     assert abs(out["loss_temporal"] - ref_l["loss_temporal"]) < 3.5e-2 * abs(ref_l["loss_temporal"])
     assert abs(out["loss_fb"] - ref_lfb) < 1e-2 * abs(ref_lfb)
     errs = _report("autograd phase 2: ft grads", g_ft, ref_g, min_cos=0.6, med_cos=0.8)       # bounds of test_phase2_update_ft_vs_oracle
-    # the single worst tensor is the noisiest statistic of this comparison (one full-suite run had mlp.fc1.weight -- behind a BatchNorm1d
-    # over 4 samples -- at 0.95 with cosine 0.75, the usual worst being 0.62-0.72): bound the 90th percentile tightly and the maximum loosely;
-    # the direction of EVERY tensor is held by the cosine bounds inside _report
+    # run in deterministic mode (the `deterministic` fixture): the numbers repeat from run to run -- median 0.481, worst 0.702 (i3d.bn1.weight) -- so the bounds
+    # carry no slack for the float-atomic order any more (with the mode off one full-suite run had had mlp.fc1.weight at 0.95, and the bound was 1.3)
     ev = sorted(errs.values())
-    assert float(np.median(ev)) < 0.6 and ev[int(0.9 * (len(ev) - 1))] < 0.75 and ev[-1] < 1.3
+    assert float(np.median(ev)) < 0.6 and ev[int(0.9 * (len(ev) - 1))] < 0.75 and ev[-1] < 0.9
     errs = _report("autograd phase 2: fb grads", g_fb, ref_gb, min_cos=0.5, med_cos=0.75, tiny=1e-3)
     assert float(np.median(list(errs.values()))) < 0.7
     assert int(ft.i3d.bn1.num_batches_tracked) == 3 and int(ft.mlp.bn1.num_batches_tracked) == 3 and int(fb[0].bn1.num_batches_tracked) == 2   # Q14
