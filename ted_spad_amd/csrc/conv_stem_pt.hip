@@ -579,6 +579,51 @@ __global__ __launch_bounds__(256) void clip_to_tp_kernel(const float *x, uint16_
     }
 }
 
+// The same layout pass with 16-byte loads (rows 16-byte aligned, W % 4 == 0): the kernel above issues 24 four-byte loads per thread and pair and re-reads the four
+// frames two neighbouring pairs share -- 2 x the clip's bytes in 256-byte wave-instructions, which is what it spent its time on (the CU's address unit, not HBM).
+// Here a workgroup still owns 64 consecutive pixels of a row; for a group of four pairs it loads each of the 20 frames x 3 channels ONCE as float4 (16 lanes per
+// 64-pixel segment), converts, and scatters the values into an LDS tile [64 px][20 frames x 3 channels] (136-byte rows); the record of (pair g, pixel) is then the
+// 48 bytes at offset 24 g of its row, and every (pair, plane) leaves as one contiguous 1.5 KB run as before.
+template <typename T>
+__global__ __launch_bounds__(256) void clip_to_tp4_kernel(const float *x, uint16_t *y, int c, int t, int h, int w, long sn, long sc, long st, long sh,
+                                                          int pt, int stt, int tp_n, int wtiles) {
+    constexpr int ROWB = 136;                                               // 20 x 3 x 2 = 120 bytes used; 34 dwords: a quarter-wave of the scatter hits 8 banks twice
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * ROWB];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int wt = b % wtiles; b /= wtiles;
+    const int ih = b % h;
+    const long n = b / h;
+    const int wq_n = w >> 1;
+    const int npx = min(64, w - wt * 64);
+    const int nrec = npx >> 1;                                              // records per plane in this tile
+    const float *xr = x + n * sn + ih * sh + wt * 64;
+    for (int tp0 = 0; tp0 < tp_n; tp0 += 4) {
+        const int f0 = 2 * stt * tp0 - pt;                                  // first frame slot of the group
+        for (int i = tid; i < 60 * 16; i += 256) {
+            const int seg = i >> 4, q = i & 15;                             // segment = (frame slot, channel), pixels 4q .. 4q + 3
+            const int fs = seg / 3, ch = seg - fs * 3, tt = f0 + fs;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (4 * q < npx && tt >= 0 && tt < t && ch < c) v = *reinterpret_cast<const f32x4 *>(xr + ch * sc + tt * st + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint16_t *>(tile + (4 * q + j) * ROWB + seg * 2) = T::from_f32(v[j]);
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * 96; i += 256) {
+            const int run = i / 96, j = i - run * 96;                       // run = (pair of the group, plane); j-th 16-byte piece of its 32 records
+            const int g = run >> 1, bb = run & 1;
+            if (tp0 + g < tp_n && j < nrec * 3) {
+                const int rec = j / 3, k3 = j - rec * 3;
+                const unsigned char *src = tile + (2 * rec + bb) * ROWB + 24 * g + 16 * k3;        // 8-byte aligned
+                const uint2 lo = *reinterpret_cast<const uint2 *>(src), hi = *reinterpret_cast<const uint2 *>(src + 8);
+                uint4 *dst = reinterpret_cast<uint4 *>(y) + ((((n * tp_n + tp0 + g) * h + ih) * 2 + bb) * (long)wq_n + wt * 32) * 3;
+                dst[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 }  // namespace tedspad
 
@@ -594,6 +639,11 @@ extern "C" int32_t tedspad_clip_to_tp(const float *x, void *y, int32_t n, int32_
     const int wtiles = (w + 63) / 64;
     const dim3 g((unsigned)((long)n * h * wtiles));
     hipStream_t s = (hipStream_t)stream;
+    if (w % 4 == 0 && ((uintptr_t)x | (uintptr_t)(sn * 4) | (uintptr_t)(sc * 4) | (uintptr_t)(st * 4) | (uintptr_t)(sh * 4)) % 16 == 0) {
+        if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(clip_to_tp4_kernel<F16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, stride_t, t_pairs, wtiles);
+        else hipLaunchKernelGGL(clip_to_tp4_kernel<BF16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, stride_t, t_pairs, wtiles);
+        return check_launch("tedspad_clip_to_tp");
+    }
     if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(clip_to_tp_kernel<F16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, stride_t, t_pairs, wtiles);
     else hipLaunchKernelGGL(clip_to_tp_kernel<BF16>, g, dim3(256), 0, s, x, (uint16_t *)y, c, t, h, w, (long)sn, (long)sc, (long)st, (long)sh, pad_t, stride_t, t_pairs, wtiles);
     return check_launch("tedspad_clip_to_tp");

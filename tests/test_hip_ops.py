@@ -226,18 +226,22 @@ def test_temporal_conv_on_two_frames_as_one_folded_gemm(dims, dtype, monkeypatch
         tp(xa)
 
 
-def test_clip_to_frame_pair_layout():
+@pytest.mark.parametrize("shape,lo,frames", [((2, 3, 48, 10, 70), 16, 16), ((2, 3, 40, 6, 72), 4, 32), ((1, 3, 16, 5, 224), 0, 16)])
+def test_clip_to_frame_pair_layout(shape, lo, frames):
     """tedspad_clip_to_tp: record (tp, h, b, wq) value dt*3 + c = x[n][c][4*tp - 2 + dt][h][2*wq + b], zeros outside the clip;
-    strided (Q15) input views, a ragged last tile."""
+    strided (Q15) input views, a ragged last tile. W = 70: the four-byte-load kernel; W = 72 / 224 (16-byte aligned rows): the float4 kernel, with 32 frames two
+    groups of four pairs."""
     from ted_spad_amd import engine as E
-    big = synth_tensor(6, "tcbig", (2, 3, 48, 10, 70))
-    x = big[:, :, 16:32]                                          # a torch.split-style view: not contiguous
+    big = synth_tensor(6, "tcbig%d" % shape[-1], shape)
+    x = big[:, :, lo:lo + frames]                                 # a torch.split-style view: not contiguous
+    n, _, _, h, w = shape
+    tp_n = frames // 4
     st = E.StemPT(torch.zeros(64, 3, 5, 7, 7), None, None, dtype="f16", device="cuda")
-    got = st.layout(x.cuda()).float().cpu()                       # (2, 4, 10, 2, 35, 24)
-    xp = torch.zeros(2, 3, 2 + 16 + 4, 10, 70)
-    xp[:, :, 2:18] = x.half().float()
-    ref = torch.stack([xp[:, :, 4 * tp:4 * tp + 8] for tp in range(4)], dim=1)      # (n, tp, c, dt, h, w)
-    ref = ref.permute(0, 1, 4, 5, 3, 2).reshape(2, 4, 10, 35, 2, 24).permute(0, 1, 2, 4, 3, 5)
+    got = st.layout(x.cuda()).float().cpu()                       # (n, tp, h, 2, w / 2, 24)
+    xp = torch.zeros(n, 3, 2 + frames + 4, h, w)
+    xp[:, :, 2:2 + frames] = x.half().float()
+    ref = torch.stack([xp[:, :, 4 * tp:4 * tp + 8] for tp in range(tp_n)], dim=1)      # (n, tp, c, dt, h, w)
+    ref = ref.permute(0, 1, 4, 5, 3, 2).reshape(n, tp_n, h, w // 2, 2, 24).permute(0, 1, 2, 4, 3, 5)
     assert torch.equal(got, ref)
 
 
