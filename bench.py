@@ -48,6 +48,14 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def train_sources_sha() -> str:
+    """kernel_sources_sha() + the training-side launch sequences."""
+    h = hashlib.sha256(kernel_sources_sha().encode())
+    for f in ("train_engine.py", "train_nets.py", "train_step.py", "unet.py"):
+        h.update(open(os.path.join(ROOT, "ted_spad_amd", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def bench_train(dev, steps=10, warmup=45, hw=112):
     """cfg3 on this GPU: ms per phase-1 / phase-2 iteration, algorithmic TFLOP/s, kernel launches per iteration.
     hw = 224: the per-rank batch of cfg5 (8 x 48 x 224^2; its FLOP are 4x cfg3's, every conv scales with the pixels)."""
@@ -103,6 +111,13 @@ def bench_train(dev, steps=10, warmup=45, hw=112):
         step.step_fa(video, labels); step.step_ft(video, labels)
     torch.cuda.synchronize()
     out["iteration_ms_async_losses"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+    # HBM traffic of one iteration from the PMC passes over the same iteration (scripts/profile_train.sh), quoted only for the kernels it was measured on
+    out["traffic"] = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_train_cfg3.json")
+    if hw == 112 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("kernel_sources_sha") == train_sources_sha():
+            out["traffic"] = tj["traffic_bytes_per_iteration"]
     return out
 
 

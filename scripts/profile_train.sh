@@ -19,3 +19,14 @@ python3 scripts/summarize_train.py --trace $(find $O/trace -name '*kernel_trace.
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
 find $O -name '*kernel_trace.csv' -size +8M -delete; find $O -name '*counter_collection.csv' -size +8M -delete
 cat $O/summary.txt
+python3 - <<'PY'
+import json, sys
+sys.path.insert(0, '.')
+import bench
+s = json.loads(open('gpurun_out/prof_train/summary.txt').read().strip().splitlines()[-1])
+json.dump({'traffic_bytes_per_iteration': s['traffic_bytes_per_iteration'], 'ms_per_iteration_kernels': s['ms_per_iteration_kernels'],
+           'launches_per_iteration': s['launches_per_iteration'], 'kernel_sources_sha': bench.train_sources_sha(),
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over scripts/train_prof_run.py (3 iterations of cfg3: UNet fa + I3Res50 ft, 8 x 48 x 112^2) on MI355X, scripts/profile_train.sh; FETCH_SIZE doubled (gfx950 correction)'},
+          open('gpurun_out/prof_train/traffic_train_cfg3.json', 'w'), indent=1)
+PY
+
