@@ -217,8 +217,14 @@ def bench_train_main(args, dev, world, rank, dry):
         if dry:
             res["dry_run"] = True
         else:
+            traffic = None          # per rank, from the PMC passes over the cfg3 iteration (scripts/profile_train.sh); only for the sources it was measured on
+            tpath = os.path.join(ROOT, "profiles", "traffic_train_cfg3.json")
+            if hw == 112 and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("kernel_sources_sha") == train_sources_sha():
+                    traffic = tj["traffic_bytes_per_iteration"]
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": round(ach / (MFMA_PEAK_TFLOPS * world), 4),
-                               "traffic": None, "kernel": "both phases of one iteration on every rank (conv / linear MACs x 2 of BASELINE.md section 2 over the iteration time)"}
+                               "traffic": traffic, "kernel": "both phases of one iteration on every rank (conv / linear MACs x 2 of BASELINE.md section 2 over the iteration time)"}
             res.update(losses)
     if world > 1:
         flags = [None] * world
