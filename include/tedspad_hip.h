@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TEDSPAD_ABI_VERSION 2   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2) */
+#define TEDSPAD_ABI_VERSION 3   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat, the fp32-clip stem entry (round 4) */
 
 enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
@@ -114,6 +114,8 @@ typedef struct tedspad_conv_extras {
     int32_t     stats_rows;  /* 0: one set of statistics over all output rows. > 0 (>= 256): output rows [g*stats_rows, (g+1)*stats_rows) are
                                 statistics GROUP g and accumulate into stats + g*2*stats_ld -- the three clips of a training step run through the
                                 network as ONE batch while their BatchNorms keep separate batch statistics (train_anonymizer.py:169-175) */
+    int32_t     nosat;       /* 1: f16 results are NOT clamped to +-65504 (the training path: an overflow stays inf / NaN, as under the reference's fp16
+                                autocast, train_anonymizer.py:78, so that a loss scale's non-finite check sees it). 0: saturate (inference) */
 } tedspad_conv_extras;
 
 int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed,

@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtedspad_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
-ABI_VERSION = 2          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
+ABI_VERSION = 3          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
 
 
 class ConvDesc(C.Structure):
@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
 
 class ConvExtras(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("stats", C.c_void_p), ("y32", C.c_void_p)] + [(n, C.c_int32) for n in (
-        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "fold_hw", "fold_c", "fold_ldy", "stats_rows")]
+        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "fold_hw", "fold_c", "fold_ldy", "stats_rows", "nosat")]
 
 
 class PackJob(C.Structure):              # tedspad_pack_job

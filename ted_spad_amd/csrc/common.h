@@ -47,6 +47,12 @@ struct F16 {
         f = __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);  // saturate instead of inf
         return __builtin_bit_cast(uint16_t, (_Float16)f);
     }
+    // the same with the clamp at +-lim: 65504 (inference: saturate) or +inf (training path: an overflow stays visible as inf / NaN in the
+    // gradients, where the loss scale's non-finite check finds it, as in the reference's fp16-autocast run)
+    static __device__ __forceinline__ uint16_t from_f32_lim(float f, float lim) {
+        f = __builtin_fminf(__builtin_fmaxf(f, -lim), lim);
+        return __builtin_bit_cast(uint16_t, (_Float16)f);
+    }
     static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {   // element-wise max of two packed pairs
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)));
@@ -63,6 +69,7 @@ struct BF16 {
     }
     static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
     static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+    static __device__ __forceinline__ uint16_t from_f32_lim(float f, float) { return from_f32(f); }   // bf16 has fp32's range: never clamped
     static __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
         const float lo = __builtin_fmaxf(__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, b << 16));
         const float hi = __builtin_fmaxf(__builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b & 0xffff0000u));
@@ -85,6 +92,14 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f32(f[2 * i]) | ((uint32_t)T::from_f32(f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack8_lim(const float (&f)[8], float lim) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f32_lim(f[2 * i], lim) | ((uint32_t)T::from_f32_lim(f[2 * i + 1], lim) << 16);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 

@@ -37,6 +37,7 @@ struct ConvKP {
     const float *scale2, *shift2;
     int ldx2;
     int nk1, Hi2, Wi2, sh2, sw2;     // conv_p8.hip DUAL: K tiles of the first source; grid and spatial stride of the second
+    float sat;              // clamp of the f16 stores: 65504 (saturate), +inf on the training path (tedspad_conv_extras.nosat)
 };
 
 constexpr int BK = 64;                  // K elements per LDS tile row (8 chunks of 16 bytes)

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const ConvKP p, const Fl
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
         }
-        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8_lim<T>(v, p.sat);
     }
 }
 
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void conv_tflat_kernel(const ConvKP p, const T
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
         }
-        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T_>(v);
+        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8_lim<T_>(v, p.sat);
     }
 }
 

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
         }
-        if (p.y) *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8<T>(v);
+        if (p.y) *reinterpret_cast<uint4 *>(p.y + op * p.ldy + n) = pack8_lim<T>(v, p.sat);
         if (p.y32) {
             *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4 *>(p.y32 + op * p.ldy32 + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256 * FR * KS) void conv_stem_halo_kernel(const Con
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
         }
-        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+        *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8_lim<T>(v, p.sat);
     }
     if (p.stats) {   // block-level reduction over the NT / 8 row groups, then one atomic per channel (workgroup-uniform branch)
         constexpr int RG = NT / 8;
@@ -880,6 +880,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     p.fold_hw = 0; p.fold_c = 0; p.fold_f = 1;
     p.ost = p.osh = p.osw = 1; p.oot = p.ooh = p.oow = 0; p.TF = d->to; p.HF = d->ho; p.WF = d->wo;
     p.x2 = p.w2 = nullptr; p.scale2 = p.shift2 = nullptr; p.ldx2 = 0; p.nk1 = 0; p.Hi2 = p.Wi2 = 0; p.sh2 = p.sw2 = 1;
+    p.sat = (ex && ex->nosat) ? __builtin_inff() : 65504.f;
     if (dual && dual->nk1 > 0) {      // K-concatenated pair on the ping-pong kernel (tedspad_conv_p8_dual_fwd)
         TS_REQUIRE(p.pointwise && d->cin % BK == 0 && !residual && !ex && !sigmoid && !pool_t && d->cout % 256 == 0,
                    "tedspad_conv_p8_dual_fwd: first conv 1x1x1 stride 1 with cin %% 64 == 0, cout %% 256 == 0");

@@ -319,11 +319,11 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
         constexpr int S16 = 256 + 8;                        // 16-bit elements per staged row
         static_assert(BM * S16 * 2 <= LDS_BYTES, "16-bit staging tile");
         uint16_t *stg16 = reinterpret_cast<uint16_t *>(smem);
-        const float lo = p.relu ? 0.f : (T::kDtype == TEDSPAD_F16 ? -65504.f : -3.3e38f);
+        const float lo = p.relu ? 0.f : (T::kDtype == TEDSPAD_F16 ? -p.sat : -3.3e38f);
         auto pack2 = [&](float a, float b) -> unsigned {
             if constexpr (T::kDtype == TEDSPAD_F16) {
                 unsigned pk;
-                const float x = __builtin_amdgcn_fmed3f(a, lo, 65504.f), y = __builtin_amdgcn_fmed3f(b, lo, 65504.f);
+                const float x = __builtin_amdgcn_fmed3f(a, lo, p.sat), y = __builtin_amdgcn_fmed3f(b, lo, p.sat);
                 asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(x), "v"(y));
                 return pk;
             } else {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
                 }
                 size_t orow = (size_t)m;
                 if (p.fold_hw) orow += (size_t)(m / p.fold_hw) * (size_t)((p.fold_f - 1) * p.fold_hw) + (size_t)nsel * p.fold_hw;
-                *reinterpret_cast<uint4 *>(p.y + orow * p.ldy + n) = pack8<T>(v);
+                *reinterpret_cast<uint4 *>(p.y + orow * p.ldy + n) = pack8_lim<T>(v, p.sat);
             }
         }
         P8_STAMP(3 + j);

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
                 }
-                if (p.y) *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8<T>(v);
+                if (p.y) *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8_lim<T>(v, p.sat);
                 if (p.y32) {
                     *reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch + 4) = f32x4{v[4], v[5], v[6], v[7]};

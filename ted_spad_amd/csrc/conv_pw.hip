@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKP p, const int 
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], keep[j][i]);
                     }
-                    gstore16(p.y + (obase + row) * p.ldy + n, __builtin_bit_cast(u32x4, pack8<T>(v)));
+                    gstore16(p.y + (obase + row) * p.ldy + n, __builtin_bit_cast(u32x4, pack8_lim<T>(v, p.sat)));
                 }
             }
         }

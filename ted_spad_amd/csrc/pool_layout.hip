@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void upsample_nearest2x_bwd_kernel(const uint4
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] += v[i];
             }
-        *dst = pack8<T>(s);
+        *dst = pack8_lim<T>(s, __builtin_inff());      // gradients: never clamped (an overflow must stay visible)
     }
 }
 
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void add_channels_kernel(const uint4 *x, uint4
         unpack8<T>(y[px * ldy8 + c8], b);
 #pragma unroll
         for (int i = 0; i < 8; ++i) b[i] += a[i];
-        y[px * ldy8 + c8] = pack8<T>(b);
+        y[px * ldy8 + c8] = pack8_lim<T>(b, __builtin_inff());
     }
 }
 

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *z, const flo
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
         }
-        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8<T>(v);
+        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8_lim<T>(v, __builtin_inff());
     }
 }
 
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
         }
-        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8<T>(v);
+        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8_lim<T>(v, __builtin_inff());
     }
 }
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
         }
-        if (dres) *reinterpret_cast<uint4 *>(dres + px * lddres + c8 * 8) = pack8<T>(g);
+        if (dres) *reinterpret_cast<uint4 *>(dres + px * lddres + c8 * 8) = pack8_lim<T>(g, __builtin_inff());
         {
             float ka[8], kb[8];
             *reinterpret_cast<f32x4 *>(ka) = *reinterpret_cast<const f32x4 *>(kt + C);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const uint16_t *dy, c
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = ks[i] * g[i] + (ka[i] * zz[i] + kb[i]);
         }
-        *reinterpret_cast<uint4 *>(dz + px * lddz + c8 * 8) = pack8<T>(g);
+        *reinterpret_cast<uint4 *>(dz + px * lddz + c8 * 8) = pack8_lim<T>(g, __builtin_inff());
         if (DB) {
             if (fixed) {
                 mine = c8;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolBKP p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = xv[i] > 0.f ? acc[i] : 0.f;
         }
-        *reinterpret_cast<uint4 *>(p.dx + xi * p.lddx + c8 * 8) = pack8<T>(acc);
+        *reinterpret_cast<uint4 *>(p.dx + xi * p.lddx + c8 * 8) = pack8_lim<T>(acc, __builtin_inff());
     }
 }
 
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float *dfeat, co
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
         }
-        *reinterpret_cast<uint4 *>(dx + px * lddx + c8 * 8) = pack8<T>(v);
+        *reinterpret_cast<uint4 *>(dx + px * lddx + c8 * 8) = pack8_lim<T>(v, __builtin_inff());
     }
 }
 
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const uint16_t *dy,
                 for (int i = 0; i < 8; ++i) acc[i] += wh * ww * g[i];
             }
         }
-        *reinterpret_cast<uint4 *>(dx + ((n * h + ih) * w + iw) * (long)lddx + c8 * 8) = pack8<T>(acc);
+        *reinterpret_cast<uint4 *>(dx + ((n * h + ih) * w + iw) * (long)lddx + c8 * 8) = pack8_lim<T>(acc, __builtin_inff());
     }
 }
 
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void nchw_grad_to_cl_kernel(const float *dy, c
             if (y) { const float s = y[o]; g *= s * (1.f - s); }
             v[ch] = g;
         }
-        *reinterpret_cast<uint4 *>(out + idx * 8) = pack8<T>(v);
+        *reinterpret_cast<uint4 *>(out + idx * 8) = pack8_lim<T>(v, __builtin_inff());
     }
 }
 

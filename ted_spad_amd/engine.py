@@ -334,6 +334,8 @@ class PackedConv:
     weights [cout_pad][kpad] 16-bit with K ordered (dt, dh, dw, ci); fp32 scale/shift;
     per-input-geometry K-chunk gather tables."""
 
+    nosat = False       # True on the training path (train_engine.ConvLayer): tedspad_conv_extras.nosat
+
     def __init__(self, weight: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride=(1, 1, 1),
                  dtype: str = DEFAULT_DTYPE, device="cuda", pair_w: Optional[int] = None):
         """weight: (cout, cin, kt, kh, kw) fp32 (2-D convs: kt = 1).
@@ -607,8 +609,9 @@ class PackedConv:
         y32 = z32 is not None
         d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
         ex = None
-        if mask is not None or stats is not None or out_map is not None or y32:
+        if mask is not None or stats is not None or out_map is not None or y32 or self.nosat:
             ex = _lib.ConvExtras()
+            ex.nosat = int(self.nosat)
             if y32:
                 ex.y32, ex.ldy32 = z32.data_ptr(), self.cout
             if mask is not None:

@@ -64,5 +64,8 @@ class LinearParams(_NoForward):
 
 
 def params_signature(module: nn.Module):
-    """Changes whenever any parameter/buffer is written in place, replaced or moved."""
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
+    """Changes whenever any parameter/buffer is written in place, replaced or moved. `_tedspad_rev` (train_engine.mark_updated)
+    counts the writes torch's version counter does not see: a fused optimizer's step leaves `_version` alone, and the eval-mode
+    weight images keyed on this signature would otherwise survive it."""
+    return tuple((t.data_ptr(), t._version + int(getattr(t, "_tedspad_rev", 0)), str(t.device))
+                 for t in list(module.parameters()) + list(module.buffers()))

@@ -77,7 +77,9 @@ TRAIN_Z16 = os.environ.get("TEDSPAD_TRAIN_Z16", "1") != "0"
 # Gradients entering the networks through the autograd bridge (autograd.py: the reference's own training loop) are multiplied by this power of two and every
 # gradient leaving them is divided by it again: gfx950's matrix cores flush f16 SUBNORMAL operands, and the per-pixel activation gradients of the anonymizer's
 # high-resolution levels are below 6e-5 at the reference's scale. 1: the reference's literal arithmetic. (AnonymizerTrainStep has its own
-# `loss_scale`, with the non-finite check of a GradScaler; the bridge cannot skip a step, an overflow shows as non-finite gradients exactly as in the reference's fp16 run.)
+# `loss_scale`, with the non-finite check of a GradScaler; the bridge cannot skip a step, an overflow shows as non-finite gradients exactly as in the reference's fp16 run: every f16 store of the training path -- conv epilogues
+# with tedspad_conv_extras.nosat, csrc/train_ops.hip -- converts WITHOUT the +-65504 clamp the inference path has, so inf / NaN reach the parameter gradients and a
+# torch GradScaler around the bridge backs off as it does in train_anonymized_action.py:92-94.)
 GRAD_SCALE = float(os.environ.get("TEDSPAD_GRAD_SCALE", "256"))
 DB_SLOTS = 64           # rows of the conv-bias gradient accumulator of tedspad_bn_bwd_apply
 NO_ARENA = bool(os.environ.get("TEDSPAD_NO_ARENA"))       # every request its own torch.zeros (debugging)
@@ -201,6 +203,7 @@ class DgradPlan:
                         continue
                     geo = tuple(E) + tuple(cs) + tuple(stride_k)            # tap = c + s*(E-1-e): the flipped taps of this class
                     pc = PackedConv.dgrad_sub(w5, wscale, geo, pair_w, dtype)
+                    pc.nosat = True        # training path: f16 stores do not saturate (an overflow must reach the non-finite check)
                     self.subs.append((r, pc, tuple(pf2), tuple(J)))
         self.stride = tuple(stride_k)
 
@@ -256,6 +259,7 @@ class ConvLayer:
             w = self._w5()
             sf = (self.bias.detach() if self.bias is not None else None) if shift is None else shift
             pc = PackedConv(w, scale, sf, stride=self.stride, dtype=self.dtype, device=w.device, pair_w=self.pair_w)
+            pc.nosat = True
             old = ent[1] if ent is not None else self._last
             if old is not None:   # same geometry: keep the gather tables and the tuned tile choice
                 pc._ktabs, pc._cfgs = old._ktabs, old._cfgs

@@ -78,10 +78,6 @@ class AnonymizerTrainStep:
         self.loss_scale = float(loss_scale)
         E.apply_env_determinism()
         self.batch_clips = os.environ.get("TEDSPAD_TRAIN_BATCH_CLIPS", "1") != "0"   # the three clips of an iteration as one ft batch (0: three passes, A/B)
-        # phase 2's ft forward + losses + backward (~350 of its 530 launches, 5-40 us each) captured once as a hipGraph and replayed: possible because
-        # nothing in that sequence moves any more -- weight images are rewritten in place, the arena hands out the same slices, gradients are bucket views
-        self.use_graph = os.environ.get("TEDSPAD_TRAIN_GRAPH", "0") == "1"
-        self._g2, self._g2_warm = None, 0
         self.lazy_losses = os.environ.get("TEDSPAD_TRAIN_LAZY_LOSSES", "0") == "1"
         from .unetpp import UnetPlusPlus
         self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
@@ -248,28 +244,7 @@ class AnonymizerTrainStep:
                 self.ft_tr.backward(tape, self._scaled(P3.grad), self._scaled(F3.grad), on_bucket_done=self.red_ft.bucket_ready)
                 return losses
 
-            from . import engine as E
-            if not (self.use_graph and mode == "train" and dm is None and self.red_ft.world() == 1 and not E.tuning_pending()):
-                return body(x3, labels)
-            key = (tuple(x3.shape), str(x3.device), TE.ARENA.used)
-            if self._g2 is None or self._g2["key"] != key:
-                if self._g2_warm < 3:                                  # eager steps first: every image, job table and gather table exists
-                    self._g2_warm += 1
-                    return body(x3, labels)
-                st = dict(key=key, x=x3.clone(), labels=labels.clone())
-                torch.cuda.synchronize()
-                st["g"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(st["g"]):
-                    st["out"] = body(st["x"], st["labels"])
-                if TE._PENDING_GRAD or TE._PENDING_COUNT:
-                    raise RuntimeError("graph capture of the ft pass left deferred gradient / counter updates behind")
-                st["arena"] = (TE.ARENA.used, TE.ARENA.high)
-                self._g2 = st
-            st = self._g2
-            st["x"].copy_(x3); st["labels"].copy_(labels)
-            st["g"].replay()
-            TE.ARENA.used, TE.ARENA.high = max(TE.ARENA.used, st["arena"][0]), max(TE.ARENA.high, st["arena"][1])   # the next reset re-zeroes what the graph used
-            return st["out"]
+            return body(x3, labels)
         tapes, leaves = [], []
         for k, c in enumerate(clips):
             pred, feat, tape = self.ft_tr.forward(c, mode, drop_mask=None if drop_masks is None else drop_masks[k])

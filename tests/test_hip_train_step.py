@@ -174,6 +174,53 @@ def test_action_training_step_frozen_bn_vs_oracle():
     assert all(torch.equal(v, fa_before[k]) for k, v in fa.state_dict().items())                          # fa is not trained here
 
 
+def test_eval_forward_after_a_fused_optimizer_step_sees_the_new_weights():
+    """A fused Adam step leaves every Parameter._version alone; the eval-mode weight images (I3Res50.packed(), keyed on
+    params.params_signature) must still notice it -- the reference validates with the same modules after every training epoch
+    (train_anonymized_action.py). Pack, step_action (frozen BatchNorm: no running statistic moves either), extract features: equal
+    to the features of a fresh model loaded with the stepped weights, and different from the features before the step."""
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, _, _ = _models()
+    clips = synth_tensor(3, "evalclips", (2, 3, 16, 64, 64), 0, 1).cuda()
+    ft.eval()
+    before = ft.i3d.extract_features(clips).clone()                   # builds the eval images
+    from types import SimpleNamespace
+    from ted_spad_amd.train_step import DEFAULT_PARAMS
+    step = AnonymizerTrainStep(fa, ft, params=SimpleNamespace(**{**vars(DEFAULT_PARAMS), "learning_rate_ft": 1e-3}))
+    video = synth_train_video(0, "train_video64", (4, 48, 3, 64, 64))
+    out = step.step_action(video.cuda(), torch.tensor([5, 77, 101, 1]).cuda())
+    assert not out.get("skipped", False)
+    ft.eval()
+    after = ft.i3d.extract_features(clips)
+    fresh = load_ft_model("largei3d", num_classes=102)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in ft.state_dict().items()}, strict=True)
+    want = fresh.cuda().eval().i3d.extract_features(clips)
+    assert rel_l2(after.cpu(), want.cpu()) < 1e-6, "stale weight images after a fused optimizer step"
+    assert rel_l2(after.cpu(), before.cpu()) > 1e-4, "the step did not move the feature: the test would not see a stale image"
+
+
+@pytest.mark.parametrize("phase", [1, 2])
+def test_a_gradient_overflow_is_seen_and_the_step_skipped(phase):
+    """The f16 stores of the training path do not saturate (tedspad_conv_extras.nosat, csrc/train_ops.hip): with an absurd loss scale the activation
+    gradients overflow to inf, the parameter gradients come out non-finite, `_unscale`'s check finds them and the optimizer step is skipped and
+    reported -- GradScaler.step's behaviour (train_anonymized_action.py:92-94). With the inference path's +-65504 clamp the overflow was silently clipped."""
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, _, _ = _models()
+    video = synth_train_video(0, "train_video", (2, 48, 3, 32, 32)).cuda()
+    labels = torch.tensor([5, 77]).cuda()
+    step = AnonymizerTrainStep(fa, ft, loss_scale=2.0 ** 60)
+    net = fa if phase == 1 else ft
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    out = step.step_fa(video, labels) if phase == 1 else step.step_ft(video, labels)
+    assert out["skipped"] is True
+    assert all(torch.equal(p.detach(), before[k]) for k, p in net.named_parameters()), "a skipped step must leave the parameters alone"
+    step.loss_scale = 256.0
+    out = step.step_fa(video, labels) if phase == 1 else step.step_ft(video, labels)
+    assert out["skipped"] is False
+    assert any(not torch.equal(p.detach(), before[k]) for k, p in net.named_parameters())
+
+
 def _smooth(sd, beta=4.0):
     """Every BatchNorm bias = +4: almost no pre-activation is near 0, so the ReLUs are (nearly) the identity and
     the networks are smooth -- the end-to-end gradient error of the tests above (ReLU branch flips) disappears and
