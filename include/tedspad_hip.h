@@ -235,6 +235,16 @@ int64_t tedspad_stem_pt_side_bytes(int32_t n, int32_t t_pairs, int32_t h, int32_
 int32_t tedspad_stem_pt_pool_fwd(const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
                                  int32_t t_pairs, int32_t h, int32_t w, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,
                                  int32_t dtype, void *stream);
+/* The pool-fused 16x16x32 stem WITHOUT the layout pass: x is the fp32 (n, c, t, h, w) clip batch exactly as the reference hands it to
+ * `I3Res50.extract_features` / `forward` (large_i3d.py:229-232,251-254; produced by dali_extraction.py:38-50 / st_feature_extraction.py:18-26), element
+ * strides sn, sc, st, sh, sw = 1, rows 16-byte aligned (w % 4 == 0, x and every stride multiples of 4 elements). The persistent workgroups build their halo
+ * images from it themselves (register-staged 16-byte loads requested a whole patch ahead, converted to the 16-bit dtype on the way into LDS): the 9.6 MB
+ * per clip of tedspad_clip_to_tp records are never written or read. Same arithmetic, same results as tedspad_clip_to_tp + tedspad_stem_pt_pool_fwd(variant 6).
+ * w_img16: the tap-pair image; variant: bits 8..10 timing ablations only. */
+int32_t tedspad_stem_pt_pool_clip_fwd(const float *x, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc, int64_t st, int64_t sh,
+                                      int64_t sw, int32_t pad_t, int32_t stride_t, int32_t t_pairs, const void *w_img16, const float *scale,
+                                      const float *shift, void *y, void *side, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,
+                                      int32_t dtype, void *stream);
 
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
  * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be

@@ -64,7 +64,7 @@ constexpr int PT_LDS_POOL = pt_lds_pool(32);
 static_assert(pt_lds_pool(16) <= 160 * 1024 && pt_xb_off(16) % 128 == 0 && pt_xb_off(32) % 128 == 0, "MF = 16 image: exactly 160 KB");
 constexpr int PT_POOL_PIECES = 4 * 9 * 8;            // 16-byte pieces a patch hands to the pooled tensor (4 pooled rows x 9 slots x 8)
 static_assert(PT_LDS_POOL <= 160 * 1024, "weights + halo (+ pooled rows) must fit the CU's LDS");
-static_assert(PT_W_BYTES % 1024 == 0 && (4 * PT_ROWB) % 256 == 0, "LDS image alignment");
+static_assert(PT_W_BYTES % 1024 == 0 && (4 * PT_ROWB) % 256 == 0 && PT_ROWB % 32 == 0, "LDS image alignment");
 
 struct StemPT {
     const unsigned char *x;       // X[n][tp][h][b][wq][24] 16-bit (tedspad_clip_to_tp)
@@ -78,6 +78,10 @@ struct StemPT {
     uint16_t *side;               // POOL: S[n][tp][hp][tiles_w][64], column 0 of every patch pooled over rows
     int Hp, Wp;                   // POOL: pooled rows / columns
     int dbg;                      // timing ablations (wrong results): 1 = no halo DMA after the first patch, 2 = no stores, 4 = no MFMA phases
+    // DIRECT: the kernel reads the fp32 (n, c, t, h, w) clip itself (no layout pass): element strides, W contiguous
+    const float *xf;
+    long sN;
+    int sC, sT, sHf, C, T, W, pad_t;
 };
 
 __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
@@ -173,9 +177,17 @@ __device__ __forceinline__ void stem_pt_phase16(const unsigned char *dsm, const 
 // bytes each: pooled rows 4*th .. 4*th + 2 from this patch, row 4*th - 1 from rows 6, 7 of the patch above (carried in registers)
 // and row 0 of this one. The window a patch shares with its right neighbour is written as two partial maxima (slot 7 into the
 // pooled tensor, slot 8 into the side buffer) that stem_pool_fix_kernel joins. 1.44 GB per 225 clips no longer leave the chip.
-template <typename T, int NW, bool POOL, int MF = 32>
+//
+// DIRECT: no layout pass in front (tedspad_clip_to_tp: 4.3 GB of traffic and 790 us per 225 clips for a pure copy). The halo image is built from the fp32
+// NCTHW clip by the workgroup itself: thread = (half-position slot group): halo row, 4 consecutive columns (one 16-byte load per (frame, channel) plane: the
+// halo's first column 2 wo0 - 4 is a multiple of 4), output frame f, k8-half hs -> 8 (7) loads of the planes (frame slot, channel) = value 6 f + 8 hs + e,
+// converted and written as 4 x 16 bytes (one k8-half of 4 positions). 440 / 400 tasks per row-parity region: one per thread. The loads are ordinary vector
+// loads into registers, so they need no LDS slot while in flight: the rows of patch i + 2 are requested a WHOLE patch before they are written (right after the
+// rows of patch i + 1 left the same registers), which no LDS-DMA ring could afford here (160 KB are full).
+template <typename T, int NW, bool POOL, int MF = 32, bool DIRECT = false>
 __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     static_assert(MF == 32 || (MF == 16 && NW == 8 && POOL), "the 16x16x32 form is built for 8 waves with the pool fused");
+    static_assert(!DIRECT || (MF == 16 && NW == 8 && POOL), "the fp32-clip loader is built for the production form");
     constexpr int NA = NW == 8 ? 1 : 2;
     constexpr int XB_OFF = pt_xb_off(MF);
     constexpr int PIT = (PT_POOL_PIECES + 64 * NW - 1) / (64 * NW);
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
 
     // patch coordinates advance by a constant step (nx patches): mixed-radix addition with carries instead of three integer
     // divisions per patch
-    struct Patch { const unsigned char *pb; int ih0, wqm2, n, tp, th, tw, ho0, wo0; };
+    struct Patch { const unsigned char *pb; const float *pf; int ih0, wqm2, n, tp, th, tw, ho0, wo0; };
     auto split = [&](int r, int &n_, int &tp_, int &th_, int &tw_) {
         tw_ = r % p.tiles_w; r /= p.tiles_w;
         if (POOL) th_ = 0;                                  // r counts strips
@@ -228,7 +240,8 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     auto locate = [&](Patch &q) {
         q.ho0 = q.th * PT_TH; q.wo0 = q.tw * PT_TW;
         q.ih0 = 2 * q.ho0 - 3; q.wqm2 = q.wo0 - 2;
-        q.pb = p.x + ((long)q.n * p.Tp + q.tp) * p.sTp + (long)q.ih0 * p.sH + (long)q.wo0 * PT_REC;
+        if (DIRECT) q.pf = p.xf + (long)q.n * p.sN + (long)(4 * q.tp - p.pad_t) * p.sT + (long)q.ih0 * p.sHf + (2 * q.wo0 - 4);   // frame slot 0, halo row 0, halo column 0
+        else q.pb = p.x + ((long)q.n * p.Tp + q.tp) * p.sTp + (long)q.ih0 * p.sH + (long)q.wo0 * PT_REC;
     };
     int dn, dtp, dth, dtw;
     split(nx, dn, dtp, dth, dtw);
@@ -257,11 +270,77 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         }
     };
 
+    // ---- DIRECT: this thread's task of either region: (frame f, half hs) = tid / (rows * 10), halo row, column quad q4c ------------------------------
+    // so[par][e]: element offset of plane e's 4 columns from the patch base; fsch[par]: 3 bits frame slot + 2 bits channel per e; ldst[par]: LDS byte
+    // address of the first of the 4 positions' halves (j -> + (j >> 1) * 32 + (j & 1) * plane); dcol / drow: halo column / row of the task
+    int so[2][8], fsch[2][2], ldst[2], dcol[2], drow[2];
+    f32x4 stage[2][8];
+    if (DIRECT) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int per = pt_rows(par) * 10;
+            const int fh = tid / per, rem = tid - fh * per;
+            const int row = rem / 10, q4c = rem - row * 10;
+            const int f = fh >> 1, hs = fh & 1, hr = 2 * row + par;
+            const bool task = fh < 4;
+            drow[par] = task ? hr : (1 << 20);                 // no task: a row outside every clip -> zero page, and nothing is written (ldst < 0)
+            dcol[par] = 4 * q4c;
+            ldst[par] = task ? pt_off(par) + f * pt_frame(par) + row * PT_ROWB + 2 * q4c * 32 + 16 * hs : -1;
+            fsch[par][0] = fsch[par][1] = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int v = 6 * f + 8 * hs + e, fs = v / 3, ch = v - 3 * fs;
+                so[par][e] = ch * p.sC + fs * p.sT + hr * p.sHf + 4 * q4c;
+                fsch[par][e >> 2] |= (fs | (ch << 3)) << (8 * (e & 3));
+            }
+        }
+    }
+    auto issue_d = [&](int par, const Patch &q) {           // par is a literal at every call site
+        const bool rowok = (unsigned)(q.ih0 + drow[par]) < (unsigned)p.H && (unsigned)(2 * q.wo0 - 4 + dcol[par]) < (unsigned)p.W;
+        const int tt0 = 4 * q.tp - p.pad_t;
+        const bool hs1 = ldst[par] >= 0 && ((ldst[par] >> 4) & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int code = (fsch[par][e >> 2] >> (8 * (e & 3))) & 255;
+            const bool ok = rowok && (unsigned)(tt0 + (code & 7)) < (unsigned)p.T && (code >> 3) < p.C && !(e == 7 && hs1);   // value 15 of a position meets a zero weight
+            const float *src = ok ? q.pf + so[par][e] : reinterpret_cast<const float *>(zero);
+            stage[par][e] = *reinterpret_cast<const f32x4 *>(src);
+        }
+        asm volatile("" ::: "memory");                       // the loads stay here (the registers are meant to be live across the next MFMA phase)
+    };
+    auto cvt2 = [&](float a, float b) -> unsigned {         // two values -> packed 16-bit pair, saturated like T::from_f32 (one v_med3_f32 per value)
+        if constexpr (T::kDtype == TEDSPAD_F16) {
+            unsigned pk;
+            const float x = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), y = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(x), "v"(y));
+            return pk;
+        } else {
+            return (unsigned)T::from_f32(a) | ((unsigned)T::from_f32(b) << 16);
+        }
+    };
+    auto commit_d = [&](int par) {                           // registers -> 4 x 16 bytes of the region's LDS image
+        if (ldst[par] < 0) return;
+        const bool last = dcol[par] == 36;                   // columns 38, 39 are outside the halo (19 positions per plane)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = make_uint4(cvt2(stage[par][0][j], stage[par][1][j]), cvt2(stage[par][2][j], stage[par][3][j]),
+                                       cvt2(stage[par][4][j], stage[par][5][j]), cvt2(stage[par][6][j], stage[par][7][j]));
+            if (j < 2 || !last) *reinterpret_cast<uint4 *>(dsm + ldst[par] + (j >> 1) * 32 + (j & 1) * (PT_PP * 32)) = v;
+        }
+    };
+
     Patch cur;
     split(base + k, cur.n, cur.tp, cur.th, cur.tw);
     locate(cur);
-    issue(0, cur);
-    issue(1, cur);
+    if (DIRECT) {
+        issue_d(0, cur);
+        issue_d(1, cur);
+        commit_d(0);
+        commit_d(1);
+    } else {
+        issue(0, cur);
+        issue(1, cur);
+    }
 
     // ---- fragment bases ---------------------------------------------------------------------------------------------------------
     const int l15 = lane & 15, rsel = (lane >> 4) & 1, lh = lane >> 5, l31 = lane & 31;
@@ -310,7 +389,22 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(sc[a][r]), "+v"(sf[a][r]));   // hipcc's wait for these loads happens here, not in the loop
 
+    // the successor of patch (c, kc) in this workgroup's walk (and whether there is one)
+    auto successor = [&](const Patch &c, int kc, Patch &out, int &kout) -> bool {
+        const bool wrap = !POOL || c.th + 1 == p.tiles_h;
+        kout = wrap ? kc + nx : kc;
+        out = c;
+        if (kout >= lim) return false;                      // workgroup-uniform
+        out = advance(c);
+        return true;
+    };
+    const bool dma = !(p.dbg & 1);
+    if (DIRECT && dma) {                                    // the second patch's rows are in flight before the first one starts
+        Patch n1; int k1;
+        if (successor(cur, k, n1, k1)) { issue_d(0, n1); issue_d(1, n1); }
+    }
     wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // weights + both halo regions of the first patch visible
     asm volatile("" ::: "memory");
 
@@ -349,15 +443,15 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         }
     };
 
-    const bool dma = !(p.dbg & 1);
     bool pending = false;                                   // POOL: the column-pooled rows of `prev` wait in LDS
     Patch prev = cur;
     while (true) {
-        const bool wrap = !POOL || cur.th + 1 == p.tiles_h;
-        const int kn = wrap ? k + nx : k;
-        const bool more = kn < lim;                         // workgroup-uniform
-        Patch nxt = cur;
-        if (more) nxt = advance(cur);
+        Patch nxt, nn;
+        int kn, kn2 = 0;
+        const bool more = successor(cur, k, nxt, kn);       // workgroup-uniform
+        bool more2 = false;
+        nn = nxt;
+        if (DIRECT && more) more2 = successor(nxt, kn, nn, kn2);
         if (POOL && pending) pool_rows(prev);               // before this patch's mid barrier; the epilogue after it rewrites the rows
 
         f32x16 acc[NA][2];
@@ -377,10 +471,16 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
 
         if (MF == 16) { if (!(p.dbg & 4)) stem_pt_phase16<T, 0>(dsm, pb16, wa16, acc16); }
         else if (!(p.dbg & 4)) stem_pt_phase<T, 0, NA>(dsm, pa, wa, acc);             // taps dh = 0, 2, 4, 6 on the even halo rows
-        wait_vmcnt<0>();                                    // odd rows of this patch (the youngest operation of this wave) landed
+        if (!DIRECT) wait_vmcnt<0>();                       // odd rows of this patch (the youngest operation of this wave) landed
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // DIRECT: this wave's writes of the odd rows (after the previous barrier) are in LDS
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the even rows
         asm volatile("" ::: "memory");
-        if (more && dma) issue(0, nxt);                     // even rows of the NEXT patch land under the odd taps + epilogue
+        if (DIRECT) {
+            if (more && dma) {
+                commit_d(0);                                // even rows of the NEXT patch: requested a patch ago, written under the odd taps
+                if (more2) issue_d(0, nn);                  // ... and the ones after them take over the registers
+            }
+        } else if (more && dma) issue(0, nxt);              // even rows of the NEXT patch land under the odd taps + epilogue
         if (MF == 16) { if (!(p.dbg & 4)) stem_pt_phase16<T, 1>(dsm, pb16, wa16, acc16); }
         else if (!(p.dbg & 4)) stem_pt_phase<T, 1, NA>(dsm, pa, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
 
@@ -500,10 +600,16 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         if (!more) break;
         // even rows of the next patch landed; this patch's stores (issued after them; vector-memory operations retire in issue
         // order on gfx9) stay in flight
-        if (stored) wait_vmcnt<2 * NA>(); else wait_vmcnt<0>();
+        if (DIRECT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the even rows this wave wrote after the mid barrier are in LDS
+        else if (stored) wait_vmcnt<2 * NA>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the odd rows
         asm volatile("" ::: "memory");
-        if (dma) issue(1, nxt);                             // odd rows of the next patch land under its even taps
+        if (DIRECT) {
+            if (dma) {
+                commit_d(1);
+                if (more2) issue_d(1, nn);
+            }
+        } else if (dma) issue(1, nxt);                      // odd rows of the next patch land under its even taps
         prev = cur;
         pending = POOL;
         cur = nxt;
@@ -655,8 +761,10 @@ extern "C" int32_t tedspad_stem_pt_wimg16_bytes(void) { return PT_W16_BYTES; }
 // shared launcher: pool = the spatial 3x3 / 2 max-pool fused as well (y is the pooled tensor then, side its scratch)
 static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_img, const float *scale, const float *shift, void *y, void *side, int32_t n,
                               int32_t t_pairs, int32_t h, int32_t w, int32_t ho, int32_t wo, int32_t hp, int32_t wp, int32_t ldy, int32_t relu, int32_t nwg,
-                              int32_t variant, int32_t dtype, bool pool, hipStream_t s) {
+                              int32_t variant, int32_t dtype, bool pool, hipStream_t s, const StemPT *direct = nullptr) {
     StemPT p;
+    p.xf = nullptr; p.sN = 0; p.sC = p.sT = p.sHf = 0; p.C = 3; p.T = 0; p.W = w; p.pad_t = 0;
+    if (direct) { p.xf = direct->xf; p.sN = direct->sN; p.sC = direct->sC; p.sT = direct->sT; p.sHf = direct->sHf; p.C = direct->C; p.T = direct->T; p.pad_t = direct->pad_t; }
     p.x = (const unsigned char *)x_tp; p.wimg = (const unsigned char *)w_img; p.scale = scale; p.shift = shift; p.y = (uint16_t *)y;
     p.side = (uint16_t *)side; p.Hp = hp; p.Wp = wp;
     p.Wq = w / 2; p.sP = p.Wq * PT_REC; p.sH = 2 * p.sP; p.sTp = (long)h * p.sH;
@@ -674,8 +782,21 @@ static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_i
     if ((long)grid > total + 7) grid = (int)((total + 7) / 8 * 8);
     static thread_local int attr_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int w8 = (variant >> 1) & 1;
-    p.dbg = (variant >> 8) & 7;
-    if (pool && (variant & 4)) {           // 16x16x32 MFMA form (8 waves; w_img in the tap-pair layout)
+    p.dbg = (variant >> 8) & 15;
+    if (direct) {                          // the same form reading the fp32 clip itself
+        static thread_local int attrd[2] = {0, 0};
+        const int ti = dtype == TEDSPAD_F16 ? 0 : 1;
+        const void *fnd = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16, true> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16, true>;
+        if (!attrd[ti]) {
+            if (hipFuncSetAttribute(fnd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("%s: cannot raise the dynamic LDS limit", who);
+                return TEDSPAD_ELAUNCH;
+            }
+            attrd[ti] = 1;
+        }
+        if (ti == 0) hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true, 16, true>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+        else hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16, true>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+    } else if (pool && (variant & 4)) {           // 16x16x32 MFMA form (8 waves; w_img in the tap-pair layout)
         static thread_local int attr16[2] = {0, 0};
         const int ti = dtype == TEDSPAD_F16 ? 0 : 1;
         const void *fn16 = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16>;
@@ -755,4 +876,28 @@ extern "C" int32_t tedspad_stem_pt_pool_fwd(const void *x_tp, const void *w_img,
     TS_REQUIRE((long)h * w * PT_REC < (1L << 31), "tedspad_stem_pt_pool_fwd: frame too large for 32-bit halo offsets");
     return stem_pt_launch("tedspad_stem_pt_pool_fwd", x_tp, w_img, scale, shift, y, side, n, t_pairs, h, w, ho, wo, hp, wp, ldy, 1, nwg, variant, dtype, true,
                           (hipStream_t)stream);
+}
+
+// The same launch WITHOUT the layout pass: x is the fp32 (n, c, t, h, w) clip batch the boundary hands over (element strides sn, sc, st, sh; sw = 1), read by the
+// stem's own loader (conv1 -> bn1 -> relu -> maxpool1 on the NCTHW tensor: large_i3d.py:229-232; its producer is dali_extraction.py:38-50). w_img16: the
+// tap-pair image of the 16x16x32 form. Rows must be 16-byte aligned (w % 4 == 0, every stride a multiple of 4 elements).
+extern "C" int32_t tedspad_stem_pt_pool_clip_fwd(const float *x, int32_t n, int32_t c, int32_t t, int32_t h, int32_t w, int64_t sn, int64_t sc, int64_t st, int64_t sh,
+                                                 int64_t sw, int32_t pad_t, int32_t stride_t, int32_t t_pairs, const void *w_img16, const float *scale,
+                                                 const float *shift, void *y, void *side, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,
+                                                 int32_t dtype, void *stream) {
+    TS_REQUIRE(x && w_img16 && scale && shift && y && side && n > 0 && c > 0 && c <= 3 && t > 0 && h > 0 && w > 0 && t_pairs > 0 && pad_t >= 0,
+               "tedspad_stem_pt_pool_clip_fwd: bad arguments");
+    TS_REQUIRE(stride_t == 2, "tedspad_stem_pt_pool_clip_fwd: temporal stride 2");
+    TS_REQUIRE(sw == 1 && w % 4 == 0 && ((uintptr_t)x | (uintptr_t)(sn * 4) | (uintptr_t)(sc * 4) | (uintptr_t)(st * 4) | (uintptr_t)(sh * 4)) % 16 == 0,
+               "tedspad_stem_pt_pool_clip_fwd: rows must be contiguous and 16-byte aligned (w %% 4 == 0, strides multiples of 4 elements)");
+    TS_REQUIRE(sc >= 0 && st >= 0 && sh >= 0 && sn >= 0 && (c - 1) * sc + (long)(t + 8) * st + (long)(h + 32) * sh + w + 64 < (1L << 31),
+               "tedspad_stem_pt_pool_clip_fwd: a sample must fit 32-bit element offsets");
+    const int ho = (h + 1) / 2, wo = w / 2;
+    TS_REQUIRE(ho >= 3 && wo >= 3 && hp == (ho - 3) / 2 + 1 && wp == (wo - 3) / 2 + 1, "tedspad_stem_pt_pool_clip_fwd: 3x3 stride-2 unpadded pool of the ceil(h/2) x w/2 stem output");
+    TS_REQUIRE(ldy >= 64 && ldy % 8 == 0 && ((uintptr_t)w_img16 | (uintptr_t)y | (uintptr_t)side) % 16 == 0, "tedspad_stem_pt_pool_clip_fwd: 64 output channels, 16-byte aligned pointers");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_stem_pt_pool_clip_fwd: bad dtype");
+    StemPT d;
+    d.xf = x; d.sN = (long)sn; d.sC = (int)sc; d.sT = (int)st; d.sHf = (int)sh; d.C = c; d.T = t; d.pad_t = pad_t;
+    return stem_pt_launch("tedspad_stem_pt_pool_clip_fwd", nullptr, w_img16, scale, shift, y, side, n, t_pairs, h, w, ho, wo, hp, wp, ldy, 1, nwg, variant | 6, dtype, true,
+                          (hipStream_t)stream, &d);
 }

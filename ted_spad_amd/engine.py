@@ -32,6 +32,7 @@ BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # laye
 TPAIR_MIN_COUT = int(os.environ.get("TEDSPAD_TPAIR_MIN_COUT", "128"))   # smallest cout that takes the folded form (256: layer2's 128-channel temporal convs stay on the temporal chunk-major tile)
 TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
+STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
@@ -992,6 +993,30 @@ class StemPT:
         check(_lib.lib().tedspad_stem_pt_pool_fwd(xtp.data_ptr(), (self.wimg16 if v & 4 else self.wimg).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
                                                   out.ptr, side.data_ptr(), n, tp, h, w, hp, wp, out.ld, self.nwg, v, self.dtype_code, _stream_ptr()),
               "tedspad_stem_pt_pool_fwd")
+        return out
+
+    def direct_applies(self, x: torch.Tensor) -> bool:
+        """The stem can read this fp32 clip batch itself (16-byte aligned rows)."""
+        if not (self.applies(x) and x.dtype == torch.float32 and x.shape[4] % 4 == 0 and x.data_ptr() % 16 == 0):
+            return False
+        n, c, t, h, w = x.shape
+        sn, sc, st, sh, _ = x.stride()
+        return (all(s_ % 4 == 0 and s_ >= 0 for s_ in (sn, sc, st, sh)) and (c - 1) * sc + (t + 8) * st + (h + 32) * sh + w + 64 < (1 << 31) and
+                (h + 1) // 2 >= 3 and w // 2 >= 3)
+
+    def conv_pool_clip(self, x: torch.Tensor, variant=0) -> Act:
+        """conv1 + bn1 + ReLU + MaxPool3d((2,3,3), 2) (large_i3d.py:229-232) straight from the fp32 (n, c, t, h, w) clip batch: no layout pass."""
+        require_cuda(x, "StemPT")
+        n, c, t, h, w = x.shape
+        tp = self.frame_pairs(t)
+        ho, wo = (h + 1) // 2, w // 2
+        hp, wp = (ho - 3) // 2 + 1, (wo - 3) // 2 + 1
+        out = Act.empty(n, tp, hp, wp, 64, self.torch_dtype, x.device)
+        side = torch.empty(_lib.lib().tedspad_stem_pt_side_bytes(n, tp, h, w), dtype=torch.uint8, device=x.device)
+        sn, sc, st, sh, sw = x.stride()
+        check(_lib.lib().tedspad_stem_pt_pool_clip_fwd(x.data_ptr(), n, c, t, h, w, sn, sc, st, sh, sw, self.pad_t, self.stride_t, tp, self.wimg16.data_ptr(),
+                                                       self.scale.data_ptr(), self.shift.data_ptr(), out.ptr, side.data_ptr(), hp, wp, out.ld, self.nwg,
+                                                       variant, self.dtype_code, _stream_ptr()), "tedspad_stem_pt_pool_clip_fwd")
         return out
 
     def __call__(self, x: torch.Tensor, relu=True) -> Act:

@@ -124,7 +124,10 @@ class I3Res50(nn.Module):
             # is never written
             st = P["stem_pt"]
             if E.STEM_POOL and x.shape[3] >= 5 and x.shape[4] >= 6:
-                a = st.conv_pool(st.layout(x))                           # ... and the spatial half: only the pooled tensor is written
+                if E.STEM_CLIP and (st.VARIANT & 4) and st.direct_applies(x):
+                    a = st.conv_pool_clip(x)                             # ... straight from the fp32 NCTHW clip: no layout pass either
+                else:
+                    a = st.conv_pool(st.layout(x))                       # ... and the spatial half: only the pooled tensor is written
             else:
                 a = E.maxpool(st(x), (1, 3, 3), (1, 2, 2))               # the spatial half of MaxPool3d((2,3,3), 2)
         else:

@@ -152,6 +152,18 @@ def test_stem_persistent_with_temporal_pool(shape, variant, dtype):
             assert bool(((got_p - ref_pool).abs() <= ulp * ref_pool.abs() + 2e-3).all()), "max err %g" % float((got_p - ref_pool).abs().max())
             assert rel_l2(got_p, ref_pool) < (4e-4 if dtype == "f16" else 3e-3)
         assert bool(((f16x - fused).abs() <= ulp * fused.abs() + 1e-3).all())
+        # ... and WITHOUT the layout pass: the kernel's own loader reads the fp32 NCTHW clip (tedspad_stem_pt_pool_clip_fwd) -- the same 16-bit values as
+        # the 16x16x32 form on the tedspad_clip_to_tp records; also from a non-contiguous view (a T-slice of a longer clip, Q15)
+        if w % 4 == 0:
+            xg = clip.cuda()
+            assert st.direct_applies(xg)
+            direct = st.conv_pool_clip(xg).buf.float().cpu()
+            assert torch.equal(direct, f16x)
+            big = torch.zeros((n, c, t + 8, h, w), device="cuda")
+            big[:, :, 4:4 + t] = xg
+            view = big[:, :, 4:4 + t]
+            assert not view.is_contiguous() and st.direct_applies(view)
+            assert torch.equal(st.conv_pool_clip(view).buf.float().cpu(), f16x)
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
