@@ -854,6 +854,56 @@ class BneckFrame:
         return out
 
 
+class BneckL1:
+    """A plain layer1 bottleneck of I3Res50 (large_i3d.py:61-84, layer1.1 / layer1.2) as ONE launch (csrc/conv_bneck_l1.hip, tedspad_bneck_l1_fwd): a workgroup owns
+    8 x 14 output pixels x all T <= 4 frames, conv1 recomputed on the tile's halo, both 64-channel tensors in LDS. Holds the weight units in the kernel's
+    consumption order and the folded BatchNorm vectors."""
+
+    def __init__(self, w1: torch.Tensor, s1, b1, w2: torch.Tensor, s2, b2, w3: torch.Tensor, s3, b3, dtype: str = DEFAULT_DTYPE, device="cuda"):
+        assert self.supported(w1, w2, w3)
+        device = torch.device(device)
+        self.torch_dtype, self.dtype_code = DTYPES[dtype]
+        self.cin, self.kt = w1.shape[1], w1.shape[2]
+        self.wimg = self.pack(w1, w2, w3).to(device=device, dtype=self.torch_dtype).contiguous()
+        assert self.wimg.numel() * 2 == 4096 * _lib.lib().tedspad_bneck_l1_units(self.cin, self.kt)
+        f32 = lambda v: v.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.vecs = [f32(v) for v in (s1, b1, s2, b2, s3, b3)]
+
+    @staticmethod
+    def supported(w1, w2, w3) -> bool:
+        return (tuple(w1.shape[:2]) == (64, 256) and tuple(w1.shape[3:]) == (1, 1) and w1.shape[2] in (1, 3) and tuple(w2.shape) == (64, 64, 1, 3, 3) and
+                tuple(w3.shape) == (256, 64, 1, 1, 1))
+
+    @staticmethod
+    def pack(w1, w2, w3) -> torch.Tensor:
+        """fp32 weight units: stage 1 [chunk c][tap dt], stage 2 [tap][ks], stage 3 [cb][ks], each [tile j 0..3][k group kg 0..3][i 0..15][8]."""
+        w1, w2, w3 = (w.detach().float().cpu() for w in (w1, w2, w3))
+        i = torch.arange(16)
+        j = torch.arange(4).view(4, 1)
+        co12 = 16 * (i >> 2) + 4 * j + (i & 3)                                  # (4, 16): output channel of MFMA row i of tile j (stages 1, 2)
+        kt = w1.shape[2]
+
+        def units(wm, co):                                                        # wm (cout, K) -> (K / 32, 4, 4, 16, 8)
+            a = wm[co]                                                            # (4, 16, K)
+            return a.view(4, 16, -1, 4, 8).permute(2, 0, 3, 1, 4).contiguous()   # [K step][j][kg][i][8]
+        u1 = torch.stack([units(w1[:, :, dt, 0, 0], co12) for dt in range(kt)], dim=1)                    # (cin / 32, kt, ...)
+        u2 = torch.stack([units(w2[:, :, 0, t // 3, t % 3], co12) for t in range(9)], dim=0)              # (9, 2, ...)
+        u3 = torch.stack([units(w3[:, :, 0, 0, 0], 64 * cb + 4 * i + j) for cb in range(4)], dim=0)        # (4, 2, ...)
+        return torch.cat([u.reshape(-1) for u in (u1, u2, u3)])
+
+    def applies(self, x: Act) -> bool:
+        n, t, h, w = x.dims
+        return x.c == self.cin and t <= 4 and x.buf.dtype == self.torch_dtype and t * h * w * x.ld * 2 < (1 << 31)
+
+    def __call__(self, x: Act, relu=True) -> Act:
+        n, t, h, w = x.dims
+        out = Act(torch.empty_like(x.buf), 256, x.coff) if x.ld != 256 else Act.empty(n, t, h, w, 256, self.torch_dtype, x.buf.device)
+        assert out.ld == x.ld
+        check(_lib.lib().tedspad_bneck_l1_fwd(x.ptr, x.ld, out.ptr, out.ld, n, t, h, w, self.cin, self.kt, self.wimg.data_ptr(), *[v.data_ptr() for v in self.vecs],
+                                              int(relu), self.dtype_code, _stream_ptr()), "tedspad_bneck_l1_fwd")
+        return out
+
+
 def maxpool(x: Act, k, s, pads=(0, 0, 0), pads_back=None, pad_zero=False, out: Optional[Act] = None, return_idx=False):
     n, t, h, w = x.dims
     pb = pads if pads_back is None else pads_back
