@@ -34,19 +34,20 @@ def timed(fn, reps=7):
 for _ in range(40):      # let the tuner settle
     m = c1(x, pads=(1, 0, 0))
 old = tail(m, pads=(0, 1, 1), residual=x)
-new = blk(x)
+var = int(os.environ.get('L1_VARIANT', '1'))
+new = blk(x, variant=var)
 d = (old.buf.float() - new.buf.float()).abs()
 print("max |diff| vs the two launches %.4g (max |value| %.3g)" % (float(d.max()), float(old.buf.float().abs().max())))
 flop = 2.0 * n * t * h * w * (768 * 64 + 576 * 64 + 64 * 256)
-t1, t2, t3 = timed(lambda: c1(x, pads=(1, 0, 0))), timed(lambda: tail(m, pads=(0, 1, 1), residual=x)), timed(lambda: blk(x))
-print("conv1 %.0f us + tail %.0f us = %.0f us; whole block %.0f us (%.0f TFLOP/s algorithmic)" % (t1, t2, t1 + t2, t3, flop / t3 * 1e-6))
+t1, t2, t3 = timed(lambda: c1(x, pads=(1, 0, 0))), timed(lambda: tail(m, pads=(0, 1, 1), residual=x)), timed(lambda: blk(x, variant=var))
+print("variant %d: conv1 %.0f us + tail %.0f us = %.0f us; whole block %.0f us (%.0f TFLOP/s algorithmic); pooled %.0f us" % (var, t1, t2, t1 + t2, t3, flop / t3 * 1e-6, timed(lambda: blk(x, pool_t2=True, variant=var))))
 if os.environ.get("TEDSPAD_L1_ABLATE_SWEEP"):
     pass
 # stage stamps of every workgroup (wave 0): cycles between the stage boundaries
-nwg = n * 7 * 4
+nwg = n * (14 if var & 1 else 7) * 4
 buf = torch.zeros((nwg, 8), dtype=torch.int64, device="cuda")
 os.environ["TEDSPAD_L1_STAMPS"] = str(buf.data_ptr())
-blk(x); torch.cuda.synchronize()
+blk(x, variant=var); torch.cuda.synchronize()
 del os.environ["TEDSPAD_L1_STAMPS"]
 st = buf.cpu().double()
 d = (st[:, 1:] - st[:, :-1]).mean(0)

@@ -30,7 +30,7 @@ namespace {
 
 struct BneckL1KP {
     const uint16_t *x;          // block input (n, t, h, w, cin), pixel stride ldx: conv1 operand and residual
-    uint16_t *y;                // block output (n, t, h, w, 256), pixel stride ldy
+    uint16_t *y;                // block output (n, t | t / 2, h, w, 256), pixel stride ldy
     const uint16_t *wimg;       // weight units of 4 KB in consumption order: stage 1 (cin / 32 chunks x kt taps), stage 2 (9 taps x 2), stage 3 (4 x 2)
     const float *scale1, *shift1, *scale2, *shift2, *scale3, *shift3;
     int N, T, H, W, ldx, ldy, cin, kt, tiles_h, tiles_w, relu;
@@ -38,16 +38,32 @@ struct BneckL1KP {
     int dbg;                    // timing ablations (wrong results; TEDSPAD_L1_ABLATE): 1 no stage 1, 2 no stage 2, 4 no stage 3, 8 no residual loads / stores, 16 no stage-1 x DMA, 32 no MFMAs in stage 1
 };
 
-constexpr int L1_TH = 8, L1_TW = 14, L1_HH = 10, L1_HW = 16, L1_NPOS = L1_HH * L1_HW, L1_NPX = L1_TH * L1_TW;
+constexpr int L1_TW = 14, L1_HW = 16;                     // tile / halo width
 constexpr int L1_ROWB = 144;                              // bytes per M row: 9 sixteen-byte slots -> 16 consecutive rows at one chunk cover all 16 slot residues
 constexpr int L1_TMAX = 4;
-constexpr int L1_R0 = 3 * L1_TMAX * L1_NPOS * 64;         // 122 880: three x slots (stage 1) | M1 (92 160) | M2
-constexpr int L1_XSLOT = L1_TMAX * L1_NPOS * 64;          // 40 960
 constexpr int L1_UNIT = 4096;
-constexpr int L1_RW = L1_R0;                              // weight region
-constexpr int L1_RWBYTES = 9 * L1_UNIT;                   // 36 KB: stage 1: 3 x 3 units, stage 2: 3 x 2 units, stage 3: 8 units
-constexpr int L1_LDS = L1_RW + L1_RWBYTES;                // 159 744
-static_assert(L1_TMAX * L1_NPOS * L1_ROWB <= L1_R0 && L1_LDS <= 160 * 1024, "M1 lives in the region of the x slots; everything fits the CU's LDS");
+
+// Geometry of a variant: TH output rows per tile, NW waves.
+//   TH = 8, NW = 8: one workgroup per CU (156 KB), three x slots.
+//   TH = 4, NW = 4: TWO workgroups per CU (78 KB each): while one streams its x chunks from HBM (a CU pulls ~23 GB/s of misses whatever it does) the other multiplies
+//                   or stores -- the stages of ONE workgroup run one after the other. conv1 is recomputed on 6 x 16 halos (1.71 x instead of 1.43 x).
+template <int TH, int NW>
+struct L1Geo {
+    static constexpr int HH = TH + 2, NPOS = HH * L1_HW, NPX = TH * L1_TW;
+    static constexpr int NXS = TH == 8 ? 3 : 2;                                   // x slots
+    static constexpr int XSLOT = L1_TMAX * NPOS * 64;
+    static constexpr int M1B = L1_TMAX * NPOS * L1_ROWB;
+    static constexpr int NT2 = (L1_TMAX * NPX + 15) / 16;                          // stage-2 / stage-3 M tiles of a full clip
+    static constexpr int M2B = NT2 * 16 * L1_ROWB;
+    static constexpr int EXB = (L1_TMAX / 2) * NPX * 128;                          // pooled variant: the odd frames' packed results of a pass
+    static constexpr int R0 = (NXS * XSLOT > M1B ? NXS * XSLOT : M1B) > M2B + EXB ? (NXS * XSLOT > M1B ? NXS * XSLOT : M1B) : M2B + EXB;
+    static constexpr int RWU = TH == 8 ? 9 : 6;                                    // weight region in units
+    static constexpr int ZOFF = R0 + RWU * L1_UNIT;                                // 1 KB of zeros: the pixel fragment of a temporal tap outside the clip
+    static constexpr int LDS = ZOFF + 1024;
+    static constexpr int NI1 = L1_TMAX * HH / NW;                                  // stage-1 tiles per wave
+    static constexpr int NI2 = (NT2 + NW - 1) / NW;                                // stage-2 / 3 tiles per wave (at most)
+    static_assert(L1_TMAX * HH % NW == 0 && LDS <= (NW == 8 ? 160 : 80) * 1024, "tiles deal evenly over the waves; the LDS image fits");
+};
 
 __device__ uint4 g_l1_zero;
 __device__ uint2 g_l1_sink[64];      // where the results of pixels outside the frame go (never read)
@@ -85,8 +101,11 @@ __device__ __forceinline__ unsigned l1_pair_res(float a0, float a1, float s0, fl
     }
 }
 
-template <typename T_>
-__global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
+
+template <typename T_, int TH, int NW, bool POOL>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(const BneckL1KP p) {
+    typedef L1Geo<TH, NW> G;
+    constexpr int HH = G::HH, NPX = G::NPX, NI1 = G::NI1, NI2 = G::NI2, RW = G::R0;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,32 +115,39 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
     const int tw = tile % p.tiles_w; tile /= p.tiles_w;
     const int th = tile % p.tiles_h;
     const int n = tile / p.tiles_h;
-    const int oh0 = th * L1_TH, ow0 = tw * L1_TW;
+    const int oh0 = th * TH, ow0 = tw * L1_TW;
     const int T = p.T, nc1 = (p.dbg & 1) ? 0 : p.cin >> 5, kt = p.kt, pt = kt >> 1;
-    const int ntile1 = T * L1_HH;                              // stage-1 M tiles
     constexpr float HI = T_::kDtype == TEDSPAD_F16 ? 65504.f : 3.3e38f;
 
-    // ---- stage 1 sources: piece pc = (frame f, halo row hr) = wave + 8 i; lane (hc = l15, k group g) <- x[n, f, clamp(oh0 - 1 + hr), clamp(ow0 - 1 + hc), 32 c + 8 g ..]
+    // ---- stage 1 sources: piece pc = (frame f, halo row hr) = wave + NW i; lane (hc = l15, k group g) <- x[n, f, clamp(oh0 - 1 + hr), clamp(ow0 - 1 + hc), 32 c + 8 g ..]
     const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x + (size_t)n * T * p.H * p.W * p.ldx);
     const unsigned colo = ((unsigned)min(max(ow0 - 1 + l15, 0), p.W - 1) * (unsigned)p.ldx + (unsigned)g * 8u) * 2u;
-    unsigned rowo[5];
-    int t1[5], hr1[5];
+    // Tiles of a wave: i < 4: (frame i, halo row `wave`) -- the frame, hence which temporal taps stay inside the clip, is a COMPILE-TIME property of i: no branch in the
+    // K loop; i >= 4: the halo rows NW .. HH - 1 of all frames, dealt over the waves (their frame depends on the wave: a tap outside the clip multiplies a zero fragment)
+    unsigned rowo[NI1];
+    int t1[NI1], hr1[NI1], pc1[NI1];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int pc = wave + 8 * i;
-        const int f = pc / L1_HH, hr = pc - f * L1_HH;
-        t1[i] = pc < ntile1 ? f : -8;                           // no tile: every tap "leaves the clip"
+    for (int i = 0; i < NI1; ++i) {
+        int f = i, hr = wave;
+        if (i >= 4) {
+            const int idx = wave * (NI1 - 4) + (i - 4);
+            f = idx / (HH - NW);
+            hr = NW + idx - f * (HH - NW);
+        }
+        const bool has = f < T;
+        t1[i] = has ? f : -8;                                   // no tile: every tap "leaves the clip"
         hr1[i] = hr;
+        pc1[i] = has ? f * HH + hr : -1;
         rowo[i] = (unsigned)((min(f, T - 1) * p.H + min(max(oh0 - 1 + hr, 0), p.H - 1)) * p.W) * (unsigned)p.ldx * 2u;
     }
     auto issue_x = [&](int c, int slot) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (wave + 8 * i < ntile1 && !(p.dbg & 16)) lds_dma16(xb + rowo[i] + colo + c * 64, lds0 + slot * L1_XSLOT + (wave + 8 * i) * 1024);
+        for (int i = 0; i < NI1; ++i)
+            if (pc1[i] >= 0 && !(p.dbg & 16)) lds_dma16(xb + rowo[i] + colo + c * 64, lds0 + slot * G::XSLOT + pc1[i] * 1024);
     };
     const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.wimg);
     auto issue_w = [&](int unit0, int nunits, unsigned dst) {   // units unit0 .. of the stream -> dst; 4 pieces per unit, dealt over the waves
-        for (int i = wave; i < nunits * 4; i += 8) lds_dma16(wb + (size_t)unit0 * L1_UNIT + i * 1024 + lane * 16, lds0 + dst + i * 1024);
+        for (int i = wave; i < nunits * 4; i += NW) lds_dma16(wb + (size_t)unit0 * L1_UNIT + i * 1024 + lane * 16, lds0 + dst + i * 1024);
     };
 
     // bn1's scale / shift of this lane's 16 channels (16 g + 4 j + e), requested now: their round trip is long over when stage 1 ends
@@ -131,58 +157,86 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
         *reinterpret_cast<f32x4 *>(sc1 + 4 * q) = *reinterpret_cast<const f32x4 *>(p.scale1 + 16 * g + 4 * q);
         *reinterpret_cast<f32x4 *>(sh1 + 4 * q) = *reinterpret_cast<const f32x4 *>(p.shift1 + 16 * g + 4 * q);
     }
+    if (tid < 64) *reinterpret_cast<uint4 *>(dsm + G::ZOFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);      // visible behind the first chunk's barrier
     long long st_[8];
 #define L1_STAMP(k) { if (p.stamps) st_[k] = __builtin_amdgcn_s_memtime(); }
     L1_STAMP(0);
-    f32x4 acc[4][5];
+    f32x4 acc[4][NI1];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NI1; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ================================ stage 1: conv1 on the halo of all frames ================================
-    // Three slots: the chunks c + 1 and c + 2 are in flight while chunk c is multiplied (with one chunk in flight a chunk took 4.7 k cycles -- 52 KB per HBM round
-    // trip of ~3 us -- against 1.6 k cycles of MFMA work). A wave issues npc pieces per chunk: its wait for chunk c leaves the npc pieces of chunk c + 1 in flight.
+    // NXS slots: the chunks c + 1 .. c + NXS - 1 are in flight while chunk c is multiplied. A wave issues npc pieces per chunk: its wait for chunk c leaves the
+    // pieces of the younger chunks in flight.
     int npc = 0;
-    for (int i = 0; i < 5; ++i) npc += (wave + 8 * i < ntile1 && !(p.dbg & 16)) ? 1 : 0;
-    for (int i = wave; i < kt * 4; i += 8) ++npc;
-    auto wait_chunk = [&](bool last) {                          // this wave's pieces of the oldest chunk in flight
-        if (last) { wait_vmcnt<0>(); return; }
-        switch (npc) {
-            case 1: wait_vmcnt<1>(); break;
-            case 2: wait_vmcnt<2>(); break;
-            case 3: wait_vmcnt<3>(); break;
-            case 4: wait_vmcnt<4>(); break;
-            case 5: wait_vmcnt<5>(); break;
-            case 6: wait_vmcnt<6>(); break;
-            case 7: wait_vmcnt<7>(); break;
+    for (int i = 0; i < NI1; ++i) npc += (pc1[i] >= 0 && !(p.dbg & 16)) ? 1 : 0;
+    if (!(p.dbg & 64)) for (int i = wave; i < kt * 4; i += NW) ++npc;
+    auto wait_n = [&](int k) {                                  // s_waitcnt vmcnt(k), k a run-time (wave-uniform) count
+        switch (k) {
+            case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
+            case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;   case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;
+            case 8: wait_vmcnt<8>(); break;   case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+            case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break; case 15: wait_vmcnt<15>(); break;
+            case 16: wait_vmcnt<16>(); break; case 17: wait_vmcnt<17>(); break; case 18: wait_vmcnt<18>(); break;
             default: wait_vmcnt<0>(); break;
         }
     };
     auto issue_chunk = [&](int c) {
-        issue_x(c, c % 3);
-        issue_w(c * kt, kt, L1_RW + (c % 3) * 3 * L1_UNIT);
+        issue_x(c, c % G::NXS);
+        if (!(p.dbg & 64)) issue_w(c * kt, kt, RW + (c % G::NXS) * 3 * L1_UNIT);
     };
-    if (nc1) issue_chunk(0);
-    if (nc1 > 1) issue_chunk(1);
+    const bool fast1 = T == 4 && kt == 3 && !(p.dbg & 32);
+    for (int c = 0; c < G::NXS - 1; ++c)
+        if (c < nc1) issue_chunk(c);
     for (int c = 0; c < nc1; ++c) {
-        wait_chunk(c + 1 >= nc1);                               // this wave's pieces of chunk c
+        wait_n(npc * min(G::NXS - 2, nc1 - 1 - c));            // this wave's pieces of chunk c
         __builtin_amdgcn_s_barrier();                           // ... everybody's; everybody is done with chunk c - 1
         asm volatile("" ::: "memory");
         if (c == 0) L1_STAMP(1);
-        if (c + 2 < nc1) issue_chunk(c + 2);                    // into the slot of chunk c - 1
-        const int xs = (c % 3) * L1_XSLOT, ws = L1_RW + (c % 3) * 3 * L1_UNIT;
-        for (int dt = 0; dt < kt; ++dt) {
-            uint4 a[4];
+        if (c + G::NXS - 1 < nc1) issue_chunk(c + G::NXS - 1);  // into the slot of chunk c - 1
+        const int xs = (c % G::NXS) * G::XSLOT, ws = RW + (c % G::NXS) * 3 * L1_UNIT;
+        if (fast1) {
+            // T == 4 frames, 3 taps: straight-line code (every fragment read of a tap is issued before its MFMAs; behind a branch per tile the LDS latency of each
+            // read was exposed: 3.5 k cycles per chunk for 1.6 k of MFMA work)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = L1_LDS16(ws + dt * L1_UNIT + j * 1024 + lane * 16);
+            for (int dt = 0; dt < 3; ++dt) {
+                uint4 a[4], b[NI1];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int f = t1[i] + dt - pt;                  // input frame of this tap (wave-uniform)
-                if ((unsigned)f < (unsigned)T && !(p.dbg & 32)) {
-                    const uint4 b = L1_LDS16(xs + (f * L1_HH + hr1[i]) * 1024 + lane * 16);
+                for (int j = 0; j < 4; ++j) a[j] = L1_LDS16(ws + dt * L1_UNIT + j * 1024 + lane * 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j][i] = T_::mfma16(a[j], b, acc[j][i]);
+                for (int i = 0; i < NI1; ++i) {
+                    if (i < 4) {
+                        if (i + dt - 1 >= 0 && i + dt - 1 <= 3) b[i] = L1_LDS16(xs + ((i + dt - 1) * HH + hr1[i]) * 1024 + lane * 16);
+                    } else {
+                        const int f = t1[i] + dt - 1;
+                        b[i] = L1_LDS16(((unsigned)f < 4u ? xs + (f * HH + hr1[i]) * 1024 : G::ZOFF) + lane * 16);
+                    }
+                }
+                if (p.dbg & 128) continue;
+#pragma unroll
+                for (int i = 0; i < NI1; ++i)
+                    if (i >= 4 || (i + dt - 1 >= 0 && i + dt - 1 <= 3)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][i] = T_::mfma16(a[j], b[i], acc[j][i]);
+                    }
+            }
+        } else {
+            for (int dt = 0; dt < kt; ++dt) {
+                uint4 a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = L1_LDS16(ws + dt * L1_UNIT + j * 1024 + lane * 16);
+                if (p.dbg & 128) continue;                              // no pixel fragment reads, no MFMAs
+#pragma unroll
+                for (int i = 0; i < NI1; ++i) {
+                    const int f = t1[i] + dt - pt;                  // input frame of this tap (wave-uniform)
+                    if ((unsigned)f < (unsigned)T && !(p.dbg & 32)) {
+                        const uint4 b = L1_LDS16(xs + (f * HH + hr1[i]) * 1024 + lane * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][i] = T_::mfma16(a[j], b, acc[j][i]);
+                    }
                 }
             }
         }
@@ -191,34 +245,49 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
     __builtin_amdgcn_s_barrier();                               // every wave is done with the x slots and the stage-1 weight slots
     asm volatile("" ::: "memory");
     const int u2 = (p.cin >> 5) * kt;                           // first stage-2 unit
-    issue_w(u2, 4, L1_RW);                                      // taps 0, 1 -> ring slots 0, 1 (one piece per wave and tap)
-    // stages 2 and 3: wave = (frame t2, half h2): M tiles 4 h2 .. of the frame's 7 (4 | 3); the two waves of a SIMD (w, w + 4) hold 4 + 3
-    const int t2 = wave >> 1, h2 = (wave & 1) ^ (wave >> 2);
-    const int tl0 = 4 * h2, ntl = t2 < T ? (h2 ? 3 : 4) : 0;
-    // The residual rows of a stage-3 pass are requested one pass ahead of their use, those of pass 0 here, a whole stage 2 ahead (requested at the start of their own
-    // pass they were 8-byte loads from HBM with 32 MFMAs to hide behind: 19 k of a tile's 103 k cycles)
-    unsigned go[4][4];                                          // byte offset of pixel (tile i, row 4 g + e) in x / y (ldx == ldy), channel 4 l15; ~0u: outside the frame
+    issue_w(u2, 4, RW);                                         // taps 0, 1 -> ring slots 0, 1
+    constexpr int NP2 = 8 / NW;                                 // pieces per wave and tap
+
+    // stages 2 and 3: rows r = frame * NPX + tile pixel (flat), M tiles of 16 rows dealt over the waves: base + (wave < rem) each, consecutive
+    const int NR = T * NPX, nt2 = (NR + 15) >> 4;
+    const int cnt2 = nt2 / NW + (wave < nt2 % NW ? 1 : 0), tl0 = wave * (nt2 / NW) + min(wave, nt2 % NW);
+    // byte offset of row (tile i, 4 g + e) in x (and y, ldx == ldy) at channel 4 l15; ~0u: outside the frame / past the clip. The residual rows of a stage-3 pass are
+    // requested one pass ahead of their use, those of pass 0 here, a whole stage 2 ahead.
+    unsigned go[NI2][4];
+    unsigned oddm = 0, evenm = 0;                               // POOL: bit 4 i + e: the row belongs to an odd frame / to an even frame with a partner
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI2; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int j2 = 16 * (tl0 + i) + 4 * g + e;
+            const int r = 16 * (tl0 + i) + 4 * g + e;
+            const int t = r / NPX, j2 = r - t * NPX;
             const int oh = j2 / L1_TW, ow = j2 - oh * L1_TW;
-            const bool in = i < ntl && oh0 + oh < p.H && ow0 + ow < p.W;
-            go[i][e] = in ? ((unsigned)((t2 * p.H + oh0 + oh) * p.W + ow0 + ow) * (unsigned)p.ldx + 4u * (unsigned)l15) * 2u : ~0u;
+            const bool in = i < cnt2 && r < NR && oh0 + oh < p.H && ow0 + ow < p.W;
+            go[i][e] = in ? ((unsigned)((t * p.H + oh0 + oh) * p.W + ow0 + ow) * (unsigned)p.ldx + 4u * (unsigned)l15) * 2u : ~0u;
+            if (POOL && in && (t & 1)) oddm |= 1u << (4 * i + e);
+            if (POOL && in && !(t & 1) && t + 1 < T) evenm |= 1u << (4 * i + e);
         }
     const unsigned char *zsrc = reinterpret_cast<const unsigned char *>(&g_l1_zero) + (lane & 1) * 8;
     unsigned char *sink = reinterpret_cast<unsigned char *>(g_l1_sink) + lane * 8;
-    uint2 res[2][4][4];                                         // residual rows of pass cb in res[cb & 1]: requested one pass (pass 0: a whole stage 2) ahead
+    uint2 res[2][NI2][4];
     auto load_res = [&](int cb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI2; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                // no branch per access (pixels outside the frame read a zero line, their results go to a sink line): behind a conditional block hipcc waits with
+                // no branch per access (rows outside the frame read a zero line, their results go to a sink line): behind a conditional block hipcc waits with
                 // vmcnt(0) before every access -- sixteen serialised round trips per pass, 8.5 k cycles
                 const unsigned char *src = go[i][e] != ~0u ? xb + go[i][e] + cb * 128 : zsrc;
-                res[cb & 1][i][e] = *reinterpret_cast<const uint2 *>(src);
+                if (!(p.dbg & 8)) res[cb & 1][i][e] = *reinterpret_cast<const uint2 *>(src);
+            }
+    };
+    auto load_res_now = [&](int cb) {                            // POOL (register-bound): one buffer, the pass's rows requested at its start
+#pragma unroll
+        for (int i = 0; i < NI2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned char *src = go[i][e] != ~0u ? xb + go[i][e] + cb * 128 : zsrc;
+                if (!(p.dbg & 8)) res[0][i][e] = *reinterpret_cast<const uint2 *>(src);
             }
     };
     load_res(0);
@@ -228,10 +297,10 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
         const float (&sc)[16] = sc1, (&sh)[16] = sh1;
         const bool colin = (unsigned)(ow0 - 1 + l15) < (unsigned)p.W;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            if (wave + 8 * i < ntile1) {
+        for (int i = 0; i < NI1; ++i) {
+            if (pc1[i] >= 0) {
                 const float hi = colin && (unsigned)(oh0 - 1 + hr1[i]) < (unsigned)p.H ? HI : 0.f;      // outside the frame: zeros (conv2's padding)
-                unsigned char *row = dsm + ((t1[i] * L1_HH + hr1[i]) * L1_HW + l15) * L1_ROWB + g * 32;
+                unsigned char *row = dsm + ((t1[i] * HH + hr1[i]) * L1_HW + l15) * L1_ROWB + g * 32;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     unsigned d[4];
@@ -247,17 +316,18 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
     }
 
     // ================================ stage 2: conv2 from M1 ================================
-    f32x4 acc2[4][4];
+    f32x4 acc2[4][NI2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc2[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int m1a[4];                                                 // M1 byte address of the lane's pixel (tile pixel 16 (tl0 + i) + l15) at tap (0, 0), chunk g
+        for (int i = 0; i < NI2; ++i) acc2[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int m1a[NI2];                                               // M1 byte address of the lane's row (16 (tl0 + i) + l15) at tap (0, 0), chunk g
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j2 = 16 * (tl0 + i) + l15;
+    for (int i = 0; i < NI2; ++i) {
+        const int r = min(16 * (tl0 + i) + l15, NR - 1);        // rows past the clip (the last tile's padding): a valid row, results never stored
+        const int t = r / NPX, j2 = r - t * NPX;
         const int oh = j2 / L1_TW, ow = j2 - oh * L1_TW;
-        m1a[i] = ((min(t2, L1_TMAX - 1) * L1_HH + oh) * L1_HW + ow) * L1_ROWB + g * 16;
+        m1a[i] = ((t * HH + oh) * L1_HW + ow) * L1_ROWB + g * 16;
     }
     float sc2[16], sh2[16];                                     // bn2, requested a whole stage ahead
 #pragma unroll
@@ -272,12 +342,12 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
     L1_STAMP(3);
     for (int tap = 0; tap < ((p.dbg & 2) ? 1 : 9); ++tap) {
         if (tap > 0) {
-            if (tap < 8) wait_vmcnt<1>(); else wait_vmcnt<0>();  // this tap's piece of this wave (issued two taps ago); the next tap's may fly
+            if (tap < 8) wait_vmcnt<NP2>(); else wait_vmcnt<0>();  // this tap's pieces of this wave (issued two taps ago); the next tap's may fly
             __builtin_amdgcn_s_barrier();                       // ... everybody's; everybody is done with tap - 1
             asm volatile("" ::: "memory");
         }
-        if (tap + 2 < 9) issue_w(u2 + 2 * (tap + 2), 2, L1_RW + ((tap + 2) % 3) * 2 * L1_UNIT);
-        const int ws = L1_RW + (tap % 3) * 2 * L1_UNIT;
+        if (tap + 2 < 9) issue_w(u2 + 2 * (tap + 2), 2, RW + ((tap + 2) % 3) * 2 * L1_UNIT);
+        const int ws = RW + (tap % 3) * 2 * L1_UNIT;
         const int dh = tap / 3, dw = tap - 3 * dh;
         const int toff = (dh * L1_HW + dw) * L1_ROWB;
 #pragma unroll
@@ -286,8 +356,8 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = L1_LDS16(ws + ks * L1_UNIT + j * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < ntl) {
+            for (int i = 0; i < NI2; ++i)
+                if (i < cnt2) {
                     const uint4 b = L1_LDS16(m1a[i] + toff + ks * 64);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc2[j][i] = T_::mfma16(a[j], b, acc2[j][i]);
@@ -298,15 +368,16 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
     __builtin_amdgcn_s_barrier();                               // every wave is done with M1 and the ring
     asm volatile("" ::: "memory");
     const int u3 = u2 + 18;
-    issue_w(u3, 8, L1_RW);                                      // the whole conv3 image: 4 pieces per wave
+    constexpr int NU3 = G::RWU >= 8 ? 8 : G::RWU;               // conv3 units resident at first (all 8, or 6: passes 0 .. 2; the last two follow behind pass 1)
+    issue_w(u3, NU3, RW);
 
-    // ---- relu(bn2(.)) -> M2[frame][tile pixel][64] over M1 -------------------------------------------------------------------------------
+    // ---- relu(bn2(.)) -> M2[row][64] over M1 -------------------------------------------------------------------------------
     {
         const float (&sc)[16] = sc2, (&sh)[16] = sh2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < ntl) {
-                unsigned char *row = dsm + (t2 * L1_NPX + 16 * (tl0 + i) + l15) * L1_ROWB + g * 32;
+        for (int i = 0; i < NI2; ++i)
+            if (i < cnt2) {
+                unsigned char *row = dsm + (16 * (tl0 + i) + l15) * L1_ROWB + g * 32;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     unsigned d[4];
@@ -321,10 +392,12 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
     }
 
     // ================================ stage 3: conv3 + bn3 + residual + ReLU ================================
-    // pixels = A: D[pixel 4 g + e of the tile][channel column l15]; the host orders the rows of tile jt so that column l15 is channel 4 l15 + jt of the pass's 64:
-    // a lane holds 4 consecutive channels of 4 pixels
-    unsigned char *yb = reinterpret_cast<unsigned char *>(p.y + (size_t)n * T * p.H * p.W * p.ldy);
-    const int m2a = (min(t2, L1_TMAX - 1) * L1_NPX + 16 * tl0 + l15) * L1_ROWB + g * 16;
+    // pixels = A: D[row 4 g + e of the tile][channel column l15]; the host orders the rows of tile jt so that column l15 is channel 4 l15 + jt of the pass's 64:
+    // a lane holds 4 consecutive channels of 4 rows
+    // POOL (MaxPool3d((2,1,1)) of the block's output, large_i3d.py:139): y has T / 2 frames; the rows of ODD frames leave their packed results in LDS (EX), the
+    // rows of EVEN frames take the maximum with their partner (row + NPX) and store at frame t / 2
+    unsigned char *yb = reinterpret_cast<unsigned char *>(p.y + (size_t)n * (POOL ? T / 2 : T) * p.H * p.W * p.ldy);
+    const int m2a = (16 * tl0 + l15) * L1_ROWB + g * 16;
     const float lo = p.relu ? 0.f : -HI;
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -334,37 +407,86 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         if (p.dbg & 4) break;
-        // (bn3 first: vector memory retires in order, a wait for these two leaves the 16 younger residual loads of the next pass in flight)
+        int wslot = cb * 2;                                     // unit of (cb, ks = 0) inside RW
+        if (G::RWU < 8) {
+            if (cb == 2) {                                      // units 6, 7 (pass 3) replace units 0, 1: every wave is done with passes 0, 1
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_w(u3 + 6, 2, RW);
+            }
+            if (cb == 3) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                wslot = 0;
+            }
+        }
+        // (bn3 first: vector memory retires in order, a wait for these two leaves the younger residual loads of the next pass in flight)
         const f32x4 s3 = *reinterpret_cast<const f32x4 *>(p.scale3 + 64 * cb + 4 * l15), b3 = *reinterpret_cast<const f32x4 *>(p.shift3 + 64 * cb + 4 * l15);
         asm volatile("" ::: "memory");
-        if (cb + 1 < 4) load_res(cb + 1);
-        f32x4 acc3[4][4];
+        if (!POOL && cb + 1 < 4) load_res(cb + 1);
+        if (POOL && cb > 0) load_res_now(cb);
+        f32x4 acc3[4][NI2];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc3[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NI2; ++i) acc3[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 bw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bw[j] = L1_LDS16(L1_RW + (cb * 2 + ks) * L1_UNIT + j * 1024 + lane * 16);
+            for (int j = 0; j < 4; ++j) bw[j] = L1_LDS16(RW + (wslot + ks) * L1_UNIT + j * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < ntl) {
+            for (int i = 0; i < NI2; ++i)
+                if (i < cnt2) {
                     const uint4 am = L1_LDS16(m2a + i * 16 * L1_ROWB + ks * 64);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc3[j][i] = T_::mfma16(am, bw[j], acc3[j][i]);
                 }
         }
         if (!(p.dbg & 8)) {
+            uint2 o[NI2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI2; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint2 o = make_uint2(l1_pair_res<T_>(acc3[0][i][e], acc3[1][i][e], s3[0], s3[1], b3[0], b3[1], res[cb & 1][i][e].x, lo),
-                                               l1_pair_res<T_>(acc3[2][i][e], acc3[3][i][e], s3[2], s3[3], b3[2], b3[3], res[cb & 1][i][e].y, lo));
-                    *reinterpret_cast<uint2 *>(go[i][e] != ~0u ? yb + go[i][e] + cb * 128 : sink) = o;
-                }
+                for (int e = 0; e < 4; ++e)
+                    o[i][e] = make_uint2(l1_pair_res<T_>(acc3[0][i][e], acc3[1][i][e], s3[0], s3[1], b3[0], b3[1], res[POOL ? 0 : cb & 1][i][e].x, lo),
+                                         l1_pair_res<T_>(acc3[2][i][e], acc3[3][i][e], s3[2], s3[3], b3[2], b3[3], res[POOL ? 0 : cb & 1][i][e].y, lo));
+            if (!POOL) {
+#pragma unroll
+                for (int i = 0; i < NI2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<uint2 *>(go[i][e] != ~0u ? yb + go[i][e] + cb * 128 : sink) = o[i][e];
+            } else {
+                // EX[(row - NPX * ((t + 1) / 2 ...)]: indexed by the EVEN partner's row compacted over frame pairs: pair q = t / 2, pixel j2 -> (q * NPX + j2) * 128 + 8 l15
+                unsigned char *ex = dsm + G::M2B + l15 * 8;
+#pragma unroll
+                for (int i = 0; i < NI2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 16 * (tl0 + i) + 4 * g + e;
+                        const int t = r / NPX, j2 = r - t * NPX;
+                        if ((oddm >> (4 * i + e)) & 1u) *reinterpret_cast<uint2 *>(ex + ((t >> 1) * NPX + j2) * 128) = o[i][e];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < NI2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 16 * (tl0 + i) + 4 * g + e;
+                        const int t = r / NPX, j2 = r - t * NPX;
+                        const bool ev = (evenm >> (4 * i + e)) & 1u;
+                        const uint2 q = *reinterpret_cast<const uint2 *>(ex + (ev ? ((t >> 1) * NPX + j2) * 128 : 0));
+                        const uint2 m = make_uint2(T_::pk_max(o[i][e].x, q.x), T_::pk_max(o[i][e].y, q.y));
+                        // frame t / 2 of y: the clip's offset minus (t - t / 2) frames
+                        *reinterpret_cast<uint2 *>(ev ? yb + (go[i][e] - (unsigned)((t - (t >> 1)) * p.H * p.W) * (unsigned)p.ldy * 2u) + cb * 128 : sink) = m;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // EX is read: the next pass may overwrite it
+                asm volatile("" ::: "memory");
+            }
         }
     }
     if (p.stamps) {
@@ -380,47 +502,62 @@ __global__ __launch_bounds__(512) void bneck_l1_kernel(const BneckL1KP p) {
 
 using namespace tedspad;
 
-extern "C" int32_t tedspad_bneck_l1_lds_bytes(void) { return L1_LDS; }
+extern "C" int32_t tedspad_bneck_l1_lds_bytes(int32_t variant) { (void)variant; return L1Geo<8, 8>::LDS; }
 extern "C" int32_t tedspad_bneck_l1_units(int32_t cin, int32_t kt) { return (cin / 32) * kt + 18 + 8; }
 
+template <typename T_, int TH, int NW, bool POOL>
+static int32_t l1_launch(const BneckL1KP &p, long grid, hipStream_t s) {
+    static thread_local int attr_set = 0;
+    const void *kfn = (const void *)bneck_l1_kernel<T_, TH, NW, POOL>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L1Geo<TH, NW>::LDS) != hipSuccess) {
+            set_error("tedspad_bneck_l1_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set = 1;
+    }
+    constexpr int lds = L1Geo<TH, NW>::LDS;
+    hipLaunchKernelGGL((bneck_l1_kernel<T_, TH, NW, POOL>), dim3((unsigned)grid), dim3(64 * NW), lds, s, p);
+    return check_launch("tedspad_bneck_l1_fwd");
+}
+
 // A plain layer1 bottleneck of I3Res50 (large_i3d.py:61-84, no downsample branch: layer1.1, layer1.2) in one launch.
-// x: (n, t, h, w, cin) 16-bit channels-last (pixel stride ldx); y: (n, t, h, w, 256) (pixel stride ldy == ldx: the block's input is its residual, cin == 256).
+// x: (n, t, h, w, cin) 16-bit channels-last (pixel stride ldx); y: (n, t, h, w, 256), or (n, t / 2, h, w, 256) with pool_t2 (maxpool2, large_i3d.py:139, fused);
+// pixel stride ldy == ldx: the block's input is its residual, cin == 256.
 // w_img: tedspad_bneck_l1_units(cin, kt) units of 4 KB in the kernel's consumption order, packed by the host (engine.BneckL1.pack):
 //   stage 1, unit c * kt + dt  : [j 0..3][lane = 16 kg + i][8] = W1[co = 16 (i >> 2) + 4 j + (i & 3)][dt][ci = 32 c + 8 kg ..]   (conv1, kt x 1 x 1, 64 outputs)
 //   stage 2, unit tap * 2 + ks : [j][lane = 16 kg + i][8]      = W2[co = 16 (i >> 2) + 4 j + (i & 3)][tap][ci = 32 ks + 8 kg ..] (conv2, 1 x 3 x 3)
 //   stage 3, unit cb * 2 + ks  : [j][lane = 16 kg + i][8]      = W3[co = 64 cb + 4 i + j][ci = 32 ks + 8 kg ..]                    (conv3, 256 outputs)
-// scale / shift: the folded BatchNorms (fp32; 64, 64, 256 values).
+// scale / shift: the folded BatchNorms (fp32; 64, 64, 256 values). variant bit 0: tiles of 4 x 14 pixels, two 4-wave workgroups per CU (else 8 x 14, one of 8 waves).
 extern "C" int32_t tedspad_bneck_l1_fwd(const void *x, int32_t ldx, void *y, int32_t ldy, int32_t n, int32_t t, int32_t h, int32_t w, int32_t cin, int32_t kt,
                                         const void *w_img, const float *scale1, const float *shift1, const float *scale2, const float *shift2,
-                                        const float *scale3, const float *shift3, int32_t relu, int32_t dtype, void *stream) {
+                                        const float *scale3, const float *shift3, int32_t relu, int32_t pool_t2, int32_t variant, int32_t dtype, void *stream) {
     TS_REQUIRE(x && y && w_img && scale1 && shift1 && scale2 && shift2 && scale3 && shift3, "tedspad_bneck_l1_fwd: null pointer");
     TS_REQUIRE(n > 0 && t > 0 && t <= L1_TMAX && h > 0 && w > 0, "tedspad_bneck_l1_fwd: 1 <= t <= 4 frames per clip (all of them live in one workgroup)");
     TS_REQUIRE(cin == 256 && (kt == 1 || kt == 3), "tedspad_bneck_l1_fwd: 256 -> 64 -> 64 -> 256 channels, conv1 1x1x1 or 3x1x1");
     TS_REQUIRE(ldx >= cin && ldy == ldx && ldx % 8 == 0, "tedspad_bneck_l1_fwd: bad strides (ldy must equal ldx)");
+    TS_REQUIRE(!pool_t2 || t >= 2, "tedspad_bneck_l1_fwd: the pooled output needs two frames");
     TS_REQUIRE(((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_img | (uintptr_t)scale1 | (uintptr_t)shift1 | (uintptr_t)scale2 | (uintptr_t)shift2 | (uintptr_t)scale3 |
                 (uintptr_t)shift3) % 16 == 0, "tedspad_bneck_l1_fwd: pointers must be 16-byte aligned");
     TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_bneck_l1_fwd: bad dtype");
     TS_REQUIRE((long)t * h * w * ldx * 2 < (1L << 31), "tedspad_bneck_l1_fwd: a clip must fit 32-bit byte offsets");
+    (void)variant;      // (bit 0 selected 4 x 14 tiles with two 4-wave workgroups per CU: measured no faster -- the CU's LDS read bandwidth bounds either form -- and removed)
+    const int th = 8;
     BneckL1KP p;
     p.x = (const uint16_t *)x; p.y = (uint16_t *)y; p.wimg = (const uint16_t *)w_img;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2; p.scale3 = scale3; p.shift3 = shift3;
     p.N = n; p.T = t; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.cin = cin; p.kt = kt; p.relu = relu;
-    p.tiles_h = (h + L1_TH - 1) / L1_TH; p.tiles_w = (w + L1_TW - 1) / L1_TW;
+    p.tiles_h = (h + th - 1) / th; p.tiles_w = (w + L1_TW - 1) / L1_TW;
     { const char *e = getenv("TEDSPAD_L1_ABLATE"); p.dbg = e ? atoi(e) : 0; }
     { const char *e = getenv("TEDSPAD_L1_STAMPS"); p.stamps = e ? (long long *)strtoull(e, nullptr, 0) : nullptr; }
     const long grid = (long)n * p.tiles_h * p.tiles_w;
     TS_REQUIRE(grid < (1L << 31), "tedspad_bneck_l1_fwd: too many tiles");
     hipStream_t s = (hipStream_t)stream;
-    static thread_local int attr_set[2] = {0, 0};
-    const void *kfn = dtype == TEDSPAD_F16 ? (const void *)bneck_l1_kernel<F16> : (const void *)bneck_l1_kernel<BF16>;
-    if (!attr_set[dtype]) {
-        if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            set_error("tedspad_bneck_l1_fwd: cannot raise the dynamic LDS limit");
-            return TEDSPAD_ELAUNCH;
-        }
-        attr_set[dtype] = 1;
+    const int sel = (dtype == TEDSPAD_F16 ? 0 : 2) + (pool_t2 ? 1 : 0);
+    switch (sel) {
+        case 0: return l1_launch<F16, 8, 8, false>(p, grid, s);
+        case 1: return l1_launch<F16, 8, 8, true>(p, grid, s);
+        case 2: return l1_launch<BF16, 8, 8, false>(p, grid, s);
+        default: return l1_launch<BF16, 8, 8, true>(p, grid, s);
     }
-    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL(bneck_l1_kernel<F16>, dim3((unsigned)grid), dim3(512), L1_LDS, s, p);
-    else hipLaunchKernelGGL(bneck_l1_kernel<BF16>, dim3((unsigned)grid), dim3(512), L1_LDS, s, p);
-    return check_launch("tedspad_bneck_l1_fwd");
 }

@@ -32,6 +32,8 @@ BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # laye
 TPAIR_MIN_COUT = int(os.environ.get("TEDSPAD_TPAIR_MIN_COUT", "128"))   # smallest cout that takes the folded form (256: layer2's 128-channel temporal convs stay on the temporal chunk-major tile)
 TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
+BNECK_L1 = os.environ.get("TEDSPAD_BNECK_L1", "0") != "0"     # layer1's plain bottlenecks as ONE launch each (BneckL1: conv1 recomputed on tile halos, mid tensors in LDS); 0: temporal conv + fused tail (two launches)
+BNECK_L1_POOL = os.environ.get("TEDSPAD_BNECK_L1_POOL", "0") != "0"   # ... the last block with maxpool2 inside as well
 STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
@@ -895,12 +897,15 @@ class BneckL1:
         n, t, h, w = x.dims
         return x.c == self.cin and t <= 4 and x.buf.dtype == self.torch_dtype and t * h * w * x.ld * 2 < (1 << 31)
 
-    def __call__(self, x: Act, relu=True) -> Act:
+    VARIANT = 0          # (reserved; a 4 x 14-tile form with two 4-wave workgroups per CU was measured no faster and removed)
+
+    def __call__(self, x: Act, relu=True, pool_t2=False, variant=None) -> Act:
         n, t, h, w = x.dims
-        out = Act(torch.empty_like(x.buf), 256, x.coff) if x.ld != 256 else Act.empty(n, t, h, w, 256, self.torch_dtype, x.buf.device)
-        assert out.ld == x.ld
+        to = t // 2 if pool_t2 else t
+        out = Act(torch.empty((n, to, h, w, x.ld), dtype=self.torch_dtype, device=x.buf.device), 256, x.coff)
         check(_lib.lib().tedspad_bneck_l1_fwd(x.ptr, x.ld, out.ptr, out.ld, n, t, h, w, self.cin, self.kt, self.wimg.data_ptr(), *[v.data_ptr() for v in self.vecs],
-                                              int(relu), self.dtype_code, _stream_ptr()), "tedspad_bneck_l1_fwd")
+                                              int(relu), int(pool_t2), self.VARIANT if variant is None else variant, self.dtype_code, _stream_ptr()),
+              "tedspad_bneck_l1_fwd")
         return out
 
 

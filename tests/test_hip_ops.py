@@ -321,9 +321,10 @@ def test_bottleneck_tail_fused_vs_oracle_and_unfused(dims, staged, dual, dtype, 
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("kt", [3, 1])
 @pytest.mark.parametrize("dims", [(3, 4, 55, 55), (2, 3, 7, 9), (1, 1, 16, 16), (5, 2, 28, 30), (2, 4, 27, 27), (1, 4, 9, 15)])
-def test_whole_layer1_bottleneck_vs_oracle_and_unfused(dims, kt, dtype):
+def test_whole_layer1_bottleneck_vs_oracle_and_unfused(dims, kt, variant, dtype):
     """engine.BneckL1 (csrc/conv_bneck_l1.hip): a plain layer1 block of I3Res50 (large_i3d.py:61-84: conv1 kt x 1 x 1 256 -> 64 + bn1 + ReLU, conv2 1 x 3 x 3 + bn2 + ReLU,
     conv3 64 -> 256 + bn3 + residual + ReLU) in ONE launch, against the oracle (both 64-channel tensors rounded to the storage type where the unfused path stores
     them) and against the three unfused launches. Frames that are no multiple of the 8 x 14 tile, frames smaller than a tile, 1-4 frames per clip (the temporal
@@ -347,7 +348,7 @@ def test_whole_layer1_bottleneck_vs_oracle_and_unfused(dims, kt, dtype):
     blk = E.BneckL1(w1, s1, b1, w2, s2, b2, w3, s3, b3, dtype=dtype, device="cuda")
     xa = E.Act(x.to(tdt).cuda(), 256)
     assert blk.applies(xa)
-    got = blk(xa)
+    got = blk(xa, variant=variant)
     torch.cuda.synchronize()
     got = got.buf.float().cpu()
     assert got.shape == ref.shape
@@ -364,7 +365,13 @@ def test_whole_layer1_bottleneck_vs_oracle_and_unfused(dims, kt, dtype):
     assert bool(((got - old).abs() <= 2 * ulp * old.abs() + 3e-3).all())
     assert rel_l2(got, old) < (3e-4 if dtype == "f16" else 3e-3)
     # two launches repeat bit for bit (no atomics, fixed summation order)
-    assert torch.equal(blk(xa).buf.float().cpu(), got)
+    assert torch.equal(blk(xa, variant=variant).buf.float().cpu(), got)
+    if t >= 2:
+        # maxpool2 (MaxPool3d((2,1,1), stride (2,1,1)), large_i3d.py:139) fused as well: the SAME values as pooling the block's output (an odd last frame is dropped)
+        pooled = blk(xa, pool_t2=True, variant=variant).buf.float().cpu()
+        want = torch.maximum(got[:, 0:2 * (t // 2):2], got[:, 1:2 * (t // 2):2])
+        assert pooled.shape == want.shape
+        assert torch.equal(pooled, want)
 
 
 POOLS = [
