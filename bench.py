@@ -36,6 +36,11 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_CLIP = {"largei3d": 32.829145088, "i3d": 55.575138304}  # BASELINE.md §2 (conv MACs x 2)
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
 TRAIN_TFLOP = {"phase1": 18.040, "phase2": 6.480}                 # BASELINE.md §2, cfg3 (fb branch excluded)
+# the privacy branch of train_anonymizer.py:80-84,153-157 on the two VISPR views (2 x 12 images of 3 x 224 x 224, params_anonymization.py:29), counted like
+# BASELINE.md §2 (scripts/count_macs.py: hooks on the oracle's functional convs): UNet 61.232 GFLOP and fb (ResNet-50 + MLP) 8.183 GFLOP per image.
+# phase 1: fa trained (fwd + dgrad + wgrad = 3 x) under a frozen fb (fwd + dgrad = 2 x); phase 2: fa forward only, fb trained (3 x)
+FB_TFLOP = {"phase1": 24 * (3 * 61.232 + 2 * 8.183) * 1e-3, "phase2": 24 * (61.232 + 3 * 8.183) * 1e-3}
+UNETPP_GFLOP_PER_FRAME = 24.626        # smp UnetPlusPlus(resnet18), one 3 x 224 x 224 frame: 12 312 788 992 MACs (scripts/count_macs.py on oracle/unetpp_ref.py)
 
 
 def kernel_sources_sha() -> str:
@@ -56,24 +61,31 @@ def train_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def bench_train(dev, steps=10, warmup=45, hw=112):
-    """cfg3 on this GPU: ms per phase-1 / phase-2 iteration, algorithmic TFLOP/s, kernel launches per iteration.
+def bench_train(dev, steps=10, warmup=45, hw=112, with_fb=True):
+    """cfg3 on this GPU: ms per phase-1 / phase-2 iteration, algorithmic TFLOP/s.
+    with_fb: the WHOLE train_epoch body (train_anonymizer.py:71-198): the privacy branch fb (ResNet-50 + MLP) on the two VISPR views 2 x (12, 3, 224, 224) and the
+    NT-Xent term inside both phases (phase 1: loss_fa = -NTXent + 0.7 (CE + 0.1 triplet), fa trained through the frozen fb; phase 2: fb trained on NT-Xent, ft on the
+    utility loss), beside the utility-only iteration of the earlier rounds (`*_utility_only`).
     hw = 224: the per-rank batch of cfg5 (8 x 48 x 224^2; its FLOP are 4x cfg3's, every conv scales with the pixels)."""
     from ted_spad_amd import engine as E
-    from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
-    from ted_spad_amd.synth import synth_state_dict, synth_train_video
+    from ted_spad_amd.model_loaders import load_fa_model, load_fb_model, load_ft_model
+    from ted_spad_amd.synth import synth_state_dict, synth_tensor, synth_train_video
     from ted_spad_amd.train_step import AnonymizerTrainStep
     with contextlib.redirect_stdout(io.StringIO()):
         fa, ft = load_fa_model(arch="unet"), load_ft_model("largei3d", num_classes=102)
+        fb = load_fb_model(arch="r50", ssl=True, pretrained=False) if with_fb else None
     fa.load_state_dict(synth_state_dict(fa.state_dict(), 0))
     ft.load_state_dict(synth_state_dict(ft.state_dict(), 0))
     fa, ft = fa.to(dev), ft.to(dev)
-    step = AnonymizerTrainStep(fa, ft)
     video = synth_train_video(0, "bench_train", (8, 48, 3, hw, hw), device=dev)
     fl = (hw / 112.0) ** 2
     labels = torch.randint(1, 102, (8,), device=dev)
-    out = {"config": "%s train_anonymizer.py iteration: UNet anonymizer + I3Res50 + CE + 0.1 x triplet, batch 8 x 48 x %d^2, f16 "
-                     "activations / fp32 accumulate, fb branch excluded, Adam step included" % ("cfg3" if hw == 112 else "cfg5 per-rank", hw), "steps": steps}
+    out = {"config": "%s train_anonymizer.py iteration (train_epoch :71-198, both phases): UNet anonymizer + I3Res50 + CE + 0.1 x triplet on a batch of 8 x 48 x %d^2%s, f16 "
+                     "activations / fp32 accumulate, Adam steps included" % (
+                         "cfg3" if hw == 112 else "cfg5 per-rank", hw,
+                         ", privacy branch fb (ResNet-50 + MLP) + NT-Xent (T = 0.1) on the VISPR views 2 x (12, 3, 224, 224)" if with_fb else ", fb branch excluded"), "steps": steps}
+    # ---- the utility-only iteration (the figure of rounds 1-3; what profiles/traffic_train_cfg3.json was measured on) -----------------------------------------
+    step = AnonymizerTrainStep(fa, ft)
     for name, fn in (("phase1", step.step_fa), ("phase2", step.step_ft)):
         for i in range(4 * warmup):              # until the tile tuner has settled every conv geometry of this phase
             if i >= warmup and not E.tuning_pending():
@@ -85,18 +97,49 @@ def bench_train(dev, steps=10, warmup=45, hw=112):
             r = fn(video, labels)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        out[name + "_ms"] = round(ms, 3)
-        out[name + "_tflops"] = round(fl * TRAIN_TFLOP[name] / ms * 1e3, 1)
-        out[name + "_mfma_frac"] = round(fl * TRAIN_TFLOP[name] / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
-        out[name + "_loss"] = round(float(r["loss_ft"]), 5)
+        sfx = "_utility_only" if with_fb else ""
+        out[name + "_ms" + sfx] = round(ms, 3)
+        out[name + "_tflops" + sfx] = round(fl * TRAIN_TFLOP[name] / ms * 1e3, 1)
+        out[name + "_mfma_frac" + sfx] = round(fl * TRAIN_TFLOP[name] / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
+        out[name + "_loss" + sfx] = round(float(r["loss_ft"]), 5)
+    if with_fb:
+        # ---- the whole train_epoch body: fb + NT-Xent in both phases -----------------------------------------------------------------------------------------
+        fb.load_state_dict(synth_state_dict(fb.state_dict(), 0))
+        fb = fb.to(dev)
+        views = [synth_tensor(0, "vispr_view%d" % v, (12, 3, 224, 224), device=dev) for v in range(2)]
+        del step
+        step = AnonymizerTrainStep(fa, ft, fb_model=fb)
+        for name, fn in (("phase1", lambda: step.step_fa(video, labels, views)), ("phase2", lambda: step.step_ft(video, labels, inputs_vispr=views))):
+            for i in range(4 * warmup):
+                if i >= max(4, warmup // 4) and not E.tuning_pending():
+                    break
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            tf = fl * TRAIN_TFLOP[name] + FB_TFLOP[name]
+            out[name + "_ms"] = round(ms, 3)
+            out[name + "_tflops"] = round(tf / ms * 1e3, 1)
+            out[name + "_mfma_frac"] = round(tf / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
+            out[name + "_loss"] = round(float(r["loss_ft"]), 5)
+            out[name + "_loss_fb"] = round(float(r["loss_fb"]), 5)
+        out["tflop_per_iteration"] = round(fl * (TRAIN_TFLOP["phase1"] + TRAIN_TFLOP["phase2"]) + FB_TFLOP["phase1"] + FB_TFLOP["phase2"], 3)
+        _fa, _ft = step.step_fa, step.step_ft
+        step_fa = lambda v, l: _fa(v, l, views)
+        step_ft = lambda v, l: _ft(v, l, inputs_vispr=views)
+    else:
+        step_fa, step_ft = step.step_fa, step.step_ft
     # the reference's loop runs BOTH phases per batch (train_anonymizer.py:87-123 then :137-191): each phase then starts from the
     # other network's fresh weights (frozen-BN folds and 16-bit weight images rebuilt), which the per-phase loops above never pay
     for _ in range(max(3, warmup // 8)):
-        step.step_fa(video, labels); step.step_ft(video, labels)
+        step_fa(video, labels); step_ft(video, labels)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step.step_fa(video, labels); step.step_ft(video, labels)
+        step_fa(video, labels); step_ft(video, labels)
     torch.cuda.synchronize()
     out["iteration_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
     # the same loop with the losses handed back as device tensors (AnonymizerTrainStep.lazy_losses): the reference reads `loss.item()` every
@@ -104,11 +147,11 @@ def bench_train(dev, steps=10, warmup=45, hw=112):
     # every k-th iteration does not pay it
     step.lazy_losses = True
     for _ in range(3):
-        step.step_fa(video, labels); step.step_ft(video, labels)
+        step_fa(video, labels); step_ft(video, labels)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step.step_fa(video, labels); step.step_ft(video, labels)
+        step_fa(video, labels); step_ft(video, labels)
     torch.cuda.synchronize()
     out["iteration_ms_async_losses"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
     # HBM traffic of one iteration from the PMC passes over the same iteration (scripts/profile_train.sh), quoted only for the kernels it was measured on
@@ -116,9 +159,58 @@ def bench_train(dev, steps=10, warmup=45, hw=112):
     tpath = os.path.join(ROOT, "profiles", "traffic_train_cfg3.json")
     if hw == 112 and os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("kernel_sources_sha") == train_sources_sha():
+        if tj.get("kernel_sources_sha") == train_sources_sha() and bool(tj.get("with_fb", False)) == bool(with_fb):
             out["traffic"] = tj["traffic_bytes_per_iteration"]
     return out
+
+
+def bench_anon_extract(dev, n_clips=225, batch=25, steps=3):
+    """The extraction the reference's scripts actually run (`anonymized = True`, `arch='unet++'` hard-coded: dali_extraction.py:108,122,169-178,
+    st_feature_extraction.py:72): every clip -> fa = UnetPlusPlus(resnet18) on its 16 frames of 224 x 224 -> the Q1 reshape feed -> I3Res50.extract_features.
+    clips/s over `n_clips` clips (`batch` per forward), the algorithmic work per clip (16 x UNet++ frame + I3Res50 clip, conv MACs x 2), the fraction of the
+    MFMA roofline and the feature's rel-L2 against the CPU oracle (oracle/unetpp_ref -> extract_ref.q1_feed -> i3res50_ref) on 2 clips."""
+    from ted_spad_amd import engine as E, extraction
+    from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
+    from ted_spad_amd.synth import synth_clips, synth_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        fa, ft = load_fa_model(), load_ft_model("largei3d", num_classes=102)          # load_fa_model's default arch IS 'unet++' (model_loaders.py:17)
+    sd_a, sd_t = synth_state_dict(fa.state_dict(), 0), synth_state_dict(ft.state_dict(), 0)
+    fa.load_state_dict(sd_a); ft.load_state_dict(sd_t)
+    fa, ft = fa.to(dev).eval(), ft.to(dev).eval()
+    clips = torch.empty((n_clips, 16, 3, 224, 224), dtype=torch.float32, device=dev)   # the loaders' layout (B, 16, 3, H, W)
+    for i in range(0, n_clips, 25):
+        k = min(25, n_clips - i)
+        clips[i:i + k] = synth_clips(0, k, (3, 16, 224, 224), device=dev, first=i).view(k, 16, 3, 224, 224)
+    out = torch.empty((n_clips, 2048), dtype=torch.float32, device=dev)
+
+    def step():
+        for i in range(0, n_clips, batch):
+            out[i:i + batch] = ft.i3d.extract_features(extraction.feed(clips[i:i + batch], fa, "reference")).flatten(1)
+    with torch.no_grad():
+        for i in range(40):                       # until the tile tuner has settled the anonymizer's conv geometries
+            step()
+            if i >= 2 and not E.tuning_pending():
+                break
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        from oracle import extract_ref, i3res50_ref, unetpp_ref
+        xs = clips[:2].cpu()
+        sdc = {k[4:]: v for k, v in sd_t.items() if k.startswith("i3d.")}
+        ref = i3res50_ref.extract_features(extract_ref.q1_feed(xs, lambda fr: unetpp_ref.forward(fr, sd_a)), sdc).flatten(1)
+    got = out[:2].cpu()
+    rel = (got.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1)
+    gf = 16 * UNETPP_GFLOP_PER_FRAME + GFLOP_PER_CLIP["largei3d"]
+    cps = n_clips / dt
+    return {"config": "dali_extraction.py:151-182 as the reference runs it (anonymized = True): fa = unet++ (smp UnetPlusPlus, resnet18 encoder) on 16 frames of 3 x 224 x 224 "
+                      "-> Q1 reshape feed -> largei3d extract_features; %d clips, %d per forward, f16 activations / fp32 accumulate, random-init weights" % (n_clips, batch),
+            "clips_per_s": round(cps, 1), "ms_per_clip": round(1e3 / cps, 4), "gflop_per_clip": round(gf, 3),
+            "gflop_per_clip_parts": {"unetpp_16_frames": round(16 * UNETPP_GFLOP_PER_FRAME, 3), "i3res50_clip": GFLOP_PER_CLIP["largei3d"]},
+            "achieved_tflops": round(cps * gf * 1e-3, 1), "frac": round(cps * gf * 1e-3 / MFMA_PEAK_TFLOPS, 4),
+            "feature_rel_l2_max": float(rel.max()), "feature_rel_l2_tol": 1e-3, "parity_clips": 2, "steps": steps}
 
 
 def bench_train_main(args, dev, world, rank, dry):
@@ -527,6 +619,8 @@ def main():
         res["act_absmax"] = {k: round(float(v.buf.float().abs().max()), 3) for k, v in taps.items()}   # f16 saturates at 65504
     if world == 1 and not args.no_train:
         del clips, feats
+        torch.cuda.empty_cache()
+        res["anon_extract"] = bench_anon_extract(dev)
         torch.cuda.empty_cache()
         res["train_cfg3"] = bench_train(dev)
     print(json.dumps(res))

@@ -105,13 +105,24 @@ def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anon
 
 
 @torch.no_grad()
-def extract_video_sharded(ft_model, clips_cthw_local: torch.Tensor, T: int, ncrops: int = 1, batch: int = 75,
-                          group=None) -> torch.Tensor:
+def extract_video_sharded(ft_model, clips_local: torch.Tensor, T: int, ncrops: int = 1, batch: int = 75,
+                          group=None, fa_model=None, layout: str = "reference", fa_batch: int = 25) -> torch.Tensor:
     """Multi-GPU extraction of ONE video. Each rank passes ITS block of clips
-    (sharding.shard_range(T, rank, world) clip times x ncrops crops, crop-minor order,
-    shape (T_r*ncrops, 3, 16, H, W)); returns the full (T, ncrops, F) fp32 tensor on every rank
-    after one RCCL all-gather."""
-    f = extract_clip_features(ft_model, clips_cthw_local, batch)
+    (sharding.shard_range(T, rank, world) clip times x ncrops crops, crop-minor order); returns the full
+    (T, ncrops, F) fp32 tensor on every rank after one RCCL all-gather.
+
+    Without `fa_model` the block is the ft input itself, (T_r*ncrops, 3, 16, H, W). With `fa_model` it is the loader's layout
+    (T_r*ncrops, 16, 3, H, W) and every clip goes through the anonymizer first, exactly as the reference's extractors do with their
+    hard-coded `anonymized = True` (dali_extraction.py:108,169-178, st_feature_extraction.py:24-30): frames -> fa -> the Q1 reshape
+    (`layout='reference'`) or the geometrically meaningful permute -> ft.extract_features; `fa_batch` clips per anonymizer forward."""
+    if fa_model is None:
+        f = extract_clip_features(ft_model, clips_local, batch)
+    else:
+        n = clips_local.shape[0]
+        f = torch.empty((n, feature_width(ft_model)), dtype=torch.float32, device=clips_local.device)
+        fx = _extract_fn(ft_model)
+        for i in range(0, n, fa_batch):           # an empty shard launches nothing and still joins the collective
+            f[i:i + fa_batch] = fx(feed(clips_local[i:i + fa_batch], fa_model, layout)).flatten(1)
     f = f.view(-1, ncrops, f.shape[1])
     return sharding.gather_video_features(f, T, group)
 

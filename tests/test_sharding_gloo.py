@@ -194,3 +194,58 @@ def test_extract_video_sharded_with_empty_shards(T):
         assert shape == (T, 2, 6) and ok, (rank, shape, ok)
     if T == 1:
         assert sorted(n for _, _, _, n in res) == [0, 1]
+
+
+class _StubAnonymizer:
+    """Host-logic stand-in for fa (NOT a compute fallback): a per-frame function that depends on the colour channel, so that the Q1 reshape feed and the
+    permute feed give different clips."""
+
+    def __call__(self, frames):                 # (n, 3, H, W)
+        return frames * torch.tensor([1.0, 2.0, 3.0]).view(1, 3, 1, 1) + 0.5
+
+
+class _StubExtractorCT:
+    feature_dim = 4
+
+    def extract_features(self, x):              # (b, 3, T, H, W): a function that sees WHICH (channel, frame) slot a value sits in
+        w = torch.arange(1, 3 * x.shape[2] + 1, dtype=torch.float32).view(1, 3, x.shape[2], 1, 1)
+        return (x * w).flatten(1).sum(1, keepdim=True).repeat(1, 4).view(-1, 4, 1, 1, 1)
+
+
+def _anon_worker(rank, world, port, T, layout, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ted_spad_amd import extraction
+        ncrops = 2
+        g = torch.Generator().manual_seed(7)
+        clips = torch.rand((T * ncrops, 4, 3, 2, 2), generator=g)                      # loader layout (n, frames, 3, H, W)
+        lo, hi = sharding.shard_range(T, rank, world)
+        fa, ft = _StubAnonymizer(), _StubExtractorCT()
+        full = extraction.extract_video_sharded(ft, clips[lo * ncrops:hi * ncrops], T, ncrops=ncrops, fa_model=fa, layout=layout, fa_batch=3)
+        # the single-process answer: every clip through extraction.feed (the reference's fa + reshape feed) and the extractor
+        want = ft.extract_features(extraction.feed(clips, fa, layout)).flatten(1).view(T, ncrops, 4)
+        other = ft.extract_features(extraction.feed(clips, fa, "permute" if layout == "reference" else "reference")).flatten(1).view(T, ncrops, 4)
+        q.put((rank, tuple(full.shape), bool(torch.allclose(full, want)), bool(torch.allclose(full, other))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", ["reference", "permute"])
+@pytest.mark.parametrize("T", [5, 1])
+def test_extract_video_sharded_with_the_anonymizer(T, layout):
+    """The sharded path runs what the reference's extractors actually do (anonymized = True hard-coded, dali_extraction.py:108,169-178): clip -> fa -> Q1 feed ->
+    ft.extract_features -> all-gather; world 2, ragged and empty shards; the gathered block equals the single-process result and the two feeds differ."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_anon_worker, args=(r, 2, port, T, layout, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shape, ok, same_as_other in res:
+        assert shape == (T, 2, 4) and ok and not same_as_other, (rank, shape, ok, same_as_other)
