@@ -730,7 +730,9 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  32  16 x 16 patch halo (conv_patch.hip): stride-1 'same' 1 x kh x kw convs with cin % 64 == 0, cout <= 128 (the UNet's wide outer levels)
 //  33  the same with flat tiles (256 consecutive output pixels, halo = one contiguous run as tile 27): cin % 64 == 0, cout <= 128, narrow frames
 //  34  the same for kt x 1 x 1 'same' convs: a tile is all T <= 4 frames of 256 / T spatial positions, taps outside the clip skipped (cout <= 512)
-constexpr int NUM_CFGS = 34;
+//  35  128 x 128 split-K over 8 waves, table-free, ring 3 (tile 23 waits 61 % of its wave-cycles with one K tile in flight on layer4's M = 22 050: profiles/r03_bench_cfg2_mfma_util.md)
+//  36  the same with ring 4;  37  256 x 128 split-K over 16 waves, table-free, ring 3 (tile 24 without the K table)
+constexpr int NUM_CFGS = 37;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
@@ -744,6 +746,9 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 22: return launch<T, 128, 128, 2, 2, 2, KTAB_MAX_BYTES, 2>(p, s);
         case 23: return launch<T, 128, 128, 2, 2, 2, 0, 2>(p, s);
         case 24: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES, 2>(p, s);
+        case 35: return launch<T, 128, 128, 2, 2, 3, 0, 2>(p, s);
+        case 36: return launch<T, 128, 128, 2, 2, 4, 0, 2>(p, s);
+        case 37: return launch<T, 256, 128, 4, 2, 3, 0, 2>(p, s);
         case 15:
         case 16:   // the 8-wave halo-direct kernel (round 1) never won the tuner once the chunk-major tiles 32-34 existed: retired, ids kept
             set_error("tedspad_conv_fwd: tile_cfg 15 / 16 are retired");

@@ -498,7 +498,7 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
                 continue                                   # configuration not applicable to this geometry
     finally:
         E.FORCE_TILE_CFG = None
-    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33, 34)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
+    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33, 34, 35, 36, 37)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
     generic = {c: o for c, o in outs.items() if c not in REASSOC}
     assert len(generic) >= 4, sorted(outs)
     first = next(iter(generic.values()))
