@@ -18,11 +18,11 @@ import torch
 from . import i3res50_ref, losses_ref, resnet50_ref, unet_ref, unetpp_ref
 
 
-def _fa(x, sd, train, q=None):
+def _fa(x, sd, train, q=None, checkpoint=False):
     """The anonymizer the state dict belongs to: UNet (arch='unet') or the default smp UnetPlusPlus (model_loaders.py:17-30). q: the UNet's rounding hook."""
     if "encoder.conv1.weight" in sd:
         return unetpp_ref.forward(x, sd, train=train)
-    return unet_ref.forward(x, sd, train=train, q=q or unet_ref._id)
+    return unet_ref.forward(x, sd, train=train, q=q or unet_ref._id, checkpoint=checkpoint)
 
 
 def _grad_sd(sd):
@@ -44,19 +44,20 @@ def _utility(ft_sd, clips, labels, train, tlw=0.1, frozen_bn=False, rounding=Non
     return ce + tlw * trip, ce, trip
 
 
-def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_frames=16, vispr=None, fb_sd=None, fb_loss_weight=1.0, fa_rounding=None, ft_rounding=None):
+def phase1(video_b48, labels, fa_sd, ft_sd, ft_loss_weight=0.7, tlw=0.1, num_frames=16, vispr=None, fb_sd=None, fb_loss_weight=1.0, fa_rounding=None, ft_rounding=None,
+           fb_fn=None, checkpoint=False):
     """Returns (losses dict, grads of fa parameters dict, d(loss)/d(anon)). With `vispr` = [view0, view1] (N,3,H,W)
     and `fb_sd`, the privacy term -fb_loss_weight * NTXent(fb(fa(v0)), fb(fa(v1))) is included (fa in train mode on
-    each view separately, fb in eval mode: :73-84). fa_rounding: the UNet's hook q(tensor, kind); ft_rounding: as in `phase2` (per clip) -- the forward-point parity test
+    each view separately, fb in eval mode: :73-84); `fb_fn` replaces the ResNet-50 by any callable image -> unit-norm embedding (golden g7's stub). fa_rounding: the UNet's hook q(tensor, kind); ft_rounding: as in `phase2` (per clip) -- the forward-point parity test
     hands both the device's forward tensors."""
     fa = _grad_sd(fa_sd)
     loss_fb = None
     if vispr is not None:
-        z = [resnet50_ref.forward(_fa(x, fa, True), fb_sd, train=False) for x in vispr]
+        z = [fb_fn(_fa(x, fa, True)) if fb_fn is not None else resnet50_ref.forward(_fa(x, fa, True), fb_sd, train=False) for x in vispr]
         loss_fb = losses_ref.nt_xent_torch(z[0], z[1], 0.1)
     v = video_b48.permute(0, 2, 1, 3, 4)
     b, c, t, h, w = v.shape
-    anon = _fa(v.reshape(-1, c, h, w), fa, True, q=fa_rounding).reshape(b, c, t, h, w)
+    anon = _fa(v.reshape(-1, c, h, w), fa, True, q=fa_rounding, checkpoint=checkpoint).reshape(b, c, t, h, w)      # checkpoint: the full cfg3 batch on the host
     anon.retain_grad()
     clips = torch.split(anon, [num_frames] * 3, dim=2)
     loss_ft, ce, trip = _utility(ft_sd, clips, labels, train=False, tlw=tlw, rounding=ft_rounding)

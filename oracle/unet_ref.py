@@ -51,16 +51,27 @@ def up(x1, skip, sd, p, q=_id, train=False):
     return double_conv(torch.cat([skip, x1], dim=1), sd, p + "conv.double_conv.", q, train)
 
 
-def forward(x, sd, q=_id, train=False, taps=None):
-    """x: (N,3,H,W) fp32 in [0,1] -> (N,3,H,W) in (0,1)."""
-    x1 = double_conv(x, sd, "inc.double_conv.", q, train)
+def forward(x, sd, q=_id, train=False, taps=None, checkpoint=False):
+    """x: (N,3,H,W) fp32 in [0,1] -> (N,3,H,W) in (0,1).
+    checkpoint: every level (DoubleConv / Up) under torch.utils.checkpoint -- autograd keeps the level inputs only and recomputes a level's inside in its backward, so
+    that the full cfg3 batch (384 pseudo-images of 112 x 112) fits the host memory; same arithmetic, same gradients (not with `_track_running` state dicts: a
+    recomputed train-mode forward would update the running statistics twice)."""
+    if checkpoint:
+        from torch.utils.checkpoint import checkpoint as _ck
+        assert not sd.get("_track_running", False)
+        dc = lambda t, p: _ck(lambda t_: double_conv(t_, sd, p, q, train), t, use_reentrant=False)
+        upf = lambda a, b, p: _ck(lambda a_, b_: up(a_, b_, sd, p, q, train), a, b, use_reentrant=False)
+    else:
+        dc = lambda t, p: double_conv(t, sd, p, q, train)
+        upf = lambda a, b, p: up(a, b, sd, p, q, train)
+    x1 = dc(x.requires_grad_() if (checkpoint and not x.requires_grad and x.is_leaf) else x, "inc.double_conv.")
     feats = [x1]
     h = x1
     for i in (1, 2, 3, 4):
-        h = double_conv(F.max_pool2d(h, 2), sd, "down%d.maxpool_conv.1.double_conv." % i, q, train)
+        h = dc(F.max_pool2d(h, 2), "down%d.maxpool_conv.1.double_conv." % i)
         feats.append(h)
     for i, skip in zip((1, 2, 3, 4), (feats[3], feats[2], feats[1], feats[0])):
-        h = up(h, skip, sd, "up%d." % i, q, train)
+        h = upf(h, skip, "up%d." % i)
         if taps is not None:
             taps["up%d" % i] = h
     logits = F.conv2d(q(h, "act"), q(sd["outc.conv.weight"], "w"), sd["outc.conv.bias"])

@@ -40,6 +40,7 @@ class GradBucketReducer:
         self.issued: List[int] = [] # bucket indices in launch order of the current step (tests, logging)
         self.ready = set()
         self.exchange = True        # False: the buckets are not all-reduced (bench.py times a step with and without the exchange: its share)
+        self.force = False          # True: the collectives are launched at world size 1 too (tests: the asynchronous RCCL path on a one-GPU box)
 
     def nbytes(self) -> int:
         """Bytes one step's all-reduce moves per rank (fp32 gradients of every bucket)."""
@@ -86,7 +87,7 @@ class GradBucketReducer:
                     v.copy_(p.grad)
                 p.grad = v
         self.issued.append(i)
-        if self.exchange and self.world() > 1:
+        if self.exchange and (self.world() > 1 or (self.force and dist.is_initialized())):
             self.pending.append((i, dist.all_reduce(self.flats[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def finish(self):

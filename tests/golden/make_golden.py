@@ -286,6 +286,36 @@ def train_step_golden():
     loss_ft.backward()
     meta["phase2"] = dict(loss_ft=loss_ft.item(), grad_l2={k: float(p.grad.norm()) for k, p in ft.named_parameters()},
                           num_batches_tracked=int(ft.i3d.bn1.num_batches_tracked))
+    # ---- phase 1 WITH the privacy term (train_anonymizer.py:73-84,119): the reference's own NTXentLoss inside a golden step. The real fb (torchvision ResNet-50)
+    #      is not importable here; a small conv net defined HERE stands in for it (frozen, eval): what is pinned is the loss algebra
+    #      -fb_loss_weight * NTXent(fb(fa(v0)), fb(fa(v1))) + ft_loss_weight * loss_ft, the two extra train-mode fa forwards and the gradient flow into fa ----
+    from aux_code.nt_xent_original import NTXentLoss
+    fa.load_state_dict(synth_state_dict(fa.state_dict(), SEED)); fa.zero_grad(); ft.zero_grad()
+    ft.load_state_dict(synth_state_dict(ft.state_dict(), SEED))
+    fa.train(); ft.eval()
+    stub = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, stride=2, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+                               torch.nn.Linear(8, 128))
+    with torch.no_grad():
+        stub[0].weight.copy_(synth_tensor(SEED, "stubfb.conv.weight", (8, 3, 3, 3), -0.5, 0.5)); stub[0].bias.copy_(synth_tensor(SEED, "stubfb.conv.bias", (8,), -0.1, 0.1))
+        stub[4].weight.copy_(synth_tensor(SEED, "stubfb.fc.weight", (128, 8), -1, 1)); stub[4].bias.copy_(synth_tensor(SEED, "stubfb.fc.bias", (128,), -0.1, 0.1))
+    stub.eval()
+    fb = lambda x: torch.nn.functional.normalize(stub(x), p=2, dim=1)
+    views = [synth_tensor(SEED, "vispr_view%d" % v, (4, 3, 32, 32)) for v in range(2)]
+    video = synth_train_video(SEED, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    output1 = [fb(fa(v)) for v in views]                                  # :80
+    loss_fb = NTXentLoss("cpu", 4, 0.1, False)(output1[0], output1[1])    # :82-84
+    iv = video.permute(0, 2, 1, 3, 4)
+    ori = iv.shape
+    anon = fa(iv.reshape(-1, ori[1], ori[3], ori[4])).reshape(ori)
+    i1, i2, i3 = torch.split(anon, [16, 16, 16], dim=2)
+    out, f1 = ft(i1); _, f2 = ft(i2); _, f3 = ft(i3)
+    loss_ft = crit(out, labels) + 0.1 * trip(f1, f2, f3)
+    loss_fa = -1.0 * loss_fb + 0.7 * loss_ft                              # :119
+    loss_fa.backward()
+    meta["phase1_fb"] = dict(loss_fa=loss_fa.item(), loss_ft=loss_ft.item(), loss_fb=loss_fb.item(),
+                             grad_l2={k: float(p.grad.norm()) for k, p in fa.named_parameters()},
+                             num_batches_tracked=int(fa.inc.double_conv[1].num_batches_tracked))
     path = os.path.join(HERE, "golden_meta.json")
     full = json.load(open(path))
     full["train_step"] = meta

@@ -49,3 +49,70 @@ def test_rccl_collectives_on_device_tensors():
         p.kill()
         pytest.fail("RCCL worker hung")
     assert q.get(timeout=5) == "ok"
+
+
+def _reducer_worker(port, q):
+    """AnonymizerTrainStep with group = WORLD over a 1-rank nccl (= RCCL) group, its bucketed reducers forced to launch their asynchronous all-reduces: both phases
+    against the same steps with group = None, in deterministic mode (bit-equal gradients, losses and updated parameters)."""
+    import contextlib
+    import io
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from ted_spad_amd import engine as E
+        from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
+        from ted_spad_amd.synth import synth_state_dict, synth_train_video
+        from ted_spad_amd.train_step import AnonymizerTrainStep
+        E.set_deterministic(True)
+        video = synth_train_video(0, "rccl_video", (2, 48, 3, 32, 32)).cuda()
+        labels = torch.tensor([5, 77]).cuda()
+
+        def run(group):
+            with contextlib.redirect_stdout(io.StringIO()):
+                fa, ft = load_fa_model(arch="unet"), load_ft_model("largei3d", num_classes=102)
+            fa.load_state_dict(synth_state_dict(fa.state_dict(), 0)); ft.load_state_dict(synth_state_dict(ft.state_dict(), 0))
+            ft.i3d.drop_p = 0.0
+            step = AnonymizerTrainStep(fa.cuda(), ft.cuda(), group=group)
+            issued = []
+            if group is not None:
+                for r in (step.red_fa, step.red_ft):
+                    r.force = True
+            o1 = step.step_fa(video, labels)
+            g1 = {k: p.grad.clone() for k, p in fa.named_parameters() if p.grad is not None}
+            if group is not None:
+                issued.append((list(step.red_fa.issued), len(step.red_fa.buckets)))
+            o2 = step.step_ft(video, labels)
+            g2 = {k: p.grad.clone() for k, p in ft.named_parameters() if p.grad is not None}
+            if group is not None:
+                issued.append((list(step.red_ft.issued), len(step.red_ft.buckets)))
+            w = {k: v.detach().clone() for k, v in list(fa.state_dict().items()) + list(ft.state_dict().items())}
+            return (o1["loss_fa"], o2["loss_ft"]), g1, g2, w, issued
+
+        la, a1, a2, wa, _ = run(None)
+        lb, b1, b2, wb, issued = run(dist.group.WORLD)
+        ok = la == lb and all(torch.equal(a1[k], b1[k]) for k in a1) and all(torch.equal(a2[k], b2[k]) for k in a2) and all(torch.equal(wa[k], wb[k]) for k in wa)
+        ok = ok and len(a1) > 20 and len(a2) > 100 and all(sorted(i) == list(range(n)) and n >= 2 for i, n in issued)
+        q.put("ok" if ok else "mismatch: losses %r %r, buckets %r" % (la, lb, issued))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put("error: %r\n%s" % (e, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_reducer_runs_against_rccl():
+    """grad_reduce.GradBucketReducer's asynchronous per-bucket all-reduce (launched from inside the backward pass) against the nccl backend itself -- one rank
+    (a GPU box has one MI355X), the collectives forced on: the sums of one rank are the rank's own gradients, so both phases must give the bits of the
+    group = None run. (World 2 semantics: tests/test_sharding_gloo.py.)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_reducer_worker, args=(port, q))
+    p.start()
+    p.join(420)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL worker hung")
+    assert q.get(timeout=5) == "ok"

@@ -422,6 +422,28 @@ def test_phase1_at_cfg3_resolution_vs_oracle():
     assert med < 0.3 and worst < 0.5
 
 
+def test_phase1_at_the_full_cfg3_batch_vs_oracle():
+    """Phase 1 at cfg3's REAL batch: 8 x 48 x 112 x 112 = 384 pseudo-images through the train-mode UNet, 24 clips through the frozen I3Res50
+    (BASELINE.json configs[2]; train_anonymizer.py:71-123). The fp32 autograd oracle runs the UNet under torch.utils.checkpoint per level
+    (oracle/unet_ref.forward(checkpoint=True): level inputs kept, insides recomputed -- the same gradients, test_oracle checks them bit-equal on a small
+    case) so that the batch fits the host. Loss within 5e-3; fa's parameter gradients within the bounds held at batch 2."""
+    from oracle import train_step_ref
+    from ted_spad_amd.train_step import AnonymizerTrainStep
+    fa, ft, sd_u, sd_l = _models()
+    video = synth_train_video(SEED, "train_cfg3_full", (8, 48, 3, 112, 112))
+    labels = torch.tensor([5, 77, 101, 1, 9, 33, 60, 2])
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref_l, ref_g, _ = train_step_ref.phase1(video, labels, sd_u, sd_l, checkpoint=True)
+    step = AnonymizerTrainStep(fa, ft)
+    step.opt_fa = torch.optim.SGD(fa.parameters(), lr=0.0)
+    out = step.step_fa(video.cuda(), labels.cuda())
+    assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * abs(ref_l["loss_fa"]), (out["loss_fa"], ref_l["loss_fa"])
+    errs = _report("full cfg3 batch, phase 1: fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g, min_cos=0.85, med_cos=0.95, tiny=1e-2, abs_tol=0.2)
+    med, worst = float(np.median(list(errs.values()))), max(errs.values())
+    print("full cfg3 batch, phase 1: median rel-L2 %.3f, worst %.3f" % (med, worst))
+    assert med < 0.3 and worst < 0.5
+
+
 # ---- (3) the full cfg2 batch ---------------------------------------------------------------------------------------------------
 
 def test_full_size_batch_vs_oracle_and_single_clips():

@@ -209,6 +209,40 @@ def test_train_step_oracle_vs_reference_modules(golden_meta, sd_largei3d, sd_une
     assert g["phase2"]["num_batches_tracked"] == 3   # Q14: three train-mode forwards per step
 
 
+def test_checkpointed_unet_oracle_gives_the_same_gradients(sd_largei3d, sd_unet):
+    """oracle/unet_ref.forward(checkpoint=True) (what lets the full cfg3 batch of phase 1 fit the host in tests/test_hip_train_golden.py) is the same function:
+    loss and every fa gradient bit-equal to the plain path."""
+    from oracle import train_step_ref
+    video = synth_train_video(SEED, "train_video", (2, 48, 3, 32, 32))
+    labels = torch.tensor([5, 77])
+    a = train_step_ref.phase1(video, labels, sd_unet, sd_largei3d)
+    b = train_step_ref.phase1(video, labels, sd_unet, sd_largei3d, checkpoint=True)
+    assert a[0] == b[0] and set(a[1]) == set(b[1])
+    assert all(torch.equal(a[1][k], b[1][k]) for k in a[1])
+
+
+def test_train_step_phase1_with_the_privacy_term_vs_reference_modules(golden_meta, sd_largei3d, sd_unet):
+    """Phase 1 WITH the NT-Xent term (train_anonymizer.py:73-84,119): golden g7 `phase1_fb` ran the reference's UNet / I3Res50 modules and its own
+    NTXentLoss class through those lines with a small conv net standing in for fb (make_golden.py; the real ResNet-50 is torchvision's). The oracle with the
+    same stand-in: loss_fa = -1.0 * NTXent + 0.7 * loss_ft, every term and the gradient norm of every fa parameter."""
+    import torch.nn.functional as F
+    from oracle import train_step_ref
+    from ted_spad_amd.synth import synth_tensor
+    g = golden_meta["train_step"]["phase1_fb"]
+    cw, cb = synth_tensor(SEED, "stubfb.conv.weight", (8, 3, 3, 3), -0.5, 0.5), synth_tensor(SEED, "stubfb.conv.bias", (8,), -0.1, 0.1)
+    fw, fbias = synth_tensor(SEED, "stubfb.fc.weight", (128, 8), -1, 1), synth_tensor(SEED, "stubfb.fc.bias", (128,), -0.1, 0.1)
+    fb = lambda x: F.normalize(F.linear(F.relu(F.conv2d(x, cw, cb, stride=2, padding=1)).mean((2, 3)), fw, fbias), p=2, dim=1)
+    views = [synth_tensor(SEED, "vispr_view%d" % v, (4, 3, 32, 32)) for v in range(2)]
+    video = synth_train_video(SEED, "train_video", (2, 48, 3, 32, 32))
+    l1, grads, _ = train_step_ref.phase1(video, torch.tensor([5, 77]), sd_unet, sd_largei3d, vispr=views, fb_fn=fb)
+    for k in ("loss_fa", "loss_ft", "loss_fb"):
+        assert abs(l1[k] - g[k]) < 3e-4 * abs(g[k]), (k, l1[k], g[k])
+    assert abs(l1["loss_fa"] - (-1.0 * l1["loss_fb"] + 0.7 * l1["loss_ft"])) < 1e-5
+    for k, ref in g["grad_l2"].items():
+        assert abs(float(grads[k].norm()) - ref) <= 5e-3 * ref + 2e-5, k
+    assert g["num_batches_tracked"] == 3        # Q14: fa's BatchNorms saw the two views and the video's pseudo-images
+
+
 @pytest.mark.parametrize("hw", [(480, 856), (97, 131), (224, 224)])
 def test_pil_resample_tables_reproduce_pillow(hw):
     """Host logic of the shanghai pre-processing path: `preprocess.pil_table` (libImaging/Resample.c restated) driving the two-pass
