@@ -564,7 +564,7 @@ def main():
     fwd_clips = sum(n for _, _, n in ev)
     achieved = fwd_clips * GFLOP_PER_CLIP[args.arch] / fwd_ms  # GFLOP / ms == TFLOP/s
     n_fwd = len(ev) * ((n_local + args.batch - 1) // args.batch)
-    traffic = None
+    traffic = traffic_all = None
     tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # PMC result of the same command (scripts/profile_bench.sh)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -572,6 +572,7 @@ def main():
         if (tj.get("arch") == args.arch and tj.get("batch") == args.batch and tj.get("dtype") == args.dtype and
                 tj.get("kernel_sources_sha") == kernel_sources_sha()):
             traffic = tj["conv_traffic_bytes_per_forward"]
+            traffic_all = tj.get("all_traffic_bytes_per_forward")
     # sustained shader clock of THIS box under matrix load (DVFS lowers it below the 2.4 GHz the nominal peak assumes): reported beside the nominal peak, never instead
     clock_mhz = None
     try:
@@ -587,6 +588,7 @@ def main():
         print("clock probe failed: %s" % e, file=sys.stderr)
     res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                       "traffic_all_kernels": traffic_all,      # `traffic` counts the conv kernels of a forward; this one every kernel between its first and last launch (pools, fix-up, average pool)
                        "clock_mhz_under_mfma_load": None if clock_mhz is None else round(clock_mhz, 1),
                        "peak_at_clock": None if clock_mhz is None else round(MFMA_PEAK_TFLOPS * clock_mhz / 2400.0, 1),
                        "kernel": "conv stack of one batch forward (conv_stem_pt_kernel + conv_p8 / conv_patch / conv_flat / conv_igemm / conv_pw "

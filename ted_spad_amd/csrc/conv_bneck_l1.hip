@@ -39,7 +39,9 @@ struct BneckL1KP {
 };
 
 constexpr int L1_TW = 14, L1_HW = 16;                     // tile / halo width
-constexpr int L1_ROWB = 144;                              // bytes per M row: 9 sixteen-byte slots -> 16 consecutive rows at one chunk cover all 16 slot residues
+constexpr int L1_ROWB = 160;                              // bytes per M row: 10 sixteen-byte slots. A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19,
+                                                          // 28-31} (+ 32): with lane = (row l15, chunk g) those 16 lanes hit 16 different slots mod 16 at strides of 10, 14, 18 slots --
+                                                          // and two of them the same one at 9 (144 bytes, the first version: stage 2 ran at its LDS time, 15.6 k cycles for 8 k of MFMAs)
 constexpr int L1_TMAX = 4;
 constexpr int L1_UNIT = 4096;
 
@@ -55,7 +57,7 @@ struct L1Geo {
     static constexpr int M1B = L1_TMAX * NPOS * L1_ROWB;
     static constexpr int NT2 = (L1_TMAX * NPX + 15) / 16;                          // stage-2 / stage-3 M tiles of a full clip
     static constexpr int M2B = NT2 * 16 * L1_ROWB;
-    static constexpr int EXB = (L1_TMAX / 2) * NPX * 128;                          // pooled variant: the odd frames' packed results of a pass
+    static constexpr int EXB = 0;
     static constexpr int R0 = (NXS * XSLOT > M1B ? NXS * XSLOT : M1B) > M2B + EXB ? (NXS * XSLOT > M1B ? NXS * XSLOT : M1B) : M2B + EXB;
     static constexpr int RWU = TH == 8 ? 9 : 6;                                    // weight region in units
     static constexpr int ZOFF = R0 + RWU * L1_UNIT;                                // 1 KB of zeros: the pixel fragment of a temporal tap outside the clip
@@ -200,27 +202,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
         if (fast1) {
             // T == 4 frames, 3 taps: straight-line code (every fragment read of a tap is issued before its MFMAs; behind a branch per tile the LDS latency of each
             // read was exposed: 3.5 k cycles per chunk for 1.6 k of MFMA work)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // The tiles i < 4 of a wave are the SAME halo row of frames 0..3: their pixel fragments are read once per chunk (4 reads) and serve all three taps
+            // (tile i, tap dt multiplies frame i + dt - 1): 19 fragment reads per chunk and wave instead of 27 -- the CU's LDS read port, not the matrix pipe, bounded
+            // this loop.
+            uint4 bf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bf[f] = L1_LDS16(xs + (f * HH + hr1[0]) * 1024 + lane * 16);
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt) {
-                uint4 a[4], b[NI1];
+                uint4 a[4], bx[NI1 - 4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[j] = L1_LDS16(ws + dt * L1_UNIT + j * 1024 + lane * 16);
 #pragma unroll
-                for (int i = 0; i < NI1; ++i) {
-                    if (i < 4) {
-                        if (i + dt - 1 >= 0 && i + dt - 1 <= 3) b[i] = L1_LDS16(xs + ((i + dt - 1) * HH + hr1[i]) * 1024 + lane * 16);
-                    } else {
-                        const int f = t1[i] + dt - 1;
-                        b[i] = L1_LDS16(((unsigned)f < 4u ? xs + (f * HH + hr1[i]) * 1024 : G::ZOFF) + lane * 16);
-                    }
+                for (int i = 4; i < NI1; ++i) {
+                    const int f = t1[i] + dt - 1;
+                    bx[i - 4] = L1_LDS16(((unsigned)f < 4u ? xs + (f * HH + hr1[i]) * 1024 : G::ZOFF) + lane * 16);
                 }
                 if (p.dbg & 128) continue;
 #pragma unroll
                 for (int i = 0; i < NI1; ++i)
                     if (i >= 4 || (i + dt - 1 >= 0 && i + dt - 1 <= 3)) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j][i] = T_::mfma16(a[j], b[i], acc[j][i]);
+                        for (int j = 0; j < 4; ++j) acc[j][i] = T_::mfma16(a[j], i < 4 ? bf[i + dt - 1 < 0 ? 0 : i + dt - 1 > 3 ? 3 : i + dt - 1] : bx[i - 4], acc[j][i]);
                     }
             }
         } else {
@@ -253,19 +256,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
     const int cnt2 = nt2 / NW + (wave < nt2 % NW ? 1 : 0), tl0 = wave * (nt2 / NW) + min(wave, nt2 % NW);
     // byte offset of row (tile i, 4 g + e) in x (and y, ldx == ldy) at channel 4 l15; ~0u: outside the frame / past the clip. The residual rows of a stage-3 pass are
     // requested one pass ahead of their use, those of pass 0 here, a whole stage 2 ahead.
+    // Stage 3's M tiles of this wave. Plain: the stage-2 tiles. POOL (MaxPool3d((2,1,1)) over frame pairs fused, large_i3d.py:139): wave = (pair q = wave >> 2, s = wave & 3)
+    // takes tiles 2 s, 2 s + 1 of the frame's 7 (s = 3: tile 6) in BOTH frames 2 q, 2 q + 1 -- slots 0, 1 the even frame, 2, 3 the odd one: the maximum over the
+    // pair is taken between accumulator registers of one lane (a first version pooled across waves through LDS: two more barriers per pass, 1 524 vs 1 181 us)
+    int tile3[NI2];
+#pragma unroll
+    for (int i = 0; i < NI2; ++i) {
+        if (POOL) {
+            const int q = wave >> 2, k = 2 * (wave & 3) + (i & 1), f = 2 * q + (i >> 1);
+            tile3[i] = (f < 2 * (T / 2) && k < NPX / 16) ? f * (NPX / 16) + k : -1;
+        } else {
+            tile3[i] = i < cnt2 ? tl0 + i : -1;
+        }
+    }
+    static_assert(!POOL || (NPX % 16 == 0 && NI2 == 4 && NW == 8), "the pooled wave mapping: whole tiles per frame, 2 + 2 tiles per wave");
     unsigned go[NI2][4];
-    unsigned oddm = 0, evenm = 0;                               // POOL: bit 4 i + e: the row belongs to an odd frame / to an even frame with a partner
 #pragma unroll
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int r = 16 * (tl0 + i) + 4 * g + e;
+            const int r = 16 * max(tile3[i], 0) + 4 * g + e;
             const int t = r / NPX, j2 = r - t * NPX;
             const int oh = j2 / L1_TW, ow = j2 - oh * L1_TW;
-            const bool in = i < cnt2 && r < NR && oh0 + oh < p.H && ow0 + ow < p.W;
+            const bool in = tile3[i] >= 0 && r < NR && oh0 + oh < p.H && ow0 + ow < p.W;
             go[i][e] = in ? ((unsigned)((t * p.H + oh0 + oh) * p.W + ow0 + ow) * (unsigned)p.ldx + 4u * (unsigned)l15) * 2u : ~0u;
-            if (POOL && in && (t & 1)) oddm |= 1u << (4 * i + e);
-            if (POOL && in && !(t & 1) && t + 1 < T) evenm |= 1u << (4 * i + e);
         }
     const unsigned char *zsrc = reinterpret_cast<const unsigned char *>(&g_l1_zero) + (lane & 1) * 8;
     unsigned char *sink = reinterpret_cast<unsigned char *>(g_l1_sink) + lane * 8;
@@ -279,15 +293,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
                 // vmcnt(0) before every access -- sixteen serialised round trips per pass, 8.5 k cycles
                 const unsigned char *src = go[i][e] != ~0u ? xb + go[i][e] + cb * 128 : zsrc;
                 if (!(p.dbg & 8)) res[cb & 1][i][e] = *reinterpret_cast<const uint2 *>(src);
-            }
-    };
-    auto load_res_now = [&](int cb) {                            // POOL (register-bound): one buffer, the pass's rows requested at its start
-#pragma unroll
-        for (int i = 0; i < NI2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned char *src = go[i][e] != ~0u ? xb + go[i][e] + cb * 128 : zsrc;
-                if (!(p.dbg & 8)) res[0][i][e] = *reinterpret_cast<const uint2 *>(src);
             }
     };
     load_res(0);
@@ -394,10 +399,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
     // ================================ stage 3: conv3 + bn3 + residual + ReLU ================================
     // pixels = A: D[row 4 g + e of the tile][channel column l15]; the host orders the rows of tile jt so that column l15 is channel 4 l15 + jt of the pass's 64:
     // a lane holds 4 consecutive channels of 4 rows
-    // POOL (MaxPool3d((2,1,1)) of the block's output, large_i3d.py:139): y has T / 2 frames; the rows of ODD frames leave their packed results in LDS (EX), the
-    // rows of EVEN frames take the maximum with their partner (row + NPX) and store at frame t / 2
     unsigned char *yb = reinterpret_cast<unsigned char *>(p.y + (size_t)n * (POOL ? T / 2 : T) * p.H * p.W * p.ldy);
-    const int m2a = (16 * tl0 + l15) * L1_ROWB + g * 16;
+    int m2a[NI2];
+#pragma unroll
+    for (int i = 0; i < NI2; ++i) m2a[i] = (16 * max(tile3[i], 0) + l15) * L1_ROWB + g * 16;
     const float lo = p.relu ? 0.f : -HI;
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -424,8 +429,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
         // (bn3 first: vector memory retires in order, a wait for these two leaves the younger residual loads of the next pass in flight)
         const f32x4 s3 = *reinterpret_cast<const f32x4 *>(p.scale3 + 64 * cb + 4 * l15), b3 = *reinterpret_cast<const f32x4 *>(p.shift3 + 64 * cb + 4 * l15);
         asm volatile("" ::: "memory");
-        if (!POOL && cb + 1 < 4) load_res(cb + 1);
-        if (POOL && cb > 0) load_res_now(cb);
+        if (cb + 1 < 4) load_res(cb + 1);
         f32x4 acc3[4][NI2];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
             for (int j = 0; j < 4; ++j) bw[j] = L1_LDS16(RW + (wslot + ks) * L1_UNIT + j * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < NI2; ++i)
-                if (i < cnt2) {
-                    const uint4 am = L1_LDS16(m2a + i * 16 * L1_ROWB + ks * 64);
+                if (tile3[i] >= 0) {
+                    const uint4 am = L1_LDS16(m2a[i] + ks * 64);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc3[j][i] = T_::mfma16(am, bw[j], acc3[j][i]);
                 }
@@ -450,42 +454,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bneck_l1_kernel(cons
             for (int i = 0; i < NI2; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[i][e] = make_uint2(l1_pair_res<T_>(acc3[0][i][e], acc3[1][i][e], s3[0], s3[1], b3[0], b3[1], res[POOL ? 0 : cb & 1][i][e].x, lo),
-                                         l1_pair_res<T_>(acc3[2][i][e], acc3[3][i][e], s3[2], s3[3], b3[2], b3[3], res[POOL ? 0 : cb & 1][i][e].y, lo));
+                    o[i][e] = make_uint2(l1_pair_res<T_>(acc3[0][i][e], acc3[1][i][e], s3[0], s3[1], b3[0], b3[1], res[cb & 1][i][e].x, lo),
+                                         l1_pair_res<T_>(acc3[2][i][e], acc3[3][i][e], s3[2], s3[3], b3[2], b3[3], res[cb & 1][i][e].y, lo));
             if (!POOL) {
 #pragma unroll
                 for (int i = 0; i < NI2; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) *reinterpret_cast<uint2 *>(go[i][e] != ~0u ? yb + go[i][e] + cb * 128 : sink) = o[i][e];
             } else {
-                // EX[(row - NPX * ((t + 1) / 2 ...)]: indexed by the EVEN partner's row compacted over frame pairs: pair q = t / 2, pixel j2 -> (q * NPX + j2) * 128 + 8 l15
-                unsigned char *ex = dsm + G::M2B + l15 * 8;
+                // frame 2 q of x -> frame q of y: the even row's offset minus q frames
+                const unsigned back = (unsigned)((wave >> 2) * p.H * p.W) * (unsigned)p.ldy * 2u;
 #pragma unroll
-                for (int i = 0; i < NI2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 16 * (tl0 + i) + 4 * g + e;
-                        const int t = r / NPX, j2 = r - t * NPX;
-                        if ((oddm >> (4 * i + e)) & 1u) *reinterpret_cast<uint2 *>(ex + ((t >> 1) * NPX + j2) * 128) = o[i][e];
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < NI2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int r = 16 * (tl0 + i) + 4 * g + e;
-                        const int t = r / NPX, j2 = r - t * NPX;
-                        const bool ev = (evenm >> (4 * i + e)) & 1u;
-                        const uint2 q = *reinterpret_cast<const uint2 *>(ex + (ev ? ((t >> 1) * NPX + j2) * 128 : 0));
-                        const uint2 m = make_uint2(T_::pk_max(o[i][e].x, q.x), T_::pk_max(o[i][e].y, q.y));
-                        // frame t / 2 of y: the clip's offset minus (t - t / 2) frames
-                        *reinterpret_cast<uint2 *>(ev ? yb + (go[i][e] - (unsigned)((t - (t >> 1)) * p.H * p.W) * (unsigned)p.ldy * 2u) + cb * 128 : sink) = m;
+                        const uint2 m = make_uint2(T_::pk_max(o[i][e].x, o[i + 2][e].x), T_::pk_max(o[i][e].y, o[i + 2][e].y));
+                        *reinterpret_cast<uint2 *>((go[i][e] != ~0u && go[i + 2][e] != ~0u) ? yb + (go[i][e] - back) + cb * 128 : sink) = m;
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                   // EX is read: the next pass may overwrite it
-                asm volatile("" ::: "memory");
             }
         }
     }

@@ -32,8 +32,9 @@ BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # laye
 TPAIR_MIN_COUT = int(os.environ.get("TEDSPAD_TPAIR_MIN_COUT", "128"))   # smallest cout that takes the folded form (256: layer2's 128-channel temporal convs stay on the temporal chunk-major tile)
 TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
-BNECK_L1 = os.environ.get("TEDSPAD_BNECK_L1", "0") != "0"     # layer1's plain bottlenecks as ONE launch each (BneckL1: conv1 recomputed on tile halos, mid tensors in LDS); 0: temporal conv + fused tail (two launches)
-BNECK_L1_POOL = os.environ.get("TEDSPAD_BNECK_L1_POOL", "0") != "0"   # ... the last block with maxpool2 inside as well
+BNECK_L1_MODE = int(os.environ.get("TEDSPAD_BNECK_L1", "0"))     # 0 off, 1 every plain block of layer1 (the last one with maxpool2 inside if TEDSPAD_BNECK_L1_POOL), 2 only the last (pooled) block
+BNECK_L1 = BNECK_L1_MODE != 0     # layer1's plain bottlenecks as ONE launch each (BneckL1: conv1 recomputed on tile halos, mid tensors in LDS); 0: temporal conv + fused tail (two launches)
+BNECK_L1_POOL = os.environ.get("TEDSPAD_BNECK_L1_POOL", "1") != "0"   # ... the last block with maxpool2 inside as well
 STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try

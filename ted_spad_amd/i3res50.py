@@ -153,7 +153,7 @@ class I3Res50(nn.Module):
                 if l1 is not None and l1.applies(a):
                     last = li == 1 and i == len(layer) - 1
                     do_pool = last and E.BNECK_L1_POOL and a.dims[1] % 2 == 0
-                    if not last or do_pool:
+                    if (not last and E.BNECK_L1_MODE == 1) or do_pool:
                         a = l1(a, pool_t2=do_pool)                       # conv1 -> conv2 -> conv3 + residual (+ maxpool2): x in, y out
                         pooled = pooled or do_pool
                         continue
