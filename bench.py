@@ -348,7 +348,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--arch", default="largei3d", choices=["largei3d", "i3d"])
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--batch", type=int, default=225, help="clips per forward (225: the 256 x 256 ping-pong tiles of layer3/4 need >= 1 workgroup per CU)")
+    ap.add_argument("--batch", type=int, default=375, help="clips per forward. 375 = 6 forwards per 2 250-clip step: layer3's 256 x 256 tiles and the one-frame-per-workgroup "
+                                                            "bottleneck kernel then fill 8.97 / 2.93 rounds of the 256 CUs (225 clips: 5.38 / 1.76 rounds, a tenth of each idle); measured +1.2 %% clips/s")
     ap.add_argument("--clip-times", type=int, default=225, help="clip times per GPU (7200 frames / 32)")
     ap.add_argument("--crops", type=int, default=10)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the clip batches alternate over (fills the tail of one forward with the next)")

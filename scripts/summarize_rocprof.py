@@ -25,7 +25,9 @@ def short(n):
     return n[:90]
 
 rows = [r for r in csv.DictReader(open(a.trace)) if 'tedspad' in r['Kernel_Name'] and 'clock_probe' not in r['Kernel_Name']]      # (bench.py's clock probe runs after the timed region)
-FIRST = ('clip_to_channels_last', 'to_channels_last', 'clip_to_tp')      # the first kernel of a forward (layout pass)
+FIRST = ('clip_to_channels_last', 'to_channels_last', 'clip_to_tp')      # the first kernel of a forward: the layout pass ...
+if not any(any(f in r['Kernel_Name'] for f in FIRST) for r in rows):
+    FIRST = ('conv_stem_pt_kernel',)                                    # ... or, since round 4 (the stem reads the fp32 clip itself), the persistent stem
 starts = [i for i, r in enumerate(rows) if any(f in r['Kernel_Name'] for f in FIRST)]
 first = starts[-a.forwards] if len(starts) >= a.forwards else starts[0]
 sel = rows[first:]

@@ -24,6 +24,8 @@ for r in rows:
     d[r['Counter_Name']] = float(r['Counter_Value'])
 ids = sorted(disp)
 starts = [i for i in ids if 'to_channels_last' in disp[i]['name'] or 'clip_to_tp' in disp[i]['name']]
+if not starts:       # round 4: the stem reads the fp32 clip itself -- it is the first kernel of a forward
+    starts = [i for i in ids if 'conv_stem_pt_kernel' in disp[i]['name']]
 sel = [disp[i] for i in ids if i >= starts[-1]]
 agg = collections.OrderedDict()
 for d in sel:

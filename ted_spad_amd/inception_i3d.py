@@ -43,6 +43,7 @@ PLAN = (
 
 
 FUSE_REDUCE = os.environ.get("TEDSPAD_I3D_FUSE_REDUCE", "1") != "0"   # Mixed_*: the b1a / b2a 1x1x1 convs as one GEMM (0: two launches, A/B)
+FUSE_B0 = os.environ.get("TEDSPAD_I3D_FUSE_B0", "1") != "0"           # ... and branch 0's 1x1x1 conv in the same GEMM, writing its concat slice directly (0: its own launch, A/B)
 
 
 class Unit3D(nn.Module):
@@ -119,6 +120,11 @@ class InceptionI3d(nn.Module):
                         sb, bb = E.fold_bn(ub.bn.weight, ub.bn.bias, ub.bn.running_mean, ub.bn.running_var, ub.bn.eps)
                         P[name_ + ".b12a"] = E.PackedConv(torch.cat([ua.conv3d.weight, ub.conv3d.weight]), torch.cat([sa, sb]), torch.cat([ba, bb]),
                                                           dtype=self.compute_dtype, device=dev)
+                        # ... and branch 0 (i3d.py:144-149: all three read the module input x): ONE GEMM over [W_1a ; W_2a ; W_0]. Its output channels are
+                        # contiguous in a buffer laid out [t1 | t2 | b0 | b1b | b2b | b3b]: the module's output is the channel slice behind t2 (no copy)
+                        s0, b0_ = E.fold_bn(m.b0.bn.weight, m.b0.bn.bias, m.b0.bn.running_mean, m.b0.bn.running_var, m.b0.bn.eps)
+                        P[name_ + ".b012a"] = E.PackedConv(torch.cat([ua.conv3d.weight, ub.conv3d.weight, m.b0.conv3d.weight]), torch.cat([sa, sb, s0]),
+                                                           torch.cat([ba, bb, b0_]), dtype=self.compute_dtype, device=dev)
             self._packed, self._packed_sig = P, sig
         return self._packed
 
@@ -156,7 +162,23 @@ class InceptionI3d(nn.Module):
             else:
                 oc = arg[1]
                 n, t, h, w = a.dims
-                out = E.Act.empty(n, t, h, w, oc[0] + oc[2] + oc[4] + oc[5], a.buf.dtype, a.buf.device)
+                OC = oc[0] + oc[2] + oc[4] + oc[5]
+                if (name_ + ".b012a") in P and taps is None and FUSE_REDUCE and FUSE_B0:
+                    # [pad | t1 | t2 | b0 | b1b | b2b | b3b]: the reduce tensors in front of the module's output, padded so that the output slice starts on a 128-byte line
+                    red = oc[1] + oc[3]
+                    off = (red + 63) // 64 * 64
+                    big = E.Act.empty(n, t, h, w, off + OC, a.buf.dtype, a.buf.device)
+                    self._unit(P[name_ + ".b012a"], a, one, one, out=E.Act(big.buf, red + oc[0], off - red))
+                    t1, t2 = E.Act(big.buf, oc[1], off - red), E.Act(big.buf, oc[3], off - red + oc[1])
+                    out = E.Act(big.buf, OC, off)
+                    self._unit(P[name_ + ".b1b"], t1, three, one, out=out.slice(oc[0], oc[2]))
+                    self._unit(P[name_ + ".b2b"], t2, three, one, out=out.slice(oc[0] + oc[2], oc[4]))
+                    pf, pb = self._same(a.dims[1:], three, one)
+                    t3 = E.maxpool(a, three, one, pf, pb, pad_zero=True)
+                    self._unit(P[name_ + ".b3b"], t3, one, one, out=out.slice(oc[0] + oc[2] + oc[4], oc[5]))
+                    a = out
+                    continue
+                out = E.Act.empty(n, t, h, w, OC, a.buf.dtype, a.buf.device)
                 self._unit(P[name_ + ".b0"], a, one, one, out=out.slice(0, oc[0]))
                 if (name_ + ".b12a") in P and taps is None and FUSE_REDUCE:
                     t12 = self._unit(P[name_ + ".b12a"], a, one, one)
