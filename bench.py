@@ -297,6 +297,7 @@ def bench_train_main(args, dev, world, rank, dry):
     for _ in range(2):
         it()
     with_x = timed_loop(it, steps)
+    losses_x = dict(losses)              # the losses of the loop WITH the exchange (the one below lets the replicas drift apart at N > 1: local-gradient Adam steps)
     for r in reducers:
         r.exchange = False
     for _ in range(2):
@@ -326,7 +327,8 @@ def bench_train_main(args, dev, world, rank, dry):
                     traffic = tj["traffic_bytes_per_iteration"]
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": round(ach / (MFMA_PEAK_TFLOPS * world), 4),
                                "traffic": traffic, "kernel": "both phases of one iteration on every rank (conv / linear MACs x 2 of BASELINE.md section 2 over the iteration time)"}
-            res.update(losses)
+            res.update(losses_x)
+            res["note"] = "iteration_ms_without_exchange is timed LAST, on the same step object, with local gradients only: the replicas' weights differ afterwards"
     if world > 1:
         flags = [None] * world
         dist.all_gather_object(flags, bool(ok[0]))

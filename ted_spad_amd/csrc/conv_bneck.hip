@@ -913,6 +913,8 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     p.res = (const uint16_t *)residual; p.x2 = (const uint16_t *)x2; p.y = (uint16_t *)y;
     p.M = (int)M; p.Kpad = tedspad_conv_kpad(d2); p.W = d2->w; p.H = d2->h; p.kh = d2->kh; p.kw = d2->kw; p.ph = d2->ph; p.pw = d2->pw;
     p.ldx = d2->ldx; p.ldres = ldres; p.ldx2 = ldx2; p.ldy = ldy; p.cout3 = cout3; p.relu = relu;
+    // the prologue's (t * winv) >> 20 / (hh * hinv) >> 20 are exact divisions only while t * W < 2^20 (t < W + 256) and hh < 2 H < 2^11
+    TS_REQUIRE((long)(d2->w + 256) * d2->w < (1L << 20) && d2->h < 1024, "tedspad_bneck_tail_fwd: frame too wide / tall for the prologue's multiply-shift divisions (w <= 903, h < 1024)");
     p.winv = ((1u << 20) + d2->w - 1) / d2->w; p.hinv = ((1u << 20) + d2->h - 1) / d2->h;
     p.R = d2->ph * d2->w + d2->pw; p.NP = BT_BM + (d2->kh - 1) * d2->w + (d2->kw - 1); p.ntaps = d2->kh * d2->kw;
     TS_REQUIRE(p.Kpad == p.ntaps * d2->cin, "tedspad_bneck_tail_fwd: unexpected K padding of the conv2 weights");

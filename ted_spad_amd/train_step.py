@@ -159,6 +159,15 @@ class AnonymizerTrainStep:
             if fused:       # a fused step leaves the parameters' version counters alone: say that they changed (TE.mark_updated)
                 TE.mark_updated(module.parameters())
 
+    @staticmethod
+    def _check_deterministic():
+        """Deterministic mode (engine.set_deterministic): a workgroup that gave up waiting for its turn opened the gate for the rest of the launch -- that step is
+        not reproducible. The give-up counter is sticky until the mode is set again, so it is surfaced here, once per step, as an error (one device read: this
+        mode is for tests and debugging)."""
+        if E.DETERMINISTIC and E.deterministic_giveups() > 0:
+            raise RuntimeError("deterministic mode: %d workgroup(s) gave up their ordered turn in an atomic section during this step; "
+                               "its result is not reproducible (call engine.set_deterministic(True) again to re-arm)" % E.deterministic_giveups())
+
     def _opts(self):
         return [o for o in (self.opt_fa, self.opt_fb, self.opt_ft) if o is not None]
 
@@ -222,6 +231,7 @@ class AnonymizerTrainStep:
         self.red_fa.finish()
         skipped = self._opt_step(self.opt_fa, self._unscale(self.fa), self.fa)     # :123
         self.iteration += 1
+        self._check_deterministic()
         return dict(phase=1, loss_fa=self._val(loss_fa), loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
                     loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=skipped)
 
@@ -294,6 +304,7 @@ class AnonymizerTrainStep:
         self.red_ft.finish()
         skipped = self._opt_step(self.opt_ft, self._unscale(self.ft), self.ft)     # :193
         self.iteration += 1
+        self._check_deterministic()
         return dict(phase=2, loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
                     loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=skipped)
 
@@ -317,6 +328,7 @@ class AnonymizerTrainStep:
         self.red_ft.finish()
         skipped = self._opt_step(self.opt_ft, self._unscale(self.ft), self.ft)     # :87
         self.iteration += 1
+        self._check_deterministic()
         return dict(phase="action", loss=self._val(loss), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
                     skipped=skipped)
 
