@@ -56,7 +56,7 @@ def kernel_sources_sha() -> str:
 def train_sources_sha() -> str:
     """kernel_sources_sha() + the training-side launch sequences."""
     h = hashlib.sha256(kernel_sources_sha().encode())
-    for f in ("train_engine.py", "train_nets.py", "train_step.py", "unet.py"):
+    for f in ("train_engine.py", "train_nets.py", "train_step.py", "unet.py", "resnet50.py"):
         h.update(open(os.path.join(ROOT, "ted_spad_amd", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -375,3 +375,19 @@ def test_bn_bwd_apply_rejects_channel_counts_beyond_its_lds():
                                          h.data_ptr(), None, None, 1, 8, 4096, 4096, 4096, 4096, 4096, 0, 0, 1, _lib.F16,
                                          Ct.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0
+
+
+@pytest.mark.parametrize("B,K,N", [(2, 2048, 512), (12, 2048, 2048), (16, 2048, 128), (24, 2048, 102), (2048, 12, 2048), (128, 24, 130), (512, 7, 64), (5, 130, 33), (3, 2050, 9)])
+def test_linear_kernels_vs_torch(B, K, N):
+    """head.linear (tedspad_linear_fwd: Linear (+ folded scale / shift) (+ ReLU), exact fp32) on its three kernels -- a wavefront per output, a wavefront per output
+    column for small batches (the mlp heads, model_loaders.py:250-254), a thread per output column for short reductions (their weight gradients dW = dY^T . X) --
+    against torch on the CPU (float64 accumulation): forward heads, the transposed products of the backward, K not a multiple of 4."""
+    from ted_spad_amd import head
+    g = torch.Generator().manual_seed(B * 131 + K)
+    x, w, b = torch.randn(B, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = (x.double() @ w.double().t() + b.double())
+    got = head.linear(x.cuda(), w.cuda(), b.cuda()).cpu()
+    assert got.shape == (B, N)
+    assert rel_l2(got, ref.float()) < 2e-6
+    got_r = head.linear(x.cuda(), w.cuda(), b.cuda(), relu=True).cpu()
+    assert rel_l2(got_r, ref.clamp_min(0).float()) < 2e-6
