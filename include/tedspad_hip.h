@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TEDSPAD_ABI_VERSION 3   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat, the fp32-clip stem entry (round 4) */
+#define TEDSPAD_ABI_VERSION 3   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4) */
 
 enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
@@ -116,6 +116,15 @@ typedef struct tedspad_conv_extras {
                                 network as ONE batch while their BatchNorms keep separate batch statistics (train_anonymizer.py:169-175) */
     int32_t     nosat;       /* 1: f16 results are NOT clamped to +-65504 (the training path: an overflow stays inf / NaN, as under the reference's fp16
                                 autocast, train_anonymizer.py:78, so that a loss scale's non-finite check sees it). 0: saturate (inference) */
+    int32_t     nchunk_src;  /* > 0 (= cin / 64, <= 8; tile_cfg 32 / 33 only, kt = 1): the input is a GATHERED CONCATENATION -- the 64-channel chunk k of every
+                                input pixel is read from chunk_src[k] (pointer to that chunk's first channel at pixel 0, 16-byte aligned) with pixel stride
+                                chunk_ld[k]; bit k of chunk_up: that source is a (n, h/2, w/2) tensor read through a nearest x2 upsample (pixel (h, w) <-
+                                (h >> 1, w >> 1); h, w even). `x` / d->ldx are not read. This is `torch.cat([F.interpolate(x, scale_factor=2, mode='nearest'),
+                                *skips], dim=1)` of the default anonymizer's decoder blocks (arch='unet++', aux_code/model_loaders.py:17-30; smp
+                                decoders/unetplusplus/decoder.py DecoderBlock.forward) without the upsampled tensor or the concat buffer ever being written */
+    int32_t     chunk_up;
+    int32_t     chunk_ld[8];
+    const void *chunk_src[8];
 } tedspad_conv_extras;
 
 int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed,

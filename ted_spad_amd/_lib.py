@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
 
 class ConvExtras(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("stats", C.c_void_p), ("y32", C.c_void_p)] + [(n, C.c_int32) for n in (
-        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "fold_hw", "fold_c", "fold_ldy", "stats_rows", "nosat")]
+        "ldmask", "stats_ld", "ldy32", "out_strided", "ost", "osh", "osw", "oot", "ooh", "oow", "tf", "hf", "wf", "fold_hw", "fold_c", "fold_ldy", "stats_rows", "nosat", "nchunk_src", "chunk_up")] + [
+        ("chunk_ld", C.c_int32 * 8), ("chunk_src", C.c_void_p * 8)]
 
 
 class PackJob(C.Structure):              # tedspad_pack_job

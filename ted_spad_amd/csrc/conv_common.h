@@ -67,6 +67,12 @@ int32_t launch_conv_flat(int dtype, const ConvKP &p, int cin, hipStream_t s);
 int32_t launch_conv_tflat(int dtype, const ConvKP &p, int N, int cin, hipStream_t s);
 
 // conv_patch.hip: 16 x 16 patch-halo kernel for stride-1 'same' 1 x kh x kw convs with cin % 64 == 0, cout <= 128 on wide frames (tile_cfg 32).
-int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode = 0);   // mode 1: tile_cfg 33 (256 consecutive pixels), 2: tile_cfg 34 (temporal)
+// gathered concatenation (tedspad_conv_extras.nchunk_src): per 64-channel chunk its own source tensor, optionally read through a nearest x2 upsample
+struct PatchSrc {
+    const uint16_t *ptr[8];
+    int ld[8];
+    int up, n;
+};
+int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode = 0, const PatchSrc *src = nullptr);   // mode 1: tile_cfg 33 (256 consecutive pixels), 2: tile_cfg 34 (temporal)
 
 }  // namespace tedspad

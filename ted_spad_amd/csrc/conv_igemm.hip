@@ -735,7 +735,7 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 constexpr int NUM_CFGS = 37;
 
 template <typename T>
-int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
+int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr) {
     switch (cfg) {
         case 9: return launch_stem_halo<T, 1, 1>(p, N, s);
         case 20: return launch_stem_halo<T, 2, 1>(p, N, s);
@@ -772,8 +772,8 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s) {
         case 25: return launch_conv_p8(T::kDtype, p, s);
         case 27: return launch_conv_flat(T::kDtype, p, cin, s);
         case 28: return launch_conv_tflat(T::kDtype, p, N, cin, s);
-        case 32: return launch_conv_patch(T::kDtype, p, N, cin, s);
-        case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, 1);
+        case 32: return launch_conv_patch(T::kDtype, p, N, cin, s, 0, src);
+        case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, 1, src);
         case 34: return launch_conv_patch(T::kDtype, p, N, cin, s, 2);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
@@ -855,7 +855,8 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
                                        const float *scale, const float *shift, const void *residual, void *y, int32_t sigmoid,
                                        const tedspad_conv_extras *ex, void *stream, int pool_t, const ConvKP *dual = nullptr) {
     TS_REQUIRE(desc_ok(d), "tedspad_conv_fwd: bad descriptor (cin/cout/ld* multiples of 8, kernel dims <= 7)");
-    TS_REQUIRE(x && w_packed && ktab && scale && shift && (y || (ex && ex->y32)), "tedspad_conv_fwd: null pointer");
+    const bool gathered = ex && ex->nchunk_src > 0;
+    TS_REQUIRE((x || gathered) && w_packed && ktab && scale && shift && (y || (ex && ex->y32)), "tedspad_conv_fwd: null pointer");
     TS_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) % 16 == 0,
                "tedspad_conv_fwd: pointers must be 16-byte aligned");
     TS_REQUIRE(!residual || (d->ldres % 8 == 0 && d->ldres >= d->cout), "tedspad_conv_fwd: bad ldres");
@@ -865,7 +866,7 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
                "tedspad_conv_fwd: output extent reaches past the input");
     const long in_elems = (long)d->n * d->t * d->h * d->w * d->ldx;
     const long M = (long)d->n * d->to * d->ho * d->wo;
-    TS_REQUIRE(in_elems < (1L << 31) && M < (1L << 31), "tedspad_conv_fwd: tensor too large for 32-bit gather offsets; split the batch");
+    TS_REQUIRE((gathered || in_elems < (1L << 31)) && M < (1L << 31), "tedspad_conv_fwd: tensor too large for 32-bit gather offsets; split the batch");
     ConvKP p;
     p.x = (const uint16_t *)x; p.w = (const uint16_t *)w_packed; p.ktab = (const int2 *)ktab;
     p.scale = scale; p.shift = shift; p.res = (const uint16_t *)residual; p.y = (uint16_t *)y;
@@ -932,6 +933,24 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         return launch_conv_pw(d->dtype, p, s, true);
     }
     int cfg = d->tile_cfg > 0 ? d->tile_cfg : heuristic_cfg(p, extras ? 0 : d->cin);
+    PatchSrc gsrc{};
+    if (gathered) {       // the input is a gathered concatenation: patch / flat halo tiles only
+        if (d->tile_cfg <= 0) cfg = (d->kh - 1) * d->w + d->kw - 1 + 256 <= 384 - 1 ? 33 : 32;
+        if (cfg != 32 && cfg != 33) {
+            set_error("tedspad_conv_fwd_ex: gathered sources (nchunk_src) run on tile_cfg 32 / 33 only");
+            return TEDSPAD_EUNSUPPORTED;
+        }
+        TS_REQUIRE(!dual && !pool_t && !p.fold_hw && d->kt == 1 && d->cin % 64 == 0 && ex->nchunk_src == d->cin / 64 && ex->nchunk_src <= 8,
+                   "tedspad_conv_fwd_ex: gathered sources: kt = 1, cin %% 64 == 0, nchunk_src = cin / 64 <= 8");
+        gsrc.n = ex->nchunk_src; gsrc.up = ex->chunk_up & ((1 << gsrc.n) - 1);
+        TS_REQUIRE(!gsrc.up || (d->h % 2 == 0 && d->w % 2 == 0), "tedspad_conv_fwd_ex: an upsampled source needs even h and w");
+        for (int k = 0; k < gsrc.n; ++k) {
+            const long px = (gsrc.up >> k) & 1 ? (long)d->n * d->t * (d->h / 2) * (d->w / 2) : (long)d->n * d->t * d->h * d->w;
+            TS_REQUIRE(ex->chunk_src[k] && (uintptr_t)ex->chunk_src[k] % 16 == 0 && ex->chunk_ld[k] >= 64 && ex->chunk_ld[k] % 8 == 0 && px * ex->chunk_ld[k] < (1L << 31),
+                       "tedspad_conv_fwd_ex: gathered sources: null / misaligned chunk_src, chunk_ld < 64 or not a multiple of 8, or a source beyond 2^31 elements");
+            gsrc.ptr[k] = (const uint16_t *)ex->chunk_src[k]; gsrc.ld[k] = ex->chunk_ld[k];
+        }
+    }
     if (p.fold_hw) {
         if (d->tile_cfg <= 0) cfg = 25;
         TS_REQUIRE(cfg == 25 || cfg == 26, "tedspad_conv_fwd_ex: folded output frames run on the ping-pong kernel only (tile_cfg 25 / 26)");
@@ -942,7 +961,8 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
         TS_REQUIRE(!p.stats || !p.stats_rows || ((long)d->to * d->ho * d->wo > 0 && p.stats_rows % ((long)d->to * d->ho * d->wo) == 0),
                    "tedspad_conv_fwd_ex: halo-direct tiles need statistics groups of whole samples");
     }
-    return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, d->cin, s) : launch_cfg<BF16>(cfg, p, d->n, d->cin, s);
+    const PatchSrc *gp = gathered ? &gsrc : nullptr;
+    return d->dtype == TEDSPAD_F16 ? launch_cfg<F16>(cfg, p, d->n, d->cin, s, gp) : launch_cfg<BF16>(cfg, p, d->n, d->cin, s, gp);
 }
 
 extern "C" int32_t tedspad_conv_fwd_ex(const tedspad_conv_desc *d, const void *x, const void *w_packed, const int32_t *ktab,

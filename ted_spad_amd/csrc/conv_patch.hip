@@ -34,9 +34,13 @@ struct PatchGeo {
 // MODE 2 (TEMPORAL, tile_cfg 34): kt x 1 x 1 'same' convs, the generalisation of conv_tflat_kernel to cout <= 512: a tile is PXF spatial positions of
 // ALL T <= 4 frames of a clip (position = frame * PXF + pixel), the chunk's T x PXF input positions are the halo, a tap moves a whole
 // frame (delta = +-PXF positions) and taps that leave the clip are skipped wave-uniformly (T = 2: a third of a 3 x 1 x 1 conv's taps).
-template <typename T, int BN, int MODE = 0>
-__global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const PatchGeo g) {
+// SRC (patch / FLAT with kt = 1): the input is a gathered concatenation (tedspad_conv_extras.nchunk_src): chunk k of a halo position comes from its own
+// tensor gs.ptr[k] (pixel stride gs.ld[k]), through a nearest x2 upsample when bit k of gs.up is set -- a slot keeps the PIXEL index of its position at full and
+// at half resolution instead of an element offset; the LDS image, the K order and therefore the sums are those of the same conv on the materialised concat buffer.
+template <typename T, int BN, int MODE = 0, bool SRC = false>
+__global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const PatchGeo g, const PatchSrc gs) {
     constexpr bool FLAT = MODE == 1, TEMP = MODE == 2;
+    static_assert(!SRC || MODE != 2, "gathered sources: patch and flat modes only");
     constexpr int NT = 256;
     constexpr int WS = BN == 64 ? 3 : 2;                  // weight ring slots ([BN][64] 16-bit each)
     constexpr int WSTAGE = BN * BK * 2;
@@ -63,6 +67,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     // ---- halo slots of this thread: slot s -> position s >> 3 = (row, col) of the halo, stored chunk s & 7 -----------------------
     constexpr int NHMAX = 12;                              // 12 x 256 slots = 384 positions (e.g. 19 x 19 for a 4 x 4 kernel)
     int hsrc[NHMAX];                                       // element offset of the slot's source (without the channel chunk), or -1
+    int hsrcU[SRC ? NHMAX : 1];                            // SRC: hsrc = pixel index of the position, hsrcU = pixel index in a half-resolution source
+    const int swo = ((tid & 7) ^ ((tid >> 4) & 7)) << 3;   // SRC: the slot's swizzled 8-channel piece ((s & 7) ^ ((pos >> 1) & 7) does not depend on i)
     const int NH = (Sr + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NHMAX; ++i) {
@@ -77,9 +83,20 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             if (i < NH && pos < g.NP && s0 + px < g.HW) hsrc[i] = (int)((((long)nclip * g.T + f) * g.HW + s0 + px) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
         } else if (FLAT) {
             const int q = q0 - g.R + pos;
-            if (i < NH && pos < g.NP && (unsigned)q < (unsigned)p.M) hsrc[i] = (int)((long)q * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
-        } else if (i < NH && pos < g.NP && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-            hsrc[i] = (int)((((long)b * p.Hi + ih) * p.Wi + iw) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+            if (SRC) {
+                hsrcU[i] = -1;
+                if (i < NH && pos < g.NP && (unsigned)q < (unsigned)p.M) {
+                    const int fr = q / g.HW, r = q - fr * g.HW, qh = r / p.Wi, qw = r - qh * p.Wi;
+                    hsrc[i] = q;
+                    hsrcU[i] = (fr * (p.Hi >> 1) + (qh >> 1)) * (p.Wi >> 1) + (qw >> 1);
+                }
+            } else if (i < NH && pos < g.NP && (unsigned)q < (unsigned)p.M) hsrc[i] = (int)((long)q * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+        } else if (i < NH && pos < g.NP && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+            if (SRC) {
+                hsrc[i] = (b * p.Hi + ih) * p.Wi + iw;
+                hsrcU[i] = (b * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1);
+            } else hsrc[i] = (int)((((long)b * p.Hi + ih) * p.Wi + iw) * p.ldx) + ((cs ^ ((pos >> 1) & 7)) << 3);
+        }
     }
     const int rsub = wave * 8 + (lane >> 3);
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
@@ -144,11 +161,23 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         started = true;
         asm volatile("" ::: "memory");
         issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
+        if (SRC) {
+            const uint16_t *sp = gs.ptr[chc] + swo;
+            const long sl = gs.ld[chc];
+            const bool up = (gs.up >> chc) & 1;
+#pragma unroll
+            for (int i = 0; i < NHMAX; ++i) {
+                if (i * NT + wave * 64 >= Sr) break;       // wave-uniform
+                const int pi = up ? hsrcU[i] : hsrc[i];
+                lds_dma16(hsrc[i] >= 0 ? sp + pi * sl : zero, lds0 + (i * NT + wave * 64) * 16);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NHMAX; ++i) {
             if (i * NT + wave * 64 >= Sr) break;           // wave-uniform
             const long so = hsrc[i] + fshift;            // FLAT: the shifted run may leave the tensor at either end
             lds_dma16((hsrc[i] >= 0 && so >= 0 && so < g.xelems) ? p.x + so + chc * 64 : zero, lds0 + (i * NT + wave * 64) * 16);
+        }
         }
         if (g.ntaps > 1) issue_w(ch, 1, 1);
         int dh = 0, dw = 0;
@@ -317,8 +346,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     }
 }
 
-template <typename T, int BN, int MODE = 0>
-int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
+template <typename T, int BN, int MODE = 0, bool SRC = false>
+int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s, const PatchSrc *src = nullptr) {
     constexpr bool FLAT = MODE == 1, TEMP = MODE == 2;
     PatchGeo g;
     g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
@@ -337,7 +366,9 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
     const int stage_bytes = 256 * (64 + 4) * 4;
     const int lds = main_bytes > stage_bytes ? main_bytes : stage_bytes;
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_patch_kernel<T, BN, MODE>;
+    auto kfn = conv_patch_kernel<T, BN, MODE, SRC>;
+    PatchSrc gs{};
+    if (SRC) gs = *src;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -345,14 +376,18 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s) {
         }
         attr_set[T::kDtype] = 1;
     }
-    hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 255) / 256 : TEMP ? (NTf / p.Ti) * g.tiles_w : NTf * g.tiles_h * g.tiles_w) * g.tiles_n), dim3(256), lds, s, p, g);
+    hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 255) / 256 : TEMP ? (NTf / p.Ti) * g.tiles_w : NTf * g.tiles_h * g.tiles_w) * g.tiles_n), dim3(256), lds, s, p, g, gs);
     return check_launch("tedspad_conv_fwd(patch halo)");
 }
 
 }  // namespace
 
-int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode) {
+int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode, const PatchSrc *src) {
     const bool flat = mode == 1;
+    if (src && (mode == 2 || p.kt != 1 || src->n != cin / 64 || cin % 64 != 0)) {
+        set_error("tedspad_conv_fwd_ex: gathered sources (nchunk_src) need tile_cfg 32 / 33, kt = 1 and one source per 64-channel chunk");
+        return TEDSPAD_EINVAL;
+    }
     if (mode == 2) {
         const bool same_t = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi && p.ph == 0 && p.pw == 0 && p.pt < p.kt;
         if (cin % 64 != 0 || p.kh != 1 || p.kw != 1 || p.kt < 2 || p.kt > 3 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same_t || p.Ti > 4 || p.Cout > 512 ||
@@ -372,6 +407,15 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;
+    if (src) {
+        const bool f16 = dtype == TEDSPAD_F16;
+        if (flat) {
+            if (p.Cout <= 64) return f16 ? launch_patch_t<F16, 64, 1, true>(p, frames, cin, s, src) : launch_patch_t<BF16, 64, 1, true>(p, frames, cin, s, src);
+            return f16 ? launch_patch_t<F16, 128, 1, true>(p, frames, cin, s, src) : launch_patch_t<BF16, 128, 1, true>(p, frames, cin, s, src);
+        }
+        if (p.Cout <= 64) return f16 ? launch_patch_t<F16, 64, 0, true>(p, frames, cin, s, src) : launch_patch_t<BF16, 64, 0, true>(p, frames, cin, s, src);
+        return f16 ? launch_patch_t<F16, 128, 0, true>(p, frames, cin, s, src) : launch_patch_t<BF16, 128, 0, true>(p, frames, cin, s, src);
+    }
     if (flat) {
         if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64, 1>(p, frames, cin, s) : launch_patch_t<BF16, 64, 1>(p, frames, cin, s);
         return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128, 1>(p, frames, cin, s) : launch_patch_t<BF16, 128, 1>(p, frames, cin, s);

@@ -34,6 +34,7 @@ TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
 BNECK_L1_MODE = int(os.environ.get("TEDSPAD_BNECK_L1", "0"))     # 0 off, 1 every plain block of layer1 (the last one with maxpool2 inside if TEDSPAD_BNECK_L1_POOL), 2 only the last (pooled) block
 BNECK_L1 = BNECK_L1_MODE != 0     # layer1's plain bottlenecks as ONE launch each (BneckL1: conv1 recomputed on tile halos, mid tensors in LDS); 0: temporal conv + fused tail (two launches)
+GATHER_CAT = os.environ.get("TEDSPAD_GATHER_CAT", "1") != "0"          # unet++ decoder blocks read upsample + concat in place (PackedConv.gather)
 BNECK_L1_POOL = os.environ.get("TEDSPAD_BNECK_L1_POOL", "1") != "0"   # ... the last block with maxpool2 inside as well
 STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
@@ -184,6 +185,13 @@ class Act:
     @staticmethod
     def empty(n, t, h, w, c, dtype, device) -> "Act":
         return Act(torch.empty((n, t, h, w, c), dtype=dtype, device=device), c)
+
+
+class _Geo:
+    """Pixel grid of a gathered input (PackedConv.gather): what the conv descriptor needs of an Act, without a tensor."""
+
+    def __init__(self, dims, c):
+        self.dims, self.c, self.ld, self.ptr = tuple(dims), c, c, None
 
 
 def conv_out(size, k, s, pf, pb):
@@ -607,15 +615,23 @@ class PackedConv:
               "tedspad_conv_p8_dual_fwd")
         return out
 
-    def _run(self, x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid):
+    def _run(self, x, pads, o, out, residual, mask, stats, out_map, z32, relu, sigmoid, sources=None):
         """One launch (through the tuner) on tensors small enough for the kernel's 32-bit offsets."""
         n, t, h, w = x.dims
         y32 = z32 is not None
         d = self._desc(n, t, h, w, x.ld, pads, o, out.ld, residual.ld if residual is not None else 0, relu)
         ex = None
-        if mask is not None or stats is not None or out_map is not None or y32 or self.nosat:
+        if mask is not None or stats is not None or out_map is not None or y32 or self.nosat or sources is not None:
             ex = _lib.ConvExtras()
             ex.nosat = int(self.nosat)
+            if sources is not None:      # gathered concatenation: one descriptor per 64-channel chunk (tedspad_conv_extras.nchunk_src)
+                k = 0
+                for a, up in sources:
+                    for j in range(a.c // 64):
+                        ex.chunk_src[k], ex.chunk_ld[k] = a.ptr + j * 128, a.ld
+                        ex.chunk_up |= int(bool(up)) << k
+                        k += 1
+                ex.nchunk_src = k
             if y32:
                 ex.y32, ex.ldy32 = z32.data_ptr(), self.cout
             if mask is not None:
@@ -631,11 +647,36 @@ class PackedConv:
                 (ex.ost, ex.osh, ex.osw), (ex.oot, ex.ooh, ex.oow) = out_map
                 ex.out_strided = 1
                 _, ex.tf, ex.hf, ex.wf = out.dims
-        args = (C.byref(d), x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+        args = (C.byref(d), None if sources is not None else x.ptr, self.w.data_ptr(), self._ktab(d).data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
                 residual.ptr if residual is not None else None, None if y32 else out.ptr, int(sigmoid),
                 C.byref(ex) if ex is not None else None)
-        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map, y32)
+        key = (n, t, h, w, x.ld, tuple(pads), o, out.ld, residual is not None, mask is not None, stats is not None, out_map, y32,
+               None if sources is None else tuple((a.c, a.ld, bool(up)) for a, up in sources))
         self._launch_tuned(key, d, args)
+
+    def gather(self, sources, pads=(0, 0, 0), out: Optional[Act] = None, relu=True) -> Act:
+        """The conv on `torch.cat([s (nearest x2 upsampled if up) for s, up in sources], dim=1)` without that tensor: every source (an Act with a multiple
+        of 64 channels; `up` sources at half the height and width) is read in place by the patch / flat halo kernels (tile_cfg 32 / 33,
+        tedspad_conv_extras.nchunk_src) -- the decoder blocks of the default anonymizer (unet++: smp DecoderBlock.forward = interpolate + cat + conv).
+        Stride-1 'same' convs with kt = 1; same sums, in the same order, as the conv on the materialised concat buffer under the same tile_cfg."""
+        assert sources and all(a.c % 64 == 0 for a, _ in sources) and sum(a.c for a, _ in sources) == self.cin and self.cin <= 512 and self.k[0] == 1
+        full = [a.dims if not up else (a.dims[0], a.dims[1], 2 * a.dims[2], 2 * a.dims[3]) for a, up in sources]
+        assert all(f == full[0] for f in full), "gather: the sources' pixel grids differ: %s" % (full,)
+        n, t, h, w = full[0]
+        kt, kh, kw = self.k
+        o = (t, conv_out(h, kh, 1, pads[1], pads[1]), conv_out(w, kw, 1, pads[2], pads[2]))
+        assert self.stride == (1, 1, 1) and o == (t, h, w), "gather: stride-1 'same' convolutions only"
+        if out is None:
+            out = Act.empty(n, t, h, w, self.cout, self.torch_dtype, sources[0][0].buf.device)
+        assert out.dims == (n, t, h, w) and out.c == self.cout
+        worst = t * h * w * max(max(a.ld // (4 if up else 1) for a, up in sources), out.ld)
+        nc = n if n * worst < MAX_ELEMS else batch_chunk(n, [worst], MAX_ELEMS)
+        for n0 in range(0, n, nc):
+            n1 = min(n, n0 + nc)
+            sub = [(Act(a.buf[n0:n1], a.c, a.coff), up) for a, up in sources]
+            geo = _Geo((n1 - n0, t, h, w), self.cin)
+            self._run(geo, pads, o, Act(out.buf[n0:n1], out.c, out.coff), None, None, None, None, None, relu, False, sources=sub)
+        return out
 
     def __call__(self, x: Act, pads=(0, 0, 0), pads_back=None, out: Optional[Act] = None,
                  residual: Optional[Act] = None, relu=True, sigmoid=False, mask: Optional[Act] = None,

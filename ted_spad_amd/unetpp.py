@@ -164,6 +164,39 @@ class UnetPlusPlus(nn.Module):
         assert out.dims == x.dims and out.c == x.c
         check(_lib.lib().tedspad_copy_channels(x.ptr, out.ptr, n * h * w, x.c, x.ld, out.ld, _stream_ptr()), "tedspad_copy_channels")
 
+    def _forward_gathered(self, x: torch.Tensor, P, taps=None) -> torch.Tensor:
+        """The eval forward with every decoder block's `interpolate(x, 2, 'nearest')` + `torch.cat([x, *skips])` read IN PLACE by its first conv
+        (PackedConv.gather: per-64-channel-chunk sources, half-resolution ones through the x2 index map): no upsampled tensor, no concat buffer, no copies."""
+        pad = (0, 1, 1)
+        a = E.clip_to_act(x.unsqueeze(2), cpad=4, dtype=self.compute_dtype)
+        st = P["stem"]
+        f1 = st(a, pads=(0, 3, st.pair_pw), pads_back=(0, 3, st.k[2] - 1 - st.pair_pw))
+        cur = E.maxpool(f1, (1, 3, 3), (1, 2, 2), pads=(0, 1, 1))
+        feats = {1: f1}
+        for li in (1, 2, 3):
+            for bi, blk in enumerate(getattr(self.encoder, "layer%d" % li)):
+                p = "layer%d.%d." % (li, bi)
+                h = P[p + "conv1"](cur, pads=pad)
+                res = P[p + "down"](cur, relu=False) if blk.downsample is not None else cur
+                cur = P[p + "conv2"](h, pads=pad, residual=res, relu=True)
+            feats[li + 1] = cur
+        f2, f3, f4 = feats[2], feats[3], feats[4]
+
+        def block(name, *sources):          # sources in smp's torch.cat order: the upsampled input first, then the skips
+            return P[name + ".conv2"](P[name + ".conv1"].gather([(sources[0], True)] + [(s, False) for s in sources[1:]], pads=pad), pads=pad)
+
+        x00 = block("x_0_0", f4, f3)
+        x11 = block("x_1_1", f3, f2)
+        x22 = block("x_2_2", f2, f1)
+        x01 = block("x_0_1", x00, x11, f2)
+        x12 = block("x_1_2", x11, x22, f1)
+        x02 = block("x_0_2", x01, x12, x22, f1)
+        x03 = block("x_0_3", x02)
+        if taps is not None:
+            taps.update(f1=f1, f2=f2, f3=f3, f4=f4, x00=x00, x11=x11, x22=x22, x01=x01, x12=x12, x02=x02, x03=x03)
+        y = P["head"](x03, pads=pad, relu=False)
+        return E.act_to_nchw(y, 3).squeeze(2)
+
     def forward(self, x: torch.Tensor, taps=None) -> torch.Tensor:
         if self.training:
             # train(): batch-statistics BatchNorm + a tape for loss.backward() (train_anonymizer.py:73-123); under no_grad the same
@@ -184,6 +217,8 @@ class UnetPlusPlus(nn.Module):
             return Act.empty(n, 1, H // div, W // div, c, tdt, dev)
 
         pad = (0, 1, 1)
+        if E.GATHER_CAT:
+            return self._forward_gathered(x, P, taps)
         # concat buffers (leading slice = the upsampled input of the block, then the skips in smp's torch.cat order)
         B00, B11, B22 = buf(384, 8), buf(192, 4), buf(128, 2)      # [up(f4)|f3]  [up(f3)|f2]  [up(f2)|f1]
         B01, B12, B02 = buf(384, 4), buf(192, 2), buf(320, 2)      # [up(x00)|x11|f2]  [up(x11)|x22|f1]  [up(x01)|x12|x22|f1]

@@ -623,6 +623,58 @@ def test_flat_halo_kernels_on_awkward_geometries():
     assert ran[27] >= 6 and ran[28] >= 5, ran
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dims,chans,cout,k", [((3, 1, 36, 40), (64, 64), 64, (1, 3, 3)), ((2, 1, 28, 28), (128, 64, 64), 128, (1, 3, 3)), ((1, 2, 18, 50), (64,), 32, (1, 3, 3)),
+                                               ((2, 1, 64, 72), (128, 64, 64, 64), 64, (1, 3, 3)), ((5, 1, 14, 14), (256, 128), 256, (1, 3, 3)), ((1, 1, 2, 2), (64, 128), 24, (1, 3, 3))])
+def test_conv_on_a_gathered_concatenation_equals_the_materialised_one(dims, chans, cout, k, dtype):
+    """PackedConv.gather (tedspad_conv_extras.nchunk_src): the first conv of a unet++ decoder block reads `cat([interpolate(x, 2, 'nearest'), *skips])`
+    in place -- source 0 at half resolution through the x2 index map, the skips from tensors with their own pixel strides (slices of wider
+    buffers). Against the same tile configuration on the materialised concat buffer: bit for bit (same LDS image, same K order); against the
+    oracle's conv on the torch-built concatenation: the conv tolerance."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import _lib, engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, t, h, w = dims
+    cin = sum(chans)
+    pf = (0, (k[1] - 1) // 2, (k[2] - 1) // 2)
+    pb = (0, k[1] - 1 - pf[1], k[2] - 1 - pf[2])
+    wgt = (synth_tensor(31, "gc_w", (cout, cin) + k, -1, 1) * (2.0 / (cin * k[1] * k[2])) ** 0.5).to(tdt).float()
+    scale, shift = synth_tensor(31, "gc_s", (cout,), 0.5, 1.5), synth_tensor(31, "gc_b", (cout,), -0.3, 0.3)
+    pc = E.PackedConv(wgt, scale, shift, dtype=dtype, device="cuda")
+    srcs, parts = [], []
+    for i, c in enumerate(chans):
+        hh, ww = (h // 2, w // 2) if i == 0 else (h, w)
+        wide = synth_tensor(31, "gc_x%d" % i, (n, t, hh, ww, c + 16 * i), -1, 1).to(tdt).cuda()        # the skips are channel slices of wider buffers
+        a = E.Act(wide, c, 8 * i)
+        srcs.append((a, i == 0))
+        v = wide[..., 8 * i:8 * i + c]
+        parts.append(v.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) if i == 0 else v)
+    cat = torch.cat(parts, dim=-1).contiguous()
+    ref = conv_cl(cat.float().cpu(), wgt, scale, shift, (1, 1, 1), pf, pb, None, True)
+    ran = 0
+    for cfg in (32, 33):
+        E.FORCE_TILE_CFG = cfg
+        try:
+            want = pc(E.Act(cat, cin), pads=pf, pads_back=pb).buf
+            got = pc.gather(srcs, pads=pf).buf
+        except _lib.TedSpadHipError:
+            continue                                  # the flat form declines wide frames
+        finally:
+            E.FORCE_TILE_CFG = None
+        ran += 1
+        assert torch.equal(got, want), (cfg, dims, chans)
+        assert rel_l2(got.float().cpu()[..., :cout], ref) < (2e-3 if dtype == "f16" else 1.2e-2), cfg
+    assert ran >= 1
+    got = pc.gather(srcs, pads=pf).buf                # default path (tuner / heuristic)
+    assert rel_l2(got.float().cpu()[..., :cout], ref) < (2e-3 if dtype == "f16" else 1.2e-2)
+    E.FORCE_TILE_CFG = 5
+    try:
+        with pytest.raises(_lib.TedSpadHipError):     # the generic tiles do not take gathered sources
+            pc.gather(srcs, pads=pf)
+    finally:
+        E.FORCE_TILE_CFG = None
+
+
 @pytest.mark.parametrize("dims,c1,c2,cout,stride", [((3, 2, 14, 14), 128, 256, 512, 2), ((2, 2, 7, 9), 256, 512, 1024, 2), ((1, 3, 5, 5), 64, 64, 256, 1),
                                                     ((2, 1, 28, 27), 128, 64, 256, 2)])
 def test_dual_p8_k_concatenated_pair(dims, c1, c2, cout, stride):
