@@ -25,6 +25,7 @@ struct PatchGeo {
     long xelems;             // ... elements of the input tensor (M * ldx)
     int ncc, fstride;        // patch mode with kt > 1 (3 x 3 x 3 convs): channel chunks per temporal tap (nchunks = kt * ncc), elements per input frame
     int R;                   // FLAT: halo positions in front of the tile (ph * W + pw)
+    int dbg;                 // timing ablations (wrong results; TEDSPAD_PATCH_ABLATE): 1 = weight stages only for the first tap of a tile, 2 = halo only for the first chunk
     int T, HW, PXF;          // TEMPORAL: frames of a clip, pixels of a frame, pixels per frame in a tile (256 / T rounded to a power of two)
 };
 
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
     const uint16_t *wsrc = p.w + (size_t)(n0 + rsub) * p.Kpad + kc * 8;
     auto issue_w = [&](int ch, int tap, int slot) {          // ch: chunk index; patch mode with kt > 1: (dt, channel chunk) -> K offset ((dt * taps + tap) * cin + chunk * 64)
+        if ((g.dbg & 1) && (ch | tap)) return;
         const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
         const int dtw = TEMP ? 0 : ch / g.ncc;
         const uint16_t *src = wsrc + (dtw * g.ntaps + tap) * p.cin + (ch - dtw * g.ncc) * 64;
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         started = true;
         asm volatile("" ::: "memory");
         issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
-        if (SRC) {
+        if ((g.dbg & 2) && ch) {
+        } else if (SRC) {
             const uint16_t *sp = gs.ptr[chc] + swo;
             const long sl = gs.ld[chc];
             const bool up = (gs.up >> chc) & 1;
@@ -194,24 +197,45 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 xswz[bq] = (unsigned)(pos >> 1) & 7u;
             }
             if (kt + 1 < g.ntaps) wait_vmcnt<WL>(); else wait_vmcnt<0>();   // stage kt (and, on kt = 0, the halo) landed; stage kt+1 may stay in flight
-            __builtin_amdgcn_s_barrier();
+            if (!(g.dbg & 4) || kt == 0) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (WS == 3 && kt + 2 < g.ntaps) issue_w(ch, kt + 2, (kt + 2) % WS);
             const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * WSTAGE) + l31 * BK;
             if (tap_on) {
+                // fragment reads run PD k-steps ahead of the MFMAs that use them (the compiler's own order was read -> lgkmcnt(0) -> MFMA, one LDS latency per
+                // pair of MFMAs): BN = 64 reads the whole tap first (64 VGPRs of fragments), BN = 128 keeps two k-steps in flight (48 + 24)
+                constexpr int PD = BN == 64 ? 4 : 2;
+                uint4 fa[4][2], fw[4][NA];
+                auto reads = [&](int ks) {
+                    const unsigned c = (unsigned)((ks << 1) | lh);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const unsigned c = (unsigned)((ks << 1) | lh);
-                uint4 fa[2], fw[NA];
+                    for (int bq = 0; bq < 2; ++bq) fa[ks][bq] = *reinterpret_cast<const uint4 *>(dsm + xoff[bq] + ((c ^ xswz[bq]) << 4));
 #pragma unroll
-                for (int bq = 0; bq < 2; ++bq) fa[bq] = *reinterpret_cast<const uint4 *>(dsm + xoff[bq] + ((c ^ xswz[bq]) << 4));
+                    for (int a = 0; a < NA; ++a) fw[ks][a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+                };
+                if ((g.dbg & 8) && (ch | kt)) {
 #pragma unroll
-                for (int a = 0; a < NA; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
+                    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int a = 0; a < NA; ++a)
+                        for (int bq = 0; bq < 2; ++bq) fa[ks][bq] = uint4{(unsigned)kt, (unsigned)ch, 0u, 0u};
 #pragma unroll
-                    for (int bq = 0; bq < 2; ++bq) acc[a][bq] = T::mfma(fw[a], fa[bq], acc[a][bq]);
-            }
+                        for (int a = 0; a < NA; ++a) fw[ks][a] = uint4{(unsigned)kt, 1u, (unsigned)ch, 0u};
+                    }
+                } else
+#pragma unroll
+                for (int ks = 0; ks < PD; ++ks) reads(ks);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                        for (int bq = 0; bq < 2; ++bq) acc[a][bq] = T::mfma(fw[ks][a], fa[ks][bq], acc[a][bq]);
+                    if (ks + PD < 4 && !((g.dbg & 8) && (ch | kt))) {
+                        reads(ks + PD);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             if (WS == 2 && kt + 1 < g.ntaps) {             // two slots: stage kt+1 can only be issued once every wave has read stage kt-1 ... and kt
                 __builtin_amdgcn_s_barrier();
@@ -353,6 +377,8 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s, const P
     g.HH = PT_S + p.kh - 1; g.WH = PT_S + p.kw - 1; g.NP = g.HH * g.WH; g.ntaps = p.kh * p.kw; g.nchunks = cin / 64;
     g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.R = 0; g.tiles_n = (p.Cout + BN - 1) / BN;
     if (FLAT) { g.WH = p.Wi; g.NP = 256 + (p.kh - 1) * p.Wi + (p.kw - 1); g.R = p.ph * p.Wi + p.pw; g.tiles_h = 1; g.tiles_w = 1; }
+    static const int dbg_env = getenv("TEDSPAD_PATCH_ABLATE") ? atoi(getenv("TEDSPAD_PATCH_ABLATE")) : 0;
+    g.dbg = dbg_env;
     g.ncc = g.nchunks; g.fstride = p.Hi * p.Wi * p.ldx; g.xelems = (long)p.M * p.ldx;
     if (MODE != 2 && p.kt > 1) g.nchunks = p.kt * g.ncc;       // 3 x 3 x 3: (temporal tap, channel chunk)
     g.T = p.Ti; g.HW = p.Hi * p.Wi; g.PXF = p.Ti <= 1 ? 256 : p.Ti == 2 ? 128 : 64;
@@ -378,6 +404,261 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s, const P
     }
     hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 255) / 256 : TEMP ? (NTf / p.Ti) * g.tiles_w : NTf * g.tiles_h * g.tiles_w) * g.tiles_n), dim3(256), lds, s, p, g, gs);
     return check_launch("tedspad_conv_fwd(patch halo)");
+}
+
+
+// ---- two patches per workgroup (tile_cfg 38) ---------------------------------------------------------------------------------------------------------
+// What bounds conv_patch_kernel<., 64> on the wide 3 x 3 layers (measured with TEDSPAD_PATCH_ABLATE on 400 x 112 x 112, cin 320 -> 64: 2353 us; without the
+// weight stages 1943, without the halo 2000, without either 1692, without the per-tap barriers the same, without the fragment reads 1498; MFMA alone ~1045 at
+// the clock the chip holds): the LDS-DMA fill. A (patch, 64-channel chunk) takes 41.5 KB of halo and 73.7 KB of weights into LDS for 18.9 MFLOP -- two resident
+// workgroups ask for ~42 GB/s per CU, the rate this fill path gives -- and two thirds of those bytes are weights that the neighbouring patch streams again.
+// Here a workgroup owns TWO 16 x 16 patches (any two consecutive ones of the patch list: they share nothing but the weights) and walks K in HALF chunks of 32
+// channels, a 3-tap kernel row per weight stage:
+//   * halo: [2 patches][18 x 18 positions][64 B], piece c of position p at (c ^ ((p >> 1) & 3)) -- conflict-free for the 16 x 16 x 32 MFMA's fragment read
+//     (16 consecutive positions x the lane's k-group; checked over every base offset) -- 41.5 KB, the same as one patch's 64-channel halo;
+//   * weights: ring of 3 stages [3 taps dw][64 co][32 k] = 12 KB; one barrier per stage = per 96 MFMAs (16 per barrier in the one-patch form);
+//   * a wave owns rows 4w .. 4w+3 of both patches x 64 channels: 8 pixel groups x 4 channel groups of 16 x 16 x 32 MFMAs, 128 accumulator registers;
+//   * per (two patches, 64 channels): 83 KB of halo + 73.7 KB of weights for 37.7 MFLOP -- 32 % fewer bytes through the fill path; 76.5 KB of LDS, two
+//     workgroups per CU as before. K is walked (half chunk, dh, dw): fp32 sums re-associated like tiles 15 / 16 / 28 / 32.
+// Stride-1 'same' 1 x 3 x 3 convs with cin % 64 == 0 (cout tiles of 64), plain input or a gathered concatenation; the epilogue is the one-patch kernel's.
+constexpr int P2_WH = 18, P2_NP = P2_WH * P2_WH, P2_PSLOTS = P2_NP * 4;            // 1296 16-byte slots per patch
+constexpr int P2_HALO = (2 * P2_PSLOTS + 63) / 64 * 64 * 16;                       // 41984: the last wave-instruction's upper half is padding
+constexpr int P2_WST = 3 * 64 * 64, P2_NWS = 3;
+constexpr int P2_MAIN = P2_HALO + P2_NWS * P2_WST;
+constexpr int P2_LDS = P2_MAIN > 256 * 68 * 4 ? P2_MAIN : 256 * 68 * 4;
+static_assert(P2_LDS <= 80 * 1024, "two workgroups per CU");
+constexpr int P2_NHI = 2 * P2_PSLOTS / 256;                                        // 10 full DMA instructions per thread (+ one more in wave 0)
+
+struct Patch2Geo {
+    int tiles_h, tiles_w, tiles_n, npatch, nhc, dbg;
+};
+
+template <typename T, bool SRC>
+__global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const Patch2Geo g, const PatchSrc gs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (b % g.tiles_n) * 64;                   // channel tile fastest: consecutive workgroups share their halos through L2
+    b /= g.tiles_n;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16q);
+    int pf[2], ph0[2], pw0[2];
+    bool pon[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int pi = 2 * b + q;
+        pon[q] = pi < g.npatch;
+        if (!pon[q]) pi = 2 * b;
+        const int tw = pi % g.tiles_w, t2 = pi / g.tiles_w;
+        pw0[q] = tw * PT_S; ph0[q] = (t2 % g.tiles_h) * PT_S; pf[q] = t2 / g.tiles_h;
+    }
+    // ---- halo slots of this thread: slot s -> patch s / 1296, position (s % 1296) >> 2, LDS piece s & 3 --------------------------------------------
+    int hpos[P2_NHI + 1], hposU[SRC ? P2_NHI + 1 : 1], hc8[P2_NHI + 1];
+#pragma unroll
+    for (int i = 0; i <= P2_NHI; ++i) {
+        const int s = i * 256 + tid;
+        const int q = s >= P2_PSLOTS ? 1 : 0, r = s - q * P2_PSLOTS;
+        const int pos = r >> 2, hr = pos / P2_WH, hcl = pos - hr * P2_WH;
+        const int ih = ph0[q] - 1 + hr, iw = pw0[q] - 1 + hcl;
+        hc8[i] = ((r & 3) ^ ((pos >> 1) & 3)) << 3;
+        hpos[i] = -1;
+        if (SRC) hposU[i] = -1;
+        if (s < 2 * P2_PSLOTS && pon[q] && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+            hpos[i] = (pf[q] * p.Hi + ih) * p.Wi + iw;
+            if (SRC) hposU[i] = (pf[q] * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1);
+        }
+    }
+    auto issue_halo = [&](int hcx) {
+        if ((g.dbg & 2) && hcx) return;
+        const uint16_t *sp = p.x + hcx * 32;
+        long sl = p.ldx;
+        bool up = false;
+        if (SRC) {
+            const int ck = hcx >> 1;
+            sp = gs.ptr[ck] + (hcx & 1) * 32; sl = gs.ld[ck]; up = (gs.up >> ck) & 1;
+        }
+        if (wave == 0) {      // the 41st wave-instruction (slots 2560 .. 2623, the upper 32 are padding) goes FIRST: the counted waits below see the same tail in every wave
+            const int pi = SRC && up ? hposU[P2_NHI] : hpos[P2_NHI];
+            lds_dma16(hpos[P2_NHI] >= 0 ? sp + pi * sl + hc8[P2_NHI] : zero, lds0 + P2_NHI * 256 * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < P2_NHI; ++i) {
+            const int pi = SRC && up ? hposU[i] : hpos[i];
+            lds_dma16(hpos[i] >= 0 ? sp + pi * sl + hc8[i] : zero, lds0 + (i * 256 + wave * 64) * 16);
+        }
+    };
+    // ---- weight stage (hc, dh): [dw][co][32 k], piece c of row co at c ^ ((co >> 1) & 3) ----------------------------------------------------------
+    int wof[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int s = j * 256 + tid, row = s >> 2, dw = row >> 6, co = row & 63;
+        wof[j] = (n0 + co) * p.Kpad + dw * p.cin + (((s & 3) ^ ((co >> 1) & 3)) << 3);
+    }
+    auto issue_w = [&](int st) {
+        if ((g.dbg & 1) && st) return;
+        const int hcx = st / 3, dh = st - hcx * 3;
+        const unsigned dst = lds0 + P2_HALO + (st % P2_NWS) * P2_WST + wave * 1024;
+        const uint16_t *src = p.w + dh * 3 * p.cin + hcx * 32;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) lds_dma16(src + wof[j], dst + j * 4096);
+    };
+    // ---- MFMA roles --------------------------------------------------------------------------------------------------------------------------------
+    const int l15 = lane & 15, kg = lane >> 4;
+    const unsigned wrd = (unsigned)(l15 * 64 + ((kg ^ ((l15 >> 1) & 3)) << 4));       // this lane's piece of weight row (16 a + l15) of a stage
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[q][r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int S = g.nhc * 3;
+    issue_halo(0);
+    issue_w(0);
+    if (S > 1) issue_w(1);
+    for (int st = 0; st < S; ++st) {
+        const int hcx = st / 3, dh = st - hcx * 3;
+        // stage st (and, on dh = 0, the half chunk's halo, issued after the previous stages' successors) landed; stage st + 1 may stay in flight
+        if (dh == 0 || st + 1 >= S) wait_vmcnt<0>(); else wait_vmcnt<3>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 2 < S) issue_w(st + 2);                   // its slot held stage st - 1: every wave is past it
+        const unsigned wb = (unsigned)(P2_HALO + (st % P2_NWS) * P2_WST) + wrd;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            uint4 fw[4], fa[2][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + dw * 4096 + a * 1024);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pos = (4 * wave + r + dh) * P2_WH + dw + l15;
+                const unsigned ao = (unsigned)(pos * 64 + ((kg ^ ((pos >> 1) & 3)) << 4));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) fa[q][r] = *reinterpret_cast<const uint4 *>(dsm + q * (P2_PSLOTS * 16) + ao);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[q][r][a] = T::mfma16(fw[a], fa[q][r], acc[q][r][a]);
+        }
+        if (dh == 2 && hcx + 1 < g.nhc) {                  // the one halo buffer: the next half chunk can only follow once every wave has read this one
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_halo(hcx + 1);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue, patch by patch: [256 px][64 co] fp32 through LDS -> coalesced 16-byte rows (as conv_patch_kernel) --------------------------------
+    constexpr int STG_LD = 64 + 4;
+    float *stg = reinterpret_cast<float *>(dsm);
+    const int cc = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q) __syncthreads();
+        if (pon[q]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    *reinterpret_cast<f32x4 *>(stg + ((4 * wave + r) * 16 + l15) * STG_LD + 16 * a + 4 * kg) = acc[q][r][a];
+        }
+        __syncthreads();
+        const int nch = n0 + cc * 8;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        const int ho0 = ph0[q], wo0 = pw0[q];
+        const size_t mfirst = ((size_t)pf[q] * p.Ho + ho0) * p.Wo + wo0;       // a patch lies inside one frame: it never straddles a statistics group
+        const size_t sgrp = p.stats_rows ? mfirst / (size_t)p.stats_rows : 0;
+        if (pon[q] && nch < p.Cout) {
+            float sc[8], sf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = p.scale[nch + i]; sf[i] = p.shift[nch + i]; }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = r0 + it * 32;
+                const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
+                if (ho >= p.Ho || wo >= p.Wo) continue;
+                const size_t m = ((size_t)pf[q] * p.Ho + ho) * p.Wo + wo;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
+                if (p.stats) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                }
+                if (p.res) {
+                    float rr[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(p.res + m * p.ldres + nch), rr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += rr[i];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+                }
+                if (p.mask) {
+                    float mk[8];
+                    unpack8<T>(*reinterpret_cast<const uint4 *>(p.mask + m * p.ldmask + nch), mk);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
+                }
+                if (p.y) *reinterpret_cast<uint4 *>(p.y + m * p.ldy + nch) = pack8_lim<T>(v, p.sat);
+                if (p.y32) {
+                    *reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        }
+        if (p.stats) {
+            __syncthreads();
+            float *red = stg;   // [2][32][64]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[r0 * 64 + cc * 8 + i] = s1[i];
+                red[(32 + r0) * 64 + cc * 8 + i] = s2[i];
+            }
+            __syncthreads();
+            float *so = p.stats + sgrp * 2 * p.stats_ld;
+            const bool det = det_enter(q, 2);
+            if (pon[q] && tid < 64 && n0 + tid < p.Cout) {
+                float sa = 0.f, sb = 0.f;
+                for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
+                atomicAdd(so + n0 + tid, sa);
+                atomicAdd(so + p.stats_ld + n0 + tid, sb);
+            }
+            det_exit(det, q, 2);
+        }
+    }
+}
+
+template <typename T, bool SRC>
+int32_t launch_patch2_t(const ConvKP &p, int frames, int cin, hipStream_t s, const PatchSrc *src) {
+    Patch2Geo g;
+    g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.tiles_n = (p.Cout + 63) / 64;
+    g.npatch = frames * g.tiles_h * g.tiles_w; g.nhc = cin / 32;
+    static const int dbg_env = getenv("TEDSPAD_PATCH_ABLATE") ? atoi(getenv("TEDSPAD_PATCH_ABLATE")) : 0;
+    g.dbg = dbg_env;
+    static thread_local int attr_set[2] = {0, 0};
+    auto kfn = conv_patch2_kernel<T, SRC>;
+    if (!attr_set[T::kDtype]) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
+            return TEDSPAD_ELAUNCH;
+        }
+        attr_set[T::kDtype] = 1;
+    }
+    PatchSrc gs{};
+    if (SRC) gs = *src;
+    hipLaunchKernelGGL(kfn, dim3((g.npatch + 1) / 2 * g.tiles_n), dim3(256), P2_LDS, s, p, g, gs);
+    return check_launch("tedspad_conv_fwd(two-patch halo)");
 }
 
 }  // namespace
@@ -422,6 +703,20 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
     }
     if (p.Cout <= 64) return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 64>(p, frames, cin, s) : launch_patch_t<BF16, 64>(p, frames, cin, s);
     return dtype == TEDSPAD_F16 ? launch_patch_t<F16, 128>(p, frames, cin, s) : launch_patch_t<BF16, 128>(p, frames, cin, s);
+}
+
+
+int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src) {
+    const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi;
+    if (cin % 64 != 0 || p.kt != 1 || p.kh != 3 || p.kw != 3 || p.pt != 0 || p.ph != 1 || p.pw != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same ||
+        p.Kpad != 9 * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32) || (src && src->n != cin / 64) || (long)N * p.Ti * p.Hi * p.Wi >= (1L << 31)) {
+        set_error("tedspad_conv_fwd: two-patch halo config (tile_cfg 38) needs a stride-1 'same' 1 x 3 x 3 conv with cin %% 64 == 0 (mask / stats / fp32 output allowed, no strided output map)");
+        return TEDSPAD_EINVAL;
+    }
+    const int frames = N * p.Ti;
+    const bool f16 = dtype == TEDSPAD_F16;
+    if (src) return f16 ? launch_patch2_t<F16, true>(p, frames, cin, s, src) : launch_patch2_t<BF16, true>(p, frames, cin, s, src);
+    return f16 ? launch_patch2_t<F16, false>(p, frames, cin, s, nullptr) : launch_patch2_t<BF16, false>(p, frames, cin, s, nullptr);
 }
 
 }  // namespace tedspad
