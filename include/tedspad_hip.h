@@ -269,6 +269,17 @@ int32_t tedspad_bneck_l1_fwd(const void *x, int32_t ldx, void *y, int32_t ldy, i
                              const void *w_img, const float *scale1, const float *shift1, const float *scale2, const float *shift2,
                              const float *scale3, const float *shift3, int32_t relu, int32_t pool_t2, int32_t variant, int32_t dtype, void *stream);
 
+/* The block that ends the default anonymizer's decoder (arch = 'unet++', aux_code/model_loaders.py:17-30; smp 0.3.3 UnetPlusPlusDecoder blocks['x_0_3'] =
+ * DecoderBlock(64, 0, 32) followed by SegmentationHead(32, 3, kernel_size 3)) in ONE launch, at full resolution:
+ *     y = conv3x3(relu(bn(conv3x3(relu(bn(conv3x3(interpolate(x, 2, 'nearest'))))))) ) + bias         64 -> 32 -> 32 -> 3
+ * x: (n, h/2, w/2, 64) channels-last 16-bit, pixel stride ldx; y: (n, 3, h, w) fp32 NCHW (the model's output as the extraction loops consume it,
+ * dali_extraction.py:169-173); both 32-channel tensors stay in LDS. w_img: tedspad_unetpp_tail_wimg_bytes() bytes, the three weight tensors in the kernel's
+ * LDS image: [hc 2][tap 9][co 32][32 ci] | [tap 9][co 32][32 ci] | [tap 9][co 16 (3 used)][32 ci] 16-bit, the four 16-byte pieces of a 64-byte row stored at
+ * piece ^ ((co >> 1) & 3) (unetpp.py packs it); scale / shift: the folded BatchNorms (32 values each), bias3: 3 values. */
+int32_t tedspad_unetpp_tail_wimg_bytes(void);
+int32_t tedspad_unetpp_tail_fwd(const void *x, int32_t ldx, float *y, int32_t n, int32_t h, int32_t w, const void *w_img, const float *scale1,
+                                const float *shift1, const float *scale2, const float *shift2, const float *bias3, int32_t dtype, void *stream);
+
 /* Weight gradient: dw[co][k] += sum over output pixels of dy[m][co] * x[m @ tap(k)][ci(k)], fp32, in the
  * packed [cout_pad][kpad] layout of the forward weights (k ordered (dt,dh,dw,ci)). `dw` must be
  * zeroed by the caller (hipMemsetAsync on the same stream); accumulation uses float atomics.

@@ -107,6 +107,8 @@ SYMBOLS = {
     "tedspad_bneck_l1_lds_bytes": (_I32, [_I32]),
     "tedspad_bneck_l1_units": (_I32, [_I32, _I32]),
     "tedspad_bneck_l1_fwd": (_I32, [_P, _I32, _P, _I32] + [_I32] * 6 + [_P] * 7 + [_I32] * 4 + [_P]),
+    "tedspad_unetpp_tail_wimg_bytes": (_I32, []),
+    "tedspad_unetpp_tail_fwd": (_I32, [_P, _I32, _P, _I32, _I32, _I32] + [_P] * 6 + [_I32, _P]),
     "tedspad_stem_pt_pool_clip_fwd": (_I32, [_P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 3 + [_P] * 5 + [_I32] * 6 + [_P]),
     "tedspad_upsample_nearest2x_fwd": (_I32, [_P, _P] + [_I32] * 6 + [_P]),
     "tedspad_copy_channels": (_I32, [_P, _P, _I64, _I32, _I32, _I32, _P]),

@@ -420,7 +420,8 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s, const P
 //   * a wave owns rows 4w .. 4w+3 of both patches x 64 channels: 8 pixel groups x 4 channel groups of 16 x 16 x 32 MFMAs, 128 accumulator registers;
 //   * per (two patches, 64 channels): 83 KB of halo + 73.7 KB of weights for 37.7 MFLOP -- 32 % fewer bytes through the fill path; 76.5 KB of LDS, two
 //     workgroups per CU as before. K is walked (half chunk, dh, dw): fp32 sums re-associated like tiles 15 / 16 / 28 / 32.
-// Stride-1 'same' 1 x 3 x 3 convs with cin % 64 == 0 (cout tiles of 64), plain input or a gathered concatenation; the epilogue is the one-patch kernel's.
+// Stride-1 'same' 1 x 3 x 3 convs with cin % 32 == 0 (cout tiles of 64; 16-channel groups beyond cout are neither fetched nor multiplied: the 64 -> 32 -> 32 -> 3
+// block at full resolution that ends the unet++ decoder), plain input or a gathered concatenation (cin % 64 == 0); the epilogue is the one-patch kernel's.
 constexpr int P2_WH = 18, P2_NP = P2_WH * P2_WH, P2_PSLOTS = P2_NP * 4;            // 1296 16-byte slots per patch
 constexpr int P2_HALO = (2 * P2_PSLOTS + 63) / 64 * 64 * 16;                       // 41984: the last wave-instruction's upper half is padding
 constexpr int P2_WST = 3 * 64 * 64, P2_NWS = 3;
@@ -495,8 +496,9 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
         const int s = j * 256 + tid, row = s >> 2, dw = row >> 6, co = row & 63;
         wof[j] = (n0 + co) * p.Kpad + dw * p.cin + (((s & 3) ^ ((co >> 1) & 3)) << 3);
     }
-    auto issue_w = [&](int st) {
-        if ((g.dbg & 1) && st) return;
+    const int na = (p.Cout - n0 + 15) >> 4 < 4 ? (p.Cout - n0 + 15) >> 4 : 4;      // 16-channel groups this tile really has (cout 32 / 8: the unet++ head block)
+    auto issue_w = [&](int st) {           // wave w moves channel group w (16 rows x 3 taps): groups beyond cout are not fetched
+        if (((g.dbg & 1) && st) || wave >= na) return;
         const int hcx = st / 3, dh = st - hcx * 3;
         const unsigned dst = lds0 + P2_HALO + (st % P2_NWS) * P2_WST + wave * 1024;
         const uint16_t *src = p.w + dh * 3 * p.cin + hcx * 32;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
     for (int st = 0; st < S; ++st) {
         const int hcx = st / 3, dh = st - hcx * 3;
         // stage st (and, on dh = 0, the half chunk's halo, issued after the previous stages' successors) landed; stage st + 1 may stay in flight
-        if (dh == 0 || st + 1 >= S) wait_vmcnt<0>(); else wait_vmcnt<3>();
+        if (dh == 0 || st + 1 >= S || wave >= na) wait_vmcnt<0>(); else wait_vmcnt<3>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (st + 2 < S) issue_w(st + 2);                   // its slot held stage st - 1: every wave is past it
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
         for (int dw = 0; dw < 3; ++dw) {
             uint4 fw[4], fa[2][4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + dw * 4096 + a * 1024);
+            for (int a = 0; a < 4; ++a) if (a < na) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + dw * 4096 + a * 1024);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pos = (4 * wave + r + dh) * P2_WH + dw + l15;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[q][r][a] = T::mfma16(fw[a], fa[q][r], acc[q][r][a]);
+                    for (int a = 0; a < 4; ++a) if (a < na) acc[q][r][a] = T::mfma16(fw[a], fa[q][r], acc[q][r][a]);
         }
         if (dh == 2 && hcx + 1 < g.nhc) {                  // the one halo buffer: the next half chunk can only follow once every wave has read this one
             __builtin_amdgcn_s_barrier();
@@ -708,9 +710,9 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
 
 int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src) {
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi;
-    if (cin % 64 != 0 || p.kt != 1 || p.kh != 3 || p.kw != 3 || p.pt != 0 || p.ph != 1 || p.pw != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same ||
-        p.Kpad != 9 * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32) || (src && src->n != cin / 64) || (long)N * p.Ti * p.Hi * p.Wi >= (1L << 31)) {
-        set_error("tedspad_conv_fwd: two-patch halo config (tile_cfg 38) needs a stride-1 'same' 1 x 3 x 3 conv with cin %% 64 == 0 (mask / stats / fp32 output allowed, no strided output map)");
+    if (cin % 32 != 0 || (src && cin % 64 != 0) || p.kt != 1 || p.kh != 3 || p.kw != 3 || p.pt != 0 || p.ph != 1 || p.pw != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same ||
+        p.Kpad < 9 * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32) || (src && src->n != cin / 64) || (long)N * p.Ti * p.Hi * p.Wi >= (1L << 31)) {
+        set_error("tedspad_conv_fwd: two-patch halo config (tile_cfg 38) needs a stride-1 'same' 1 x 3 x 3 conv with cin %% 32 == 0 (gathered sources: %% 64; mask / stats / fp32 output allowed, no strided output map)");
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;

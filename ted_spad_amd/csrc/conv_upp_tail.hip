@@ -1,0 +1,297 @@
+// The block that ends the default anonymizer's decoder, in one launch (arch = 'unet++', aux_code/model_loaders.py:17-30; smp 0.3.3
+// decoders/unetplusplus/decoder.py: blocks['x_0_3'] = DecoderBlock(64, 0, 32), base/heads.py SegmentationHead(32, 3, kernel_size = 3)):
+//     y = conv3x3_{32->3}( relu(bn(conv3x3_{32->32}( relu(bn(conv3x3_{64->32}( interpolate(x, 2, 'nearest') ))) ))) ) + bias            (fp32 NCHW out)
+// at FULL resolution (16 x 224 x 224 pixels per clip). As separate launches these layers are latency-bound streams (profiles/r04_anon_extract_kernels_1stream.md:
+// 64 -> 32 at 2.0 ms, 32 -> 32 at 1.4 ms, 32 -> 3 at 1.1-1.4 ms per 400 frames, each moving 1.3-3.9 GB for 0.2-0.7 TFLOP); fused, HBM sees the half-resolution
+// 64-channel input (0.64 GB) and the 3-channel fp32 output (0.24 GB).
+//
+// One PERSISTENT 8-wave workgroup per CU; ALL weights (63 KB) are loaded into LDS once per launch; the workgroup walks 16 x 16 output patches:
+//   X   the patch's input: 12 x 12 half-resolution positions x 64 channels as two half-chunk images (64-byte positions, piece c of position p at
+//       c ^ ((p >> 1) & 3): the 16 x 16 x 32 MFMA's fragment read is conflict-free on it), double-buffered: the next patch's X lands while this one is computed;
+//   M1  conv1's output on the 20 x 20 halo conv2 needs, 32 channels = one 64-byte position each; positions outside the image are ZERO (conv2 pads conv1's
+//       output, not its input);  M2  conv2's output on 18 x 18, likewise;  the head writes y straight from the accumulators.
+// The nearest x2 upsample is the fragment address: M1 position (r, c), tap (dh, dw) reads X position ((r + dh + 1) >> 1, (c + dw + 1) >> 1).
+// Work split: 16-pixel groups of the stage's output (25 / 21 / 16 of them) dealt round-robin to the 8 waves, every wave computing all of a group's channels.
+// Three barriers per patch; no weight stream, no per-tap barrier. conv1 re-computes a 20 x 20 halo per 16 x 16 patch (1.56 x), conv2 18 x 18 (1.27 x).
+#include "conv_common.h"
+
+namespace tedspad {
+namespace {
+
+__device__ uint4 g_zero16t;
+
+constexpr int UT_W1 = 2 * 9 * 32 * 64, UT_W2 = 9 * 32 * 64, UT_W3 = 9 * 16 * 64;     // bytes: [hc][tap][co][32 ci], [tap][co][32], [tap][16 co][32]
+constexpr int UT_WIMG = UT_W1 + UT_W2 + UT_W3;                                      // 64512
+constexpr int UT_M1P = 20 * 20, UT_M2P = 18 * 18, UT_XP = 12 * 12;
+constexpr int UT_OFF_M1 = UT_WIMG, UT_OFF_M2 = UT_OFF_M1 + UT_M1P * 64, UT_OFF_X = UT_OFF_M2 + UT_M2P * 64;
+constexpr int UT_XBYTES = 2 * UT_XP * 64;                                            // 18432 per buffer
+constexpr int UT_LDS = UT_OFF_X + 2 * UT_XBYTES;                                     // 147712
+static_assert(UT_LDS <= 160 * 1024 && UT_WIMG % 1024 == 0, "LDS budget");
+
+struct UppTailKP {
+    const uint16_t *x;
+    const uint16_t *wimg;
+    const float *sc1, *sh1, *sc2, *sh2, *b3;
+    float *y;
+    int ldx, N, H, W, tiles_h, tiles_w, npatch;
+};
+
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float a, float b);
+template <>
+__device__ __forceinline__ unsigned pack2<F16>(float a, float b) {
+    return (unsigned)F16::from_f32_lim(a, 65504.f) | ((unsigned)F16::from_f32_lim(b, 65504.f) << 16);
+}
+template <>
+__device__ __forceinline__ unsigned pack2<BF16>(float a, float b) {
+    return (unsigned)BF16::from_f32_lim(a, 3.3e38f) | ((unsigned)BF16::from_f32_lim(b, 3.3e38f) << 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16t);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+
+    // ---- the weight image, once ---------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i * 512 + wave * 64 < UT_WIMG / 16) lds_dma16(p.wimg + (size_t)(i * 512 + tid) * 8, lds0 + (i * 512 + wave * 64) * 16);
+
+    // ---- X slots of this thread: slot s -> half chunk s / 576, position (s % 576) >> 2, LDS piece s & 3 (the same for every patch) -------------------
+    int xr[3], xc[3], xo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int s = i * 512 + tid, hcx = s >= 4 * UT_XP ? 1 : 0, r = s - hcx * 4 * UT_XP, pos = r >> 2;
+        xr[i] = pos / 12; xc[i] = pos - xr[i] * 12;
+        xo[i] = hcx * 32 + (((r & 3) ^ ((pos >> 1) & 3)) << 3);
+    }
+    auto patch_org = [&](int pi, int &f, int &oy, int &ox) {
+        const int tx = pi % p.tiles_w, t2 = pi / p.tiles_w;
+        ox = tx * 16; oy = (t2 % p.tiles_h) * 16; f = t2 / p.tiles_h;
+    };
+    auto issue_x = [&](int pi, int buf) {
+        int f, oy, ox;
+        patch_org(pi, f, oy, ox);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i * 512 + wave * 64 >= 8 * UT_XP) break;               // 1152 slots: the third instruction in waves 0 and 1 only
+            const int y2 = (oy >> 1) - 2 + xr[i], x2 = (ox >> 1) - 2 + xc[i];
+            const bool in = (unsigned)y2 < (unsigned)H2 && (unsigned)x2 < (unsigned)W2;
+            lds_dma16(in ? p.x + ((size_t)(f * H2 + y2) * W2 + x2) * p.ldx + xo[i] : zero, lds0 + UT_OFF_X + buf * UT_XBYTES + (i * 512 + wave * 64) * 16);
+        }
+    };
+
+    // ---- per-lane constants -----------------------------------------------------------------------------------------------------------------------------
+    const unsigned wrd = (unsigned)(l15 * 64 + ((kg ^ ((l15 >> 1) & 3)) << 4));      // this lane's piece of weight row (16 a + l15)
+    float sc1[2][4], sh1[2][4], sc2[2][4], sh2[2][4], b3[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = 16 * a + 4 * kg + e;
+            sc1[a][e] = p.sc1[co]; sh1[a][e] = p.sh1[co]; sc2[a][e] = p.sc2[co]; sh2[a][e] = p.sh2[co];
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b3[e] = (4 * kg + e) < 3 ? p.b3[4 * kg + e] : 0.f;
+
+    int pi = blockIdx.x;
+    if (pi < p.npatch) issue_x(pi, 0);
+    int buf = 0;
+    for (; pi < p.npatch; pi += gridDim.x, buf ^= 1) {
+        int f, oy, ox;
+        patch_org(pi, f, oy, ox);
+        wait_vmcnt<0>();                                   // this patch's X (and, the first time, the weights) landed; the previous patch's stores are out
+        __syncthreads();                                   // ... in every wave; and every wave is done with the previous patch's M2 and the other X buffer
+        if (pi + (int)gridDim.x < p.npatch) issue_x(pi + gridDim.x, buf ^ 1);
+
+        // ---- conv1: 64 (upsampled) -> 32 on the 20 x 20 halo: groups g = wave, wave + 8, ... of 16 consecutive M1 positions ---------------------------
+        {
+            f32x4 acc[4][2];
+            int rr[4], cq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = (wave + 8 * j) * 16 + l15;
+                rr[j] = i / 20; cq[j] = i - rr[j] * 20;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[j][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int ng = wave == 0 ? 4 : 3;              // 25 groups
+            const unsigned xb = (unsigned)(UT_OFF_X + buf * UT_XBYTES);
+#pragma unroll 1
+            for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const unsigned wb = (unsigned)((hc * 9 + dh * 3 + dw) * 32 * 64) + wrd;
+                        uint4 fw[2], fa[4];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < ng) {
+                                const int xp = ((rr[j] + dh + 1) >> 1) * 12 + ((cq[j] + dw + 1) >> 1);
+                                fa[j] = *reinterpret_cast<const uint4 *>(dsm + xb + hc * (UT_XP * 64) + xp * 64 + ((kg ^ ((xp >> 1) & 3)) << 4));
+                            }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < ng) {
+#pragma unroll
+                                for (int a = 0; a < 2; ++a) acc[j][a] = T::mfma16(fw[a], fa[j], acc[j][a]);
+                            }
+                    }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ng) {
+                    const int i = (wave + 8 * j) * 16 + l15;
+                    const bool in = (unsigned)(oy - 2 + rr[j]) < (unsigned)p.H && (unsigned)(ox - 2 + cq[j]) < (unsigned)p.W;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = in ? __builtin_fmaxf(acc[j][a][e] * sc1[a][e] + sh1[a][e], 0.f) : 0.f;
+                        uint2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                        *reinterpret_cast<uint2 *>(dsm + UT_OFF_M1 + i * 64 + (((2 * a + (kg >> 1)) ^ ((i >> 1) & 3)) << 4) + (kg & 1) * 8) = pk;
+                    }
+                }
+        }
+        __syncthreads();
+
+        // ---- conv2: 32 -> 32 on 18 x 18: 21 groups of 16 consecutive M2 positions (the last one has 4) ------------------------------------------------
+        {
+            f32x4 acc[3][2];
+            int rr[3], cq[3], idx[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int i = (wave + 8 * j) * 16 + l15;
+                idx[j] = i;
+                const int ic = i < UT_M2P ? i : UT_M2P - 1;
+                rr[j] = ic / 18; cq[j] = ic - rr[j] * 18;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[j][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int ng = wave < 5 ? 3 : 2;               // 21 groups
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const unsigned wb = (unsigned)(UT_W1 + (dh * 3 + dw) * 32 * 64) + wrd;
+                    uint4 fw[2], fa[3];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < ng) {
+                            const int mp = (rr[j] + dh) * 20 + cq[j] + dw;
+                            fa[j] = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M1 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
+                        }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < ng) {
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) acc[j][a] = T::mfma16(fw[a], fa[j], acc[j][a]);
+                        }
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < ng && idx[j] < UT_M2P) {
+                    const int i = idx[j];
+                    const bool in = (unsigned)(oy - 1 + rr[j]) < (unsigned)p.H && (unsigned)(ox - 1 + cq[j]) < (unsigned)p.W;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = in ? __builtin_fmaxf(acc[j][a][e] * sc2[a][e] + sh2[a][e], 0.f) : 0.f;
+                        uint2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                        *reinterpret_cast<uint2 *>(dsm + UT_OFF_M2 + i * 64 + (((2 * a + (kg >> 1)) ^ ((i >> 1) & 3)) << 4) + (kg & 1) * 8) = pk;
+                    }
+                }
+        }
+        __syncthreads();
+
+        // ---- head: 32 -> 3 (+ bias) on 16 x 16: output rows wave, wave + 8; fp32 NCHW straight from the accumulators ----------------------------------
+        {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const uint4 fw = *reinterpret_cast<const uint4 *>(dsm + (unsigned)(UT_W1 + UT_W2 + (dh * 3 + dw) * 16 * 64) + wrd);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int mp = (wave + 8 * j + dh) * 18 + l15 + dw;
+                        const uint4 fa = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M2 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
+                        acc[j] = T::mfma16(fw, fa, acc[j]);
+                    }
+                }
+            if (kg == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int yy = oy + wave + 8 * j, xx = ox + l15;
+                    if (yy < p.H && xx < p.W) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) p.y[(((size_t)f * 3 + e) * p.H + yy) * p.W + xx] = acc[j][e] + b3[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace tedspad
+
+using namespace tedspad;
+
+extern "C" int32_t tedspad_unetpp_tail_wimg_bytes(void) { return UT_WIMG; }
+
+extern "C" int32_t tedspad_unetpp_tail_fwd(const void *x, int32_t ldx, float *y, int32_t n, int32_t h, int32_t w, const void *w_img, const float *scale1,
+                                           const float *shift1, const float *scale2, const float *shift2, const float *bias3, int32_t dtype, void *stream) {
+    TS_REQUIRE(x && y && w_img && scale1 && shift1 && scale2 && shift2 && bias3, "tedspad_unetpp_tail_fwd: null pointer");
+    TS_REQUIRE(((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_img) % 16 == 0, "tedspad_unetpp_tail_fwd: pointers must be 16-byte aligned");
+    TS_REQUIRE(n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && ldx >= 64 && ldx % 8 == 0, "tedspad_unetpp_tail_fwd: h, w even; ldx >= 64, multiple of 8");
+    TS_REQUIRE((long)n * (h / 2) * (w / 2) * ldx < (1L << 31) && (long)n * 3 * h * w < (1L << 31), "tedspad_unetpp_tail_fwd: tensor too large; split the batch");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_unetpp_tail_fwd: dtype");
+    UppTailKP p;
+    p.x = (const uint16_t *)x; p.wimg = (const uint16_t *)w_img; p.sc1 = scale1; p.sh1 = shift1; p.sc2 = scale2; p.sh2 = shift2; p.b3 = bias3; p.y = y;
+    p.ldx = ldx; p.N = n; p.H = h; p.W = w; p.tiles_h = (h + 15) / 16; p.tiles_w = (w + 15) / 16; p.npatch = n * p.tiles_h * p.tiles_w;
+    static thread_local int attr_set[2] = {0, 0};
+    static thread_local int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            set_error("tedspad_unetpp_tail_fwd: cannot query the device");
+            return TEDSPAD_ELAUNCH;
+        }
+        ncu = prop.multiProcessorCount;
+    }
+    const int grid = p.npatch < ncu ? p.npatch : ncu;
+    if (dtype == TEDSPAD_F16) {
+        auto kfn = unetpp_tail_kernel<F16>;
+        if (!attr_set[0]) {
+            if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("tedspad_unetpp_tail_fwd: cannot raise the dynamic LDS limit");
+                return TEDSPAD_ELAUNCH;
+            }
+            attr_set[0] = 1;
+        }
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), UT_LDS, (hipStream_t)stream, p);
+    } else {
+        auto kfn = unetpp_tail_kernel<BF16>;
+        if (!attr_set[1]) {
+            if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("tedspad_unetpp_tail_fwd: cannot raise the dynamic LDS limit");
+                return TEDSPAD_ELAUNCH;
+            }
+            attr_set[1] = 1;
+        }
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), UT_LDS, (hipStream_t)stream, p);
+    }
+    return check_launch("tedspad_unetpp_tail_fwd");
+}

@@ -34,6 +34,7 @@ TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
 BNECK_L1_MODE = int(os.environ.get("TEDSPAD_BNECK_L1", "0"))     # 0 off, 1 every plain block of layer1 (the last one with maxpool2 inside if TEDSPAD_BNECK_L1_POOL), 2 only the last (pooled) block
 BNECK_L1 = BNECK_L1_MODE != 0     # layer1's plain bottlenecks as ONE launch each (BneckL1: conv1 recomputed on tile halos, mid tensors in LDS); 0: temporal conv + fused tail (two launches)
+UPP_TAIL = os.environ.get("TEDSPAD_UPP_TAIL", "1") != "0"              # unet++: x_0_3 + segmentation head as one launch (tedspad_unetpp_tail_fwd)
 GATHER_CAT = os.environ.get("TEDSPAD_GATHER_CAT", "1") != "0"          # unet++ decoder blocks read upsample + concat in place (PackedConv.gather)
 BNECK_L1_POOL = os.environ.get("TEDSPAD_BNECK_L1_POOL", "1") != "0"   # ... the last block with maxpool2 inside as well
 STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)

@@ -119,6 +119,7 @@ class UnetPlusPlus(nn.Module):
         sig = (params_signature(self), self.compute_dtype)
         if self._packed is not None and self._packed_sig != sig and sig[1] == self._packed_sig[1] and E.same_storage(sig[0], self._packed_sig[0]):
             self._refresh.run(self.encoder.conv1.weight.device)    # updated in place (the other phase's optimizer step): two launches
+            self._packed["tail"] = self._pack_tail(self.encoder.conv1.weight.device)
             self._packed_sig = sig
         if self._packed is None or self._packed_sig != sig:
             E.require_cuda(self.encoder.conv1.weight, "UnetPlusPlus")
@@ -148,8 +149,42 @@ class UnetPlusPlus(nn.Module):
             P["head"] = E.PackedConv(head.weight.detach().unsqueeze(2), torch.ones(head.weight.shape[0]), head.bias, dtype=dt, device=dev)
             R.pack(P["head"], head.weight)
             R.bias(P["head"], head.bias)
+            P["tail"] = self._pack_tail(dev)
             self._packed, self._packed_sig = P, sig
         return self._packed
+
+    def _pack_tail(self, dev):
+        """The LDS weight image of tedspad_unetpp_tail_fwd (csrc/conv_upp_tail.hip): x_0_3.conv1 [hc 2][tap 9][co 32][32 ci] | x_0_3.conv2 [tap 9][co 32][32 ci] |
+        head [tap 9][co 16 (3 used)][32 ci], the four 16-byte pieces of every 64-byte row stored at piece ^ ((co >> 1) & 3). BatchNorm stays in scale / shift."""
+        blk = self.decoder.blocks["x_0_3"]
+
+        def img(w, co_pad, nhc):
+            co, ci = w.shape[:2]
+            wp = torch.zeros((co_pad, nhc * 32, 3, 3), dtype=torch.float32, device=dev)
+            wp[:co, :ci] = w.detach().to(dev, torch.float32)
+            t = wp.permute(2, 3, 0, 1).reshape(9, co_pad, nhc, 4, 8).permute(2, 0, 1, 3, 4).contiguous()       # [hc][tap][co][piece][8]
+            cidx, ps = torch.arange(co_pad, device=dev), torch.arange(4, device=dev)
+            src = ps[None, :] ^ ((cidx[:, None] >> 1) & 3)                                                        # LDS piece slot -> source piece
+            return torch.gather(t, 3, src[None, None, :, :, None].expand(nhc, 9, co_pad, 4, 8)).reshape(-1)
+
+        wimg = torch.cat([img(blk.conv1[0].weight, 32, 2), img(blk.conv2[0].weight, 32, 1), img(self.segmentation_head[0].weight, 16, 1)])
+        wimg = wimg.to(E.DTYPES[self.compute_dtype][0]).contiguous()
+        assert wimg.numel() * 2 == _lib.lib().tedspad_unetpp_tail_wimg_bytes()
+        return wimg
+
+    def _tail(self, x02: Act, P) -> torch.Tensor:
+        """x_0_3 (interpolate + conv-bn-relu + conv-bn-relu) + segmentation head in one launch: (n, 1, h/2, w/2, 64) -> (n, 3, h, w) fp32."""
+        n, _, h2, w2 = x02.dims
+        c1, c2, hd = P["x_0_3.conv1"], P["x_0_3.conv2"], P["head"]
+        y = torch.empty((n, 3, 2 * h2, 2 * w2), dtype=torch.float32, device=x02.buf.device)
+        nc = max(1, min(n, ((1 << 31) - 1) // max(h2 * w2 * x02.ld, 12 * h2 * w2)))
+        for n0 in range(0, n, nc):
+            n1 = min(n, n0 + nc)
+            xs = Act(x02.buf[n0:n1], x02.c, x02.coff)
+            check(_lib.lib().tedspad_unetpp_tail_fwd(xs.ptr, xs.ld, y[n0:n1].data_ptr(), n1 - n0, 2 * h2, 2 * w2, P["tail"].data_ptr(), c1.scale.data_ptr(),
+                                                     c1.shift.data_ptr(), c2.scale.data_ptr(), c2.shift.data_ptr(), hd.shift.data_ptr(),
+                                                     E.DTYPES[self.compute_dtype][1], _stream_ptr()), "tedspad_unetpp_tail_fwd")
+        return y
 
     # ---- launch sequence ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -191,6 +226,8 @@ class UnetPlusPlus(nn.Module):
         x01 = block("x_0_1", x00, x11, f2)
         x12 = block("x_1_2", x11, x22, f1)
         x02 = block("x_0_2", x01, x12, x22, f1)
+        if E.UPP_TAIL and taps is None:
+            return self._tail(x02, P)
         x03 = block("x_0_3", x02)
         if taps is not None:
             taps.update(f1=f1, f2=f2, f3=f3, f4=f4, x00=x00, x11=x11, x22=x22, x01=x01, x12=x12, x02=x02, x03=x03)

@@ -115,6 +115,19 @@ def test_unetpp_eval_vs_oracle(unetpp, shape):
         r = rt[k if k.startswith("f") else "x_%s_%s" % (k[1], k[2])]
         assert rel_l2(got, r) < 2e-3, (k, rel_l2(got, r))
     assert rel_l2(y.cpu(), ref) < 2e-3
+    # the production launch sequence (no taps): x_0_3 + the segmentation head as ONE launch (tedspad_unetpp_tail_fwd), both 32-channel tensors in LDS --
+    # the same 16-bit rounding points as the three launches it replaces, fp32 sums in another order
+    yf = unetpp(frames.cuda())
+    assert yf.shape == ref.shape and yf.dtype == torch.float32
+    assert rel_l2(yf.cpu(), ref) < 2e-3 and rel_l2(yf.cpu(), y.cpu()) < 1e-3, (rel_l2(yf.cpu(), ref), rel_l2(yf.cpu(), y.cpu()))
+    for flag, val in (("UPP_TAIL", False), ("GATHER_CAT", False)):       # ... and the launch sequences it replaced
+        old = getattr(E, flag)
+        try:
+            setattr(E, flag, val)
+            yo = unetpp(frames.cuda())
+        finally:
+            setattr(E, flag, old)
+        assert rel_l2(yo.cpu(), ref) < 2e-3, flag
     with pytest.raises(RuntimeError):
         unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
     # train(): batch-statistics BatchNorm (train_anonymizer.py:73 puts fa in train mode), running statistics moved once per call

@@ -452,6 +452,9 @@ AGREE = [
     ("a_cflat_3x3_c128_n128", (3, 2, 13, 28), 128, 128, (1, 3, 3), (0, 1, 1), True),   # flat chunk-major tile (33): tiles cross rows / frames / clips
     ("a_temp_3x1x1_t2_c128_n256", (3, 2, 9, 15), 128, 256, (3, 1, 1), (1, 0, 0), True),  # temporal chunk-major tile (34): T = 2 (a third of the taps skipped), two channel tiles
     ("a_temp_3x1x1_t3_c64_n72", (2, 3, 5, 7), 64, 72, (3, 1, 1), (1, 0, 0), False),      # ... T = 3 (192 of 256 positions), ragged N
+    ("a_p2_3x3_c32_n32", (2, 1, 21, 37), 32, 32, (1, 3, 3), (0, 1, 1), True),             # two-patch tile (38): one half chunk, two of four channel groups, odd patch count
+    ("a_p2_3x3_c96_n8", (1, 2, 18, 20), 96, 8, (1, 3, 3), (0, 1, 1), False),              # ... three half chunks, one channel group (the unet++ head)
+    ("a_p2_3x3_c128_n136", (3, 1, 33, 16), 128, 136, (1, 3, 3), (0, 1, 1), True),          # ... three channel tiles, the last with one group
     ("a_patch_3x3_c128_n320", (2, 2, 14, 14), 128, 320, (1, 3, 3), (0, 1, 1), True),   # patch / flat chunk-major tiles with three channel tiles (N-tiling)
     ("a_patch_3x3_c64", (2, 1, 20, 37), 64, 64, (1, 3, 3), (0, 1, 1), True),          # patch-halo tile (32): ragged 16 x 16 patches, residual
     ("a_patch_3x3_c128_n128", (1, 2, 17, 16), 128, 128, (1, 3, 3), (0, 1, 1), False),  # ... two channel chunks, 128 output channels (2-slot ring)
