@@ -449,12 +449,13 @@ class FBTrainer:
     def flush_grads(self):
         self.trunk.flush_grads()
 
-    def forward(self, x: torch.Tensor, mode: str):
-        """x: (N,3,H,W) fp32 -> (embedding (N,128) unit-norm, tape)."""
+    def forward(self, x: torch.Tensor, mode: str, groups: int = 1):
+        """x: (N,3,H,W) fp32 -> (embedding (N,128) unit-norm, tape). groups > 1 (train mode): x holds `groups` batches the reference passes through fb in
+        separate calls (the two anonymised views, train_anonymizer.py:153-157): separate batch statistics per block, running statistics moved block by block."""
         assert mode in ("eval", "train")
         E.require_cuda(x, "FBTrainer")
         r, mlp = self.m[0], self.m[1]
-        f, tape = self.trunk.forward(E.clip_to_act(x.unsqueeze(2), cpad=4, dtype=r.compute_dtype), mode == "train")
+        f, tape = self.trunk.forward(E.clip_to_act(x.unsqueeze(2), cpad=4, dtype=r.compute_dtype), mode == "train", groups=groups if mode == "train" else 1)
         tape["mode"], tape["x_shape"] = mode, tuple(x.shape)
         h = head.linear(f, mlp.fc1.weight, mlp.fc1.bias, relu=True)
         g = head.linear(h, mlp.fc2.weight, mlp.fc2.bias)
@@ -518,11 +519,14 @@ class UNetTrainer:
     def flush_grads(self):
         TE.flush_conv_grads(self.conv_layers())
 
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, groups: int = 1):
         """x: (N,3,H,W) fp32 -> (y (N,3,H,W) fp32, tape). BatchNorm2d uses the batch statistics of this call
-        and updates the running stats once (the reference calls fa on the B*48 pseudo-images at once, Q2/Q14)."""
+        and updates the running stats once (the reference calls fa on the B*48 pseudo-images at once, Q2/Q14).
+        groups > 1: x holds `groups` batches of N / groups images that the reference passes through the module in SEPARATE calls (the two VISPR views,
+        train_anonymizer.py:80-84): every BatchNorm keeps one set of batch statistics per block and moves its running statistics once per block, in order."""
         m = self.m
         E.require_cuda(x, "UNetTrainer")
+        assert x.shape[0] % groups == 0
         self.refresh.run()
         n, _, H, W = x.shape
         tdt = E.DTYPES[m.compute_dtype][0]
@@ -537,15 +541,15 @@ class UNetTrainer:
                 cur, rec["pool_idx"] = E.maxpool(cur, (1, 2, 2), (1, 2, 2), return_idx=True)
                 h, w = h // 2, w // 2
             cat = Act.empty(n, 1, h, w, 2 * self.ENC[lvl], tdt, x.device)
-            mid, rec["u1"] = TE.conv_bn_act_train(units[0][0], units[0][1], cur)
-            skip, rec["u2"] = TE.conv_bn_act_train(units[1][0], units[1][1], mid, out=cat.slice(0, self.ENC[lvl]))
+            mid, rec["u1"] = TE.conv_bn_act_train(units[0][0], units[0][1], cur, groups=groups)
+            skip, rec["u2"] = TE.conv_bn_act_train(units[1][0], units[1][1], mid, out=cat.slice(0, self.ENC[lvl]), groups=groups)
             cats.append(cat)
             tape["enc"].append(rec)
             cur = skip
         rec = dict(pool_in=cur)
         cur, rec["pool_idx"] = E.maxpool(cur, (1, 2, 2), (1, 2, 2), return_idx=True)
-        mid, rec["u1"] = TE.conv_bn_act_train(self.down[3][0][0], self.down[3][0][1], cur)
-        cur, rec["u2"] = TE.conv_bn_act_train(self.down[3][1][0], self.down[3][1][1], mid)
+        mid, rec["u1"] = TE.conv_bn_act_train(self.down[3][0][0], self.down[3][0][1], cur, groups=groups)
+        cur, rec["u2"] = TE.conv_bn_act_train(self.down[3][1][0], self.down[3][1][1], mid, groups=groups)
         tape["bottom"] = rec
         for i, lvl in zip((0, 1, 2, 3), (3, 2, 1, 0)):
             cat = cats[lvl]
@@ -554,8 +558,8 @@ class UNetTrainer:
             dy, dx = sh_ - 2 * ch, sw_ - 2 * cw
             E.upsample2x_into(cur, cat.slice(self.ENC[lvl], self.ENC[lvl]), dy // 2, dx // 2)
             rec = dict(lvl=lvl, in_hw=(ch, cw), pad=(dy // 2, dx // 2))
-            mid, rec["u1"] = TE.conv_bn_act_train(self.up[i][0][0], self.up[i][0][1], cat)
-            cur, rec["u2"] = TE.conv_bn_act_train(self.up[i][1][0], self.up[i][1][1], mid)
+            mid, rec["u1"] = TE.conv_bn_act_train(self.up[i][0][0], self.up[i][0][1], cat, groups=groups)
+            cur, rec["u2"] = TE.conv_bn_act_train(self.up[i][1][0], self.up[i][1][1], mid, groups=groups)
             tape["dec"].append(rec)
         tape["u4"] = cur
         logits = self.outc.forward(cur, relu=False, sigmoid=True)       # 1x1 conv + bias + sigmoid fused

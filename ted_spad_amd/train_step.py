@@ -78,6 +78,7 @@ class AnonymizerTrainStep:
         self.loss_scale = float(loss_scale)
         E.apply_env_determinism()
         self.batch_clips = os.environ.get("TEDSPAD_TRAIN_BATCH_CLIPS", "1") != "0"   # the three clips of an iteration as one ft batch (0: three passes, A/B)
+        self.batch_views = os.environ.get("TEDSPAD_TRAIN_BATCH_VIEWS", "1") != "0"   # the two VISPR views as one fa / fb batch with per-view statistics (0: two passes)
         self.lazy_losses = os.environ.get("TEDSPAD_TRAIN_LAZY_LOSSES", "0") == "1"
         from .unetpp import UnetPlusPlus
         self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
@@ -109,6 +110,14 @@ class AnonymizerTrainStep:
         v = inputs_video.permute(0, 2, 1, 3, 4)                       # :57
         b, c, t, h, w = v.shape
         return v.reshape(-1, c, h, w), (b, c, t, h, w)                # :89 (copy: the permuted tensor is not viewable)
+
+    def _views_batchable(self, views) -> bool:
+        """The two VISPR views can run as one batch with per-view BatchNorm statistics: same shape, and every BatchNorm of fa (down to H/16) and fb (down to
+        H/32) sees >= 256 values per channel and view (a conv tile of 256 output rows straddles at most one statistics-group boundary)."""
+        if not self.batch_views or len(views) != 2 or views[0].shape != views[1].shape:
+            return False
+        nb, _, h, w = views[0].shape
+        return nb * (h // 32) * (w // 32) >= 256 and h % 32 == 0 and w % 32 == 0
 
     def _utility_losses(self, heads, labels):
         """heads: [(pred, feat)] x3 as leaf tensors -> (loss_ft, loss_ce, loss_trip)."""
@@ -191,7 +200,14 @@ class AnonymizerTrainStep:
         TE.ARENA.reset(inputs_video.device)
         self.red_fa.prepare(exclude=self._fa_off_path)                # fa's gradients: zeroed views into the buckets
         fb_ctx, loss_fb = [], None
-        if views is not None:                                         # :80-84: fa (train mode) on each view, frozen fb
+        if views is not None and self._views_batchable(views):        # :80-84 as ONE batch: fa's BatchNorms keep the statistics of each view (groups = 2), fb is frozen
+            nb = views[0].shape[0]
+            y, tape_u = self.fa_tr.forward(torch.cat(views, dim=0), groups=2)
+            emb, tape_b = self.fb_tr.forward(y, "eval")
+            z = emb.detach().requires_grad_()
+            fb_ctx.append((tape_u, tape_b, z))
+            loss_fb = NTXentLoss(inputs_video.device, nb, 0.1, False)(z[:nb], z[nb:])
+        elif views is not None:                                       # :80-84: fa (train mode) on each view, frozen fb
             for v in views:
                 y, tape_u = self.fa_tr.forward(v)
                 emb, tape_b = self.fb_tr.forward(y, "eval")
@@ -282,16 +298,27 @@ class AnonymizerTrainStep:
         if self.red_fb is not None:
             self.red_fb.prepare()
         frames, shape = self._feed(inputs_video)
+        together = views is not None and self._views_batchable(views)
         with torch.no_grad():
-            anon_views = [self.fa(v) for v in views] if views is not None else []      # :147
+            if together:                                              # fa is in eval mode here: per-sample, the two views are one batch
+                anon_views = [self.fa(torch.cat(views, dim=0))]
+            else:
+                anon_views = [self.fa(v) for v in views] if views is not None else []      # :147
             anon = self.fa(frames).reshape(shape)                     # :144-148
         loss_fb = None
         if views is not None:                                         # :153-157,190,192
             ctx = []
-            for x in anon_views:
-                emb, tape_b = self.fb_tr.forward(x, "train")
-                ctx.append((tape_b, emb.detach().requires_grad_()))
-            loss_fb = NTXentLoss(inputs_video.device, ctx[0][1].shape[0], 0.1, False)(ctx[0][1], ctx[1][1])
+            if together:                                              # fb in train mode on both views at once: separate batch statistics per view (groups = 2)
+                nb = views[0].shape[0]
+                emb, tape_b = self.fb_tr.forward(anon_views[0], "train", groups=2)
+                z = emb.detach().requires_grad_()
+                ctx.append((tape_b, z))
+                loss_fb = NTXentLoss(inputs_video.device, nb, 0.1, False)(z[:nb], z[nb:])
+            else:
+                for x in anon_views:
+                    emb, tape_b = self.fb_tr.forward(x, "train")
+                    ctx.append((tape_b, emb.detach().requires_grad_()))
+                loss_fb = NTXentLoss(inputs_video.device, ctx[0][1].shape[0], 0.1, False)(ctx[0][1], ctx[1][1])
             loss_fb.backward()
             for j, (tape_b, z) in enumerate(ctx):
                 self.fb_tr.backward(tape_b, self._scaled(z.grad), on_bucket_done=self.red_fb.bucket_ready if j == len(ctx) - 1 else None)
