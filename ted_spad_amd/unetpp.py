@@ -119,7 +119,7 @@ class UnetPlusPlus(nn.Module):
         sig = (params_signature(self), self.compute_dtype)
         if self._packed is not None and self._packed_sig != sig and sig[1] == self._packed_sig[1] and E.same_storage(sig[0], self._packed_sig[0]):
             self._refresh.run(self.encoder.conv1.weight.device)    # updated in place (the other phase's optimizer step): two launches
-            self._packed["tail"] = self._pack_tail(self.encoder.conv1.weight.device)
+            self._tail_img.copy_(self._pack_tail(self.encoder.conv1.weight.device))     # the fused tail's LDS weight image, rewritten in place
             self._packed_sig = sig
         if self._packed is None or self._packed_sig != sig:
             E.require_cuda(self.encoder.conv1.weight, "UnetPlusPlus")
@@ -149,7 +149,7 @@ class UnetPlusPlus(nn.Module):
             P["head"] = E.PackedConv(head.weight.detach().unsqueeze(2), torch.ones(head.weight.shape[0]), head.bias, dtype=dt, device=dev)
             R.pack(P["head"], head.weight)
             R.bias(P["head"], head.bias)
-            P["tail"] = self._pack_tail(dev)
+            self._tail_img = self._pack_tail(dev)
             self._packed, self._packed_sig = P, sig
         return self._packed
 
@@ -181,7 +181,7 @@ class UnetPlusPlus(nn.Module):
         for n0 in range(0, n, nc):
             n1 = min(n, n0 + nc)
             xs = Act(x02.buf[n0:n1], x02.c, x02.coff)
-            check(_lib.lib().tedspad_unetpp_tail_fwd(xs.ptr, xs.ld, y[n0:n1].data_ptr(), n1 - n0, 2 * h2, 2 * w2, P["tail"].data_ptr(), c1.scale.data_ptr(),
+            check(_lib.lib().tedspad_unetpp_tail_fwd(xs.ptr, xs.ld, y[n0:n1].data_ptr(), n1 - n0, 2 * h2, 2 * w2, self._tail_img.data_ptr(), c1.scale.data_ptr(),
                                                      c1.shift.data_ptr(), c2.scale.data_ptr(), c2.shift.data_ptr(), hd.shift.data_ptr(),
                                                      E.DTYPES[self.compute_dtype][1], _stream_ptr()), "tedspad_unetpp_tail_fwd")
         return y
