@@ -192,9 +192,9 @@ def bench_anon_extract(dev, n_clips=225, batch=25, steps=3):
         clips[i:i + k] = synth_clips(0, k, (3, 16, 224, 224), device=dev, first=i).view(k, 16, 3, 224, 224)
     out = torch.empty((n_clips, 2048), dtype=torch.float32, device=dev)
 
-    def step():
-        for i in range(0, n_clips, batch):
-            out[i:i + batch] = ft.i3d.extract_features(extraction.feed(clips[i:i + batch], fa, "reference")).flatten(1)
+    def step():         # the anonymizer on `batch` clips at a time, the encoder on 75 (extraction.feed's fa_batch: same frames, same features)
+        for i in range(0, n_clips, 75):
+            out[i:i + 75] = ft.i3d.extract_features(extraction.feed(clips[i:i + 75], fa, "reference", fa_batch=batch)).flatten(1)
     with torch.no_grad():
         for i in range(40):                       # until the tile tuner has settled the anonymizer's conv geometries
             step()
@@ -215,7 +215,7 @@ def bench_anon_extract(dev, n_clips=225, batch=25, steps=3):
     gf = 16 * UNETPP_GFLOP_PER_FRAME + GFLOP_PER_CLIP["largei3d"]
     cps = n_clips / dt
     return {"config": "dali_extraction.py:151-182 as the reference runs it (anonymized = True): fa = unet++ (smp UnetPlusPlus, resnet18 encoder) on 16 frames of 3 x 224 x 224 "
-                      "-> Q1 reshape feed -> largei3d extract_features; %d clips, %d per forward, f16 activations / fp32 accumulate, random-init weights" % (n_clips, batch),
+                      "-> Q1 reshape feed -> largei3d extract_features; %d clips, %d per anonymizer forward, 75 per encoder forward, f16 activations / fp32 accumulate, random-init weights" % (n_clips, batch),
             "clips_per_s": round(cps, 1), "ms_per_clip": round(1e3 / cps, 4), "gflop_per_clip": round(gf, 3),
             "gflop_per_clip_parts": {"unetpp_16_frames": round(16 * UNETPP_GFLOP_PER_FRAME, 3), "i3res50_clip": GFLOP_PER_CLIP["largei3d"]},
             "achieved_tflops": round(cps * gf * 1e-3, 1), "frac": round(cps * gf * 1e-3 / MFMA_PEAK_TFLOPS, 4),

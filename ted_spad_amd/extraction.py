@@ -34,7 +34,7 @@ def feature_width(ft_model) -> int:
     raise AttributeError("extraction: the feature extractor must expose `feature_dim` (I3Res50 2048, InceptionI3d 1024)")
 
 
-def feed(clips: torch.Tensor, fa_model=None, layout: str = "reference") -> torch.Tensor:
+def feed(clips: torch.Tensor, fa_model=None, layout: str = "reference", fa_batch: int = 0) -> torch.Tensor:
     """clips: (B, 16, 3, H, W) fp32 in [0,1] as the loaders deliver them -> ft input (B, 3, 16, H, W).
 
     layout='reference' reproduces st_feature_extraction.py:24-26 / dali_extraction.py:171-173: the
@@ -42,10 +42,18 @@ def feed(clips: torch.Tensor, fa_model=None, layout: str = "reference") -> torch
     (B,3,16,H,W) -- a reinterpretation of (T,C) memory as (C,T). Without fa the
     reference would hand a 16-channel tensor to a 3-channel conv; the counterpart permutes.
     layout='permute' is the geometrically meaningful feed.
+    fa_batch > 0: the anonymizer runs on `fa_batch` clips (16 x fa_batch frames) at a time -- its full-resolution activations are 40 x a clip -- while the
+    encoder behind it gets all B clips in one forward (it needs 75+ clips to fill the chip); the frames are per-sample, so the result is the same.
     """
     b, t, c, h, w = clips.shape
     if fa_model is not None:
-        frames = fa_model(clips.reshape(-1, c, h, w))
+        if fa_batch and b > fa_batch:
+            frames = torch.empty((b * t, c, h, w), dtype=torch.float32, device=clips.device)
+            for i in range(0, b, fa_batch):
+                k = min(fa_batch, b - i)
+                frames[i * t:(i + k) * t] = fa_model(clips[i:i + k].reshape(-1, c, h, w))
+        else:
+            frames = fa_model(clips.reshape(-1, c, h, w))
         if layout == "reference":
             return frames.reshape(b, c, t, h, w)
         return frames.reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
@@ -89,7 +97,7 @@ def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 75, o
 
 @torch.no_grad()
 def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anonymized, segment=False,
-                     batch: int = 75, layout: str = "reference", device="cuda"):
+                     batch: int = 75, layout: str = "reference", device="cuda", fa_batch: int = 25):
     """Drop-in for st_feature_extraction.py:16-37. full_vid: sequence of (16,3,H,W) clips;
     vid_features: preallocated float64 (len(full_vid), F) array that receives the rows;
     the array is saved to `save_path` with np.save (float64, C order)."""
@@ -97,7 +105,7 @@ def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anon
         raise NotImplementedError("segment_features is dead + buggy code in the reference (SURVEY.md Q12)")
     for i in range(0, len(full_vid), batch):
         clips = torch.stack([c for c in full_vid[i:i + batch]]).to(device, non_blocking=True)
-        x = feed(clips, fa_model if anonymized else None, layout)
+        x = feed(clips, fa_model if anonymized else None, layout, fa_batch=fa_batch)
         f = _extract_fn(ft_model)(x).flatten(1)
         vid_features[i:i + f.shape[0]] = f.cpu().numpy()
     np.save(save_path, vid_features)
@@ -121,8 +129,8 @@ def extract_video_sharded(ft_model, clips_local: torch.Tensor, T: int, ncrops: i
         n = clips_local.shape[0]
         f = torch.empty((n, feature_width(ft_model)), dtype=torch.float32, device=clips_local.device)
         fx = _extract_fn(ft_model)
-        for i in range(0, n, fa_batch):           # an empty shard launches nothing and still joins the collective
-            f[i:i + fa_batch] = fx(feed(clips_local[i:i + fa_batch], fa_model, layout)).flatten(1)
+        for i in range(0, n, batch):              # an empty shard launches nothing and still joins the collective
+            f[i:i + batch] = fx(feed(clips_local[i:i + batch], fa_model, layout, fa_batch=fa_batch)).flatten(1)
     f = f.view(-1, ncrops, f.shape[1])
     return sharding.gather_video_features(f, T, group)
 
