@@ -173,7 +173,7 @@ def bench_train(dev, steps=10, warmup=45, hw=112, with_fb=True):
     return out
 
 
-def bench_anon_extract(dev, n_clips=225, batch=25, steps=3):
+def bench_anon_extract(dev, n_clips=225, batch=75, steps=3):
     """The extraction the reference's scripts actually run (`anonymized = True`, `arch='unet++'` hard-coded: dali_extraction.py:108,122,169-178,
     st_feature_extraction.py:72): every clip -> fa = UnetPlusPlus(resnet18) on its 16 frames of 224 x 224 -> the Q1 reshape feed -> I3Res50.extract_features.
     clips/s over `n_clips` clips (`batch` per forward), the algorithmic work per clip (16 x UNet++ frame + I3Res50 clip, conv MACs x 2), the fraction of the

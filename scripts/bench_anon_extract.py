@@ -10,7 +10,7 @@ from ted_spad_amd.synth import synth_clips, synth_state_dict
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--clips', type=int, default=300); ap.add_argument('--batch', type=int, default=25)
-ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=4)
+ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=4); ap.add_argument('--ft-batch', type=int, default=75)
 ap.add_argument('--arch-fa', default='unet', choices=['unet', 'unet++'], help="the anonymizer: 'unet' or the reference's default 'unet++'")
 a = ap.parse_args()
 with contextlib.redirect_stdout(io.StringIO()):
@@ -22,10 +22,14 @@ out = torch.empty((a.clips, 2048), device='cuda')
 
 def step():
     with torch.no_grad():
-        for i in range(0, a.clips, a.batch):
-            x = extraction.feed(clips[i:i + a.batch], fa, 'reference')
-            out[i:i + a.batch] = ft.i3d.extract_features(x).flatten(1)
-for _ in range(a.warmup): step()
+        for i in range(0, a.clips, a.ft_batch):
+            x = extraction.feed(clips[i:i + a.ft_batch], fa, 'reference', fa_batch=a.batch)
+            out[i:i + a.ft_batch] = ft.i3d.extract_features(x).flatten(1)
+from ted_spad_amd import engine as E
+for i in range(max(a.warmup, 60)):
+    step()
+    if i + 1 >= a.warmup and not E.tuning_pending():
+        break
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps

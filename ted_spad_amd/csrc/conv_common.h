@@ -74,6 +74,6 @@ struct PatchSrc {
     int up, n;
 };
 int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode = 0, const PatchSrc *src = nullptr);
-int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr);   // tile_cfg 38: two patches per workgroup   // mode 1: tile_cfg 33 (256 consecutive pixels), 2: tile_cfg 34 (temporal)
+int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr, int flat = 0);   // tile_cfg 38 / 39: two patches (two flat tiles) per workgroup   // mode 1: tile_cfg 33 (256 consecutive pixels), 2: tile_cfg 34 (temporal)
 
 }  // namespace tedspad

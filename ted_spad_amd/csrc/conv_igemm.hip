@@ -734,7 +734,8 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  36  the same with ring 4;  37  256 x 128 split-K over 16 waves, table-free, ring 3 (tile 24 without the K table)
 //  38  TWO 16 x 16 patches per workgroup sharing every weight stage (conv_patch.hip, conv_patch2_kernel): 1 x 3 x 3 'same' convs, cin % 64 == 0, K in half chunks
 //      of 32 channels, a kernel row of weights per stage: a third fewer bytes through the LDS fill path than tile 32
-constexpr int NUM_CFGS = 38;
+//  39  the same on two flat tiles (512 consecutive output pixels, one contiguous halo run): the narrow frames (W <= 62) where patches would quantise
+constexpr int NUM_CFGS = 39;
 
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr) {
@@ -778,6 +779,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, cons
         case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, 1, src);
         case 34: return launch_conv_patch(T::kDtype, p, N, cin, s, 2);
         case 38: return launch_conv_patch2(T::kDtype, p, N, cin, s, src);
+        case 39: return launch_conv_patch2(T::kDtype, p, N, cin, s, src, 1);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
@@ -939,8 +941,8 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     PatchSrc gsrc{};
     if (gathered) {       // the input is a gathered concatenation: patch / flat halo tiles only
         if (d->tile_cfg <= 0) cfg = (d->kh - 1) * d->w + d->kw - 1 + 256 <= 384 - 1 ? 33 : 32;
-        if (cfg != 32 && cfg != 33 && cfg != 38) {
-            set_error("tedspad_conv_fwd_ex: gathered sources (nchunk_src) run on tile_cfg 32 / 33 / 38 only");
+        if (cfg != 32 && cfg != 33 && cfg != 38 && cfg != 39) {
+            set_error("tedspad_conv_fwd_ex: gathered sources (nchunk_src) run on tile_cfg 32 / 33 / 38 / 39 only");
             return TEDSPAD_EUNSUPPORTED;
         }
         TS_REQUIRE(!dual && !pool_t && !p.fold_hw && d->kt == 1 && d->cin % 64 == 0 && ex->nchunk_src == d->cin / 64 && ex->nchunk_src <= 8,

@@ -432,9 +432,14 @@ constexpr int P2_NHI = 2 * P2_PSLOTS / 256;                                     
 
 struct Patch2Geo {
     int tiles_h, tiles_w, tiles_n, npatch, nhc, dbg;
+    int HW, NPf;             // FLAT: pixels per frame; halo positions of a tile (512 + 2 W + 2)
 };
 
-template <typename T, bool SRC>
+// FLAT (tile_cfg 39): the two "patches" are the two halves of 512 CONSECUTIVE output pixels (flattened (n, h, w) index), the halo ONE contiguous run of
+// 512 + 2 W + 2 positions -- no tile quantisation on the narrow frames (56 x 56, 28 x 28, 14 x 14; W <= 62 so that the run fits the same 40 KB) and the halves
+// share their halo as well; a tap that leaves the frame is redirected per lane to a zero position (as tile 33 does). Everything else is the two-patch kernel.
+constexpr int P2_ZP = 639;                                                          // FLAT: a position behind every run (never written with data: zero-filled)
+template <typename T, bool SRC, bool FLAT = false>
 __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const Patch2Geo g, const PatchSrc gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -446,28 +451,41 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16q);
     int pf[2], ph0[2], pw0[2];
     bool pon[2];
+    const int q0 = b * 512;                                // FLAT: first output pixel of the tile
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         int pi = 2 * b + q;
-        pon[q] = pi < g.npatch;
+        pon[q] = FLAT ? q0 + q * 256 < p.M : pi < g.npatch;
         if (!pon[q]) pi = 2 * b;
         const int tw = pi % g.tiles_w, t2 = pi / g.tiles_w;
         pw0[q] = tw * PT_S; ph0[q] = (t2 % g.tiles_h) * PT_S; pf[q] = t2 / g.tiles_h;
     }
-    // ---- halo slots of this thread: slot s -> patch s / 1296, position (s % 1296) >> 2, LDS piece s & 3 --------------------------------------------
+    // ---- halo slots of this thread: slot s -> patch s / 1296, position (s % 1296) >> 2, LDS piece s & 3 (FLAT: position s >> 2 of the run) ----------
     int hpos[P2_NHI + 1], hposU[SRC ? P2_NHI + 1 : 1], hc8[P2_NHI + 1];
 #pragma unroll
     for (int i = 0; i <= P2_NHI; ++i) {
         const int s = i * 256 + tid;
-        const int q = s >= P2_PSLOTS ? 1 : 0, r = s - q * P2_PSLOTS;
-        const int pos = r >> 2, hr = pos / P2_WH, hcl = pos - hr * P2_WH;
-        const int ih = ph0[q] - 1 + hr, iw = pw0[q] - 1 + hcl;
-        hc8[i] = ((r & 3) ^ ((pos >> 1) & 3)) << 3;
         hpos[i] = -1;
         if (SRC) hposU[i] = -1;
-        if (s < 2 * P2_PSLOTS && pon[q] && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
-            hpos[i] = (pf[q] * p.Hi + ih) * p.Wi + iw;
-            if (SRC) hposU[i] = (pf[q] * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1);
+        if (FLAT) {
+            const int pos = s >> 2, qp = q0 - p.Wi - 1 + pos;
+            hc8[i] = ((s & 3) ^ ((pos >> 1) & 3)) << 3;
+            if (i < P2_NHI && pos < g.NPf && (unsigned)qp < (unsigned)p.M) {
+                hpos[i] = qp;
+                if (SRC) {
+                    const int fr = qp / g.HW, r = qp - fr * g.HW, qh = r / p.Wi, qw = r - qh * p.Wi;
+                    hposU[i] = (fr * (p.Hi >> 1) + (qh >> 1)) * (p.Wi >> 1) + (qw >> 1);
+                }
+            }
+        } else {
+            const int q = s >= P2_PSLOTS ? 1 : 0, r = s - q * P2_PSLOTS;
+            const int pos = r >> 2, hr = pos / P2_WH, hcl = pos - hr * P2_WH;
+            const int ih = ph0[q] - 1 + hr, iw = pw0[q] - 1 + hcl;
+            hc8[i] = ((r & 3) ^ ((pos >> 1) & 3)) << 3;
+            if (s < 2 * P2_PSLOTS && pon[q] && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+                hpos[i] = (pf[q] * p.Hi + ih) * p.Wi + iw;
+                if (SRC) hposU[i] = (pf[q] * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1);
+            }
         }
     }
     auto issue_halo = [&](int hcx) {
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
             const int ck = hcx >> 1;
             sp = gs.ptr[ck] + (hcx & 1) * 32; sl = gs.ld[ck]; up = (gs.up >> ck) & 1;
         }
-        if (wave == 0) {      // the 41st wave-instruction (slots 2560 .. 2623, the upper 32 are padding) goes FIRST: the counted waits below see the same tail in every wave
+        if (!FLAT && wave == 0) {      // the 41st wave-instruction (slots 2560 .. 2623, the upper 32 are padding) goes FIRST: the counted waits below see the same tail in every wave
             const int pi = SRC && up ? hposU[P2_NHI] : hpos[P2_NHI];
             lds_dma16(hpos[P2_NHI] >= 0 ? sp + pi * sl + hc8[P2_NHI] : zero, lds0 + P2_NHI * 256 * 16);
         }
@@ -508,6 +526,25 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
     // ---- MFMA roles --------------------------------------------------------------------------------------------------------------------------------
     const int l15 = lane & 15, kg = lane >> 4;
     const unsigned wrd = (unsigned)(l15 * 64 + ((kg ^ ((l15 >> 1) & 3)) << 4));       // this lane's piece of weight row (16 a + l15) of a stage
+    unsigned vmask[2][4];                                  // FLAT: bit (dh * 3 + dw) of [half][row group]: the tap of this lane's pixel lies inside its frame
+    if (FLAT) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + q * 256 + (4 * wave + r) * 16 + l15;
+                unsigned m = 0u;
+                if (qq < p.M) {
+                    const int r1 = qq / p.Wi, w = qq - r1 * p.Wi, h = r1 % p.Hi;
+#pragma unroll
+                    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                        for (int dw = 0; dw < 3; ++dw)
+                            if ((unsigned)(h + dh - 1) < (unsigned)p.Hi && (unsigned)(w + dw - 1) < (unsigned)p.Wi) m |= 1u << (dh * 3 + dw);
+                }
+                vmask[q][r] = m;
+            }
+    }
     f32x4 acc[2][4][4];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -535,10 +572,18 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
             for (int a = 0; a < 4; ++a) if (a < na) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + dw * 4096 + a * 1024);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int pos = (4 * wave + r + dh) * P2_WH + dw + l15;
-                const unsigned ao = (unsigned)(pos * 64 + ((kg ^ ((pos >> 1) & 3)) << 4));
+                if (FLAT) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) fa[q][r] = *reinterpret_cast<const uint4 *>(dsm + q * (P2_PSLOTS * 16) + ao);
+                    for (int q = 0; q < 2; ++q) {
+                        const int pos = (vmask[q][r] >> (dh * 3 + dw)) & 1u ? q * 256 + (4 * wave + r) * 16 + l15 + dh * p.Wi + dw : P2_ZP;
+                        fa[q][r] = *reinterpret_cast<const uint4 *>(dsm + pos * 64 + ((kg ^ ((pos >> 1) & 3)) << 4));
+                    }
+                } else {
+                    const int pos = (4 * wave + r + dh) * P2_WH + dw + l15;
+                    const unsigned ao = (unsigned)(pos * 64 + ((kg ^ ((pos >> 1) & 3)) << 4));
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) fa[q][r] = *reinterpret_cast<const uint4 *>(dsm + q * (P2_PSLOTS * 16) + ao);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -571,12 +616,13 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
         }
         __syncthreads();
         const int nch = n0 + cc * 8;
-        float s1[8], s2[8];
+        float s1[8], s2[8], t1[8], t2[8];       // t*: rows of the NEXT statistics group (FLAT: a half of 256 consecutive rows straddles at most one boundary)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; t1[i] = 0.f; t2[i] = 0.f; }
         const int ho0 = ph0[q], wo0 = pw0[q];
-        const size_t mfirst = ((size_t)pf[q] * p.Ho + ho0) * p.Wo + wo0;       // a patch lies inside one frame: it never straddles a statistics group
+        const size_t mfirst = FLAT ? (size_t)q0 + q * 256 : ((size_t)pf[q] * p.Ho + ho0) * p.Wo + wo0;       // a patch lies inside one frame: no straddling there
         const size_t sgrp = p.stats_rows ? mfirst / (size_t)p.stats_rows : 0;
+        const size_t smb = p.stats_rows ? (sgrp + 1) * (size_t)p.stats_rows : ~(size_t)0;
         if (pon[q] && nch < p.Cout) {
             float sc[8], sf[8];
 #pragma unroll
@@ -585,16 +631,21 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
             for (int it = 0; it < 8; ++it) {
                 const int r = r0 + it * 32;
                 const int ho = ho0 + (r >> 4), wo = wo0 + (r & 15);
-                if (ho >= p.Ho || wo >= p.Wo) continue;
-                const size_t m = ((size_t)pf[q] * p.Ho + ho) * p.Wo + wo;
+                if (FLAT ? mfirst + r >= (size_t)p.M : (ho >= p.Ho || wo >= p.Wo)) continue;
+                const size_t m = FLAT ? mfirst + r : ((size_t)pf[q] * p.Ho + ho) * p.Wo + wo;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
                 if (p.stats) {
+                    if (!FLAT || m < smb) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                        for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { t1[i] += v[i]; t2[i] += v[i] * v[i]; }
+                    }
                 }
                 if (p.res) {
                     float rr[8];
@@ -636,20 +687,36 @@ __global__ __launch_bounds__(256) void conv_patch2_kernel(const ConvKP p, const 
                 atomicAdd(so + n0 + tid, sa);
                 atomicAdd(so + p.stats_ld + n0 + tid, sb);
             }
+            if (FLAT && p.stats_rows && smb < mfirst + 256 && smb < (size_t)p.M) {     // only flat tiles cross samples (workgroup-uniform)
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    red[r0 * 64 + cc * 8 + i] = t1[i];
+                    red[(32 + r0) * 64 + cc * 8 + i] = t2[i];
+                }
+                __syncthreads();
+                if (pon[q] && tid < 64 && n0 + tid < p.Cout) {
+                    float sa = 0.f, sb = 0.f;
+                    for (int r = 0; r < 32; ++r) { sa += red[r * 64 + tid]; sb += red[(32 + r) * 64 + tid]; }
+                    atomicAdd(so + 2 * p.stats_ld + n0 + tid, sa);
+                    atomicAdd(so + 3 * p.stats_ld + n0 + tid, sb);
+                }
+            }
             det_exit(det, q, 2);
         }
     }
 }
 
-template <typename T, bool SRC>
+template <typename T, bool SRC, bool FLAT = false>
 int32_t launch_patch2_t(const ConvKP &p, int frames, int cin, hipStream_t s, const PatchSrc *src) {
     Patch2Geo g;
+    g.HW = p.Hi * p.Wi; g.NPf = 512 + 2 * p.Wi + 2;
     g.tiles_h = (p.Ho + PT_S - 1) / PT_S; g.tiles_w = (p.Wo + PT_S - 1) / PT_S; g.tiles_n = (p.Cout + 63) / 64;
     g.npatch = frames * g.tiles_h * g.tiles_w; g.nhc = cin / 32;
     static const int dbg_env = getenv("TEDSPAD_PATCH_ABLATE") ? atoi(getenv("TEDSPAD_PATCH_ABLATE")) : 0;
     g.dbg = dbg_env;
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_patch2_kernel<T, SRC>;
+    auto kfn = conv_patch2_kernel<T, SRC, FLAT>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -659,7 +726,7 @@ int32_t launch_patch2_t(const ConvKP &p, int frames, int cin, hipStream_t s, con
     }
     PatchSrc gs{};
     if (SRC) gs = *src;
-    hipLaunchKernelGGL(kfn, dim3((g.npatch + 1) / 2 * g.tiles_n), dim3(256), P2_LDS, s, p, g, gs);
+    hipLaunchKernelGGL(kfn, dim3((FLAT ? (p.M + 511) / 512 : (g.npatch + 1) / 2) * g.tiles_n), dim3(256), P2_LDS, s, p, g, gs);
     return check_launch("tedspad_conv_fwd(two-patch halo)");
 }
 
@@ -708,7 +775,7 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
 }
 
 
-int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src) {
+int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src, int flat) {
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi;
     if (cin % 32 != 0 || (src && cin % 64 != 0) || p.kt != 1 || p.kh != 3 || p.kw != 3 || p.pt != 0 || p.ph != 1 || p.pw != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same ||
         p.Kpad < 9 * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32) || (src && src->n != cin / 64) || (long)N * p.Ti * p.Hi * p.Wi >= (1L << 31)) {
@@ -717,6 +784,14 @@ int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream
     }
     const int frames = N * p.Ti;
     const bool f16 = dtype == TEDSPAD_F16;
+    if (flat) {
+        if (512 + 2 * p.Wi + 2 > P2_ZP) {
+            set_error("tedspad_conv_fwd: flat two-tile config (tile_cfg 39): frame too wide (W <= 62)");
+            return TEDSPAD_EINVAL;
+        }
+        if (src) return f16 ? launch_patch2_t<F16, true, true>(p, frames, cin, s, src) : launch_patch2_t<BF16, true, true>(p, frames, cin, s, src);
+        return f16 ? launch_patch2_t<F16, false, true>(p, frames, cin, s, nullptr) : launch_patch2_t<BF16, false, true>(p, frames, cin, s, nullptr);
+    }
     if (src) return f16 ? launch_patch2_t<F16, true>(p, frames, cin, s, src) : launch_patch2_t<BF16, true>(p, frames, cin, s, src);
     return f16 ? launch_patch2_t<F16, false>(p, frames, cin, s, nullptr) : launch_patch2_t<BF16, false>(p, frames, cin, s, nullptr);
 }

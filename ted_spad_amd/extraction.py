@@ -97,7 +97,7 @@ def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 75, o
 
 @torch.no_grad()
 def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anonymized, segment=False,
-                     batch: int = 75, layout: str = "reference", device="cuda", fa_batch: int = 25):
+                     batch: int = 75, layout: str = "reference", device="cuda", fa_batch: int = 75):
     """Drop-in for st_feature_extraction.py:16-37. full_vid: sequence of (16,3,H,W) clips;
     vid_features: preallocated float64 (len(full_vid), F) array that receives the rows;
     the array is saved to `save_path` with np.save (float64, C order)."""
@@ -114,7 +114,7 @@ def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anon
 
 @torch.no_grad()
 def extract_video_sharded(ft_model, clips_local: torch.Tensor, T: int, ncrops: int = 1, batch: int = 75,
-                          group=None, fa_model=None, layout: str = "reference", fa_batch: int = 25) -> torch.Tensor:
+                          group=None, fa_model=None, layout: str = "reference", fa_batch: int = 75) -> torch.Tensor:
     """Multi-GPU extraction of ONE video. Each rank passes ITS block of clips
     (sharding.shard_range(T, rank, world) clip times x ncrops crops, crop-minor order); returns the full
     (T, ncrops, F) fp32 tensor on every rank after one RCCL all-gather.

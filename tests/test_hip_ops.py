@@ -501,7 +501,7 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
                 continue                                   # configuration not applicable to this geometry
     finally:
         E.FORCE_TILE_CFG = None
-    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33, 34, 35, 36, 37, 38)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
+    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33, 34, 35, 36, 37, 38, 39)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
     generic = {c: o for c, o in outs.items() if c not in REASSOC}
     assert len(generic) >= 4, sorted(outs)
     first = next(iter(generic.values()))
@@ -560,7 +560,7 @@ def test_patch_halo_training_epilogues(cin, cout):
     mask = E.Act(synth_tensor(31, "pe_m", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
     got = {}
     try:
-        for cfg in (32, 33, 38, 5):
+        for cfg in (32, 33, 38, 39, 5):
             E.FORCE_TILE_CFG = cfg
             st1 = torch.zeros((2, pc.cpad), device="cuda"); st2 = torch.zeros((2, pc.cpad), device="cuda")
             a = pc(x, pads=(0, 1, 1), residual=res, mask=mask, relu=False).buf.float().cpu()
@@ -570,11 +570,11 @@ def test_patch_halo_training_epilogues(cin, cout):
     finally:
         E.FORCE_TILE_CFG = None
     ulp = 2.0 ** -10
-    for c in (32, 33, 38):
+    for c in (32, 33, 38, 39):
         for i in range(3):      # cin = 64 walks K like the generic tile (bit-identical), cin = 128 chunk-major (one rounding step; fp32 output: 1e-5); 38 walks half chunks
             g, r = got[c][i], got[5][i]
             assert g.shape == r.shape
-            if cin == 64 and c != 38:
+            if cin == 64 and c < 38:
                 assert torch.equal(g, r), (c, i)
             else:
                 assert bool(((g - r).abs() <= (ulp if i < 2 else 2e-5) * r.abs() + 1e-4).all()), (c, i)
@@ -655,7 +655,7 @@ def test_conv_on_a_gathered_concatenation_equals_the_materialised_one(dims, chan
     cat = torch.cat(parts, dim=-1).contiguous()
     ref = conv_cl(cat.float().cpu(), wgt, scale, shift, (1, 1, 1), pf, pb, None, True)
     ran = 0
-    for cfg in (32, 33, 38):
+    for cfg in (32, 33, 38, 39):
         E.FORCE_TILE_CFG = cfg
         try:
             want = pc(E.Act(cat, cin), pads=pf, pads_back=pb).buf
