@@ -8,7 +8,7 @@ from ted_spad_amd.model_loaders import load_fa_model, load_ft_model
 from ted_spad_amd.synth import synth_clips, synth_state_dict
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 75
-B = 25
+B = 75
 with contextlib.redirect_stdout(io.StringIO()):
     fa, ft = load_fa_model(), load_ft_model('largei3d', num_classes=102)
 fa.load_state_dict(synth_state_dict(fa.state_dict(), 0)); ft.load_state_dict(synth_state_dict(ft.state_dict(), 0))

@@ -52,7 +52,7 @@ if a.sq:
 K = a.iters
 tot = collections.Counter()
 lines = ['# %s' % a.title, '',
-         'Source: `rocprofv3 {--kernel-trace | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...} -- python3 scripts/train_prof_run.py %d`' % K,
+         'Source: `rocprofv3 {--kernel-trace | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...} -- python3 scripts/train_prof_run.py %d` (or the script named in the title)' % K,
          'on MI355X; the dispatches between the script\'s two marker launches, divided by its %d iterations (phase 1 + phase 2 each). Kernels are serialised under' % K,
          'counter collection. Traffic = FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction); MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).', '',
          '| kernel | launches / iteration | ms / iteration | share | HBM read MB | HBM written MB | TB/s | MFMA utilisation |', '|---|---|---|---|---|---|---|---|']
