@@ -371,6 +371,150 @@ __global__ __launch_bounds__(384) void conv_wgrad3_kernel(const WgradKP p) {
 }
 
 
+// ---- the nine taps from ONE 6 x 18 halo of a 4 x 16 output patch -----------------------------------------------------------------------------------------
+// conv_wgrad3_kernel walks flat pixels and takes three 66-row activation tiles per 64 outputs (33 KB with dY, each input pixel once per kernel row) plus per-lane
+// row tracking and edge masks. Here a step is a PATCH of 4 rows x 16 columns of one image: its dY tile (64 rows, 8 KB) and ONE halo of 6 x 18 input positions
+// (108 rows, 13.5 KB) that serves all nine taps -- tap (dh, dw) of patch row r is the 16 halo rows from (r + dh) * 18 + dw -- 21.5 KB per 64 outputs. Positions
+// outside the image are zero rows, decided per DMA slot from the patch origin: no edge masks, no row tracking. The 24 KB stage leaves room for a THREE-slot ring
+// at two workgroups per CU (the three-tile kernel: two slots, 70 KB), so a step's tiles are requested two steps ahead. MFMA roles, fragment layout and the flush
+// are conv_wgrad3_kernel's. Frames whose width is not a multiple of 16 pay for the zero columns (W = 56: 12.5 %): the host picks per layer (launcher below).
+constexpr int W3P_XR = 128;                        // halo rows per stage (108 used)
+constexpr int W3P_STAGE = WG_SUB + W3P_XR * 128;   // 24 KB
+constexpr int W3P_S = 3;
+
+struct Wgrad3pGeo {
+    int tiles_h, tiles_w, npatch, patches_per_split;
+};
+
+template <typename T>
+__global__ __launch_bounds__(384) void conv_wgrad3p_kernel(const WgradKP p, const Wgrad3pGeo g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cc = b % p.cc_tiles; b /= p.cc_tiles;
+    const int cot = b % p.co_tiles;
+    const int ms = b / p.co_tiles;
+    const int p_begin = ms * g.patches_per_split;
+    const int p_end = min(g.npatch, p_begin + g.patches_per_split);
+    const int nsteps = p_end - p_begin;
+    const int W = p.Wi, H = p.Hi;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16w);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+    // ---- DMA roles: 24 groups of 8 rows per step (8 of dY, 16 of halo), group j * 6 + wave for j = 0 .. 3; a lane moves chunk (lane & 7) ^ swz(row) of its row -------
+    int rr[4], rc[4], kcs[4];                         // per group: the row's patch-relative (row, column) -- halo groups: relative to the halo origin -- and its source chunk
+    bool isy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gi = j * 6 + wave;                  // wave-uniform
+        isy[j] = gi < 8;
+        const int row = (isy[j] ? gi : gi - 8) * 8 + (lane >> 3);
+        kcs[j] = ((lane & 7) ^ wg_swz(row)) * 8;
+        if (isy[j]) { rr[j] = row >> 4; rc[j] = row & 15; }
+        else { rr[j] = row < 108 ? row / 18 : 64; rc[j] = row < 108 ? row - (row / 18) * 18 : 0; }      // rows 108.. : never inside an image
+    }
+
+    auto issue = [&](int step, int slot) {
+        const int pi = p_begin + step;
+        const int tx = pi % g.tiles_w, t2 = pi / g.tiles_w;
+        const int ox = tx * 16, oy = (t2 % g.tiles_h) * 4, f = t2 / g.tiles_h;
+        const unsigned stage = lds0 + slot * W3P_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gi = j * 6 + wave;
+            const uint16_t *src;
+            if (isy[j]) {
+                const int y = oy + rr[j], x = ox + rc[j];
+                const bool ok = y < H && x < W && cot * 64 + (kcs[j]) < p.Cout;
+                src = ok ? p.dy + ((size_t)(f * H + y) * W + x) * p.ldy + cot * 64 + kcs[j] : zero;
+            } else {
+                const int y = oy - 1 + rr[j], x = ox - 1 + rc[j];
+                const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                src = ok ? p.x + ((size_t)(f * H + y) * W + x) * p.ldx + cc * 64 + kcs[j] : zero;
+            }
+            lds_dma16(src, stage + (isy[j] ? gi * 1024 : WG_SUB + (gi - 8) * 1024));
+        }
+    };
+
+
+    // ---- MFMA roles (conv_wgrad3_kernel's) ------------------------------------------------------------------------------------------------------------------------
+    const int dw = wave % 3, cih = wave / 3;
+    const int gq = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3, h = gq >> 1;
+    int offa[2][2], rowb[2];
+    const int cb = 32 * cih + 16 * (gq & 1) + 4 * pp;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int row = 8 * h + 4 * rd + q4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int c = 32 * a + 16 * (gq & 1) + 4 * pp;
+            offa[a][rd] = row * 128 + ((((c >> 3) ^ wg_swz(row))) << 4) + (c & 7) * 2;       // + ks * 16 rows: 16 * 128 bytes keep wg_swz (16 rows = 2 periods)
+        }
+        rowb[rd] = row + dw;
+    }
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][a][r] = 0.f;
+    auto tr = [&](const unsigned char *base) -> uint2 {
+        const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(base));
+        return __builtin_bit_cast(uint2, v);
+    };
+
+    if (nsteps > 0) issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) wait_vmcnt<4>(); else wait_vmcnt<0>();      // this step's four pieces landed; the next step's may stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) issue(step + 2, (step + 2) % W3P_S);        // its slot held step - 1: every wave is past it
+        const unsigned char *Y = smem + (step % W3P_S) * W3P_STAGE;
+        const unsigned char *X = Y + WG_SUB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                                   // k-step = patch row ks
+            uint4 fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const uint2 lo = tr(Y + ks * 16 * 128 + offa[a][0]), hi = tr(Y + ks * 16 * 128 + offa[a][1]);
+                fa[a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                uint2 v[2];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int rb = (ks + d) * 18 + rowb[rd];
+                    v[rd] = tr(X + rb * 128 + ((((cb >> 3) ^ wg_swz(rb))) << 4) + (cb & 7) * 2);
+                }
+                const uint4 fb = make_uint4(v[0].x, v[0].y, v[1].x, v[1].y);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[d][a] = T::mfma(fa[a], fb, acc[d][a]);
+            }
+        }
+    }
+
+    const bool det = det_enter();
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int Cin = p.cc_tiles * 64;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int k = (d * 3 + dw) * Cin + cc * 64 + cih * 32 + l31;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.Kpad + k, acc[d][a][r]);
+            }
+    }
+    det_exit(det);
+}
+
+
 // ---- the same nine taps from ONE ring of activation rows --------------------------------------------------------------------------------
 // conv_wgrad3_kernel fetches every input pixel once per kernel ROW (three 66-pixel tiles per 64 output pixels: 33 KB with dY) and is bound by exactly that L2 -> LDS
 // stream (16.3 GB per cfg3 iteration at 1.1 TB/s, profiles/r03_train_cfg3_kernels.md). In flat (n, h, w) order the three tiles of a step are the SAME pixel stream
@@ -428,7 +572,7 @@ __global__ __launch_bounds__(384) void conv_wgrad3r_kernel(const WgradKP p, int 
             lds_dma16(src, ldsY + (step & 1) * WG_SUB + 8 * gi * 128);
         }
     };
-    (void)yok;
+
 
     // ---- MFMA roles (those of conv_wgrad3_kernel) ---------------------------------------------------------------------------------------------------------------
     const int dw = wave % 3, cih = wave / 3;
@@ -641,6 +785,35 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
             }
             if (ti == 0) hipLaunchKernelGGL((conv_wgrad3r_kernel<F16>), grid3, dim3(384), lds3r, s, p, padr, kwr);
             else hipLaunchKernelGGL((conv_wgrad3r_kernel<BF16>), grid3, dim3(384), lds3r, s, p, padr, kwr);
+            return check_launch("tedspad_conv_wgrad");
+        }
+        // the patch form (4 x 16 outputs and their one 6 x 18 halo per step, three-slot ring): where the frames are wide enough that its zero columns cost less than
+        // the three-tile kernel's row re-reads. TEDSPAD_WGRAD_PATCH = 0: never, 2: wherever it applies (A/B)
+        static const int patch_mode = getenv("TEDSPAD_WGRAD_PATCH") ? atoi(getenv("TEDSPAD_WGRAD_PATCH")) : 1;
+        const int tw3 = (d->w + 15) / 16, th3 = (d->h + 3) / 4;
+        const bool patch_fits = (long)tw3 * 16 * 100 <= (long)d->w * 115 && d->w >= 14;       // <= 15 % zero columns (measured on the UNet's shapes, 384 frames: 112^2 -4 %, 56^2 +2 / -5 %, 28^2 -6 / -2 %, 14^2 -8 %, 7^2 +43 %)
+        if (patch_mode == 2 || (patch_mode == 1 && patch_fits)) {
+            Wgrad3pGeo g3;
+            g3.tiles_h = th3; g3.tiles_w = tw3; g3.npatch = d->n * d->t * th3 * tw3;
+            long sp = (wgs3 + tiles3 - 1) / tiles3;
+            const long max_sp = (g3.npatch + 7) / 8;
+            if (sp > max_sp) sp = max_sp;
+            if (sp < 1) sp = 1;
+            g3.patches_per_split = (int)((g3.npatch + sp - 1) / sp);
+            sp = (g3.npatch + g3.patches_per_split - 1) / g3.patches_per_split;
+            static thread_local int attr3p[2] = {0, 0};
+            const int ti = d->dtype == TEDSPAD_F16 ? 0 : 1;
+            if (!attr3p[ti]) {
+                const void *fn = ti == 0 ? (const void *)conv_wgrad3p_kernel<F16> : (const void *)conv_wgrad3p_kernel<BF16>;
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    set_error("tedspad_conv_wgrad: cannot raise the dynamic LDS limit");
+                    return TEDSPAD_ELAUNCH;
+                }
+                attr3p[ti] = 1;
+            }
+            const dim3 gridp((unsigned)(tiles3 * sp));
+            if (ti == 0) hipLaunchKernelGGL((conv_wgrad3p_kernel<F16>), gridp, dim3(384), W3P_S * W3P_STAGE, s, p, g3);
+            else hipLaunchKernelGGL((conv_wgrad3p_kernel<BF16>), gridp, dim3(384), W3P_S * W3P_STAGE, s, p, g3);
             return check_launch("tedspad_conv_wgrad");
         }
         if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL((conv_wgrad3_kernel<F16>), grid3, dim3(384), 0, s, p);
