@@ -166,6 +166,11 @@ def test_anonymized_extraction_with_unetpp(wrapper, unetpp):
         ref = extract_ref.extract_video(vid, lambda x: i3res50_ref.extract_features(x, sd_i), fa=lambda x: unetpp_ref.forward(x, sd_u), layout="reference")
     for t in range(3):
         assert rel_l2(feats[t], ref[t]) < TOL
+    # the anonymizer on one clip at a time and the encoder on all three (extraction.feed's fa_batch): the same rows
+    feats1 = np.zeros((3, 2048))
+    extraction.extract_features(vid, feats1, "/tmp/_upp_feats1.npy", unetpp, wrapper, True, False, batch=3, fa_batch=1)
+    for t in range(3):
+        assert rel_l2(feats1[t], ref[t]) < TOL and rel_l2(feats1[t], feats[t]) < TOL
 
 
 def test_unet_odd_size_vs_oracle(unet):
