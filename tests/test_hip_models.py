@@ -128,6 +128,13 @@ def test_unetpp_eval_vs_oracle(unetpp, shape):
         finally:
             setattr(E, flag, old)
         assert rel_l2(yo.cpu(), ref) < 2e-3, flag
+    if shape[2] == 112:      # the bf16 build of the same launch sequence (gathered convs, two-patch tiles, fused tail): bf16's 8 mantissa bits over ~20 conv layers
+        try:
+            unetpp.compute_dtype = "bf16"
+            yb = unetpp(frames.cuda())
+        finally:
+            unetpp.compute_dtype = "f16"
+        assert rel_l2(yb.cpu(), ref) < 2.5e-2, rel_l2(yb.cpu(), ref)
     with pytest.raises(RuntimeError):
         unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
     # train(): batch-statistics BatchNorm (train_anonymizer.py:73 puts fa in train mode), running statistics moved once per call
