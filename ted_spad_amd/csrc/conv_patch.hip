@@ -25,7 +25,7 @@ struct PatchGeo {
     long xelems;             // ... elements of the input tensor (M * ldx)
     int ncc, fstride;        // patch mode with kt > 1 (3 x 3 x 3 convs): channel chunks per temporal tap (nchunks = kt * ncc), elements per input frame
     int R;                   // FLAT: halo positions in front of the tile (ph * W + pw)
-    int dbg;                 // timing ablations (wrong results; TEDSPAD_PATCH_ABLATE): 1 = weight stages only for the first tap of a tile, 2 = halo only for the first chunk
+    int dbg;                 // timing ablations (wrong results; TEDSPAD_PATCH_ABLATE): 1 = weight stages only for the first tap of a tile, 2 = halo only for the first chunk, 4 = no per-tap barrier
     int T, HW, PXF;          // TEMPORAL: frames of a clip, pixels of a frame, pixels per frame in a tile (256 / T rounded to a power of two)
 };
 
@@ -202,40 +202,21 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
             if (WS == 3 && kt + 2 < g.ntaps) issue_w(ch, kt + 2, (kt + 2) % WS);
             const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * WSTAGE) + l31 * BK;
             if (tap_on) {
-                // fragment reads run PD k-steps ahead of the MFMAs that use them (the compiler's own order was read -> lgkmcnt(0) -> MFMA, one LDS latency per
-                // pair of MFMAs): BN = 64 reads the whole tap first (64 VGPRs of fragments), BN = 128 keeps two k-steps in flight (48 + 24)
-                constexpr int PD = BN == 64 ? 4 : 2;
-                uint4 fa[4][2], fw[4][NA];
-                auto reads = [&](int ks) {
-                    const unsigned c = (unsigned)((ks << 1) | lh);
+            // (reading a tap's fragments ahead of its MFMAs -- the whole tap for BN = 64, two k-steps in flight for BN = 128, behind sched_barriers -- was measured on one
+            // box against this loop: 2-5 % SLOWER on every shape; two waves per SIMD already cover the LDS latency of the compiler's read -> wait -> MFMA order)
 #pragma unroll
-                    for (int bq = 0; bq < 2; ++bq) fa[ks][bq] = *reinterpret_cast<const uint4 *>(dsm + xoff[bq] + ((c ^ xswz[bq]) << 4));
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned c = (unsigned)((ks << 1) | lh);
+                uint4 fa[2], fw[NA];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) fw[ks][a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
-                };
-                if ((g.dbg & 8) && (ch | kt)) {
+                for (int bq = 0; bq < 2; ++bq) fa[bq] = *reinterpret_cast<const uint4 *>(dsm + xoff[bq] + ((c ^ xswz[bq]) << 4));
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
+                for (int a = 0; a < NA; ++a) fw[a] = *reinterpret_cast<const uint4 *>(Wt + a * 32 * BK + ((c ^ swz) << 3));
 #pragma unroll
-                        for (int bq = 0; bq < 2; ++bq) fa[ks][bq] = uint4{(unsigned)kt, (unsigned)ch, 0u, 0u};
+                for (int a = 0; a < NA; ++a)
 #pragma unroll
-                        for (int a = 0; a < NA; ++a) fw[ks][a] = uint4{(unsigned)kt, 1u, (unsigned)ch, 0u};
-                    }
-                } else
-#pragma unroll
-                for (int ks = 0; ks < PD; ++ks) reads(ks);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                    for (int a = 0; a < NA; ++a)
-#pragma unroll
-                        for (int bq = 0; bq < 2; ++bq) acc[a][bq] = T::mfma(fw[ks][a], fa[ks][bq], acc[a][bq]);
-                    if (ks + PD < 4 && !((g.dbg & 8) && (ch | kt))) {
-                        reads(ks + PD);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                    for (int bq = 0; bq < 2; ++bq) acc[a][bq] = T::mfma(fw[a], fa[bq], acc[a][bq]);
+            }
             }
             if (WS == 2 && kt + 1 < g.ntaps) {             // two slots: stage kt+1 can only be issued once every wave has read stage kt-1 ... and kt
                 __builtin_amdgcn_s_barrier();
