@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
     const int kc = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
     const uint16_t *wsrc = p.w + (size_t)(n0 + rsub) * p.Kpad + kc * 8;
     auto issue_w = [&](int ch, int tap, int slot) {          // ch: chunk index; patch mode with kt > 1: (dt, channel chunk) -> K offset ((dt * taps + tap) * cin + chunk * 64)
-        if ((g.dbg & 1) && (ch | tap)) return;
         const unsigned dst = lds0 + halo_bytes + slot * WSTAGE + wave * 8 * (BK * 2);
         const int dtw = TEMP ? 0 : ch / g.ncc;
         const uint16_t *src = wsrc + (dtw * g.ntaps + tap) * p.cin + (ch - dtw * g.ncc) * 64;
@@ -163,8 +162,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
         started = true;
         asm volatile("" ::: "memory");
         issue_w(ch, 0, 0);                                 // issue order w(0), halo, w(1): the counted waits below rely on it
-        if ((g.dbg & 2) && ch) {
-        } else if (SRC) {
+        if (SRC) {
             const uint16_t *sp = gs.ptr[chc] + swo;
             const long sl = gs.ld[chc];
             const bool up = (gs.up >> chc) & 1;
@@ -197,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const ConvKP p, const P
                 xswz[bq] = (unsigned)(pos >> 1) & 7u;
             }
             if (kt + 1 < g.ntaps) wait_vmcnt<WL>(); else wait_vmcnt<0>();   // stage kt (and, on kt = 0, the halo) landed; stage kt+1 may stay in flight
-            if (!(g.dbg & 4) || kt == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (WS == 3 && kt + 2 < g.ntaps) issue_w(ch, kt + 2, (kt + 2) % WS);
             const uint16_t *Wt = reinterpret_cast<const uint16_t *>(wring + (kt % WS) * WSTAGE) + l31 * BK;
