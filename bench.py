@@ -192,9 +192,10 @@ def bench_anon_extract(dev, n_clips=225, batch=75, steps=3):
         clips[i:i + k] = synth_clips(0, k, (3, 16, 224, 224), device=dev, first=i).view(k, 16, 3, 224, 224)
     out = torch.empty((n_clips, 2048), dtype=torch.float32, device=dev)
 
-    def step():         # the anonymizer on `batch` clips at a time, the encoder on 75 (extraction.feed's fa_batch: same frames, same features)
-        for i in range(0, n_clips, 75):
-            out[i:i + 75] = ft.i3d.extract_features(extraction.feed(clips[i:i + 75], fa, "reference", fa_batch=batch)).flatten(1)
+    nstreams = int(os.environ.get("TEDSPAD_ANON_STREAMS", "2"))
+
+    def step():         # the anonymizer on `batch` clips at a time, the encoder on 75, the 75-clip batches alternating over two streams (as the I3D-only path does)
+        extraction.extract_anonymized_clip_features(ft, fa, clips, batch=75, fa_batch=batch, layout="reference", out=out, streams=nstreams)
     with torch.no_grad():
         for i in range(40):                       # until the tile tuner has settled the anonymizer's conv geometries
             step()

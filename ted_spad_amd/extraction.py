@@ -96,6 +96,38 @@ def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 75, o
 
 
 @torch.no_grad()
+def extract_anonymized_clip_features(ft_model, fa_model, clips: torch.Tensor, batch: int = 75, fa_batch: int = 75, layout: str = "reference",
+                                    out: torch.Tensor = None, streams: int = 2) -> torch.Tensor:
+    """clips: (n, 16, 3, H, W) fp32 on the GPU as the loaders deliver them -> fa -> `feed` layout -> ft.extract_features -> (n, F) fp32 on the GPU:
+    `batch` clips per encoder forward, `fa_batch` per anonymizer forward, the batches alternating over `streams` HIP streams (as extract_clip_features does:
+    one batch's prologues and epilogues under the other's MFMAs; results unchanged)."""
+    fx = _extract_fn(ft_model)
+    n = clips.shape[0]
+    if out is None:
+        out = torch.empty((n, feature_width(ft_model)), dtype=torch.float32, device=clips.device)
+    if n == 0:
+        return out
+    dev = clips.device
+    if dev.type != "cuda":
+        for i in range(0, n, batch):
+            f = fx(feed(clips[i:i + batch], fa_model, layout, fa_batch=fa_batch)).flatten(1)
+            out[i:i + f.shape[0]] = f
+        return out
+    pool = _STREAMS.setdefault((dev, streams), [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))])
+    main = torch.cuda.current_stream(dev)
+    for st in pool:
+        st.wait_stream(main)
+    from . import engine as E
+    for j, i in enumerate(range(0, n, batch)):
+        with torch.cuda.stream(pool[0 if E.tuning_pending() else j % len(pool)]):
+            f = fx(feed(clips[i:i + batch], fa_model, layout, fa_batch=fa_batch)).flatten(1)
+            out[i:i + f.shape[0]] = f
+    for st in pool:
+        main.wait_stream(st)
+    return out
+
+
+@torch.no_grad()
 def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anonymized, segment=False,
                      batch: int = 75, layout: str = "reference", device="cuda", fa_batch: int = 75):
     """Drop-in for st_feature_extraction.py:16-37. full_vid: sequence of (16,3,H,W) clips;
@@ -126,11 +158,7 @@ def extract_video_sharded(ft_model, clips_local: torch.Tensor, T: int, ncrops: i
     if fa_model is None:
         f = extract_clip_features(ft_model, clips_local, batch)
     else:
-        n = clips_local.shape[0]
-        f = torch.empty((n, feature_width(ft_model)), dtype=torch.float32, device=clips_local.device)
-        fx = _extract_fn(ft_model)
-        for i in range(0, n, batch):              # an empty shard launches nothing and still joins the collective
-            f[i:i + batch] = fx(feed(clips_local[i:i + batch], fa_model, layout, fa_batch=fa_batch)).flatten(1)
+        f = extract_anonymized_clip_features(ft_model, fa_model, clips_local, batch, fa_batch, layout)      # an empty shard launches nothing and still joins the collective
     f = f.view(-1, ncrops, f.shape[1])
     return sharding.gather_video_features(f, T, group)
 
