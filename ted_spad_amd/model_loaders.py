@@ -70,35 +70,33 @@ class wrapper_i3d(nn.Module):
         return pred, feature
 
 
-def build_i3d_classifier(num_classes=400, pretrained=True):
-    """model_loaders.py:171-182."""
-    from .inception_i3d import InceptionI3d
-    temp_classes = 0
+# where the Kinetics checkpoints live: the reference reads them relative to its scripts' working directory (model_loaders.py:178,192)
+SAVED_MODELS_DIR = os.environ.get("TEDSPAD_SAVED_MODELS", os.path.join("..", "saved_models"))
+
+
+def _kinetics_classifier(make, weights_file, target, new_head, num_classes, pretrained):
+    """The rule both Kinetics-pretrained classifiers follow (model_loaders.py:171-196): when the checkpoint is to be loaded the network is built with
+    Kinetics' 400 classes so that it loads strictly, and only then gets the head for `num_classes`; without it the network is built for `num_classes` directly."""
+    model = make(400 if pretrained else num_classes)
     if pretrained:
-        temp_classes = num_classes
-        num_classes = 400
-    model = InceptionI3d(num_classes=num_classes, dropout_keep_prob=0.5)
-    if pretrained:
-        saved_weights = torch.load(os.path.join("..", "saved_models", "rgb_imagenet.pt"))
-        model.load_state_dict(saved_weights, strict=True)
-    if pretrained and temp_classes != 400:
-        model.replace_logits(temp_classes)
+        target(model).load_state_dict(torch.load(os.path.join(SAVED_MODELS_DIR, weights_file)), strict=True)
+        if num_classes != 400:
+            new_head(model, num_classes)
     return model
+
+
+def build_i3d_classifier(num_classes=400, pretrained=True):
+    """model_loaders.py:171-182: InceptionI3d, `rgb_imagenet.pt`, head replaced through `replace_logits`."""
+    from .inception_i3d import InceptionI3d
+    return _kinetics_classifier(lambda n: InceptionI3d(num_classes=n, dropout_keep_prob=0.5), "rgb_imagenet.pt", lambda m: m,
+                                lambda m, n: m.replace_logits(n), num_classes, pretrained)
 
 
 def build_largei3d_classifier(num_classes=400, pretrained=True):
-    """model_loaders.py:185-196."""
-    temp_classes = 0
-    if pretrained:
-        temp_classes = num_classes
-        num_classes = 400
-    model = wrapper_i3d(num_classes=num_classes)
-    if pretrained:
-        saved_weights = torch.load(os.path.join("..", "saved_models", "i3d_r50_kinetics.pth"))
-        model.i3d.load_state_dict(saved_weights, strict=True)
-    if pretrained and temp_classes != 400:
-        model.i3d.fc = LinearParams(512 * 4, temp_classes)
-    return model
+    """model_loaders.py:185-196: wrapper_i3d around I3Res50, `i3d_r50_kinetics.pth` loaded into `.i3d`, a fresh `fc` for the new classes."""
+    def new_fc(m, n):
+        m.i3d.fc = LinearParams(512 * 4, n)
+    return _kinetics_classifier(lambda n: wrapper_i3d(num_classes=n), "i3d_r50_kinetics.pth", lambda m: m.i3d, new_fc, num_classes, pretrained)
 
 
 def _strip_module(sd):

@@ -308,3 +308,38 @@ def test_fb_model_has_torchvision_resnet50_keys():
     assert not any(k.startswith("0.fc") for k in sd)                      # fc = nn.Identity()
     pred = load_fb_model(arch="r50", ssl=False, num_pa=7)
     assert tuple(pred.state_dict()["fc.weight"].shape) == (7, 2048) and len(pred.state_dict()) == 320
+
+
+def test_kinetics_pretrained_classifiers_load_strictly_then_get_the_new_head(tmp_path, monkeypatch):
+    """model_loaders.py:171-196: with `pretrained` the network is built with Kinetics' 400 classes, the checkpoint loaded strict=True (InceptionI3d:
+    `rgb_imagenet.pt` into the model, I3Res50: `i3d_r50_kinetics.pth` into `.i3d`), then the head replaced for `num_classes`; without it the network
+    is built for `num_classes` directly. The checkpoints here are written by the test (the real ones are downloads)."""
+    import contextlib, io
+    from ted_spad_amd import model_loaders as ML
+    from ted_spad_amd.inception_i3d import InceptionI3d
+    from ted_spad_amd.synth import synth_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        big = ML.wrapper_i3d(num_classes=400)
+        inc = InceptionI3d(num_classes=400, dropout_keep_prob=0.5)
+    sd_big, sd_inc = synth_state_dict(big.i3d.state_dict(), 3), synth_state_dict(inc.state_dict(), 4)
+    torch.save(sd_big, tmp_path / "i3d_r50_kinetics.pth")
+    torch.save(sd_inc, tmp_path / "rgb_imagenet.pt")
+    monkeypatch.setattr(ML, "SAVED_MODELS_DIR", str(tmp_path))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ML.build_largei3d_classifier(num_classes=102, pretrained=True)
+        m400 = ML.build_largei3d_classifier(num_classes=400, pretrained=True)
+        i = ML.build_i3d_classifier(num_classes=102, pretrained=True)
+        fresh = ML.build_largei3d_classifier(num_classes=7, pretrained=False)
+    assert tuple(m.i3d.fc.weight.shape) == (102, 2048) and tuple(m400.i3d.fc.weight.shape) == (400, 2048) and tuple(fresh.i3d.fc.weight.shape) == (7, 2048)
+    for k, v in m.i3d.state_dict().items():
+        if not k.startswith("fc."):
+            assert torch.equal(v, sd_big[k]), k
+    assert torch.equal(m400.i3d.fc.weight, sd_big["fc.weight"])              # 400 classes: the checkpoint's own head stays
+    assert i.logits.conv3d.weight.shape[0] == 102
+    got = i.state_dict()
+    for k, v in sd_inc.items():
+        if not k.startswith("logits."):
+            assert torch.equal(got[k], v), k
+    monkeypatch.setattr(ML, "SAVED_MODELS_DIR", str(tmp_path / "nowhere"))
+    with pytest.raises(FileNotFoundError):
+        ML.build_largei3d_classifier(num_classes=102, pretrained=True)
