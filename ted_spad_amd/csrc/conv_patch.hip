@@ -398,7 +398,8 @@ int32_t launch_patch_t(const ConvKP &p, int NTf, int cin, hipStream_t s, const P
 //   * weights: ring of 3 stages [3 taps dw][64 co][32 k] = 12 KB; one barrier per stage = per 96 MFMAs (16 per barrier in the one-patch form);
 //   * a wave owns rows 4w .. 4w+3 of both patches x 64 channels: 8 pixel groups x 4 channel groups of 16 x 16 x 32 MFMAs, 128 accumulator registers;
 //   * per (two patches, 64 channels): 83 KB of halo + 73.7 KB of weights for 37.7 MFLOP -- 32 % fewer bytes through the fill path; 76.5 KB of LDS, two
-//     workgroups per CU as before. K is walked (half chunk, dh, dw): fp32 sums re-associated like tiles 15 / 16 / 28 / 32.
+//     workgroups per CU as before. Measured against tile 32 on one box (scripts/ab_probe.sh): 3-6 % faster on the 112 x 112 layers -- the bytes were not the whole
+//     story: with every DMA ablated this kernel still takes 1 332 us where its MFMAs need ~1 045. K is walked (half chunk, dh, dw): fp32 sums re-associated like tiles 15 / 16 / 28 / 32.
 // Stride-1 'same' 1 x 3 x 3 convs with cin % 32 == 0 (cout tiles of 64; 16-channel groups beyond cout are neither fetched nor multiplied: the 64 -> 32 -> 32 -> 3
 // block at full resolution that ends the unet++ decoder), plain input or a gathered concatenation (cin % 64 == 0); the epilogue is the one-patch kernel's.
 constexpr int P2_WH = 18, P2_NP = P2_WH * P2_WH, P2_PSLOTS = P2_NP * 4;            // 1296 16-byte slots per patch
