@@ -135,6 +135,16 @@ def test_unetpp_eval_vs_oracle(unetpp, shape):
         finally:
             unetpp.compute_dtype = "f16"
         assert rel_l2(yb.cpu(), ref) < 2.5e-2, rel_l2(yb.cpu(), ref)
+    if shape[2] == 48:       # the fused tail's entry refuses what it cannot run: odd sizes, a pixel stride below its 64 channels, null pointers
+        from ted_spad_amd import _lib
+        L, P = _lib.lib(), unetpp.packed()
+        xs = torch.zeros((1, 24, 40, 64), dtype=torch.float16, device="cuda")
+        yo = torch.zeros((1, 3, 48, 80), dtype=torch.float32, device="cuda")
+        c1, c2, hd = P["x_0_3.conv1"], P["x_0_3.conv2"], P["head"]
+        vec = (c1.scale.data_ptr(), c1.shift.data_ptr(), c2.scale.data_ptr(), c2.shift.data_ptr(), hd.shift.data_ptr())
+        for args in ((xs.data_ptr(), 64, yo.data_ptr(), 1, 47, 80), (xs.data_ptr(), 56, yo.data_ptr(), 1, 48, 80), (None, 64, yo.data_ptr(), 1, 48, 80)):
+            assert L.tedspad_unetpp_tail_fwd(args[0], args[1], args[2], args[3], args[4], args[5], unetpp._tail_img.data_ptr(), *vec, 0, None) != 0
+            assert b"tedspad_unetpp_tail_fwd" in L.tedspad_last_error()
     with pytest.raises(RuntimeError):
         unetpp(torch.zeros(1, 3, 40, 64, device="cuda"))           # smp's check_input_shape: H, W % 16
     # train(): batch-statistics BatchNorm (train_anonymizer.py:73 puts fa in train mode), running statistics moved once per call
