@@ -190,6 +190,20 @@ def test_anonymized_extraction_with_unetpp(wrapper, unetpp):
         assert rel_l2(feats1[t], ref[t]) < TOL and rel_l2(feats1[t], feats[t]) < TOL
 
 
+def test_anonymized_extraction_over_two_streams_keeps_rows_and_values(wrapper, unetpp):
+    """extraction.extract_anonymized_clip_features (what extract_video_sharded runs per rank): encoder batches of 2 clips alternating over two streams,
+    anonymizer on one clip at a time, against the one-stream, one-batch call: the same rows in the same order."""
+    from ted_spad_amd import extraction
+    clips = torch.stack([synth_tensor(9, "uppvid%d" % (i % 3), (16, 3, 64, 64)) * (1.0 - 0.1 * (i // 3)) for i in range(5)]).cuda()
+    one = extraction.extract_anonymized_clip_features(wrapper, unetpp, clips, batch=5, fa_batch=5, streams=1)
+    two = extraction.extract_anonymized_clip_features(wrapper, unetpp, clips, batch=2, fa_batch=1, streams=2)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape == (5, 2048)
+    for t in range(5):
+        assert rel_l2(two[t].cpu(), one[t].cpu()) < TOL, t
+    assert rel_l2(one[3].cpu(), one[0].cpu()) > 10 * TOL          # the rows do differ from each other
+
+
 def test_unet_odd_size_vs_oracle(unet):
     """Up's pad-to-skip path (unet_parts.py:56-62): 100x92 -> 6x5 at the bottom, skips are odd."""
     from oracle import unet_ref
