@@ -2,15 +2,16 @@
 1/2/4/8 MI355X, with the feature relative-L2 against the fp32 CPU path and the CPU
 extractor timed beside it.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N ranks as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one synthetic UCF-Crime-length video per GPU:
+A step = one pass of the hot path over one synthetic UCF-Crime-length video:
 225 clip times x 10 crops = 2250 clip-forwards of (3,16,224,224) fp32 (cfg2), inputs
-resident in HBM before the timed region, features all-gathered over RCCL when N > 1 (cfg4;
-weak scaling: the video grows with N, each rank keeps 225 clip times) and copied to the host
-(the .npy rows). Prints ONE JSON line on rank 0. At N = 1 the line also carries `train_cfg3`: the anonymizer training
+resident in HBM before the timed region. N > 1 (cfg4): that ONE video's clip times are split over the ranks
+(`"scaling": "strong"`, `value`), features all-gathered over RCCL and copied to the host (the .npy rows) inside
+the timed region; the weak reading (a whole video per rank) is measured right after it and reported as
+`weak_scaling` in the same line. Prints ONE JSON line on rank 0. At N = 1 the line also carries `train_cfg3`: the anonymizer training
 iteration of BASELINE.json configs[2] (UNet + I3Res50 + CE/triplet, batch 8 x 48 x 112^2), timed per phase after the
 headline measurement (`--no-train` skips it, `--train` runs only it).
 
@@ -362,15 +363,37 @@ def main():
     ap.add_argument("--train-hw", type=int, default=112, help="with --train: frame size (112: cfg3; 224: the per-rank batch of cfg5)")
     ap.add_argument("--act-range", action="store_true", help="add the per-stage max |activation| of one forward (f16 head-room) to the line")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on CPU/gloo with a stub extractor")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank keeps --clip-times clip times (the video grows with N); strong: ONE video of --clip-times clip times split over the N ranks "
-                         "(BASELINE.json north_star: 'clips of a long video shard across the 8 GPUs'; ragged shards and a ragged last batch per rank)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default at N > 1; cfg4): ONE video of --clip-times clip times split over the N ranks (BASELINE.json north_star: 'clips of a long video "
+                         "shard across the 8 GPUs'; ragged shards; a rank's shard runs as equal forwards spread over its streams) -- the weak figure is measured right "
+                         "after it and reported as `weak_scaling` in the same line; weak: every rank keeps --clip-times clip times (the video grows with N). "
+                         "At N = 1 the two are the same workload (reported as \"weak\")")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1, strong: skip the weak-scaling measurement appended to the line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver starts `--gpus 1`: this process has not touched the GPU (importing torch does not) and starts the N ranks as a
+        # CHILD `python -m torch.distributed.run` (never an exec), relays rank 0's JSON line (inherited stdout) and exits with the child's code
+        import socket
+        import subprocess
+        so = socket.socket()
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+        so.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if args.dry_run_cpu:
+            env.setdefault("OMP_NUM_THREADS", "1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
     dry = args.dry_run_cpu
     if dry:
         dev = torch.device("cpu")
@@ -413,125 +436,150 @@ def main():
         ft = ft.to(dev).eval()
         fx = ft.extract_features if hasattr(ft, "extract_features") else ft.i3d.extract_features
 
-    # ---- this rank's shard of the synthetic video, resident in HBM -------------------------------
-    T_total = args.clip_times * world if args.scaling == "weak" else args.clip_times
-    lo, hi = sharding.shard_range(T_total, rank, world)
-    n_local = (hi - lo) * args.crops
-    clips = torch.empty((n_local,) + shape, dtype=torch.float32, device=dev)
-    for i in range(0, n_local, 25):
-        k = min(25, n_local - i)
-        clips[i:i + k] = synth_clips(0, k, shape, device=dev, first=lo * args.crops + i)
-    sync()
+    def run_workload(scaling, timed_steps, tune):
+        """One measurement of the extraction step under `scaling` ("weak": every rank keeps --clip-times clip times; "strong": ONE video of --clip-times
+        clip times split over the ranks). Returns the MAX-over-ranks wall time of `timed_steps` steps (barrier + synchronize on both sides), rank 0's host copy of
+        the gathered block, the HIP-event records of the forwards and the shard geometry."""
+        T_total = args.clip_times * world if scaling == "weak" else args.clip_times
+        lo, hi = sharding.shard_range(T_total, rank, world)
+        n_local = (hi - lo) * args.crops
+        # ---- this rank's shard of the synthetic video, resident in HBM -------------------------------
+        clips = torch.empty((n_local,) + shape, dtype=torch.float32, device=dev)
+        for i in range(0, n_local, 25):
+            k = min(25, n_local - i)
+            clips[i:i + k] = synth_clips(0, k, shape, device=dev, first=lo * args.crops + i)
+        sync()
+        plan = sharding.batch_plan(n_local, args.batch, max(1, args.streams))      # [(first clip, clips)] per forward, spread evenly over the streams
 
-    feats = torch.empty((n_local, F), dtype=torch.float32, device=dev)
-    # rank 0's host copy of the gathered (T,10,F) block: pinned, so the device->host copy of a step is an asynchronous 18 MB DMA
-    # (a pageable `.cpu()` took ~5 ms of every 144 ms step with the GPU idle); it completes inside the timed region (final synchronize)
-    host_feats = torch.empty((T_total, args.crops, F), dtype=torch.float32, pin_memory=not dry) if rank == 0 else None
-    ev = []
+        feats = torch.empty((n_local, F), dtype=torch.float32, device=dev)
+        # rank 0's host copy of the gathered (T,10,F) block: pinned, so the device->host copy of a step is an asynchronous 18 MB DMA
+        # (a pageable `.cpu()` took ~5 ms of every 144 ms step with the GPU idle); it completes inside the timed region (final synchronize)
+        host_feats = torch.empty((T_total, args.crops, F), dtype=torch.float32, pin_memory=not dry) if rank == 0 else None
+        ev = []
+
+        def step(timed):
+            if dry:
+                for i, k in plan:
+                    feats[i:i + k] = fx(clips[i:i + k]).flatten(1)
+            else:
+                main_s = torch.cuda.current_stream()
+                if timed:   # HIP events on the launching (main) stream around the fork/join of the forward streams
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(main_s)
+                for st in streams:
+                    st.wait_stream(main_s)
+                for j, (i, k) in enumerate(plan):
+                    with torch.cuda.stream(streams[j % len(streams)]):
+                        feats[i:i + k] = fx(clips[i:i + k]).flatten(1)
+                for st in streams:
+                    main_s.wait_stream(st)
+                if timed:
+                    e1.record(main_s)
+                    ev.append((e0, e1, n_local))
+            full = sharding.gather_video_features(feats.view(hi - lo, args.crops, F), T_total)
+            if rank == 0:                               # the .npy rows reach the host on rank 0
+                if copy_stream is None:
+                    host_feats.copy_(full.view(T_total, args.crops, F), non_blocking=True)
+                else:
+                    if full.data_ptr() == feats.data_ptr():     # N = 1: the "gathered" block IS the buffer the next step's forwards write: snapshot it (18 MB on the device)
+                        full = full.clone()
+                    copy_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(copy_stream):
+                        host_feats.copy_(full.view(T_total, args.crops, F), non_blocking=True)
+                    full.record_stream(copy_stream)     # the gathered block is freed by the launching stream's allocator: not before the copy ran
+                return host_feats
+            return full
+
+        tiles_ok = None
+        with torch.no_grad():
+            # batch sizes (= conv geometries) any rank will run
+            sizes = sorted({k for r in range(world) for _, k in sharding.batch_plan(
+                (lambda l_, h_: (h_ - l_) * args.crops)(*sharding.shard_range(T_total, r, world)), args.batch, max(1, args.streams))}, reverse=True)
+            if not dry and tune:
+                # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are chosen in context during the
+                # first ~45 forwards of every conv geometry; do that before the counted warm-up. At N > 1 only rank 0 tunes; its table is broadcast so that
+                # every rank runs the same tiles (identical features for identical clips, no start-up skew from N tuning passes).
+                from ted_spad_amd import engine as _E
+                if rank == 0 or world == 1:
+                    for size in sizes:
+                        if not _E.AUTOTUNE or size > n_local:
+                            continue
+                        for i in range(96):                       # > number of tile configurations + TUNE_REPS pruned passes
+                            multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
+                            with torch.cuda.stream(streams[i % len(streams) if multi and i else 0]):
+                                fx(clips[:size])
+                            if i >= 48 and not _E.tuning_pending():
+                                break
+                if world > 1:
+                    sync()
+                    from ted_spad_amd.extraction import share_tile_choices
+                    share_tile_choices(ft)
+            elif dry and world > 1:
+                # rehearsal of the tile-table hand-off with stand-in objects (no kernels): rank 0 "decides", every rank must end with the same table
+                from ted_spad_amd import engine as _E
+
+                class _Tuned:
+                    def __init__(self):
+                        self._cfgs = _E._Cfgs()
+                fake = {"layer%d.conv" % i: _Tuned() for i in range(3)}
+                if rank == 0:
+                    for i, o in enumerate(fake.values()):
+                        for size in sizes:
+                            o._cfgs[(size, 2, 14, 14, 1024, (0, 1, 1), True, None)] = 17 + i
+                box = [_E.export_tile_table(fake) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                if rank != 0:
+                    _E.import_tile_table(fake, box[0])
+                mine = _E.export_tile_table(fake)
+                flags = [None] * world
+                dist.all_gather_object(flags, mine == box[0] and all(len(v) == len(sizes) for v in mine.values()))
+                tiles_ok = all(flags)
+            sync()
+            for _ in range(args.warmup):
+                step(False)
+            if world > 1:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(timed_steps):
+                out = step(True)
+            sync()
+            if world > 1:
+                dist.barrier()
+            sync()
+            dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return {"dt": float(tmax.item()), "out": out, "ev": ev, "T_total": T_total, "n_local": n_local, "clips": clips, "plan": plan, "sizes": sizes,
+                "tiles_ok": tiles_ok}
+
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))] if not dry else []
     # rank 0's device->host copy of a step runs on its own stream, under the next step's forwards (it still completes inside the timed
     # region: the final synchronize waits for every stream); on the launching stream the forward streams of the next step would wait for it
     # (0.7 ms of a 102 ms step at N = 1, N x 18 MB = ~6 ms at N = 8)
     copy_stream = torch.cuda.Stream(device=dev) if (not dry and rank == 0) else None
 
-    def step(timed):
-        if dry:
-            for i in range(0, n_local, args.batch):
-                f = fx(clips[i:i + args.batch]).flatten(1)
-                feats[i:i + f.shape[0]] = f
-        else:
-            main_s = torch.cuda.current_stream()
-            if timed:   # HIP events on the launching (main) stream around the fork/join of the forward streams
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(main_s)
-            for st in streams:
-                st.wait_stream(main_s)
-            for j, i in enumerate(range(0, n_local, args.batch)):
-                with torch.cuda.stream(streams[j % len(streams)]):
-                    f = fx(clips[i:i + args.batch]).flatten(1)
-                    feats[i:i + f.shape[0]] = f
-            for st in streams:
-                main_s.wait_stream(st)
-            if timed:
-                e1.record(main_s)
-                ev.append((e0, e1, n_local))
-        full = sharding.gather_video_features(feats.view(hi - lo, args.crops, F), T_total)
-        if rank == 0:                               # the .npy rows reach the host on rank 0
-            if copy_stream is None:
-                host_feats.copy_(full.view(T_total, args.crops, F), non_blocking=True)
-            else:
-                if full.data_ptr() == feats.data_ptr():     # N = 1: the "gathered" block IS the buffer the next step's forwards write: snapshot it (18 MB on the device)
-                    full = full.clone()
-                copy_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(copy_stream):
-                    host_feats.copy_(full.view(T_total, args.crops, F), non_blocking=True)
-                full.record_stream(copy_stream)     # the gathered block is freed by the launching stream's allocator: not before the copy ran
-            return host_feats
-        return full
-
-    with torch.no_grad():
-        # batch sizes (= conv geometries) any rank will run: the full batch and every rank's ragged last batch
-        sizes = sorted({min(args.batch, (h_ - l_) * args.crops) for l_, h_ in (sharding.shard_range(T_total, r, world) for r in range(world)) if h_ > l_} |
-                       {((h_ - l_) * args.crops) % args.batch for l_, h_ in (sharding.shard_range(T_total, r, world) for r in range(world))} - {0}, reverse=True)
-        if not dry:
-            # untimed setup (like cudnn.benchmark's first iterations in the reference): the conv tile configurations are chosen in context during the
-            # first ~45 forwards of every conv geometry; do that before the counted warm-up. At N > 1 only rank 0 tunes; its table is broadcast so that
-            # every rank runs the same tiles (identical features for identical clips, no start-up skew from N tuning passes).
-            from ted_spad_amd import engine as _E
-            if rank == 0 or world == 1:
-                for size in sizes:
-                    if not _E.AUTOTUNE or size > n_local:
-                        continue
-                    for i in range(96):                       # > number of tile configurations + TUNE_REPS pruned passes
-                        multi = os.environ.get("TEDSPAD_PRIME_MULTI") == "1" or not _E.tuning_pending()
-                        with torch.cuda.stream(streams[i % len(streams) if multi and i else 0]):
-                            fx(clips[:size])
-                        if i >= 48 and not _E.tuning_pending():
-                            break
-            if world > 1:
-                sync()
-                from ted_spad_amd.extraction import share_tile_choices
-                share_tile_choices(ft)
-        elif world > 1:
-            # rehearsal of the tile-table hand-off with stand-in objects (no kernels): rank 0 "decides", every rank must end with the same table
-            from ted_spad_amd import engine as _E
-
-            class _Tuned:
-                def __init__(self):
-                    self._cfgs = _E._Cfgs()
-            fake = {"layer%d.conv" % i: _Tuned() for i in range(3)}
-            if rank == 0:
-                for i, o in enumerate(fake.values()):
-                    for size in sizes:
-                        o._cfgs[(size, 2, 14, 14, 1024, (0, 1, 1), True, None)] = 17 + i
-            box = [_E.export_tile_table(fake) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            if rank != 0:
-                _E.import_tile_table(fake, box[0])
-            mine = _E.export_tile_table(fake)
-            flags = [None] * world
-            dist.all_gather_object(flags, mine == box[0] and all(len(v) == len(sizes) for v in mine.values()))
-            tiles_ok = all(flags)
-        sync()
-        for _ in range(args.warmup):
-            step(False)
-        if world > 1:
-            dist.barrier()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step(True)
-        sync()
-        if world > 1:
-            dist.barrier()
-        sync()
-        dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    W = run_workload(args.scaling, args.steps, tune=True)
+    dt, out, ev, T_total, n_local, clips = W["dt"], W["out"], W["ev"], W["T_total"], W["n_local"], W["clips"]
+    tiles_ok, plan, sizes = W["tiles_ok"], W["plan"], W["sizes"]
     total_clips = T_total * args.crops * args.steps
     value = total_clips / dt
+    # N > 1: the other reading of "clips/s at N GPUs" in the same line -- `value` is cfg4 as BASELINE.json words it (ONE video's clips split over the ranks,
+    # total work fixed: "strong"); `weak_scaling` keeps a whole video per rank (per-GPU work fixed), measured right after it with the same barrier / MAX rule
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak:
+        W = None
+        W2 = run_workload("weak", args.steps, tune=True)
+        weak = {"value": round(W2["T_total"] * args.crops * args.steps / W2["dt"], 2), "unit": "clips/s", "ms_per_step": round(1e3 * W2["dt"] / args.steps, 3),
+                "clips_per_step": W2["T_total"] * args.crops, "clips_per_forward": sorted({k for _, k in W2["plan"]}, reverse=True),
+                "note": "every rank keeps a whole %d-clip-time video (the video grows with N); same barrier + MAX-over-ranks timing, all-gather and D2H inside" % args.clip_times}
+        if dry:
+            want2 = torch.cat([synth_clips(0, min(25, W2["T_total"] * args.crops - i), shape, first=i).flatten(1).mean(1, keepdim=True)
+                               for i in range(0, W2["T_total"] * args.crops, 25)]) if rank == 0 else None
+            if rank == 0:
+                weak["gather_ok"] = bool(torch.allclose(W2["out"].reshape(-1, F), want2 * proj))
+        del W2
 
     if rank != 0:
         if world > 1:
@@ -543,12 +591,16 @@ def main():
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": ("DRY RUN (CPU, stub extractor, no kernels): " if dry else "") +
-                                  "cfg2 dali_extraction path: %s extract_features, %d clip times x %d crops = %d clip-forwards of "
+                                  ("cfg2" if world == 1 else "cfg4 (cfg2's video clip-sharded over %d ranks)" % world if args.scaling == "strong" else "cfg2 per rank") +
+                                  " dali_extraction path: %s extract_features, %d clip times x %d crops = %d clip-forwards of "
                                   "3x16x224x224 %s per step, random-init weights" % (args.arch, T_total if args.scaling == "strong" else args.clip_times, args.crops,
                                                                                      T_total * args.crops if args.scaling == "strong" else n_local,
-                                                                                     "in total (split over the ranks)" if args.scaling == "strong" else "per GPU"),
+                                                                                     "in total (split over the ranks)" if args.scaling == "strong" and world > 1 else "per GPU"),
                       "global_batch": args.batch * world, "clips_per_step": T_total * args.crops,
+                      "clips_per_forward": sorted({k for _, k in plan} if world == 1 else set(sizes), reverse=True),
                       "parallelism": "clip-sharded x%d + RCCL all-gather of (T,10,F) features" % world}}
+    if weak is not None:
+        res["weak_scaling"] = weak
 
     if dry:
         # the stub's rows are a known function of the global clip index: the gathered (T, crops, F) block must be complete and ordered
@@ -567,7 +619,7 @@ def main():
     fwd_ms = sum(a.elapsed_time(b) for a, b, _ in ev)
     fwd_clips = sum(n for _, _, n in ev)
     achieved = fwd_clips * GFLOP_PER_CLIP[args.arch] / fwd_ms  # GFLOP / ms == TFLOP/s
-    n_fwd = len(ev) * ((n_local + args.batch - 1) // args.batch)
+    n_fwd = len(ev) * max(1, len(plan))
     traffic = traffic_all = None
     tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")   # PMC result of the same command (scripts/profile_bench.sh)
     if os.path.exists(tpath):
@@ -597,7 +649,7 @@ def main():
                        "peak_at_clock": None if clock_mhz is None else round(MFMA_PEAK_TFLOPS * clock_mhz / 2400.0, 1),
                        "kernel": "conv stack of one batch forward (conv_stem_pt_kernel + conv_p8 / conv_patch / conv_flat / conv_igemm / conv_pw "
                                  "launches; layout, max-pool and average-pool passes included in the time)",
-                       "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": args.batch, "streams": len(streams)}
+                       "ms_per_forward": round(fwd_ms / n_fwd, 3), "clips_per_forward": max([k for _, k in plan] or [0]), "streams": len(streams)}
 
     # ---- CPU baseline + parity on a bounded sample: the oracle on this box's host cores ------------
     if not args.no_cpu_baseline:      # the parity check runs at every N (the other ranks wait at the final barrier); the CPU extractor is TIMED at N = 1 only

@@ -85,11 +85,11 @@ def extract_clip_features(ft_model, clips_cthw: torch.Tensor, batch: int = 75, o
     for st in pool:
         st.wait_stream(main)
     from . import engine as E
-    for j, i in enumerate(range(0, n, batch)):
+    # forwards of at most `batch` clips, spread evenly over the streams (a 290-clip shard of a video split over 8 ranks: 145 + 145, not 290 on one stream)
+    for j, (i, k) in enumerate(sharding.batch_plan(n, batch, len(pool))):
         # while the conv tile tuner is still timing candidates, stay on one stream (engine.tuning_pending)
         with torch.cuda.stream(pool[0 if E.tuning_pending() else j % len(pool)]):
-            f = fx(clips_cthw[i:i + batch]).flatten(1)
-            out[i:i + f.shape[0]] = f
+            out[i:i + k] = fx(clips_cthw[i:i + k]).flatten(1)
     for st in pool:
         main.wait_stream(st)
     return out

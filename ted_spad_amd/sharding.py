@@ -39,3 +39,16 @@ def gather_video_features(local: torch.Tensor, T: int, group=None) -> torch.Tens
     recv = local.new_empty((world * per,) + tail)
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     return recv[:T]
+
+
+def batch_plan(n_local: int, batch: int, streams: int = 1, min_batch: int = 32):
+    """[(first clip, clips)] forwards for a shard of `n_local` clips: as few forwards of at most `batch` clips as cover the shard -- but at least one per HIP
+    stream as long as a forward keeps `min_batch` clips -- and the clips spread evenly over them. One video split over 8 ranks (cfg4: 29 clip times x 10 crops = 290 clips per rank) becomes 145 + 145 on two streams instead of
+    one ragged 290-clip forward on one stream; 2 250 clips at 375 per forward stay 6 x 375."""
+    if n_local <= 0:
+        return []
+    nb = -(-n_local // batch)
+    if nb < streams and n_local // streams >= min_batch:
+        nb = streams
+    per = -(-n_local // nb)
+    return [(i, min(per, n_local - i)) for i in range(0, n_local, per)]

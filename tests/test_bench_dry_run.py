@@ -34,7 +34,7 @@ def test_two_rank_dry_run_prints_one_line_from_rank0():
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "3", "--warmup", "1",
-           "--clip-times", "5", "--crops", "2", "--batch", "4"]       # 5 clip times per rank, ragged last batch (10 clips in batches of 4)
+           "--clip-times", "5", "--crops", "2", "--batch", "4", "--scaling", "weak"]       # 5 clip times per rank, 10 clips in forwards of at most 4
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = _json_lines(r.stdout)
@@ -59,6 +59,41 @@ def test_two_rank_strong_scaling_dry_run_splits_one_video():
     j = j[0]
     assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["clips_per_step"] == 7 * 2
     assert j["gather_ok"] is True and j["tile_table_ok"] is True
+
+
+def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` exactly as `--gpus 1` is started (no torch.distributed.run, WORLD_SIZE unset): the parent starts the two ranks as a child
+    process, relays ONE JSON line and exits 0. N > 1 defaults to strong scaling (cfg4: one video split over the ranks) with the weak figure in the same line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1", "--clip-times", "7",
+                        "--crops", "2", "--batch", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_lines(r.stdout)
+    assert len(j) == 1, r.stdout
+    j = j[0]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["clips_per_step"] == 7 * 2 and j["gather_ok"] is True
+    w = j["weak_scaling"]
+    assert w["clips_per_step"] == 2 * 7 * 2 and w["value"] > 0 and w["gather_ok"] is True
+
+
+def test_mismatched_world_size_is_refused():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_batch_plan_spreads_a_shard_evenly_over_the_streams():
+    from ted_spad_amd.sharding import batch_plan
+    assert batch_plan(2250, 375, 2) == [(i * 375, 375) for i in range(6)]                    # cfg2 at N = 1: unchanged
+    assert batch_plan(290, 375, 2) == [(0, 145), (145, 145)]                                 # cfg4 at N = 8: 29 clip times x 10 crops, one forward per stream
+    assert batch_plan(220, 375, 2) == [(0, 110), (110, 110)]                                 # ... the last rank's 22 clip times
+    assert batch_plan(1130, 375, 2) == [(0, 283), (283, 283), (566, 283), (849, 281)]        # N = 2: 113 clip times
+    assert batch_plan(40, 375, 2) == [(0, 40)] and batch_plan(0, 375, 2) == []               # too small to split; an empty shard launches nothing
+    for n in (1, 31, 64, 65, 290, 999, 2250):
+        for st in (1, 2, 3):
+            pl = batch_plan(n, 375, st)
+            assert sum(k for _, k in pl) == n and all(k <= 375 for _, k in pl) and [i for i, _ in pl] == [sum(k for _, k in pl[:j]) for j in range(len(pl))]
 
 
 def test_two_rank_training_dry_run_drives_the_real_reducer():

@@ -73,3 +73,29 @@ def test_bf16_mode_misses_the_gate_f16_meets_it(golden):
     x = synth_clips(0, 1, (3, 16, 112, 112), device="cuda")
     r = rel_l2(w.i3d.extract_features(x).cpu().reshape(1, 2048), golden["i3res50_feat_112"])
     assert 1e-3 < r < 8e-3
+
+
+def test_cfg4_per_rank_shape_matches_the_375_clip_forward(net):
+    """cfg4 at N = 8 (BASELINE.json configs[3]; dali_extraction.py:62-73: one clip per 32 source frames): a rank's shard of the 225-clip-time video is
+    29 clip times x 10 crops = 290 clips, run as sharding.batch_plan's 145 + 145 on two HIP streams (extraction.extract_clip_features, what bench.py's
+    strong-scaling step launches). The features must be the ones the N = 1 geometry (one 375-clip forward) gives for the same clips -- other tile choices,
+    same arithmetic up to fp32 summation order -- and within the gate of the oracle's golden clip."""
+    from ted_spad_amd import engine as E, extraction, sharding
+    n = 375
+    clips = torch.cat([synth_clips(0, min(25, n - i), (3, 16, 224, 224), device="cuda", first=i) for i in range(0, n, 25)])
+    assert sharding.batch_plan(290, 375, 2) == [(0, 145), (145, 145)]
+    with torch.no_grad():
+        for _ in range(60):
+            full = net.i3d.extract_features(clips)
+            if not E.tuning_pending():
+                break
+        full = net.i3d.extract_features(clips).flatten(1)
+        for _ in range(60):
+            shard = extraction.extract_clip_features(net, clips[:290], batch=375, streams=2)
+            if not E.tuning_pending():
+                break
+        shard = extraction.extract_clip_features(net, clips[:290], batch=375, streams=2)
+    torch.cuda.synchronize()
+    rel = ((shard.double() - full[:290].double()).norm(dim=1) / full[:290].double().norm(dim=1))
+    print("cfg4 per-rank shard (145 + 145 on two streams) vs the 375-clip forward: max rel-L2 %.3e" % float(rel.max()))
+    assert float(rel.max()) < 2e-4
