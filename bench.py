@@ -685,7 +685,7 @@ def main():
             ft.i3d._trunk(clips[:10], taps=taps)
         res["act_absmax"] = {k: round(float(v.buf.float().abs().max()), 3) for k, v in taps.items()}   # f16 saturates at 65504
     if world == 1 and not args.no_train:
-        del clips, feats
+        del clips, W
         torch.cuda.empty_cache()
         res["anon_extract"] = bench_anon_extract(dev)
         torch.cuda.empty_cache()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TEDSPAD_ABI_VERSION 3   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4) */
+#define TEDSPAD_ABI_VERSION 4   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4); 4: tedspad_bneck_l1_* removed (round 5) */
 
 enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
@@ -254,20 +254,6 @@ int32_t tedspad_stem_pt_pool_clip_fwd(const float *x, int32_t n, int32_t c, int3
                                       int64_t sw, int32_t pad_t, int32_t stride_t, int32_t t_pairs, const void *w_img16, const float *scale,
                                       const float *shift, void *y, void *side, int32_t hp, int32_t wp, int32_t ldy, int32_t nwg, int32_t variant,
                                       int32_t dtype, void *stream);
-
-/* A plain layer1 bottleneck of I3Res50 (large_i3d.py:61-84 without `downsample`: layer1.1, layer1.2 of :142) in ONE launch: conv1 (kt x 1 x 1, kt = 3 | 1,
- * 256 -> 64) + bn1 + ReLU -> conv2 (1 x 3 x 3, 64 -> 64) + bn2 + ReLU -> conv3 (1x1x1, 64 -> 256) + bn3 + residual (= x) + ReLU, optionally followed by
- * maxpool2 = MaxPool3d((2,1,1), stride (2,1,1)) (large_i3d.py:139; pool_t2: y has t / 2 frames). A workgroup owns a spatial tile x all t <= 4 frames of a
- * clip; conv1 is recomputed on the tile's halo, both 64-channel tensors stay in LDS (tedspad_bneck_l1_lds_bytes(variant) of dynamic LDS): HBM sees x and y
- * only. variant bit 0: tiles of 4 x 14 output pixels, two 4-wave workgroups per CU (else 8 x 14, one 8-wave workgroup per CU).
- * x: (n, t, h, w, 256) channels-last, pixel stride ldx; y likewise, ldy == ldx.
- * w_img: tedspad_bneck_l1_units(cin, kt) units of 4 KB in the kernel's consumption order (layouts: csrc/conv_bneck_l1.hip; engine.BneckL1 packs them);
- * scale / shift: the folded BatchNorms, fp32 (64, 64, 256 values). */
-int32_t tedspad_bneck_l1_lds_bytes(int32_t variant);
-int32_t tedspad_bneck_l1_units(int32_t cin, int32_t kt);
-int32_t tedspad_bneck_l1_fwd(const void *x, int32_t ldx, void *y, int32_t ldy, int32_t n, int32_t t, int32_t h, int32_t w, int32_t cin, int32_t kt,
-                             const void *w_img, const float *scale1, const float *shift1, const float *scale2, const float *shift2,
-                             const float *scale3, const float *shift3, int32_t relu, int32_t pool_t2, int32_t variant, int32_t dtype, void *stream);
 
 /* The block that ends the default anonymizer's decoder (arch = 'unet++', aux_code/model_loaders.py:17-30; smp 0.3.3 UnetPlusPlusDecoder blocks['x_0_3'] =
  * DecoderBlock(64, 0, 32) followed by SegmentationHead(32, 3, kernel_size 3)) in ONE launch, at full resolution:

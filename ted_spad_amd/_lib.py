@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtedspad_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
-ABI_VERSION = 3          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
+ABI_VERSION = 4          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
 
 
 class ConvDesc(C.Structure):
@@ -104,9 +104,6 @@ SYMBOLS = {
     "tedspad_stem_pt_fwd": (_I32, [_P] * 5 + [_I32] * 11 + [_P]),
     "tedspad_stem_pt_side_bytes": (_I64, [_I32] * 4),
     "tedspad_stem_pt_pool_fwd": (_I32, [_P] * 6 + [_I32] * 10 + [_P]),
-    "tedspad_bneck_l1_lds_bytes": (_I32, [_I32]),
-    "tedspad_bneck_l1_units": (_I32, [_I32, _I32]),
-    "tedspad_bneck_l1_fwd": (_I32, [_P, _I32, _P, _I32] + [_I32] * 6 + [_P] * 7 + [_I32] * 4 + [_P]),
     "tedspad_unetpp_tail_wimg_bytes": (_I32, []),
     "tedspad_unetpp_tail_fwd": (_I32, [_P, _I32, _P, _I32, _I32, _I32] + [_P] * 6 + [_I32, _P]),
     "tedspad_stem_pt_pool_clip_fwd": (_I32, [_P] + [_I32] * 5 + [_I64] * 5 + [_I32] * 3 + [_P] * 5 + [_I32] * 6 + [_P]),

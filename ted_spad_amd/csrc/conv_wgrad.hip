@@ -515,207 +515,6 @@ __global__ __launch_bounds__(384) void conv_wgrad3p_kernel(const WgradKP p, cons
 }
 
 
-// ---- the same nine taps from ONE ring of activation rows --------------------------------------------------------------------------------
-// conv_wgrad3_kernel fetches every input pixel once per kernel ROW (three 66-pixel tiles per 64 output pixels: 33 KB with dY) and is bound by exactly that L2 -> LDS
-// stream (16.3 GB per cfg3 iteration at 1.1 TB/s, profiles/r03_train_cfg3_kernels.md). In flat (n, h, w) order the three tiles of a step are the SAME pixel stream
-// read at offsets -W, 0, +W: here the workgroup keeps a ring of the last 2 W + 130 input pixels in LDS (a sliding window over the stream, blocks of 64 rows), loads
-// the 64 NEW rows of a step once (8 KB + 8 KB of dY per 64 pixels) and reads the three tiles at their ring positions:
-//   * window index i = q - (m_begin - 1 - W - pad), pad chosen so that the window's end is a multiple of 64: step s needs blocks s .. s + Kw - 1, the ring holds
-//     Kw + 1 blocks, block s + Kw lands while step s is multiplied;
-//   * a tile starts at ring row (64 s + pad + d W) mod RR and is 66 rows long; rows 0 .. 71 of the ring are MIRRORED behind its end (a block that lands there is
-//     written twice), so no fragment read ever wraps; the tile start is 16 T + a_d with a_d = (pad + d W) mod 16 fixed per kernel row: the swizzled per-lane
-//     fragment offsets are loop constants, the tile base is a scalar;
-//   * rows of the image above / below the frame can no longer be zeroed when they are loaded (one ring row serves three kernel rows): like the left / right edge they
-//     are excluded on the dY side -- the output pixels of image row 0 (row H - 1) are masked out of the A fragments used for kernel row 0 (2).
-template <typename T>
-__global__ __launch_bounds__(384) void conv_wgrad3r_kernel(const WgradKP p, int pad, int Kw) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
-    const int cc = b % p.cc_tiles; b /= p.cc_tiles;
-    const int cot = b % p.co_tiles;
-    const int ms = b / p.co_tiles;
-    const int m_begin = ms * p.rows_per_split;
-    const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nsteps = (m_end - m_begin + 63) / 64;
-    const int W = p.Wi, H = p.Hi;
-    const int RR = 64 * (Kw + 1);
-    unsigned char *Xr = smem3;                                  // ring: RR + 72 rows of 128 bytes
-    unsigned char *Yb = smem3 + (RR + 72) * 128;                // dY: two [64 px][64 co] tiles
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem3;
-    const unsigned ldsY = lds0 + (RR + 72) * 128;
-    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16w);
-    const bool yok = cot * 64 + ((lane & 7) ^ wg_swz(lane >> 3)) * 8 < p.Cout;
-    const int q_base = m_begin - 1 - W - pad;
-
-    // ---- DMA: a wave-instruction moves 8 rows x 128 bytes; group gi of a 64-row block = rows 8 gi .. 8 gi + 7 (block bases are multiples of 64: the swizzle of a row
-    // is that of its index inside the block) ------------------------------------------------------------------------------------------------------------------------
-    const int rg = lane >> 3;
-    auto issue_block = [&](int blk) {                           // input pixels q_base + 64 blk .. + 63 -> ring slot (blk mod (Kw + 1)) * 64 (+ the mirror)
-        const int slot = (blk % (Kw + 1)) * 64;
-        for (int gi = wave; gi < 8; gi += 6) {
-            const int r = 8 * gi + rg;
-            const int q = q_base + 64 * blk + r;
-            const int kc = (lane & 7) ^ wg_swz(r);
-            const uint16_t *src = (q >= 0 && q < p.M) ? p.x + (ptrdiff_t)q * p.ldx + cc * 64 + kc * 8 : zero;
-            lds_dma16(src, lds0 + (slot + 8 * gi) * 128);
-            if (slot + 8 * gi < 72) lds_dma16(src, lds0 + (RR + slot + 8 * gi) * 128);      // wave-uniform
-        }
-    };
-    auto issue_dy = [&](int step) {
-        for (int gi = wave; gi < 8; gi += 6) {
-            const int r = 8 * gi + rg;
-            const int o = m_begin + 64 * step + r;
-            const int kc = (lane & 7) ^ wg_swz(r);
-            const uint16_t *src = (o < m_end && cot * 64 + kc * 8 < p.Cout) ? p.dy + (ptrdiff_t)o * p.ldy + cot * 64 + kc * 8 : zero;
-            lds_dma16(src, ldsY + (step & 1) * WG_SUB + 8 * gi * 128);
-        }
-    };
-
-
-    // ---- MFMA roles (those of conv_wgrad3_kernel) ---------------------------------------------------------------------------------------------------------------
-    const int dw = wave % 3, cih = wave / 3;
-    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
-    int offa[2][2], offb[3][2];
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        const int row = 8 * h + 4 * rd + q4;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int c = 32 * a + 16 * (g & 1) + 4 * pp;
-            offa[a][rd] = row * 128 + ((((c >> 3) ^ wg_swz(row))) << 4) + (c & 7) * 2;
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int rb = ((pad + d * W) & 15) + row + dw, cb = 32 * cih + 16 * (g & 1) + 4 * pp;      // row relative to the tile's 16-aligned base
-            offb[d][rd] = rb * 128 + ((((cb >> 3) ^ wg_swz(rb))) << 4) + (cb & 7) * 2;
-        }
-    }
-    f32x16 acc[3][2];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[d][a][r] = 0.f;
-    auto tr = [&](const unsigned char *base) -> uint2 {
-        const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v *)(base));
-        return __builtin_bit_cast(uint2, v);
-    };
-
-    // TOUCH-AHEAD. A step's 16 KB are requested one step before they are read, and a step (24 MFMAs per wave) is far shorter than an HBM round trip: the kernel ran
-    // at one step per ~3 us whatever it moved (7 k cycles for 1.2 k of MFMA work). Waves 0 / 1 therefore touch the lines of the activation block / dY tile
-    // W3_TD steps ahead with one dword load per row (never used): the LDS-DMA that follows three steps later finds them in L2. The touches are the YOUNGEST
-    // operations of their wave when it waits for its DMA pieces (vector memory retires in order): the counted wait leaves them in flight.
-    constexpr int W3_TD = 4;
-    // (LDS-DMA into a scratch KB: a touch must not own a vector register -- hipcc moves an asm statement's output register around before the load has landed)
-    const unsigned ldsT = ldsY + 2 * WG_SUB;
-    auto touch = [&](int step) {                                // step: the step whose NEW block / dY tile is touched
-        if (wave == 0) {
-            const int q = q_base + 64 * (step + Kw - 1) + lane;
-            lds_dma16((q >= 0 && q < p.M) ? p.x + (ptrdiff_t)q * p.ldx + cc * 64 : zero, ldsT);
-        } else if (wave == 1) {
-            const int o = m_begin + 64 * step + lane;
-            lds_dma16(o < m_end ? p.dy + (ptrdiff_t)o * p.ldy + cot * 64 : zero, ldsT + 1024);
-        }
-    };
-    const bool toucher = wave < 2;
-    if (nsteps > 0) {
-        for (int blk = 0; blk < Kw; ++blk) issue_block(blk);
-        issue_dy(0);
-        for (int t = 1; t < W3_TD; ++t)
-            if (t < nsteps) touch(t);
-        wait_vmcnt<0>();
-    }
-    // (row, column) of the step's first output pixel inside its image, advanced by 64 pixels per step
-    int wbase = m_begin % W, hbase = (m_begin / W) % H;
-    for (int step = 0; step < nsteps; ++step) {
-        if (toucher && step > 0 && step + W3_TD - 1 < nsteps) wait_vmcnt<1>(); else wait_vmcnt<0>();      // (the touch issued in the previous step stays in flight)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (step + 1 < nsteps) {
-            issue_block(step + Kw);
-            issue_dy(step + 1);
-        }
-        if (step + W3_TD < nsteps) touch(step + W3_TD);
-        // output pixels of this step that must not feed the wave's tap column (left / right image edge) or kernel rows 0 / 2 (top / bottom image row)
-        unsigned long long edge = 0, top = 0, bot = 0;
-        {
-            int j = -wbase, hh = hbase;                         // pixel index (inside the step) of column 0 of the image row the step starts in
-            while (j < 64) {
-                const unsigned long long rowbits = (j + W >= 64 ? ~0ull : ((1ull << (j + W)) - 1)) & (j <= 0 ? ~0ull : ~((1ull << j) - 1));
-                if (hh == 0) top |= rowbits;
-                if (hh == H - 1) bot |= rowbits;
-                if (dw == 0 && j >= 0) edge |= 1ull << j;
-                if (dw == 2 && j + W - 1 >= 0 && j + W - 1 < 64) edge |= 1ull << (j + W - 1);
-                j += W;
-                hh = hh + 1 == H ? 0 : hh + 1;
-            }
-        }
-        {
-            int wn = wbase + 64, hn = hbase;
-            while (wn >= W) { wn -= W; hn = hn + 1 == H ? 0 : hn + 1; }
-            wbase = wn; hbase = hn;
-        }
-        const unsigned char *Y = Yb + (step & 1) * WG_SUB;
-        const unsigned char *Xd[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int i = 64 * step + pad + d * W;
-            Xd[d] = Xr + ((i % RR) & ~15) * 128;                // the tile's 16-aligned base row (wave-uniform); offb carries the remainder
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            uint4 fa[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const uint2 lo = tr(Y + ks * 16 * 128 + offa[a][0]), hi = tr(Y + ks * 16 * 128 + offa[a][1]);
-                fa[a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-            const int sh = 16 * ks + 8 * h;                     // element j of the fragment = pixel 16 ks + 8 h + j
-            const unsigned be = (unsigned)(edge >> sh) & 0xffu, bt = (unsigned)(top >> sh) & 0xffu, bb = (unsigned)(bot >> sh) & 0xffu;
-            auto masked = [&](const uint4 (&f)[2], unsigned bits, uint4 (&o)[2]) {
-                unsigned mk[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mk[e] = ((bits >> (2 * e)) & 1u ? 0u : 0xffffu) | ((bits >> (2 * e + 1)) & 1u ? 0u : 0xffff0000u);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) o[a] = make_uint4(f[a].x & mk[0], f[a].y & mk[1], f[a].z & mk[2], f[a].w & mk[3]);
-            };
-            if (be) masked(fa, be, fa);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                uint4 fd[2] = {fa[0], fa[1]};
-                const unsigned bits = d == 0 ? bt : d == 2 ? bb : 0u;
-                if (bits) masked(fa, bits, fd);
-                const unsigned char *Xk = Xd[d] + ks * 16 * 128;
-                const uint2 lo = tr(Xk + offb[d][0]), hi = tr(Xk + offb[d][1]);
-                const uint4 fb = make_uint4(lo.x, lo.y, hi.x, hi.y);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) acc[d][a] = T::mfma(fd[a], fb, acc[d][a]);
-            }
-        }
-    }
-
-    wait_vmcnt<0>();
-    // ---- partial tile -> fp32 dW with float atomics: k = ((dh * 3 + dw) * Cin + cc * 64 + cih * 32 + lane % 32) -----------------------
-    const bool det = det_enter();
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int Cin = p.cc_tiles * 64;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int k = (d * 3 + dw) * Cin + cc * 64 + cih * 32 + l31;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cot * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.Cout) atomicAdd(p.dw + (size_t)co * p.Kpad + k, acc[d][a][r]);
-            }
-    }
-    det_exit(det);
-}
-
 }  // namespace
 }  // namespace tedspad
 
@@ -767,26 +566,6 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
         splits3 = (M + rows3 - 1) / rows3;
         p.rows_per_split = (int)rows3;
         const dim3 grid3((unsigned)(tiles3 * splits3));
-        // the row-ring form: every input pixel fetched once (ring of 2 W + 130 rows, 128 bytes each, + 72 mirrored rows + two dY tiles)
-        static const bool allow_ring = getenv("TEDSPAD_WGRAD_RING") != nullptr;      // opt-in: measured SLOWER than the three-tile kernel (677 vs 559 us alone on the 64 -> 64 full-resolution layer,
-        // 57.3 vs 53.6 ms per cfg3 iteration), with or without the touch-ahead: at one 6-wave workgroup per CU a step is bound by its own serial chain, not by the bytes it streams
-        const int padr = (64 - (2 * d->w + 66) % 64) % 64, kwr = (padr + 2 * d->w + 66) / 64;
-        const int lds3r = (64 * (kwr + 1) + 72) * 128 + 2 * WG_SUB + 2048;      // ring + mirror, two dY tiles, the touches' scratch
-        if (allow_ring && lds3r <= 160 * 1024 && rows3 >= 64) {
-            static thread_local int attr3r[2] = {0, 0};
-            const int ti = d->dtype == TEDSPAD_F16 ? 0 : 1;
-            if (!attr3r[ti]) {
-                const void *fn = ti == 0 ? (const void *)conv_wgrad3r_kernel<F16> : (const void *)conv_wgrad3r_kernel<BF16>;
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                    set_error("tedspad_conv_wgrad: cannot raise the dynamic LDS limit");
-                    return TEDSPAD_ELAUNCH;
-                }
-                attr3r[ti] = 1;
-            }
-            if (ti == 0) hipLaunchKernelGGL((conv_wgrad3r_kernel<F16>), grid3, dim3(384), lds3r, s, p, padr, kwr);
-            else hipLaunchKernelGGL((conv_wgrad3r_kernel<BF16>), grid3, dim3(384), lds3r, s, p, padr, kwr);
-            return check_launch("tedspad_conv_wgrad");
-        }
         // the patch form (4 x 16 outputs and their one 6 x 18 halo per step, three-slot ring): where the frames are wide enough that its zero columns cost less than
         // the three-tile kernel's row re-reads. TEDSPAD_WGRAD_PATCH = 0: never, 2: wherever it applies (A/B)
         static const int patch_mode = getenv("TEDSPAD_WGRAD_PATCH") ? atoi(getenv("TEDSPAD_WGRAD_PATCH")) : 1;

@@ -32,11 +32,8 @@ BNECK_TAIL_POOL = os.environ.get("TEDSPAD_BNECK_TAIL_POOL", "1") != "0"   # laye
 TPAIR_MIN_COUT = int(os.environ.get("TEDSPAD_TPAIR_MIN_COUT", "128"))   # smallest cout that takes the folded form (256: layer2's 128-channel temporal convs stay on the temporal chunk-major tile)
 TPAIR = os.environ.get("TEDSPAD_TPAIR", "1") != "0"   # 3x1x1 convs on two-frame tensors as one K = 2*cin GEMM over both frames (TPairConv); 0: K = 3*cin with zero taps (A/B)
 STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half of maxpool1 inside the stem kernel too (StemPT.conv_pool); 0: separate (1,3,3) max-pool (A/B)
-BNECK_L1_MODE = int(os.environ.get("TEDSPAD_BNECK_L1", "0"))     # 0 off, 1 every plain block of layer1 (the last one with maxpool2 inside if TEDSPAD_BNECK_L1_POOL), 2 only the last (pooled) block
-BNECK_L1 = BNECK_L1_MODE != 0     # layer1's plain bottlenecks as ONE launch each (BneckL1: conv1 recomputed on tile halos, mid tensors in LDS); 0: temporal conv + fused tail (two launches)
 UPP_TAIL = os.environ.get("TEDSPAD_UPP_TAIL", "1") != "0"              # unet++: x_0_3 + segmentation head as one launch (tedspad_unetpp_tail_fwd)
 GATHER_CAT = os.environ.get("TEDSPAD_GATHER_CAT", "1") != "0"          # unet++ decoder blocks read upsample + concat in place (PackedConv.gather)
-BNECK_L1_POOL = os.environ.get("TEDSPAD_BNECK_L1_POOL", "1") != "0"   # ... the last block with maxpool2 inside as well
 STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
@@ -896,59 +893,6 @@ class BneckFrame:
         check(_lib.lib().tedspad_bneck_frame_fwd(x.ptr, x.ld, out.ptr, out.ld, n, t, h, w, self.cin, self.cmid, w1e.data_ptr(), w1o.data_ptr(), self.steps1,
                                                  self.w23.data_ptr(), *[v.data_ptr() for v in self.bn], int(relu), self.dtype_code, _stream_ptr()),
               "tedspad_bneck_frame_fwd")
-        return out
-
-
-class BneckL1:
-    """A plain layer1 bottleneck of I3Res50 (large_i3d.py:61-84, layer1.1 / layer1.2) as ONE launch (csrc/conv_bneck_l1.hip, tedspad_bneck_l1_fwd): a workgroup owns
-    8 x 14 output pixels x all T <= 4 frames, conv1 recomputed on the tile's halo, both 64-channel tensors in LDS. Holds the weight units in the kernel's
-    consumption order and the folded BatchNorm vectors."""
-
-    def __init__(self, w1: torch.Tensor, s1, b1, w2: torch.Tensor, s2, b2, w3: torch.Tensor, s3, b3, dtype: str = DEFAULT_DTYPE, device="cuda"):
-        assert self.supported(w1, w2, w3)
-        device = torch.device(device)
-        self.torch_dtype, self.dtype_code = DTYPES[dtype]
-        self.cin, self.kt = w1.shape[1], w1.shape[2]
-        self.wimg = self.pack(w1, w2, w3).to(device=device, dtype=self.torch_dtype).contiguous()
-        assert self.wimg.numel() * 2 == 4096 * _lib.lib().tedspad_bneck_l1_units(self.cin, self.kt)
-        f32 = lambda v: v.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.vecs = [f32(v) for v in (s1, b1, s2, b2, s3, b3)]
-
-    @staticmethod
-    def supported(w1, w2, w3) -> bool:
-        return (tuple(w1.shape[:2]) == (64, 256) and tuple(w1.shape[3:]) == (1, 1) and w1.shape[2] in (1, 3) and tuple(w2.shape) == (64, 64, 1, 3, 3) and
-                tuple(w3.shape) == (256, 64, 1, 1, 1))
-
-    @staticmethod
-    def pack(w1, w2, w3) -> torch.Tensor:
-        """fp32 weight units: stage 1 [chunk c][tap dt], stage 2 [tap][ks], stage 3 [cb][ks], each [tile j 0..3][k group kg 0..3][i 0..15][8]."""
-        w1, w2, w3 = (w.detach().float().cpu() for w in (w1, w2, w3))
-        i = torch.arange(16)
-        j = torch.arange(4).view(4, 1)
-        co12 = 16 * (i >> 2) + 4 * j + (i & 3)                                  # (4, 16): output channel of MFMA row i of tile j (stages 1, 2)
-        kt = w1.shape[2]
-
-        def units(wm, co):                                                        # wm (cout, K) -> (K / 32, 4, 4, 16, 8)
-            a = wm[co]                                                            # (4, 16, K)
-            return a.view(4, 16, -1, 4, 8).permute(2, 0, 3, 1, 4).contiguous()   # [K step][j][kg][i][8]
-        u1 = torch.stack([units(w1[:, :, dt, 0, 0], co12) for dt in range(kt)], dim=1)                    # (cin / 32, kt, ...)
-        u2 = torch.stack([units(w2[:, :, 0, t // 3, t % 3], co12) for t in range(9)], dim=0)              # (9, 2, ...)
-        u3 = torch.stack([units(w3[:, :, 0, 0, 0], 64 * cb + 4 * i + j) for cb in range(4)], dim=0)        # (4, 2, ...)
-        return torch.cat([u.reshape(-1) for u in (u1, u2, u3)])
-
-    def applies(self, x: Act) -> bool:
-        n, t, h, w = x.dims
-        return x.c == self.cin and t <= 4 and x.buf.dtype == self.torch_dtype and t * h * w * x.ld * 2 < (1 << 31)
-
-    VARIANT = 0          # (reserved; a 4 x 14-tile form with two 4-wave workgroups per CU was measured no faster and removed)
-
-    def __call__(self, x: Act, relu=True, pool_t2=False, variant=None) -> Act:
-        n, t, h, w = x.dims
-        to = t // 2 if pool_t2 else t
-        out = Act(torch.empty((n, to, h, w, x.ld), dtype=self.torch_dtype, device=x.buf.device), 256, x.coff)
-        check(_lib.lib().tedspad_bneck_l1_fwd(x.ptr, x.ld, out.ptr, out.ld, n, t, h, w, self.cin, self.kt, self.wimg.data_ptr(), *[v.data_ptr() for v in self.vecs],
-                                              int(relu), int(pool_t2), self.VARIANT if variant is None else variant, self.dtype_code, _stream_ptr()),
-              "tedspad_bneck_l1_fwd")
         return out
 
 

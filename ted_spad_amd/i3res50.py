@@ -92,10 +92,6 @@ class I3Res50(nn.Module):
                         # layer3's plain blocks: the whole bottleneck in one launch, a workgroup per 14 x 14 frame
                         P[p + "frame"] = E.BneckFrame(blk.conv1.weight, *self._bn_fold(blk.bn1), blk.conv2.weight, *self._bn_fold(blk.bn2),
                                                       blk.conv3.weight, *self._bn_fold(blk.bn3), dtype=self.compute_dtype, device=dev)
-                    if li == 1 and blk.downsample is None and E.BneckL1.supported(blk.conv1.weight, blk.conv2.weight, blk.conv3.weight):
-                        # layer1's plain blocks: the whole bottleneck in one launch, a workgroup per spatial tile x all frames (opt-in: TEDSPAD_BNECK_L1=1)
-                        P[p + "l1"] = E.BneckL1(blk.conv1.weight, *self._bn_fold(blk.bn1), blk.conv2.weight, *self._bn_fold(blk.bn2),
-                                                blk.conv3.weight, *self._bn_fold(blk.bn3), dtype=self.compute_dtype, device=dev)
                     if li in (1, 2) and E.BneckTail.supported(P[p + "conv2"], blk.conv3.weight, blk.downsample[0].weight if blk.downsample is not None else None):
                         s3, b3 = self._bn_fold(blk.bn3)
                         if blk.downsample is not None and blk.stride == 1:
@@ -149,14 +145,6 @@ class I3Res50(nn.Module):
             layer = getattr(self, "layer%d" % li)
             for i, blk in enumerate(layer):
                 p = "layer%d.%d." % (li, i)
-                l1 = P.get(p + "l1") if (taps is None and E.BNECK_L1) else None
-                if l1 is not None and l1.applies(a):
-                    last = li == 1 and i == len(layer) - 1
-                    do_pool = last and E.BNECK_L1_POOL and a.dims[1] % 2 == 0
-                    if (not last and E.BNECK_L1_MODE == 1) or do_pool:
-                        a = l1(a, pool_t2=do_pool)                       # conv1 -> conv2 -> conv3 + residual (+ maxpool2): x in, y out
-                        pooled = pooled or do_pool
-                        continue
                 bf = P.get(p + "frame") if taps is None else None
                 if bf is not None and bf.applies(a):
                     a = bf(a)                                             # conv1 -> conv2 -> conv3 + residual: only the block input and output touch HBM

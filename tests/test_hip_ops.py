@@ -320,60 +320,6 @@ def test_bottleneck_tail_fused_vs_oracle_and_unfused(dims, staged, dual, dtype, 
         assert torch.equal(pooled, want)
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("variant", [0])
-@pytest.mark.parametrize("kt", [3, 1])
-@pytest.mark.parametrize("dims", [(3, 4, 55, 55), (2, 3, 7, 9), (1, 1, 16, 16), (5, 2, 28, 30), (2, 4, 27, 27), (1, 4, 9, 15)])
-def test_whole_layer1_bottleneck_vs_oracle_and_unfused(dims, kt, variant, dtype):
-    """engine.BneckL1 (csrc/conv_bneck_l1.hip): a plain layer1 block of I3Res50 (large_i3d.py:61-84: conv1 kt x 1 x 1 256 -> 64 + bn1 + ReLU, conv2 1 x 3 x 3 + bn2 + ReLU,
-    conv3 64 -> 256 + bn3 + residual + ReLU) in ONE launch, against the oracle (both 64-channel tensors rounded to the storage type where the unfused path stores
-    them) and against the three unfused launches. Frames that are no multiple of the 8 x 14 tile, frames smaller than a tile, 1-4 frames per clip (the temporal
-    taps that leave the clip), halo positions outside the frame (conv2 pads conv1's OUTPUT with zeros, not conv1 of zeros)."""
-    from oracle.conv_ref import conv_cl
-    from ted_spad_amd import engine as E
-    tdt = E.DTYPES[dtype][0]
-    n, t, h, w = dims
-    name = "l1b%d%d" % (h, kt)
-    x = _round(synth_tensor(9, name + "x", (n, t, h, w, 256), -1, 1), tdt)
-    w1 = _round(synth_tensor(9, name + "w1", (64, 256, kt, 1, 1), -1, 1) * (2.0 / (256 * kt)) ** 0.5, tdt)
-    w2 = _round(synth_tensor(9, name + "w2", (64, 64, 1, 3, 3), -1, 1) * (2.0 / 576) ** 0.5, tdt)
-    w3 = _round(synth_tensor(9, name + "w3", (256, 64, 1, 1, 1), -1, 1) * (2.0 / 64) ** 0.5, tdt)
-    s1, b1 = synth_tensor(9, name + "s1", (64,), 0.5, 1.5), synth_tensor(9, name + "b1", (64,), 0.1, 0.5)      # positive shifts: relu(bn1(conv1(0))) != 0 at the padding
-    s2, b2 = synth_tensor(9, name + "s2", (64,), 0.5, 1.5), synth_tensor(9, name + "b2", (64,), -0.3, 0.3)
-    s3, b3 = synth_tensor(9, name + "s3", (256,), 0.5, 1.5), synth_tensor(9, name + "b3", (256,), -0.3, 0.3)
-    pt = kt // 2
-    m1 = _round(conv_cl(x, w1, s1, b1, (1, 1, 1), (pt, 0, 0), (pt, 0, 0), None, relu=True), tdt)
-    m2 = _round(conv_cl(m1, w2, s2, b2, (1, 1, 1), (0, 1, 1), (0, 1, 1), None, relu=True), tdt)
-    ref = conv_cl(m2, w3, s3, b3, (1, 1, 1), (0, 0, 0), (0, 0, 0), x, relu=True)
-    blk = E.BneckL1(w1, s1, b1, w2, s2, b2, w3, s3, b3, dtype=dtype, device="cuda")
-    xa = E.Act(x.to(tdt).cuda(), 256)
-    assert blk.applies(xa)
-    got = blk(xa, variant=variant)
-    torch.cuda.synchronize()
-    got = got.buf.float().cpu()
-    assert got.shape == ref.shape
-    ulp = 2.0 ** -10 if dtype == "f16" else 2.0 ** -7
-    err = (got - ref).abs()
-    assert bool((err <= ulp * ref.abs() + 3e-3).all()), "max err %g" % float(err.max())
-    assert rel_l2(got, ref) < (4e-4 if dtype == "f16" else 3e-3)
-    # the three launches it replaces
-    E.FORCE_TILE_CFG = None
-    c1 = E.PackedConv(w1, s1, b1, dtype=dtype, device="cuda")
-    c2 = E.PackedConv(w2, s2, b2, dtype=dtype, device="cuda")
-    c3 = E.PackedConv(w3, s3, b3, dtype=dtype, device="cuda")
-    old = c3(c2(c1(xa, pads=(pt, 0, 0)), pads=(0, 1, 1)), residual=xa, relu=True).buf.float().cpu()
-    assert bool(((got - old).abs() <= 2 * ulp * old.abs() + 3e-3).all())
-    assert rel_l2(got, old) < (3e-4 if dtype == "f16" else 3e-3)
-    # two launches repeat bit for bit (no atomics, fixed summation order)
-    assert torch.equal(blk(xa, variant=variant).buf.float().cpu(), got)
-    if t >= 2:
-        # maxpool2 (MaxPool3d((2,1,1), stride (2,1,1)), large_i3d.py:139) fused as well: the SAME values as pooling the block's output (an odd last frame is dropped)
-        pooled = blk(xa, pool_t2=True, variant=variant).buf.float().cpu()
-        want = torch.maximum(got[:, 0:2 * (t // 2):2], got[:, 1:2 * (t // 2):2])
-        assert pooled.shape == want.shape
-        assert torch.equal(pooled, want)
-
-
 POOLS = [
     ("res_maxpool1", (2, 8, 30, 30), 64, (2, 3, 3), (2, 2, 2), (0, 0, 0), (0, 0, 0), False),
     ("res_maxpool2", (2, 4, 9, 9), 256, (2, 1, 1), (2, 1, 1), (0, 0, 0), (0, 0, 0), False),
