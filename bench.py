@@ -224,6 +224,76 @@ def bench_anon_extract(dev, n_clips=225, batch=75, steps=3):
             "feature_rel_l2_max": float(rel.max()), "feature_rel_l2_tol": 1e-3, "parity_clips": 2, "steps": steps}
 
 
+def bench_e2e_uint8(dev, n_clips=2250, batch=375, steps=3, hw=(240, 320)):
+    """From DECODED FRAMES to features (SURVEY.md section 8f row 1 -> 8a): uint8 frames (T, 240, 320, 3) resident in HBM -> HybridValPipe's clip sampling (16 frames, every
+    2nd, a clip per 32 source frames: dali_extraction.py:62-73) -> val_augmentations (/255, centre crop 0.8, antialiased resize to 224 x 224: :38-50) ->
+    I3Res50.extract_features, as extraction.extract_video_features_uint8 runs it: pre-processing writes the persistent stem's 16-bit records in ONE launch per
+    batch (tedspad_frames_crop_resize_tp), the stem reads them through its LDS-DMA loader; no fp32 clip batch exists. Beside it: the same clips through the
+    fp32 boundary (tedspad_frames_crop_resize per clip into a (n,3,16,224,224) batch -> extract_features), timed on one batch. Parity: 2 clips against the CPU
+    oracle (oracle/preprocess_ref -> oracle/i3res50_ref)."""
+    from ted_spad_amd import engine as E, extraction, preprocess
+    from ted_spad_amd.model_loaders import load_ft_model
+    from ted_spad_amd.synth import synth_state_dict
+    with contextlib.redirect_stdout(io.StringIO()):
+        ft = load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    ft.load_state_dict(sd)
+    ft = ft.to(dev).eval()
+    h, w = hw
+    t_src = n_clips * 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    frames = torch.empty((t_src, h, w, 3), dtype=torch.uint8, device=dev)
+    for i in range(0, t_src, 4000):
+        k = min(4000, t_src - i)
+        frames[i:i + k] = torch.randint(0, 256, (k, h, w, 3), dtype=torch.uint8, device=dev, generator=g)
+    out = torch.empty((n_clips, 2048), dtype=torch.float32, device=dev)
+
+    def step():
+        extraction.extract_video_features_uint8(ft, frames, batch=batch, streams=2, out=out)
+    with torch.no_grad():
+        for i in range(60):
+            step()
+            if i >= 1 and not E.tuning_pending():
+                break
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        # the fp32 boundary on one batch: a crop_resize launch per clip into the encoder's batch, then the public extract_features
+        box = preprocess.center_crop_box(h, w, int(h * 0.8), int(w * 0.8))
+        clips = torch.empty((batch, 3, 16, 224, 224), dtype=torch.float32, device=dev)
+
+        def via_fp32():
+            for q in range(batch):
+                preprocess.crop_resize(frames[32 * q:32 * q + 32:2].contiguous(), box, (224, 224), out=clips[q], layout="cthw")
+            return ft.i3d.extract_features(clips)
+        for _ in range(2):
+            f32 = via_fp32()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f32 = via_fp32()
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t0) / steps
+        same = bool(torch.equal(f32.flatten(1), out[:batch]))
+        from oracle import i3res50_ref, preprocess_ref
+        v = frames[:64].cpu().float().unsqueeze(0)                     # clips 0 and 1
+        ref_clips = torch.stack([preprocess_ref.val_augmentations(v[:, 32 * i:32 * i + 32:2], 0.8, False, 224, 224)[0].permute(1, 0, 2, 3) for i in range(2)])
+        ref = i3res50_ref.extract_features(ref_clips, {k[4:]: x for k, x in sd.items() if k.startswith("i3d.")}).flatten(1)
+    got = out[:2].cpu()
+    rel = (got.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1)
+    cps = n_clips / dt
+    return {"config": "dali_extraction.py:38-50,62-73 + large_i3d.py extract_features from uint8 frames resident in HBM: %d x %d x 3 frames, a 16-frame clip (every 2nd frame) "
+                      "per 32 source frames -> /255, centre crop 0.8, antialiased resize to 224 x 224 written as the stem's 16-bit records (one launch per %d clips) -> "
+                      "I3Res50; %d clips per step, f16 activations / fp32 accumulate, random-init weights" % (h, w, batch, n_clips),
+            "clips_per_s": round(cps, 1), "ms_per_clip": round(1e3 / cps, 4), "source_frames_per_s": round(cps * 32, 0),
+            "frac": round(cps * GFLOP_PER_CLIP["largei3d"] * 1e-3 / MFMA_PEAK_TFLOPS, 4),
+            "via_fp32_clip_clips_per_s": round(batch / dt32, 1), "features_equal_fp32_clip_path": same,
+            "feature_rel_l2_max": float(rel.max()), "feature_rel_l2_tol": 1e-3, "parity_clips": 2, "steps": steps}
+
+
 def bench_train_main(args, dev, world, rank, dry):
     """`--train` at any N (cfg3 at N = 1 / 112^2, cfg5 at N = 8 / --train-hw 224): one process per GPU, per-rank batch 8 x 48 frames, the gradients of the network
     being updated all-reduced over RCCL in per-stage buckets from inside the backward pass (grad_reduce.GradBucketReducer). Reports the iteration time (MAX over
@@ -360,8 +430,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the cfg3 training-iteration timing appended at N = 1")
     ap.add_argument("--train", action="store_true", help="only the cfg3 training-iteration timing (one JSON line)")
+    ap.add_argument("--e2e", action="store_true", help="only the uint8-frames -> features measurement (one JSON line)")
     ap.add_argument("--train-hw", type=int, default=112, help="with --train: frame size (112: cfg3; 224: the per-rank batch of cfg5)")
-    ap.add_argument("--act-range", action="store_true", help="add the per-stage max |activation| of one forward (f16 head-room) to the line")
+    ap.add_argument("--no-act-range", action="store_true", help="skip the per-stage max |activation| of one 10-clip forward (f16 head-room: storage saturates at 65504) added to the line at N = 1")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on CPU/gloo with a stub extractor")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="strong (default at N > 1; cfg4): ONE video of --clip-times clip times split over the N ranks (BASELINE.json north_star: 'clips of a long video "
@@ -411,6 +482,9 @@ def main():
 
     if args.train:
         bench_train_main(args, dev, world, rank, dry)
+        return
+    if args.e2e:
+        print(json.dumps(bench_e2e_uint8(dev)))
         return
 
     from ted_spad_amd import sharding
@@ -679,7 +753,7 @@ def main():
                                              "%d of the host's %d hardware threads (the fastest thread count measured on this host type)" % (cores, ncpu)}
         res["feature_rel_l2_max"] = float(rel.max())
         res["feature_rel_l2_tol"] = 1e-3
-    if args.act_range and args.arch == "largei3d":
+    if not args.no_act_range and world == 1 and args.arch == "largei3d":
         taps = {}
         with torch.no_grad():
             ft.i3d._trunk(clips[:10], taps=taps)
@@ -688,6 +762,8 @@ def main():
         del clips, W
         torch.cuda.empty_cache()
         res["anon_extract"] = bench_anon_extract(dev)
+        torch.cuda.empty_cache()
+        res["e2e_uint8"] = bench_e2e_uint8(dev)
         torch.cuda.empty_cache()
         res["train_cfg3"] = bench_train(dev)
     print(json.dumps(res))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TEDSPAD_ABI_VERSION 4   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4); 4: tedspad_bneck_l1_* removed (round 5) */
+#define TEDSPAD_ABI_VERSION 4   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4); 4: tedspad_bneck_l1_* removed, tedspad_frames_crop_resize_tp added (round 5) */
 
 enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
@@ -505,6 +505,17 @@ int32_t tedspad_frames_crop_resize(const void *frames, int32_t in_is_float, int3
                                    int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t oh, int32_t ow,
                                    const int32_t *ytab, const int32_t *xtab, float divisor, int32_t flip, float *out,
                                    int64_t so_t, int64_t so_c, int64_t so_h, int64_t so_w, void *stream);
+
+/* The same frames -> /divisor -> crop -> antialiased resize (-> flip), written as the INPUT RECORDS of the persistent stem (tedspad_clip_to_tp's layout,
+ * X[n][tp][oh][b][ow/2][24] 16-bit) instead of an fp32 clip: the step between the decoder's frames and I3Res50's conv1 (dali_extraction.py:38-50 ->
+ * large_i3d.py:229) without the 9.6 MB per clip of fp32 in between. Clip n of n_clips takes source frames first + n*clip_step + f*frame_step,
+ * f = 0 .. t_clip-1 (HybridValPipe: sequence_length 16, stride fix_skip = 2, step 32; dali_extraction.py:62-73); frames outside [0, T) are zero frames
+ * (pad_sequences). pad_t / stride_t / t_pairs: the stem's temporal geometry as in tedspad_clip_to_tp. Every value is the fp32 value
+ * tedspad_frames_crop_resize computes, rounded to `dtype` as tedspad_clip_to_tp rounds it: records bit-identical to crop_resize + clip_to_tp. */
+int32_t tedspad_frames_crop_resize_tp(const void *frames, int32_t in_is_float, int32_t T, int32_t H, int32_t W, int32_t C, int32_t n_clips,
+                                      int32_t first, int32_t clip_step, int32_t frame_step, int32_t t_clip, int32_t y0, int32_t x0, int32_t ch,
+                                      int32_t cw, int32_t oh, int32_t ow, const int32_t *ytab, const int32_t *xtab, float divisor, int32_t flip,
+                                      void *records, int32_t pad_t, int32_t stride_t, int32_t t_pairs, int32_t dtype, void *stream);
 
 /* `shanghai_frames_dataset.augmentation` (feature_extraction/shanghai_dl.py:27-40): uint8 frames (T,H,W,C) -> crop box -> Pillow's
  * two-pass BILINEAR resize with its 8-bit intermediate image (what torchvision's resize does for a PIL image) -> to_tensor (/255)

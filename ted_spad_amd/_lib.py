@@ -118,6 +118,7 @@ SYMBOLS = {
     "tedspad_resize_aa_taps": (_I32, [_I32, _I32]),
     "tedspad_resize_aa_table": (_I32, [_I32, _I32, _P]),
     "tedspad_frames_crop_resize": (_I32, [_P] + [_I32] * 11 + [_P, _P, C.c_float, _I32, _P] + [_I64] * 4 + [_P]),
+    "tedspad_frames_crop_resize_tp": (_I32, [_P] + [_I32] * 16 + [_P, _P, C.c_float, _I32, _P] + [_I32] * 4 + [_P]),
     "tedspad_frames_crop_resize_pil": (_I32, [_P] + [_I32] * 10 + [_P, _I32, _P, _I32, _P] + [_I64] * 4 + [_P]),
     "tedspad_segment_pool_mag": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P]),
 }

@@ -65,40 +65,183 @@ struct ResizeKP {
     long so_t, so_c, so_h, so_w;
 };
 
+// bytes a[0..3] as one dword (byte k in bits 8k..): aligned 4-byte loads (one, or two joined by v_alignbyte_b32 when `a` is not 4-byte aligned) where they stay
+// inside the buffer, single bytes at its very end. `a & 3` is wave-uniform for the callers below (uniform row pointer + 4 * lane group).
+__device__ __forceinline__ unsigned load_u8x4(const uint8_t *a, const uint8_t *end) {
+    const unsigned sh = (unsigned)((uintptr_t)a & 3u);
+    if (a + 8 <= end) {
+        const unsigned *ap = reinterpret_cast<const unsigned *>(a - sh);
+        const unsigned w0 = ap[0];
+        if (sh == 0) return w0;
+        return __builtin_amdgcn_alignbyte(ap[1], w0, sh);
+    }
+    unsigned w = 0;
+    for (int k = 0; k < 4; ++k)
+        if (a + k < end) w |= (unsigned)a[k] << (8 * k);
+    return w;
+}
+
 template <typename In> __device__ __forceinline__ float load_px(const In *p, float div);
 template <> __device__ __forceinline__ float load_px<uint8_t>(const uint8_t *p, float div) { return (float)(*p) / div; }
 template <> __device__ __forceinline__ float load_px<float>(const float *p, float div) { return *p / div; }
 
-// One workgroup per (frame, output row). Pass 1 (vertical): every lane owns interleaved (x, c) elements of the
-// cropped input row span, consecutive lanes = consecutive bytes, and reduces the <= ytaps input rows of this output
-// row into LDS. Pass 2 (horizontal): lanes own output pixels and read their taps from LDS.
+// The two passes, shared by the fp32-clip kernel and the stem-record kernel below (one source expression per value: the two kernels give the same bits).
+// Pass 1 (vertical): every lane owns interleaved (x, c) elements of the cropped input row span, consecutive lanes = consecutive bytes, and reduces the
+// <= ytaps input rows of this output row into LDS. Pass 2 (horizontal): a lane owns an output pixel and reads its taps from LDS.
+template <typename In>
+__device__ __forceinline__ void aa_vpass(const In *base, long rstride, const int32_t *ye, int span, float div, float *row) {
+    const int yn = ye[1];
+    const float *wy = (const float *)(ye + 2);
+    for (int e = threadIdx.x; e < span; e += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < yn; j++) acc += wy[j] * load_px<In>(base + j * rstride + e, div);
+        row[e] = acc;
+    }
+}
+__device__ __forceinline__ float aa_hpass(const float *row, const int32_t *xe, int C, int c) {
+    const int xmin = xe[0], xn = xe[1];
+    const float *wx = (const float *)(xe + 2);
+    float acc = 0.f;
+    for (int j = 0; j < xn; j++) acc += wx[j] * row[(xmin + j) * C + c];
+    return acc;
+}
+
+// One workgroup per (frame, output row).
 template <typename In>
 __global__ __launch_bounds__(256) void crop_resize_aa_kernel(const ResizeKP p) {
     extern __shared__ float row[];      // cw * C
     const int t = blockIdx.x / p.oh, oy = blockIdx.x % p.oh;
     const int32_t *ye = p.ytab + (size_t)oy * (2 + p.ytaps);
-    const int ymin = ye[0], yn = ye[1];
-    const float *wy = (const float *)(ye + 2);
-    const int span = p.cw * p.C;
-    const In *base = (const In *)p.in + (((long)t * p.H + p.y0 + ymin) * p.W + p.x0) * p.C;
-    const long rstride = (long)p.W * p.C;
-    for (int e = threadIdx.x; e < span; e += 256) {
-        float acc = 0.f;
-        for (int j = 0; j < yn; j++) acc += wy[j] * load_px<In>(base + j * rstride + e, p.div);
-        row[e] = acc;
-    }
+    const In *base = (const In *)p.in + (((long)t * p.H + p.y0 + ye[0]) * p.W + p.x0) * p.C;
+    aa_vpass<In>(base, (long)p.W * p.C, ye, p.cw * p.C, p.div, row);
     __syncthreads();
     for (int ox = threadIdx.x; ox < p.ow; ox += 256) {
         const int32_t *xe = p.xtab + (size_t)ox * (2 + p.xtaps);
-        const int xmin = xe[0], xn = xe[1];
-        const float *wx = (const float *)(xe + 2);
         const int oxw = p.flip ? p.ow - 1 - ox : ox;
-        for (int c = 0; c < p.C; c++) {
-            float acc = 0.f;
-            for (int j = 0; j < xn; j++) acc += wx[j] * row[(xmin + j) * p.C + c];
-            p.out[t * p.so_t + c * p.so_c + oy * p.so_h + oxw * p.so_w] = acc;
+        for (int c = 0; c < p.C; c++) p.out[t * p.so_t + c * p.so_c + oy * p.so_h + oxw * p.so_w] = aa_hpass(row, xe, p.C, c);
+    }
+}
+
+// The same resize written as the persistent stem's input records (csrc/conv_stem_pt.hip, tedspad_clip_to_tp's layout): X[n][tp][oh][b][ow/2][24] 16-bit, the
+// record of pixel (oy, 2*wq + b) for output-frame pair tp holding value dt*3 + c = clip[n][c][2*stt*tp - pt + dt][oy][2*wq + b], dt = 0..7, zero outside
+// the clip. Clip n = source frames first + n*clip_step + f*frame_step, f = 0 .. t_clip - 1 (dali_extraction.py:62-73: sequence_length 16, stride 2, step 32),
+// frames past the end of the video are zero frames (pad_sequences). The fp32 clip (9.6 MB at 16 x 224 x 224) is never written: a workgroup owns one output
+// row of one FRAME PAIR of one clip, resizes the 8 frames its records hold into an LDS tile of that row's records (10.5 KB at 224 columns) and writes each
+// plane as one contiguous run. (A frame belongs to two pairs and is resized twice; with one workgroup per (clip, row) and all four pairs' records in a 43 KB
+// tile only two workgroups fit a CU and the kernel was bound by its own load -> sync -> store chain: 9.0 ms per 375 clips instead of the 2.x ms measured here.)
+struct ResizeTpKP {
+    ResizeKP r;
+    uint16_t *rec;
+    int n_clips, first, clip_step, frame_step, t_clip, pt, stt, tp_n;
+    const uint8_t *in_end;      // one past the last byte of the frame buffer (the 4-byte loads of the uint8 path stay inside it)
+};
+
+// FG frames of the clip are resized per round (their FG x yn row loads per element are independent: the memory pipeline stays full, two barriers per round
+// instead of two per frame); uint8 frames take value / divisor from a 256-entry table built with the same division (bit-identical to dividing per sample).
+template <typename In, typename T>
+__global__ __launch_bounds__(256) void crop_resize_tp_kernel(const ResizeTpKP q) {
+    constexpr int FG = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_tp[];
+    const ResizeKP &p = q.r;
+    const int wq_n = p.ow >> 1;
+    uint4 *tile = reinterpret_cast<uint4 *>(lds_tp);                 // [plane b][wq][3 x 16 B]
+    const int tile16 = 2 * wq_n * 3;
+    const int span = p.cw * p.C;
+    float *rows = reinterpret_cast<float *>(lds_tp + (size_t)tile16 * 16);      // [FG][span]
+    float *lut = rows + FG * span;                                   // [256] (uint8 input)
+    int32_t *xt = reinterpret_cast<int32_t *>(lut + 256);            // this launch's column table [ow][2 + xtaps]: read 8 x 3 times per output pixel below
+    const int tp = blockIdx.x % q.tp_n, rowid = blockIdx.x / q.tp_n;
+    const int n = rowid / p.oh, oy = rowid % p.oh;
+    const int fbeg = 2 * q.stt * tp - q.pt;                          // the record's frame slot dt holds clip frame fbeg + dt
+    for (int i = threadIdx.x; i < tile16; i += 256) tile[i] = make_uint4(0u, 0u, 0u, 0u);      // frame slots outside the clip, channels >= C
+    if (sizeof(In) == 1) lut[threadIdx.x] = (float)threadIdx.x / p.div;
+    for (int i = threadIdx.x; i < p.ow * (2 + p.xtaps); i += 256) xt[i] = p.xtab[i];
+    const int32_t *ye = p.ytab + (size_t)oy * (2 + p.ytaps);
+    const int yn = ye[1];
+    const float *wy = (const float *)(ye + 2);
+    const long rstride = (long)p.W * p.C;
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(lds_tp);
+    for (int d0 = 0; d0 < 8; d0 += FG) {
+        const int f0 = fbeg + d0;
+        const In *base[FG];
+        bool live[FG];
+#pragma unroll
+        for (int ff = 0; ff < FG; ++ff) {
+            const long fr = (long)q.first + (long)n * q.clip_step + (long)(f0 + ff) * q.frame_step;
+            live[ff] = f0 + ff >= 0 && f0 + ff < q.t_clip && fr >= 0 && fr < p.T;    // else a zero frame: its slots stay zero (uniform)
+            base[ff] = (const In *)p.in + (((live[ff] ? fr : 0) * p.H + p.y0 + ye[0]) * p.W + p.x0) * p.C;
+        }
+        __syncthreads();                                             // the zero fill and the tables / the previous round's reads of `rows`
+        if constexpr (sizeof(In) == 1) {
+            // four consecutive bytes per lane and load (byte loads: 64 bytes per wave instruction, and the kernel spent 3.6 of its 6.6 ms per 375 clips in them)
+            for (int g = threadIdx.x; 4 * g < span; g += 256) {
+                float acc[FG][4];
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[ff][k] = 0.f;
+                for (int j = 0; j < yn; j++) {
+                    unsigned w4[FG];
+#pragma unroll
+                    for (int ff = 0; ff < FG; ++ff) w4[ff] = live[ff] ? load_u8x4(reinterpret_cast<const uint8_t *>(base[ff]) + j * rstride + 4 * g, q.in_end) : 0u;
+#pragma unroll
+                    for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[ff][k] += wy[j] * lut[(w4[ff] >> (8 * k)) & 255u];
+                }
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * g + k < span) rows[ff * span + 4 * g + k] = acc[ff][k];
+            }
+        } else {
+            for (int e = threadIdx.x; e < span; e += 256) {
+                float acc[FG];
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff) acc[ff] = 0.f;
+                for (int j = 0; j < yn; j++) {
+#pragma unroll
+                    for (int ff = 0; ff < FG; ++ff) acc[ff] += wy[j] * (live[ff] ? load_px<In>(base[ff] + j * rstride + e, p.div) : 0.f);
+                }
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff) rows[ff * span + e] = acc[ff];
+            }
+        }
+        __syncthreads();
+        for (int ox = threadIdx.x; ox < p.ow; ox += 256) {
+            const int32_t *xe = xt + ox * (2 + p.xtaps);
+            const int xmin = xe[0], xn = xe[1];
+            const float *wx = reinterpret_cast<const float *>(xe + 2);
+            const int oxw = p.flip ? p.ow - 1 - ox : ox;
+            // aa_hpass for the FG frames x 3 channels at once: a tap's weight is read once; every sum still runs over its taps in ascending order
+            float acc[FG][3];
+#pragma unroll
+            for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[ff][c] = 0.f;
+            for (int j = 0; j < xn; j++) {
+                const float wj = wx[j];
+                const float *r = rows + (xmin + j) * p.C;
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < p.C) acc[ff][c] += wj * r[ff * span + c];
+            }
+#pragma unroll
+            for (int ff = 0; ff < FG; ++ff) {
+                if (!live[ff]) continue;
+                uint16_t *rec = t16 + ((size_t)((oxw & 1) * wq_n + (oxw >> 1))) * 24 + (d0 + ff) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rec[c] = c < p.C ? T::from_f32(acc[ff][c]) : (uint16_t)0;
+            }
         }
     }
+    __syncthreads();
+    const int run16 = wq_n * 3;                                      // 16-byte pieces of one (pair, plane) run
+    uint4 *dst = reinterpret_cast<uint4 *>(q.rec) + (((long)n * q.tp_n + tp) * p.oh + oy) * 2 * (long)run16;      // both planes of the row: one contiguous run
+    for (int i = threadIdx.x; i < tile16; i += 256) dst[i] = tile[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -222,6 +365,55 @@ extern "C" int32_t tedspad_frames_crop_resize(const void *frames, int32_t in_is_
     if (in_is_float) hipLaunchKernelGGL(crop_resize_aa_kernel<float>, g, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(crop_resize_aa_kernel<uint8_t>, g, dim3(256), lds, s, p);
     return check_launch("tedspad_frames_crop_resize");
+}
+
+extern "C" int32_t tedspad_frames_crop_resize_tp(const void *frames, int32_t in_is_float, int32_t T, int32_t H, int32_t W, int32_t C, int32_t n_clips,
+                                                 int32_t first, int32_t clip_step, int32_t frame_step, int32_t t_clip, int32_t y0, int32_t x0, int32_t ch,
+                                                 int32_t cw, int32_t oh, int32_t ow, const int32_t *ytab, const int32_t *xtab, float divisor, int32_t flip,
+                                                 void *records, int32_t pad_t, int32_t stride_t, int32_t t_pairs, int32_t dtype, void *stream) {
+    TS_REQUIRE(frames && records && ytab && xtab, "tedspad_frames_crop_resize_tp: null pointer");
+    TS_REQUIRE(T > 0 && H > 0 && W > 0 && C > 0 && C <= 3 && oh > 0 && ow > 0 && ow % 2 == 0, "tedspad_frames_crop_resize_tp: bad sizes (<= 3 channels, even output width)");
+    TS_REQUIRE(n_clips > 0 && t_clip > 0 && frame_step > 0 && clip_step >= 0, "tedspad_frames_crop_resize_tp: bad clip sampling");
+    TS_REQUIRE(y0 >= 0 && x0 >= 0 && ch > 0 && cw > 0 && y0 + ch <= H && x0 + cw <= W,
+               "tedspad_frames_crop_resize_tp: crop box (%d,%d,%d,%d) outside the %dx%d frame", y0, x0, ch, cw, H, W);
+    TS_REQUIRE(divisor != 0.f, "tedspad_frames_crop_resize_tp: divisor must be non-zero");
+    TS_REQUIRE(stride_t == 2 && pad_t >= 0 && t_pairs > 0, "tedspad_frames_crop_resize_tp: temporal stride 2 (tedspad_clip_to_tp's record layout)");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_frames_crop_resize_tp: bad dtype");
+    TS_REQUIRE((uintptr_t)records % 16 == 0 && (long)n_clips * oh * t_pairs < (1L << 31), "tedspad_frames_crop_resize_tp: records must be 16-byte aligned; too many rows");
+    const size_t lds = (size_t)ow * 48 + (size_t)4 * cw * C * sizeof(float) + 1024 + (size_t)ow * (2 + aa_taps(cw, ow)) * 4;      // one pair's record row + four frames' row buffers + the value table + the column table
+    TS_REQUIRE(lds <= 160 * 1024, "tedspad_frames_crop_resize_tp: %d columns of records + four %d x %d row buffers exceed the CU's 160 KB of LDS", ow, cw, C);
+    ResizeTpKP q;
+    ResizeKP &p = q.r;
+    p.in = frames; p.out = nullptr; p.ytab = ytab; p.xtab = xtab;
+    p.T = T; p.H = H; p.W = W; p.C = C; p.y0 = y0; p.x0 = x0; p.ch = ch; p.cw = cw; p.oh = oh; p.ow = ow;
+    p.ytaps = aa_taps(ch, oh); p.xtaps = aa_taps(cw, ow); p.flip = flip; p.div = divisor;
+    p.so_t = p.so_c = p.so_h = p.so_w = 0;
+    q.rec = (uint16_t *)records; q.n_clips = n_clips; q.first = first; q.clip_step = clip_step; q.frame_step = frame_step; q.t_clip = t_clip;
+    q.pt = pad_t; q.stt = stride_t; q.tp_n = t_pairs;
+    q.in_end = (const uint8_t *)frames + (size_t)T * H * W * C * (in_is_float ? 4 : 1);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)((long)n_clips * oh * t_pairs));
+    if (lds > 64 * 1024) {                       // wide source frames (HD): raise the kernel's dynamic LDS limit once per variant
+        static thread_local bool raised[4] = {false, false, false, false};
+        const int vi = (in_is_float ? 2 : 0) + (dtype == TEDSPAD_F16 ? 0 : 1);
+        if (!raised[vi]) {
+            const void *fn = vi == 0 ? (const void *)crop_resize_tp_kernel<uint8_t, F16> : vi == 1 ? (const void *)crop_resize_tp_kernel<uint8_t, BF16> :
+                             vi == 2 ? (const void *)crop_resize_tp_kernel<float, F16> : (const void *)crop_resize_tp_kernel<float, BF16>;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("tedspad_frames_crop_resize_tp: cannot raise the dynamic LDS limit");
+                return TEDSPAD_ELAUNCH;
+            }
+            raised[vi] = true;
+        }
+    }
+    if (in_is_float) {
+        if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((crop_resize_tp_kernel<float, F16>), g, dim3(256), lds, s, q);
+        else hipLaunchKernelGGL((crop_resize_tp_kernel<float, BF16>), g, dim3(256), lds, s, q);
+    } else {
+        if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((crop_resize_tp_kernel<uint8_t, F16>), g, dim3(256), lds, s, q);
+        else hipLaunchKernelGGL((crop_resize_tp_kernel<uint8_t, BF16>), g, dim3(256), lds, s, q);
+    }
+    return check_launch("tedspad_frames_crop_resize_tp");
 }
 
 extern "C" int32_t tedspad_segment_pool_mag(const float *feat, int32_t T, int32_t ncrops, int32_t F, int32_t length, float *out,

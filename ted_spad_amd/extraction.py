@@ -163,6 +163,56 @@ def extract_video_sharded(ft_model, clips_local: torch.Tensor, T: int, ncrops: i
     return sharding.gather_video_features(f, T, group)
 
 
+@torch.no_grad()
+def extract_video_features_uint8(ft_model, frames: torch.Tensor, cropping_factor: float = 0.8, no_ar_distortion: bool = False, out_hw=(224, 224),
+                                 clip_step: int = 32, frame_step: int = 2, t_clip: int = 16, n_clips: int = None, batch: int = 375, streams: int = 2,
+                                 out: torch.Tensor = None) -> torch.Tensor:
+    """The whole per-video path of dali_extraction.py without its anonymizer, from DECODED FRAMES: frames (T,H,W,3) uint8 (or the float frames DALI hands
+    over) resident on the GPU -> HybridValPipe's clip sampling (:62-73: 16 frames, every 2nd, a clip per 32 source frames; frames past the end are zero
+    frames) -> val_augmentations (:38-50: /255, centre crop 0.8, antialiased resize) -> I3Res50.extract_features -> (n_clips, F) fp32 rows on the GPU.
+    Pre-processing writes the persistent stem's 16-bit input records directly (preprocess.crop_resize_records -> I3Res50.extract_features_records): ONE launch
+    per batch in front of the encoder, no fp32 clip batch in HBM. Encoders without the record path (InceptionI3d) take the fp32 clips."""
+    from . import preprocess
+    net = ft_model.i3d if hasattr(ft_model, "i3d") else ft_model
+    t, h, w, c = frames.shape
+    if n_clips is None:
+        n_clips = -(-t // clip_step)
+    if no_ar_distortion:
+        ch = cw = int(min(h, w) * cropping_factor)
+    else:
+        ch, cw = int(h * cropping_factor), int(w * cropping_factor)
+    box = preprocess.center_crop_box(h, w, ch, cw)
+    if out is None:
+        out = torch.empty((n_clips, feature_width(ft_model)), dtype=torch.float32, device=frames.device)
+    if n_clips == 0:
+        return out
+    dev = frames.device
+    pool = _STREAMS.setdefault((dev, streams), [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))])
+    main = torch.cuda.current_stream(dev)
+    for st in pool:
+        st.wait_stream(main)
+    from . import engine as E
+    rec_path = hasattr(net, "extract_features_records") and E.STEM_PT and E.STEM_POOL
+    stem = net.packed()["stem_pt"] if rec_path else None
+    for j, (i, k) in enumerate(sharding.batch_plan(n_clips, batch, len(pool))):
+        with torch.cuda.stream(pool[0 if E.tuning_pending() else j % len(pool)]):
+            if rec_path:
+                rec = preprocess.crop_resize_records(frames, box, out_hw, stem, k, first=i * clip_step, clip_step=clip_step, frame_step=frame_step, t_clip=t_clip)
+                out[i:i + k] = net.extract_features_records(rec).flatten(1)
+            else:
+                clips = torch.zeros((k, c, t_clip, out_hw[0], out_hw[1]), dtype=torch.float32, device=dev)
+                for q in range(k):
+                    f0 = (i + q) * clip_step
+                    idx = [f0 + f * frame_step for f in range(t_clip) if f0 + f * frame_step < t]
+                    if idx:
+                        sel = frames[idx[0]:idx[-1] + 1:frame_step].contiguous()
+                        preprocess.crop_resize(sel, box, out_hw, out=clips[q, :, :len(idx)], layout="cthw")
+                out[i:i + k] = _extract_fn(ft_model)(clips).flatten(1)
+    for st in pool:
+        main.wait_stream(st)
+    return out
+
+
 def share_tile_choices(ft_model, group=None, src: int = 0) -> int:
     """Multi-GPU jobs: broadcast rank `src`'s decided conv tile configurations (engine.export_tile_table of the packed network) to every rank, so that all
     ranks run the same tiles -- identical clips then give bit-identical features on every GPU and no rank spends its first forwards tuning. Call it once

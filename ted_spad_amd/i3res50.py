@@ -108,18 +108,31 @@ class I3Res50(nn.Module):
         return self._packed
 
     # ---- the launch sequence ---------------------------------------------------------------
-    def _trunk(self, x: torch.Tensor, taps=None) -> E.Act:
-        """conv1 .. layer4 (large_i3d.py:229-238 == :251-260) on a (B,3,T,H,W) fp32 clip batch."""
+    def _trunk(self, x: torch.Tensor, taps=None, records: torch.Tensor = None) -> E.Act:
+        """conv1 .. layer4 (large_i3d.py:229-238 == :251-260) on a (B,3,T,H,W) fp32 clip batch -- or, with `records`, on the persistent stem's own 16-bit input
+        layout X[n][tp][h][2][w/2][24] (engine.StemPT.layout; preprocess.crop_resize_records writes it straight from uint8 frames)."""
         if self.training:
             raise NotImplementedError("a bare I3Res50 in train() mode has no caller in the reference: training goes through wrapper_i3d "
                                       "(load_ft_model('largei3d'); ted_spad_amd/autograd.py) or train_step.AnonymizerTrainStep")
-        E.require_cuda(x, "I3Res50")
-        if x.dim() != 5 or x.shape[1] != 3:
-            raise ValueError("expected (B,3,T,H,W), got %s" % (tuple(x.shape),))
-        if x.shape[4] % 2:
-            raise ValueError("W must be even")
         P = self.packed()
-        if E.STEM_PT and taps is None and P["stem_pt"].applies(x):
+        if records is not None:
+            E.require_cuda(records, "I3Res50")
+            st = P["stem_pt"]
+            if records.dim() != 6 or tuple(records.shape[3:]) != (2, records.shape[4], 24) or records.dtype != st.torch_dtype or not records.is_contiguous():
+                raise ValueError("expected contiguous stem records (n, frame pairs, h, 2, w/2, 24) of %s, got %s %s" % (st.torch_dtype, tuple(records.shape), records.dtype))
+            if (records.shape[2] + 1) // 2 < 3 or records.shape[4] < 3:
+                raise ValueError("frames too small for conv1 + maxpool1")
+            a = st.conv_pool(records)                                    # conv1 + bn1 + ReLU + maxpool1 from the records (the LDS-DMA loader of csrc/conv_stem_pt.hip)
+            x = None
+        else:
+            E.require_cuda(x, "I3Res50")
+            if x.dim() != 5 or x.shape[1] != 3:
+                raise ValueError("expected (B,3,T,H,W), got %s" % (tuple(x.shape),))
+            if x.shape[4] % 2:
+                raise ValueError("W must be even")
+        if records is not None:
+            pass
+        elif E.STEM_PT and taps is None and P["stem_pt"].applies(x):
             # conv1 + bn1 + ReLU + maxpool1 on the persistent stem kernel (large_i3d.py:229-232): the 112 x 112 x 8-frame stem tensor
             # is never written
             st = P["stem_pt"]
@@ -194,6 +207,12 @@ class I3Res50(nn.Module):
         """large_i3d.py:249-263 -> (B, 2048, 1, 1, 1) fp32."""
         a = self._trunk(x)
         return E.global_avgpool(a).view(x.shape[0], -1, 1, 1, 1)
+
+    def extract_features_records(self, records: torch.Tensor) -> torch.Tensor:
+        """`extract_features` of clips handed over as the stem's input records (preprocess.crop_resize_records: uint8 frames -> records in one launch;
+        StemPT.layout: an fp32 clip batch -> records) -> (B, 2048, 1, 1, 1) fp32. Bit-identical to extract_features of the fp32 clips the records encode."""
+        a = self._trunk(None, records=records)
+        return E.global_avgpool(a).view(records.shape[0], -1, 1, 1, 1)
 
     def forward(self, x: torch.Tensor):
         """large_i3d.py:228-246 -> (logits (B,nc), feat). `feat = x.squeeze()` drops the batch

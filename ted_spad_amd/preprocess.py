@@ -89,6 +89,33 @@ def crop_resize(frames: torch.Tensor, box, out_hw, flip: bool = False, out: torc
     return out
 
 
+def crop_resize_records(frames: torch.Tensor, box, out_hw, stem, n_clips: int, first: int = 0, clip_step: int = 32, frame_step: int = 2,
+                        t_clip: int = 16, flip: bool = False, out: torch.Tensor = None, divisor: float = 255.0) -> torch.Tensor:
+    """frames: (T,H,W,C) uint8 or float32 decoder frames on the GPU -> the persistent stem's 16-bit input records X[n][tp][oh][2][ow/2][24]
+    (engine.StemPT.layout's tensor) of `n_clips` clips, clip i = frames first + i*clip_step + f*frame_step (HybridValPipe's sampling,
+    dali_extraction.py:62-73), each frame / divisor -> crop `box` -> antialiased resize to `out_hw` (val_augmentations, :38-50). ONE launch; the fp32 clip
+    batch the encoder's public entry takes is never materialised. `stem`: the engine.StemPT of the encoder (I3Res50.packed()["stem_pt"]): temporal
+    geometry and storage type. Feed the result to I3Res50.extract_features_records."""
+    require_cuda(frames, "crop_resize_records")
+    if frames.dim() != 4 or frames.dtype not in (torch.uint8, torch.float32) or not frames.is_contiguous():
+        raise ValueError("crop_resize_records: frames must be a contiguous (T,H,W,C) uint8/float32 tensor")
+    t, h, w, c = frames.shape
+    y0, x0, ch, cw = [int(v) for v in box]
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    tp = stem.frame_pairs(t_clip)
+    shape = (n_clips, tp, oh, 2, ow // 2, 24)
+    if out is None:
+        out = torch.empty(shape, dtype=stem.torch_dtype, device=frames.device)
+    if tuple(out.shape) != shape or out.dtype != stem.torch_dtype or not out.is_contiguous():
+        raise ValueError("crop_resize_records: out must be a contiguous %s tensor of %s" % (shape, stem.torch_dtype))
+    ytab, xtab = _table(ch, oh, frames.device), _table(cw, ow, frames.device)
+    check(_lib.lib().tedspad_frames_crop_resize_tp(frames.data_ptr(), int(frames.dtype == torch.float32), t, h, w, c, int(n_clips), int(first), int(clip_step),
+                                                   int(frame_step), int(t_clip), y0, x0, ch, cw, oh, ow, ytab.data_ptr(), xtab.data_ptr(), C.c_float(divisor),
+                                                   int(flip), out.data_ptr(), stem.pad_t, stem.stride_t, tp, stem.dtype_code, _stream_ptr()),
+          "tedspad_frames_crop_resize_tp")
+    return out
+
+
 def val_augmentations(video: torch.Tensor, cropping_factor: float = 0.8, no_ar_distortion: bool = False, reso_h: int = 224,
                       reso_w: int = 224) -> torch.Tensor:
     """dali_extraction.py:38-50. video: (1,T,H,W,C) frames with values 0..255 (uint8, or float as DALI delivers them)
