@@ -73,9 +73,8 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
     constexpr int BM = 256, BN = 256;
     constexpr int ROWB = BK * 2;                 // 128-byte rows
     constexpr int UNIT = 128 * ROWB;             // 16 KB
-    constexpr int STG_LD = 128 + 4;              // fp32 staging row stride (floats)
     constexpr int LDS_MAIN = 8 * UNIT;
-    constexpr int LDS_STAGE = BM * STG_LD * 4;
+    constexpr int LDS_STAGE = BM * (BN + 8) * 2;   // the epilogue's 16-bit staging tile
     constexpr int LDS_BYTES = LDS_MAIN > LDS_STAGE ? LDS_MAIN : LDS_STAGE;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -309,13 +308,16 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
 #undef P8_WAIT
     if (grp == 0) __builtin_amdgcn_s_barrier();   // pairs with the last in-loop barrier of waves 4-7
     asm volatile("" ::: "memory");
-    __syncthreads();   // ring free: reused as the fp32 staging tile
+    __syncthreads();   // ring free: reused as the staging tile
     P8_STAMP(2);
 
-    // ---- epilogue without a residual: scale / shift / ReLU / rounding in the accumulator layout, ONE pass of 16-bit rows through LDS ([256 px][256 ch], 528-byte
-    // rows), then whole 512-byte rows out. (The fp32 two-pass form below moved 2 x 128 KB in and out of LDS behind three barriers: 15 k cycles per workgroup,
-    // as long as 4.6 K tiles of the loop -- scripts/p8_cycles.py; it stays for the residual case, whose sum must be formed in fp32 in the row layout.)
-    if (!p.res) {
+    // ---- epilogue: scale / shift (+ residual) / ReLU / rounding in the accumulator layout, ONE pass of 16-bit rows through LDS ([256 px][256 ch], 528-byte
+    // rows), then whole 512-byte rows out. (The fp32 two-pass form of rounds 2-4 moved 2 x 128 KB in and out of LDS behind three barriers: 15 k cycles per workgroup
+    // without a residual, 27 k with one -- as long as the whole K = 512 loop of layer4's conv3: profiles/r05_p8_stamps.md.) With a residual its rows are
+    // requested first (coalesced 16-byte loads, the fragment registers are dead), land in the staging tile in the ROW layout, and every lane then reads back the
+    // four residual values of each of its accumulator quads, forms acc * scale + shift + residual in fp32 -- the same operations in the same order as the
+    // two-pass form: bit-identical results -- and overwrites them in place with the rounded result.
+    {
         constexpr int S16 = 256 + 8;                        // 16-bit elements per staged row
         static_assert(BM * S16 * 2 <= LDS_BYTES, "16-bit staging tile");
         uint16_t *stg16 = reinterpret_cast<uint16_t *>(smem);
@@ -330,6 +332,20 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
                 return (unsigned)T::from_f32(__builtin_fmaxf(a, lo)) | ((unsigned)T::from_f32(__builtin_fmaxf(b, lo)) << 16);
             }
         };
+        const bool has_res = p.res != nullptr;
+        if (has_res) {
+            const int cc = tid & 31, r0 = tid >> 5;         // 32 chunks of 8 channels per row, 16 rows per sweep
+            uint4 rr[BM / 16];
+#pragma unroll
+            for (int it = 0; it < BM / 16; ++it) {
+                const int m = m0 + r0 + it * 16;
+                rr[it] = make_uint4(0u, 0u, 0u, 0u);
+                if (m < p.M) rr[it] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n0 + cc * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < BM / 16; ++it) *reinterpret_cast<uint4 *>(stg16 + (r0 + it * 16) * S16 + cc * 8) = rr[it];
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int nb = n0 + 128 * j;                          // folded output frames: scale / shift are indexed inside the frame
@@ -347,6 +363,8 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
                 const int ml = (b / NXF) * 128 + 64 * grp + (b % NXF) * FR + frow;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
+                    const int ch = 128 * j + 32 * wn + (MF == 32 ? 8 * g + 4 * lh : 16 * g + 4 * lq);
+                    uint2 *slot = reinterpret_cast<uint2 *>(stg16 + ml * S16 + ch);
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -354,8 +372,12 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
                         if constexpr (MF == 32) a = acc[j][b][0][4 * g + i]; else a = acc[j][b][g][i];
                         v[i] = __builtin_fmaf(a, sc[g][i], sh[g][i]);
                     }
-                    const int ch = 128 * j + 32 * wn + (MF == 32 ? 8 * g + 4 * lh : 16 * g + 4 * lq);
-                    *reinterpret_cast<uint2 *>(stg16 + ml * S16 + ch) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                    if (has_res) {
+                        const uint2 rv = *slot;
+                        v[0] += T::to_f32((uint16_t)(rv.x & 0xffffu)); v[1] += T::to_f32((uint16_t)(rv.x >> 16));
+                        v[2] += T::to_f32((uint16_t)(rv.y & 0xffffu)); v[3] += T::to_f32((uint16_t)(rv.y >> 16));
+                    }
+                    *slot = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
                 }
             }
         }
@@ -380,89 +402,7 @@ __global__ __launch_bounds__(512) void conv_p8_kernel(const ConvKP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         P8_STAMP(5);
 #endif
-        return;
     }
-
-    // ---- epilogue: two passes of 256 pixels x 128 channels: fp32 -> LDS -> coalesced 16-byte rows ------------------------
-    // The residual rows of both passes are requested BEFORE the staging writes (the fragment registers are dead by now):
-    // their L2 / HBM round trip runs under the staging traffic instead of once per row inside the store loop.
-    float *stg = reinterpret_cast<float *>(smem);
-    constexpr int CPR = 16;            // 16-byte output chunks per staged row (128 channels)
-    constexpr int RPP = 512 / CPR;     // rows per pass of the block
-    constexpr int NR = BM / RPP;       // rows per thread and pass
-    const int cc = tid % CPR, r0 = tid / CPR;
-    uint4 rres[2][NR];
-    if (p.res) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int m = m0 + r0 + i * RPP;
-                rres[j][i] = make_uint4(0, 0, 0, 0);
-                if (m < p.M) rres[j][i] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n0 + 128 * j + cc * 8);
-            }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        // folded output frames (tedspad_conv_extras.fold_hw): this pass's 128 channels are channels nbase .. nbase + 127 of output frame `nsel`
-        int nsel = 0, nbase = n0 + 128 * j;
-        if (p.fold_hw) { nsel = nbase / p.fold_c; nbase -= nsel * p.fold_c; }
-        const int n = nbase + cc * 8;
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p.scale + n), a1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
-        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.shift + n), h1 = *reinterpret_cast<const f32x4 *>(p.shift + n + 4);
-        if (j) __syncthreads();        // pass 0's rows have been read
-#pragma unroll
-        for (int b = 0; b < 2 * NXF; ++b) {
-            const int ml = (b / NXF) * 128 + 64 * grp + (b % NXF) * FR + frow;
-#pragma unroll
-            for (int c = 0; c < NWF; ++c) {
-                if constexpr (MF == 32) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nl = 32 * wn + 8 * g + 4 * lh;
-                        f32x4 v = {acc[j][b][c][4 * g], acc[j][b][c][4 * g + 1], acc[j][b][c][4 * g + 2], acc[j][b][c][4 * g + 3]};
-                        *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + nl) = v;
-                    }
-                } else {      // 16x16 tile: lane (pixel l15) holds channels 4*lq + {0..3} of the 16-channel fragment c
-                    *reinterpret_cast<f32x4 *>(stg + ml * STG_LD + 32 * wn + 16 * c + 4 * lq) = acc[j][b][c];
-                }
-            }
-        }
-        __syncthreads();
-        float sc[8], sf[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sc[i] = a0[i]; sc[i + 4] = a1[i]; sf[i] = h0[i]; sf[i + 4] = h1[i]; }
-#pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const int r = r0 + it * RPP;
-            const int m = m0 + r;
-            if (m < p.M) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(stg + r * STG_LD + cc * 8 + 4);
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { v[i] = v0[i] * sc[i] + sf[i]; v[i + 4] = v1[i] * sc[i + 4] + sf[i + 4]; }
-                if (p.res) {
-                    float rr[8];
-                    unpack8<T>(rres[j][it], rr);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += rr[i];
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
-                }
-                size_t orow = (size_t)m;
-                if (p.fold_hw) orow += (size_t)(m / p.fold_hw) * (size_t)((p.fold_f - 1) * p.fold_hw) + (size_t)nsel * p.fold_hw;
-                *reinterpret_cast<uint4 *>(p.y + orow * p.ldy + n) = pack8_lim<T>(v, p.sat);
-            }
-        }
-        P8_STAMP(3 + j);
-    }
-#ifdef TEDSPAD_P8_ABLATIONS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    P8_STAMP(5);
-#endif
 }
 
 template <typename T>
