@@ -737,6 +737,24 @@ int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_
         return TEDSPAD_EINVAL;
     }
     const int frames = N * p.Ti;
+    // cout = 128 k + r with r <= 64 (Inception's 3 x 3 x 3 convs: 64 -> 192, 128 -> 192, 160 -> 320): the last 128-channel tile would multiply 64+ channels of
+    // zero weights (a quarter of the whole layer at cout 192). Two launches instead: 128-channel tiles over the first 128 k channels, a 64-channel tile kernel over
+    // the rest, every per-channel pointer moved to the rest's first channel. Same sums in the same order: bit-identical.
+    static const bool split_ok = getenv("TEDSPAD_PATCH_NO_SPLIT") == nullptr;      // A/B knob
+    if (split_ok && !src && p.Cout > 128 && p.Cout % 128 != 0 && p.Cout % 128 <= 64) {
+        const int head = p.Cout / 128 * 128;
+        ConvKP a = p, b = p;
+        a.Cout = head;
+        b.Cout = p.Cout - head;
+        b.w += (size_t)head * p.Kpad; b.scale += head; b.shift += head;
+        if (b.res) b.res += head;
+        if (b.y) b.y += head;
+        if (b.mask) b.mask += head;
+        if (b.stats) b.stats += head;
+        if (b.y32) b.y32 += head;
+        const int32_t rc = launch_conv_patch(dtype, a, N, cin, s, mode, nullptr);
+        return rc != TEDSPAD_OK ? rc : launch_conv_patch(dtype, b, N, cin, s, mode, nullptr);
+    }
     if (src) {
         const bool f16 = dtype == TEDSPAD_F16;
         if (flat) {

@@ -35,6 +35,7 @@ STEM_POOL = os.environ.get("TEDSPAD_STEM_POOL", "1") != "0"   # the spatial half
 UPP_TAIL = os.environ.get("TEDSPAD_UPP_TAIL", "1") != "0"              # unet++: x_0_3 + segmentation head as one launch (tedspad_unetpp_tail_fwd)
 GATHER_CAT = os.environ.get("TEDSPAD_GATHER_CAT", "1") != "0"          # unet++ decoder blocks read upsample + concat in place (PackedConv.gather)
 STEM_CLIP = os.environ.get("TEDSPAD_STEM_CLIP", "1") != "0"   # the stem kernel reads the fp32 clip itself (StemPT.conv_pool_clip); 0: tedspad_clip_to_tp layout pass in front of it (A/B)
+STEM_NWG = int(os.environ.get("TEDSPAD_STEM_NWG", "0"))   # persistent stem on fewer workgroups than CUs (a multiple of 8): its workgroups take a CU each ALONE (160 KB of LDS), the CUs it leaves free run the other stream's HBM-bound kernels meanwhile (A/B)
 STEM_PT = os.environ.get("TEDSPAD_STEM_PT", "1") != "0"   # persistent temporal-unfolded stem with the temporal max-pool fused (StemPT); 0: pixel-pair stem + full max-pool (A/B)
 SKIP_TILE_CFGS = {int(c) for c in os.environ.get("TEDSPAD_SKIP_CFGS", "").split(",") if c.strip()}   # A/B: tile configurations the tuner must not try
 AUTOTUNE = os.environ.get("TEDSPAD_AUTOTUNE", "1") != "0"
@@ -981,6 +982,8 @@ class StemPT:
         self.scale = _padded_vec(scale, co, 64, device, 1.0)
         self.shift = _padded_vec(shift, co, 64, device, 0.0)
         self.nwg = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
+        if STEM_NWG:
+            self.nwg = min(self.nwg, STEM_NWG)
 
     @staticmethod
     def supported(weight: torch.Tensor, stride, pads) -> bool:
