@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for r in $(seq 1 $R); do
   for v in 0 1; do
     for st in 2 1; do
-      env $VAR=$v timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --streams $st > gpurun_out/abenv_${VAR}_${v}_${r}_s${st}.json 2> gpurun_out/abenv_${VAR}_${v}_${r}_s${st}.err
+      env $VAR=$v timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --no-act-range --streams $st > gpurun_out/abenv_${VAR}_${v}_${r}_s${st}.json 2> gpurun_out/abenv_${VAR}_${v}_${r}_s${st}.err
       python - <<PY
 import json
 j=[json.loads(l) for l in open("gpurun_out/abenv_${VAR}_${v}_${r}_s${st}.json") if l.startswith("{")][0]

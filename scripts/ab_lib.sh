@@ -8,7 +8,7 @@ for r in $(seq 1 $R); do
   for v in old new; do
     cp ab/$v.so ted_spad_amd/libtedspad_hip.so
     for st in 2 1; do
-      timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --streams $st > gpurun_out/ab_${v}_${r}_s${st}.json 2> gpurun_out/ab_${v}_${r}_s${st}.err
+      timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --no-act-range --streams $st > gpurun_out/ab_${v}_${r}_s${st}.json 2> gpurun_out/ab_${v}_${r}_s${st}.err
       python - <<PY
 import json
 j=[json.loads(l) for l in open("gpurun_out/ab_${v}_${r}_s${st}.json") if l.startswith("{")][0]

@@ -6,13 +6,13 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/prof
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/main -o main -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train > $O/main.json 2> $O/main.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/main -o main -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-act-range > $O/main.json 2> $O/main.err
 echo "main done"; cat $O/main.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/one -o one -- python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-train > $O/one.json 2> $O/one.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/one -o one -- python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-train --no-act-range > $O/one.json 2> $O/one.err
 echo "one-stream done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --clip-times 75 --streams 1 --no-cpu-baseline --no-train > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --clip-times 75 --streams 1 --no-cpu-baseline --no-train --no-act-range > $O/fetch.json 2> $O/fetch.err
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 bench.py --steps 1 --warmup 0 --clip-times 75 --streams 1 --no-cpu-baseline --no-train > $O/write.json 2> $O/write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 bench.py --steps 1 --warmup 0 --clip-times 75 --streams 1 --no-cpu-baseline --no-train --no-act-range > $O/write.json 2> $O/write.err
 echo "write done"
 T=$(find $O/main -name '*kernel_trace.csv' | head -1); T1=$(find $O/one -name '*kernel_trace.csv' | head -1)
 F=$(find $O/fetch -name '*counter_collection.csv' | head -1); W=$(find $O/write -name '*counter_collection.csv' | head -1)
@@ -37,7 +37,7 @@ json.dump({'arch': 'largei3d', 'batch': 375, 'dtype': 'f16', 'conv_traffic_bytes
 PY
 # SQ counters of the last forward: MFMA utilisation and wave states per kernel (one more pass, kernels serialised)
 S=gpurun_out/prof_sq; rm -rf $S; mkdir -p $S
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $S -o sq -- python3 bench.py --steps 1 --warmup 0 --clip-times 75 --streams 1 --no-cpu-baseline --no-train > $S/sq.json 2> $S/sq.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $S -o sq -- python3 bench.py --steps 1 --warmup 0 --clip-times 75 --streams 1 --no-cpu-baseline --no-train --no-act-range > $S/sq.json 2> $S/sq.err
 python3 scripts/summarize_sq.py $(find $S -name '*counter_collection.csv' | head -1) --batch 375 --out $S/mfma_util.md
 find $S -name '*counter_collection.csv' -size +20M -delete
 tail -5 $S/mfma_util.md
