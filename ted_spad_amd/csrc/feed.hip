@@ -123,12 +123,15 @@ __global__ __launch_bounds__(256) void crop_resize_aa_kernel(const ResizeKP p) {
 }
 
 // The same resize written as the persistent stem's input records (csrc/conv_stem_pt.hip, tedspad_clip_to_tp's layout): X[n][tp][oh][b][ow/2][24] 16-bit, the
-// record of pixel (oy, 2*wq + b) for output-frame pair tp holding value dt*3 + c = clip[n][c][2*stt*tp - pt + dt][oy][2*wq + b], dt = 0..7, zero outside
-// the clip. Clip n = source frames first + n*clip_step + f*frame_step, f = 0 .. t_clip - 1 (dali_extraction.py:62-73: sequence_length 16, stride 2, step 32),
-// frames past the end of the video are zero frames (pad_sequences). The fp32 clip (9.6 MB at 16 x 224 x 224) is never written: a workgroup owns one output
-// row of one FRAME PAIR of one clip, resizes the 8 frames its records hold into an LDS tile of that row's records (10.5 KB at 224 columns) and writes each
-// plane as one contiguous run. (A frame belongs to two pairs and is resized twice; with one workgroup per (clip, row) and all four pairs' records in a 43 KB
-// tile only two workgroups fit a CU and the kernel was bound by its own load -> sync -> store chain: 9.0 ms per 375 clips instead of the 2.x ms measured here.)
+// record of pixel (oy, 2*wq + b) for output-frame pair tp holding value dt*3 + c = clip[n][c][4*tp - pt + dt][oy][2*wq + b], dt = 0..7 (temporal stride 2),
+// zero outside the clip. Clip n = source frames first + n*clip_step + f*frame_step, f = 0 .. t_clip - 1 (dali_extraction.py:62-73: sequence_length 16,
+// stride 2, step 32), frames past the end of the video are zero frames (pad_sequences). The fp32 clip (9.6 MB at 16 x 224 x 224) is never written.
+// A workgroup owns one output row of one QUAD of frames 4*qd - pt .. 4*qd - pt + 3 of one clip: those four frames are the first half (dt 0..3, 24 bytes) of
+// pair qd's records AND the second half (dt 4..7) of pair qd - 1's, so every frame is resized once, into one LDS tile of half records (5.3 KB at 224
+// columns), which leaves twice as 8-byte pieces; the sibling quad's workgroup (the next blockIdx) fills the other halves of the same lines right behind it.
+// One load -> sync -> resize -> sync -> store chain per workgroup, ~24 KB of LDS: six workgroups per CU. (One workgroup per (clip, row) with all four pairs'
+// records in a 43 KB tile: two per CU, 9.0 ms per 375 clips; one per (clip, row, pair), every frame resized twice: 3.5 ms; byte loads instead of 4-byte
+// loads cost 3.6 ms of an earlier 6.6: scripts/crop_tp_probe.py.)
 struct ResizeTpKP {
     ResizeKP r;
     uint16_t *rec;
@@ -136,112 +139,129 @@ struct ResizeTpKP {
     const uint8_t *in_end;      // one past the last byte of the frame buffer (the 4-byte loads of the uint8 path stay inside it)
 };
 
-// FG frames of the clip are resized per round (their FG x yn row loads per element are independent: the memory pipeline stays full, two barriers per round
-// instead of two per frame); uint8 frames take value / divisor from a 256-entry table built with the same division (bit-identical to dividing per sample).
 template <typename In, typename T>
 __global__ __launch_bounds__(256) void crop_resize_tp_kernel(const ResizeTpKP q) {
     constexpr int FG = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_tp[];
     const ResizeKP &p = q.r;
     const int wq_n = p.ow >> 1;
-    uint4 *tile = reinterpret_cast<uint4 *>(lds_tp);                 // [plane b][wq][3 x 16 B]
-    const int tile16 = 2 * wq_n * 3;
+    uint2 *tile = reinterpret_cast<uint2 *>(lds_tp);                 // [plane b][wq][3 x 8 B]: half records (4 frames x 3 channels)
+    const int tile8 = 2 * wq_n * 3;
     const int span = p.cw * p.C;
-    float *rows = reinterpret_cast<float *>(lds_tp + (size_t)tile16 * 16);      // [FG][span]
-    float *lut = rows + FG * span;                                   // [256] (uint8 input)
-    int32_t *xt = reinterpret_cast<int32_t *>(lut + 256);            // this launch's column table [ow][2 + xtaps]: read 8 x 3 times per output pixel below
-    const int tp = blockIdx.x % q.tp_n, rowid = blockIdx.x / q.tp_n;
+    float *rows = reinterpret_cast<float *>(lds_tp + (size_t)tile8 * 8);        // [FG][span]
+    float *lut = rows + FG * span;                                   // [256] (uint8 input, divisor != 255)
+    int32_t *xt = reinterpret_cast<int32_t *>(lut + 256);            // this launch's column table [ow][2 + xtaps]: read 4 x 3 times per output pixel below
+    const int nq = q.tp_n + 1;
+    const int qd = blockIdx.x % nq, rowid = blockIdx.x / nq;
     const int n = rowid / p.oh, oy = rowid % p.oh;
-    const int fbeg = 2 * q.stt * tp - q.pt;                          // the record's frame slot dt holds clip frame fbeg + dt
-    for (int i = threadIdx.x; i < tile16; i += 256) tile[i] = make_uint4(0u, 0u, 0u, 0u);      // frame slots outside the clip, channels >= C
-    if (sizeof(In) == 1) lut[threadIdx.x] = (float)threadIdx.x / p.div;
+    const int f0 = 4 * qd - q.pt;                                    // first clip frame of the quad
+    const bool div255 = p.div == 255.0f;
+    for (int i = threadIdx.x; i < tile8; i += 256) tile[i] = make_uint2(0u, 0u);               // frames outside the clip, channels >= C
+    if (sizeof(In) == 1 && !div255) lut[threadIdx.x] = (float)threadIdx.x / p.div;
     for (int i = threadIdx.x; i < p.ow * (2 + p.xtaps); i += 256) xt[i] = p.xtab[i];
     const int32_t *ye = p.ytab + (size_t)oy * (2 + p.ytaps);
     const int yn = ye[1];
     const float *wy = (const float *)(ye + 2);
     const long rstride = (long)p.W * p.C;
     uint16_t *t16 = reinterpret_cast<uint16_t *>(lds_tp);
-    for (int d0 = 0; d0 < 8; d0 += FG) {
-        const int f0 = fbeg + d0;
-        const In *base[FG];
-        bool live[FG];
+    const In *base[FG];
+    bool live[FG];
 #pragma unroll
-        for (int ff = 0; ff < FG; ++ff) {
-            const long fr = (long)q.first + (long)n * q.clip_step + (long)(f0 + ff) * q.frame_step;
-            live[ff] = f0 + ff >= 0 && f0 + ff < q.t_clip && fr >= 0 && fr < p.T;    // else a zero frame: its slots stay zero (uniform)
-            base[ff] = (const In *)p.in + (((live[ff] ? fr : 0) * p.H + p.y0 + ye[0]) * p.W + p.x0) * p.C;
-        }
-        __syncthreads();                                             // the zero fill and the tables / the previous round's reads of `rows`
-        if constexpr (sizeof(In) == 1) {
-            // four consecutive bytes per lane and load (byte loads: 64 bytes per wave instruction, and the kernel spent 3.6 of its 6.6 ms per 375 clips in them)
-            for (int g = threadIdx.x; 4 * g < span; g += 256) {
-                float acc[FG][4];
-#pragma unroll
-                for (int ff = 0; ff < FG; ++ff)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[ff][k] = 0.f;
-                for (int j = 0; j < yn; j++) {
-                    unsigned w4[FG];
-#pragma unroll
-                    for (int ff = 0; ff < FG; ++ff) w4[ff] = live[ff] ? load_u8x4(reinterpret_cast<const uint8_t *>(base[ff]) + j * rstride + 4 * g, q.in_end) : 0u;
-#pragma unroll
-                    for (int ff = 0; ff < FG; ++ff)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[ff][k] += wy[j] * lut[(w4[ff] >> (8 * k)) & 255u];
-                }
-#pragma unroll
-                for (int ff = 0; ff < FG; ++ff)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (4 * g + k < span) rows[ff * span + 4 * g + k] = acc[ff][k];
-            }
-        } else {
-            for (int e = threadIdx.x; e < span; e += 256) {
-                float acc[FG];
-#pragma unroll
-                for (int ff = 0; ff < FG; ++ff) acc[ff] = 0.f;
-                for (int j = 0; j < yn; j++) {
-#pragma unroll
-                    for (int ff = 0; ff < FG; ++ff) acc[ff] += wy[j] * (live[ff] ? load_px<In>(base[ff] + j * rstride + e, p.div) : 0.f);
-                }
-#pragma unroll
-                for (int ff = 0; ff < FG; ++ff) rows[ff * span + e] = acc[ff];
-            }
-        }
-        __syncthreads();
-        for (int ox = threadIdx.x; ox < p.ow; ox += 256) {
-            const int32_t *xe = xt + ox * (2 + p.xtaps);
-            const int xmin = xe[0], xn = xe[1];
-            const float *wx = reinterpret_cast<const float *>(xe + 2);
-            const int oxw = p.flip ? p.ow - 1 - ox : ox;
-            // aa_hpass for the FG frames x 3 channels at once: a tap's weight is read once; every sum still runs over its taps in ascending order
-            float acc[FG][3];
+    for (int ff = 0; ff < FG; ++ff) {
+        const long fr = (long)q.first + (long)n * q.clip_step + (long)(f0 + ff) * q.frame_step;
+        live[ff] = f0 + ff >= 0 && f0 + ff < q.t_clip && fr >= 0 && fr < p.T;    // else a zero frame: its slots stay zero (uniform)
+        base[ff] = (const In *)p.in + (((live[ff] ? fr : 0) * p.H + p.y0 + ye[0]) * p.W + p.x0) * p.C;
+    }
+    if constexpr (sizeof(In) == 1) {
+        if (!div255) __syncthreads();                                // the value table (uniform branch)
+        // four consecutive bytes per lane and load (byte loads: 64 bytes per wave instruction)
+        for (int g = threadIdx.x; 4 * g < span; g += 256) {
+            float acc[FG][4];
 #pragma unroll
             for (int ff = 0; ff < FG; ++ff)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[ff][c] = 0.f;
-            for (int j = 0; j < xn; j++) {
-                const float wj = wx[j];
-                const float *r = rows + (xmin + j) * p.C;
+                for (int k = 0; k < 4; ++k) acc[ff][k] = 0.f;
+            for (int j = 0; j < yn; j++) {
+                unsigned w4[FG];
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff) w4[ff] = live[ff] ? load_u8x4(reinterpret_cast<const uint8_t *>(base[ff]) + j * rstride + 4 * g, q.in_end) : 0u;
 #pragma unroll
                 for (int ff = 0; ff < FG; ++ff)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        if (c < p.C) acc[ff][c] += wj * r[ff * span + c];
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned bt = (w4[ff] >> (8 * k)) & 255u;
+                        float px;
+                        if (div255) {       // byte / 255.f without the division or a table: b * fl(1/255) corrected by one residual step is the correctly rounded
+                                            // quotient for every byte value (checked exhaustively in exact arithmetic; tests compare with the dividing kernel bit for bit)
+                            const float xb = (float)bt, r = 1.0f / 255.0f;
+                            const float q0 = xb * r;
+                            px = __builtin_fmaf(__builtin_fmaf(-q0, 255.0f, xb), r, q0);
+                        } else {
+                            px = lut[bt];
+                        }
+                        acc[ff][k] += wy[j] * px;
+                    }
             }
 #pragma unroll
-            for (int ff = 0; ff < FG; ++ff) {
-                if (!live[ff]) continue;
-                uint16_t *rec = t16 + ((size_t)((oxw & 1) * wq_n + (oxw >> 1))) * 24 + (d0 + ff) * 3;
+            for (int ff = 0; ff < FG; ++ff)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) rec[c] = c < p.C ? T::from_f32(acc[ff][c]) : (uint16_t)0;
+                for (int k = 0; k < 4; ++k)
+                    if (4 * g + k < span) rows[ff * span + 4 * g + k] = acc[ff][k];
+        }
+    } else {
+        for (int e = threadIdx.x; e < span; e += 256) {
+            float acc[FG];
+#pragma unroll
+            for (int ff = 0; ff < FG; ++ff) acc[ff] = 0.f;
+            for (int j = 0; j < yn; j++) {
+#pragma unroll
+                for (int ff = 0; ff < FG; ++ff) acc[ff] += wy[j] * (live[ff] ? load_px<In>(base[ff] + j * rstride + e, p.div) : 0.f);
             }
+#pragma unroll
+            for (int ff = 0; ff < FG; ++ff) rows[ff * span + e] = acc[ff];
+        }
+    }
+    __syncthreads();                                                 // rows, the zeroed tile and the column table are complete
+    for (int ox = threadIdx.x; ox < p.ow; ox += 256) {
+        const int32_t *xe = xt + ox * (2 + p.xtaps);
+        const int xmin = xe[0], xn = xe[1];
+        const float *wx = reinterpret_cast<const float *>(xe + 2);
+        const int oxw = p.flip ? p.ow - 1 - ox : ox;
+        // aa_hpass for the FG frames x 3 channels at once: a tap's weight is read once; every sum still runs over its taps in ascending order
+        float acc[FG][3];
+#pragma unroll
+        for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[ff][c] = 0.f;
+        for (int j = 0; j < xn; j++) {
+            const float wj = wx[j];
+            const float *r = rows + (xmin + j) * p.C;
+#pragma unroll
+            for (int ff = 0; ff < FG; ++ff)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < p.C) acc[ff][c] += wj * r[ff * span + c];
+        }
+        uint16_t *rec = t16 + ((size_t)((oxw & 1) * wq_n + (oxw >> 1))) * 12;
+#pragma unroll
+        for (int ff = 0; ff < FG; ++ff) {
+            if (!live[ff]) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rec[ff * 3 + c] = c < p.C ? T::from_f32(acc[ff][c]) : (uint16_t)0;
         }
     }
     __syncthreads();
-    const int run16 = wq_n * 3;                                      // 16-byte pieces of one (pair, plane) run
-    uint4 *dst = reinterpret_cast<uint4 *>(q.rec) + (((long)n * q.tp_n + tp) * p.oh + oy) * 2 * (long)run16;      // both planes of the row: one contiguous run
-    for (int i = threadIdx.x; i < tile16; i += 256) dst[i] = tile[i];
+    // half records -> pair qd (first halves) and pair qd - 1 (second halves); both planes of a row are one contiguous run of records
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int tp = qd - half;
+        if (tp < 0 || tp >= q.tp_n) continue;                        // uniform
+        uint2 *dst = reinterpret_cast<uint2 *>(q.rec) + ((((long)n * q.tp_n + tp) * p.oh + oy) * 2 * (long)wq_n) * 6 + half * 3;
+        for (int i = threadIdx.x; i < tile8; i += 256) {
+            const int rc = i / 3, pc = i - rc * 3;
+            dst[(long)rc * 6 + pc] = tile[i];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -379,8 +399,8 @@ extern "C" int32_t tedspad_frames_crop_resize_tp(const void *frames, int32_t in_
     TS_REQUIRE(divisor != 0.f, "tedspad_frames_crop_resize_tp: divisor must be non-zero");
     TS_REQUIRE(stride_t == 2 && pad_t >= 0 && t_pairs > 0, "tedspad_frames_crop_resize_tp: temporal stride 2 (tedspad_clip_to_tp's record layout)");
     TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_frames_crop_resize_tp: bad dtype");
-    TS_REQUIRE((uintptr_t)records % 16 == 0 && (long)n_clips * oh * t_pairs < (1L << 31), "tedspad_frames_crop_resize_tp: records must be 16-byte aligned; too many rows");
-    const size_t lds = (size_t)ow * 48 + (size_t)4 * cw * C * sizeof(float) + 1024 + (size_t)ow * (2 + aa_taps(cw, ow)) * 4;      // one pair's record row + four frames' row buffers + the value table + the column table
+    TS_REQUIRE((uintptr_t)records % 16 == 0 && (long)n_clips * oh * (t_pairs + 1) < (1L << 31), "tedspad_frames_crop_resize_tp: records must be 16-byte aligned; too many rows");
+    const size_t lds = (size_t)ow * 24 + (size_t)4 * cw * C * sizeof(float) + 1024 + (size_t)ow * (2 + aa_taps(cw, ow)) * 4;      // a row of half records + four frames' row buffers + the value table + the column table
     TS_REQUIRE(lds <= 160 * 1024, "tedspad_frames_crop_resize_tp: %d columns of records + four %d x %d row buffers exceed the CU's 160 KB of LDS", ow, cw, C);
     ResizeTpKP q;
     ResizeKP &p = q.r;
@@ -392,7 +412,7 @@ extern "C" int32_t tedspad_frames_crop_resize_tp(const void *frames, int32_t in_
     q.pt = pad_t; q.stt = stride_t; q.tp_n = t_pairs;
     q.in_end = (const uint8_t *)frames + (size_t)T * H * W * C * (in_is_float ? 4 : 1);
     hipStream_t s = (hipStream_t)stream;
-    const dim3 g((unsigned)((long)n_clips * oh * t_pairs));
+    const dim3 g((unsigned)((long)n_clips * oh * (t_pairs + 1)));
     if (lds > 64 * 1024) {                       // wide source frames (HD): raise the kernel's dynamic LDS limit once per variant
         static thread_local bool raised[4] = {false, false, false, false};
         const int vi = (in_is_float ? 2 : 0) + (dtype == TEDSPAD_F16 ? 0 : 1);
