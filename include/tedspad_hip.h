@@ -166,8 +166,8 @@ int32_t tedspad_conv_p8_dual_fwd(const tedspad_conv_desc *d, const void *x, cons
  * ((a*2 + s)*2 + h)*8 + j = conv3 weight of input channel 32 a + 16 s + 8 (j >> 2) + 4 h + (j & 3) (the k order in which an MFMA
  * accumulator tile is consumed as the next MFMA's operand), columns 64 + c = conv_d weight of input channel c. scale3 / scale_d are the two
  * BatchNorm scales, shift3 the sum of the shifts. The 64-channel tensor between conv2 and conv3 is never written.
- * variant bit 0 (plain block) / bit 1 (second source): residual and result rows go through wave-private LDS images so that every global
- * access moves whole 128-byte lines; 0: 16-byte accesses straight in the accumulator layout (same results).
+ * Residual and result rows go through wave-private LDS images, so that every global access moves whole 128-byte lines (variant bits 0 / 1, which
+ * selected that form until ABI 3, are ignored).
  * variant bit 2 (plain block only, t even): MaxPool3d((2,1,1), stride (2,1,1)) of the block's output fused (large_i3d.py:139):
  * y[n][t/2][h][w][ldy] = max over the frame pair; a workgroup runs conv2 for the same 256 pixels of both frames and stores once. */
 int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const void *x, const void *w2_packed, const float *scale2, const float *shift2,

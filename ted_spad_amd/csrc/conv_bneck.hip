@@ -100,15 +100,15 @@ struct BneckKP {
     unsigned winv, hinv;        // ceil(2^20 / W), ceil(2^20 / H): (t * inv) >> 20 == t / W for the small t the kernels divide (t < W + 256; t * W < 2^20)
 };
 
-// STAGED: residual rows in / result rows out through wave-private LDS images (whole 128-byte lines per access); otherwise 16-byte
-// loads / stores straight in the accumulator layout (32-byte pieces per pixel) and the whole weight image resident.
-// POOLT (plain block, STAGED): MaxPool3d((2,1,1), stride (2,1,1)) of the block's output fused (large_i3d.py:139 after layer1): a workgroup
+// Residual rows in / result rows out go through wave-private LDS images (whole 128-byte lines per access; the 16-byte loads / stores straight in the
+// accumulator layout of the first version touched 32 lines per instruction and were removed in round 5).
+// POOLT (plain block): MaxPool3d((2,1,1), stride (2,1,1)) of the block's output fused (large_i3d.py:139 after layer1): a workgroup
 // owns 256 pixels of an even frame AND the same pixels of the next frame: stage A runs twice (the second halo lands where the first
 // was), both 64-channel tiles stay in registers as conv3 operands, stage B computes every 64-channel step for both frames and stores
 // their maximum: the 256-channel tensor is written once, pooled (half the bytes of the unfused conv3 + pool pair's traffic again).
-template <typename T, bool DUAL, bool STAGED, bool POOLT>
+template <typename T, bool DUAL, bool POOLT>
 __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p) {
-    static_assert(!POOLT || (!DUAL && STAGED), "the pooled variant is the plain block with staged rows");
+    static_assert(!POOLT || !DUAL, "the pooled variant is the plain block");
     constexpr int NT = 256, WS = 4, KB = DUAL ? 2 : 1, NF = POOLT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     // them for the plain block (32 KB), two at a time with the second source (2 x 2 x 8 KB), so that weight image + BatchNorm vectors + the waves' row images
     // stay below the 80 KB that let two workgroups share a CU
     const int n3 = p.cout3 / 64;                           // 64-channel groups of the output
-    const int HG = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    const int HG = DUAL ? (n3 < 2 ? n3 : 2) : n3;
     auto load_w3 = [&](int g0) {                           // groups g0 .. g0 + HG - 1: slot kb * HG + (g - g0)
         for (int i = wave; i < KB * HG * 8; i += 4) {      // 8 wave-instructions (8 rows x 128 B) per tile
             const int tl = i >> 3, sub = i & 7;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
     };
     // bn2's scale / shift ([2][64] fp32) go through LDS too, past everything else: read as 4-channel vectors after stage A (64 scalar global loads per lane
     // sat between stage A and stage B before)
-    const int main_end = halo_bytes + WS * BT_WSTAGE, tail_end = wb_off + (STAGED ? 4 * 8192 : 0);
+    const int main_end = halo_bytes + WS * BT_WSTAGE, tail_end = wb_off + 4 * 8192;
     float *bn2v = reinterpret_cast<float *>(dsm + (main_end > tail_end ? main_end : tail_end));
     f32x4 bn2reg = {0.f, 0.f, 0.f, 0.f};
     if (tid < 32) bn2reg = reinterpret_cast<const f32x4 *>(tid < 16 ? p.scale2 : p.shift2)[tid & 15];
@@ -348,11 +348,14 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
             BT_STAGE(2);
             if (!BT_ABL(16)) load_w3(0);
             load_bnv();
-            if (STAGED && has_res) issue_res(0, 0);
+            if (has_res) issue_res(0, 0);
         }
         // ---- relu(bn2(.)) of the conv2 tile, packed to 16 bits ---------------------------------------------------------------------
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            // one channel half at a time: its vectors are requested behind this statement and its fragments are complete at the one below (two volatile
+            // statements keep their order); left alone hipcc requests both halves' vectors inside the last tap beside the full accumulator tile and spills
+            if (!DUAL) asm volatile("" ::: "memory");          // (the two-source variant is spill-free as hipcc orders it, and not with this)
             float sc[16], sf[16];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
@@ -370,6 +373,11 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
                     for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s + j] * sc[8 * s + j] + sf[8 * s + j], 0.f);
                     y2[f][a * 2 + s][b] = pack8<T>(v);
                 }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (!DUAL) asm volatile("" : "+v"(y2[f][a * 2 + s][b].x), "+v"(y2[f][a * 2 + s][b].y), "+v"(y2[f][a * 2 + s][b].z), "+v"(y2[f][a * 2 + s][b].w));
         }
     }
 
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 #pragma unroll
             for (int b = 0; b < 2; ++b) xin[ks][b] = *reinterpret_cast<const uint4 *>(p.x2 + mpx[b] * p.ldx2 + (ks * 2 + lh) * 8);
     }
-    if (STAGED && has_res) wait_vmcnt<8>(); else wait_vmcnt<0>();      // weight image + BatchNorm vectors landed; the 8 residual rows of step 0 may still fly
+    if (has_res) wait_vmcnt<8>(); else wait_vmcnt<0>();      // weight image + BatchNorm vectors landed; the 8 residual rows of step 0 may still fly
     __syncthreads();           // ... of every wave
     BT_STAGE(3);
 
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
         unsigned dk[POOLT ? 2 : 1][2][4][2];     // POOLT: the first frame's
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            if (STAGED && has_res) {
+            if (has_res) {
                 // the residual rows of this step landed; the previous 64-channel step's 8 stores (issued after the first frame's rows) stay in flight
                 if (f == 0 && g > 0) wait_vmcnt<8>(); else wait_vmcnt<0>();
                 asm volatile("" ::: "memory");
@@ -454,9 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 #pragma unroll
                         for (int qq = 0; qq < 2; ++qq) {
                             const unsigned c8 = (unsigned)(4 * tt + 2 * qq + lh);
-                            uint4 L = make_uint4(0u, 0u, 0u, 0u);
-                            if (STAGED) L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
-                            else if (inb[b]) L = *reinterpret_cast<const uint4 *>(p.res + mpx[b] * p.ldres + 32 * t + 16 * qq + 8 * lh);
+                            const uint4 L = *reinterpret_cast<const uint4 *>(wbuf + (b * 32 + l31) * 128 + ((c8 ^ swz) << 4));
                             auto s0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
                             auto s1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
                             rs[2 * qq][0] = s0[0]; rs[2 * qq + 1][0] = s0[1];
@@ -515,18 +521,6 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) d[tt][b][q][h] = T::pk_max(d[tt][b][q][h], dk[tt][b][q][h]);
-        }
-        if (!STAGED) {                            // 16-byte stores straight from the registers (lane: channels 16 qq + 8 lh .. + 7 of tile tt)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    if (inb[b]) {
-                        uint16_t *dst = p.y + mpx[b] * p.ldy + 64 * g + 32 * tt + 8 * lh;
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4(d[tt][b][0][0], d[tt][b][0][1], d[tt][b][1][0], d[tt][b][1][1]);
-                        *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(d[tt][b][2][0], d[tt][b][2][1], d[tt][b][3][0], d[tt][b][3][1]);
-                    }
-            continue;
         }
         // ---- results -> the wave's image (every residual read above is complete: its data was consumed) -> whole rows -> global ------------
 #pragma unroll
@@ -594,6 +588,13 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 1) & 7;
     const int NH = (Sr + NT - 1) / NT;
+    // bn2's scale / shift -> LDS, past both stages' regions (read after stage A, several barriers later)
+    float *bn2v;
+    {
+        const int main_end = halo_bytes + 2 * WSTAGE, tail_end = 2 * HG * BT_WSTAGE + 2 * p.cout3 * 4 + 4 * 8192;
+        bn2v = reinterpret_cast<float *>(dsm + (main_end > tail_end ? main_end : tail_end));
+        if (tid < 64) reinterpret_cast<f32x4 *>(bn2v)[tid] = reinterpret_cast<const f32x4 *>(tid < 32 ? p.scale2 : p.shift2)[tid & 31];
+    }
     // which taps of a pixel lie inside its frame: bit dh of rb / bit dw of cb, from the tile's (uniform) first row / column -- no division per lane (see the
     // 64-channel kernel above)
     int pj[2];
@@ -694,16 +695,20 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
         bnv[i] = p.scale3[i];
         bnv[p.cout3 + i] = p.shift3[i];
     }
-    // relu(bn2(.)) of the conv2 tile, packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel quarter a
+    // relu(bn2(.)) of the conv2 tile, packed to 16 bits: fragment (a*2 + s) = rows 16 s .. 16 s + 15 of channel quarter a. bn2's scale / shift come from LDS
+    // ([2][128] fp32 behind everything else, written before stage A) one channel quarter at a time: as 32 global loads per lane and quarter hipcc requested all
+    // four quarters' vectors up front beside the full accumulator tile and spilled 24 registers here
     uint4 y2[8][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
+        asm volatile("" ::: "memory");
         float sc[16], sf[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sc[r] = p.scale2[c];
-            sf[r] = p.shift2[c];
+        for (int rq = 0; rq < 4; ++rq) {
+            const int c = a * 32 + 8 * rq + 4 * lh;           // register 4 rq + i <-> channel c + i
+            const f32x4 vs = *reinterpret_cast<const f32x4 *>(bn2v + c), vf = *reinterpret_cast<const f32x4 *>(bn2v + 128 + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sc[4 * rq + i] = vs[i]; sf[4 * rq + i] = vf[i]; }
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -714,6 +719,12 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
                 for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaxf(acc[a][b][8 * s2 + j] * sc[8 * s2 + j] + sf[8 * s2 + j], 0.f);
                 y2[a * 2 + s2][b] = pack8<T>(v);
             }
+        // this quarter is packed before the next one's vectors are requested (two volatile statements keep their order; the reads sit behind the first)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                asm volatile("" : "+v"(y2[a * 2 + s2][b].x), "+v"(y2[a * 2 + s2][b].y), "+v"(y2[a * 2 + s2][b].z), "+v"(y2[a * 2 + s2][b].w));
     }
     wait_vmcnt<0>();
     __syncthreads();           // weight image + BN vectors visible
@@ -837,7 +848,7 @@ int32_t launch_bneck128(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
     const int main_bytes = (S + 63) / 64 * 64 * 16 + 2 * 128 * BK * 2;
     const int tail_bytes = 2 * 2 * BT_WSTAGE + 2 * p.cout3 * 4 + 4 * 8192;
-    const int lds = main_bytes > tail_bytes ? main_bytes : tail_bytes;
+    const int lds = (main_bytes > tail_bytes ? main_bytes : tail_bytes) + 1024;                          // + bn2's scale / shift
     if (lds > 160 * 1024) {
         set_error("tedspad_bneck_tail_fwd: halo does not fit LDS (%d bytes)", lds);
         return TEDSPAD_EINVAL;
@@ -855,20 +866,20 @@ int32_t launch_bneck128(const BneckKP &p, hipStream_t s) {
     return check_launch("tedspad_bneck_tail_fwd");
 }
 
-template <typename T, bool DUAL, bool STAGED, bool POOLT = false>
+template <typename T, bool DUAL, bool POOLT = false>
 int32_t launch_bneck(const BneckKP &p, hipStream_t s) {
     const int S = (p.NP + 1) * 8;
     const int main_bytes = (S + 63) / 64 * 64 * 16 + 4 * BT_WSTAGE;         // halo + the four-slot weight ring
-    const int n3 = p.cout3 / 64, hg = (DUAL && STAGED) ? (n3 < 2 ? n3 : 2) : n3;
+    const int n3 = p.cout3 / 64, hg = DUAL ? (n3 < 2 ? n3 : 2) : n3;
     const int cp = (p.cout3 + 255) & ~255;
-    const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * cp * 4 + (STAGED ? 4 * 8192 : 0);     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)
+    const int tail_bytes = (DUAL ? 2 : 1) * hg * BT_WSTAGE + 3 * cp * 4 + 4 * 8192;     // weight image + BN vectors (+ one [64 px][64 ch] image per wave)
     const int lds = (main_bytes > tail_bytes ? main_bytes : tail_bytes) + 512;                          // + bn2's scale / shift
     if (lds > 160 * 1024) {
         set_error("tedspad_bneck_tail_fwd: halo / conv3 weight image does not fit LDS (%d bytes)", lds);
         return TEDSPAD_EINVAL;
     }
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_bneck_tail_kernel<T, DUAL, STAGED, POOLT>;
+    auto kfn = conv_bneck_tail_kernel<T, DUAL, POOLT>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_bneck_tail_fwd: cannot raise the dynamic LDS limit");
@@ -921,18 +932,13 @@ extern "C" int32_t tedspad_bneck_tail_fwd(const tedspad_conv_desc *d2, const voi
     if (c128) return d2->dtype == TEDSPAD_F16 ? launch_bneck128<F16>(p, (hipStream_t)stream) : launch_bneck128<BF16>(p, (hipStream_t)stream);
     p.HW = d2->h * d2->w; p.tpf = (p.HW + BT_BM - 1) / BT_BM;
     hipStream_t s = (hipStream_t)stream;
+    const bool f16 = d2->dtype == TEDSPAD_F16;
     if (variant & 4) {
         TS_REQUIRE(!x2 && d2->t % 2 == 0, "tedspad_bneck_tail_fwd: the temporal-pool variant takes the plain block (no second source) and an even frame count");
-        return d2->dtype == TEDSPAD_F16 ? launch_bneck<F16, false, true, true>(p, s) : launch_bneck<BF16, false, true, true>(p, s);
+        return f16 ? launch_bneck<F16, false, true>(p, s) : launch_bneck<BF16, false, true>(p, s);
     }
-    const bool staged = x2 ? (variant & 2) != 0 : (variant & 1) != 0;
-    const bool f16 = d2->dtype == TEDSPAD_F16;
-    if (x2) {
-        if (staged) return f16 ? launch_bneck<F16, true, true>(p, s) : launch_bneck<BF16, true, true>(p, s);
-        return f16 ? launch_bneck<F16, true, false>(p, s) : launch_bneck<BF16, true, false>(p, s);
-    }
-    if (staged) return f16 ? launch_bneck<F16, false, true>(p, s) : launch_bneck<BF16, false, true>(p, s);
-    return f16 ? launch_bneck<F16, false, false>(p, s) : launch_bneck<BF16, false, false>(p, s);
+    if (x2) return f16 ? launch_bneck<F16, true>(p, s) : launch_bneck<BF16, true>(p, s);
+    return f16 ? launch_bneck<F16, false>(p, s) : launch_bneck<BF16, false>(p, s);
 }
 
 #ifdef TEDSPAD_BT_STAGE_STAMPS

@@ -768,7 +768,6 @@ class BneckTail:
     bottleneck (large_i3d.py:49-54,69-84) as ONE launch (csrc/conv_bneck.hip): the 64-channel tensor between the two convolutions stays in
     registers (an MFMA accumulator tile is the next MFMA's operand; the conv3 weight columns are stored in that k order)."""
 
-    VARIANT = int(os.environ.get("TEDSPAD_BNECK_VARIANT", "3"))    # bit 0: staged rows for the plain block, bit 1: for the block with the downsample branch
     # column kk = ((a*2 + s)*2 + h)*8 + j of the conv3 weight image <- input channel 32 a + 16 s + 8 (j >> 2) + 4 h + (j & 3)
     PERM = [32 * a + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for a in range(4) for s in range(2) for h in range(2) for j in range(8)]   # first 64: the 64-channel form
 
@@ -825,7 +824,7 @@ class BneckTail:
                                                 residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
                                                 x2.ptr if x2 is not None else None, x2.ld if x2 is not None else 0,
                                                 self.scale_d.data_ptr() if self.dual else None, out.ptr, out.ld, int(relu),
-                                                self.VARIANT | (4 if pool_t2 else 0), _stream_ptr()),
+                                                4 if pool_t2 else 0, _stream_ptr()),
               "tedspad_bneck_tail_fwd")
         return out
 

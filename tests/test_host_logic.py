@@ -29,11 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 # kernels that are allowed to keep private memory, with the reason; everything else in the library must have NO VGPR spill and NO scratch
 KNOWN_SCRATCH = {
-    # stage A -> stage B transition of the fused bottleneck tails: hipcc requests every BatchNorm vector up front beside the full accumulator tile; the
-    # spill / reload happens once per workgroup, outside the K loops (csrc/conv_bneck.hip; two attempts to pin the loads did not change it)
-    "conv_bneck_tail128_kernel": "once per workgroup at the stage transition",
-    "conv_bneck_tail_kernel": "pooled variant and the unstaged two-source variant: once per workgroup at the stage transition",
-    # private arrays by design (a rolling window / an 8 x 8 transpose tile), HBM-bound kernels outside the conv stack
+    # private arrays by design (a rolling window / an 8 x 8 transpose tile), HBM-bound kernels outside the conv stack. (The fused bottleneck tails, white-listed
+    # here for three rounds, are spill-free since round 5: their BatchNorm vectors are requested one channel block at a time, csrc/conv_bneck.hip.)
     "maxpool_k3s1_kernel": "rolling column maxima in a private array",
     "to_channels_last_w8_kernel": "8 x 8 transpose tile in a private array",
 }
@@ -68,8 +65,6 @@ def test_no_kernel_spills_registers():
                     bad.append((name, spill, scratch))
         assert seen > 150, "parsed only %d kernels" % seen
         assert not bad, "kernels with VGPR spills / scratch: %s" % bad
-        # the kernel this round added must be clean in both dtypes
-        assert not any("bneck_frame" in b[0] for b in bad)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -89,7 +84,7 @@ def test_tail_stage_a_keeps_its_counted_lds_waits():
         subprocess.run([B.HIPCC] + flags + ["-S", "--cuda-device-only", os.path.join(B.CSRC, "conv_bneck.hip"), "-o", out], check=True, capture_output=True)
         text = open(out).read()
     regions = re.findall(r"; BT_COUNTED_LGKM_BEGIN(.*?); BT_COUNTED_LGKM_END", text, flags=re.S)
-    assert len(regions) >= 12, "expected the marked region in every instantiation of the 64-channel tail, found %d" % len(regions)
+    assert len(regions) >= 8, "expected the marked region in every instantiation of the 64-channel tail (plain, two-source, pooled x 2 frames; f16 + bf16), found %d" % len(regions)
     for r in regions:
         assert r.count("ds_read_b128") >= 16 * 4 and r.count("s_waitcnt lgkmcnt(12)") >= 4 * 3 + 1
         loop = re.search(r"=>This Inner Loop Header.*?s_cbranch_scc\d \.LBB", r, flags=re.S)      # the steady-state taps
