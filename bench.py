@@ -766,6 +766,9 @@ def main():
         res["e2e_uint8"] = bench_e2e_uint8(dev)
         torch.cuda.empty_cache()
         res["train_cfg3"] = bench_train(dev)
+    if os.environ.get("TEDSPAD_TILE_PICKS"):          # diagnostic: the tile configurations the tuner settled on over everything this run measured
+        from ted_spad_amd import engine as _E2
+        res["tile_picks"] = {str(k): v for k, v in sorted(_E2.TILE_PICKS.items())}
     print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -731,10 +731,10 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  33  the same with flat tiles (256 consecutive output pixels, halo = one contiguous run as tile 27): cin % 64 == 0, cout <= 128, narrow frames
 //  34  the same for kt x 1 x 1 'same' convs: a tile is all T <= 4 frames of 256 / T spatial positions, taps outside the clip skipped (cout <= 512)
 //  35  128 x 128 split-K over 8 waves, table-free, ring 3 (tile 23 waits 61 % of its wave-cycles with one K tile in flight on layer4's M = 22 050: profiles/r03_bench_cfg2_mfma_util.md)
-//  36  the same with ring 4;  37  256 x 128 split-K over 16 waves, table-free, ring 3 (tile 24 without the K table)
+//  36  the same with ring 4;  37  retired (256 x 128 split-K over 16 waves, table-free, ring 3: never picked)
 //  38  TWO 16 x 16 patches per workgroup sharing every weight stage (conv_patch.hip, conv_patch2_kernel): 1 x 3 x 3 'same' convs, cin % 64 == 0, K in half chunks
 //      of 32 channels, a kernel row of weights per stage: a third fewer bytes through the LDS fill path than tile 32
-//  39  the same on two flat tiles (512 consecutive output pixels, one contiguous halo run): the narrow frames (W <= 62) where patches would quantise
+//  39  retired (the same on two flat tiles of 256 consecutive pixels: never picked)
 constexpr int NUM_CFGS = 39;
 
 template <typename T>
@@ -751,10 +751,11 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, cons
         case 24: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES, 2>(p, s);
         case 35: return launch<T, 128, 128, 2, 2, 3, 0, 2>(p, s);
         case 36: return launch<T, 128, 128, 2, 2, 4, 0, 2>(p, s);
-        case 37: return launch<T, 256, 128, 4, 2, 3, 0, 2>(p, s);
         case 15:
         case 16:   // the 8-wave halo-direct kernel (round 1) never won the tuner once the chunk-major tiles 32-34 existed: retired, ids kept
-            set_error("tedspad_conv_fwd: tile_cfg 15 / 16 are retired");
+        case 37:   // 256 x 128 split-K, table-free, ring 3 (round 4) and
+        case 39:   // two flat tiles per workgroup (round 4): never picked by the tuner over a whole bench run (extraction, anonymised extraction, training: TEDSPAD_TILE_PICKS): retired in round 5
+            set_error("tedspad_conv_fwd: tile_cfg 15 / 16 / 37 / 39 are retired");
             return TEDSPAD_EINVAL;
         case 1: return launch<T, 256, 128, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
         case 2: return launch<T, 256, 64, 4, 2, 3, KTAB_MAX_BYTES>(p, s);
@@ -779,7 +780,6 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, cons
         case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, 1, src);
         case 34: return launch_conv_patch(T::kDtype, p, N, cin, s, 2);
         case 38: return launch_conv_patch2(T::kDtype, p, N, cin, s, src);
-        case 39: return launch_conv_patch2(T::kDtype, p, N, cin, s, src, 1);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);

@@ -782,14 +782,7 @@ int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream
     }
     const int frames = N * p.Ti;
     const bool f16 = dtype == TEDSPAD_F16;
-    if (flat) {
-        if (512 + 2 * p.Wi + 2 > P2_ZP) {
-            set_error("tedspad_conv_fwd: flat two-tile config (tile_cfg 39): frame too wide (W <= 62)");
-            return TEDSPAD_EINVAL;
-        }
-        if (src) return f16 ? launch_patch2_t<F16, true, true>(p, frames, cin, s, src) : launch_patch2_t<BF16, true, true>(p, frames, cin, s, src);
-        return f16 ? launch_patch2_t<F16, false, true>(p, frames, cin, s, nullptr) : launch_patch2_t<BF16, false, true>(p, frames, cin, s, nullptr);
-    }
+    (void)flat;          // tile_cfg 39 (FLAT = true: two flat tiles per workgroup) is retired: the tuner never picked it (round 5); the kernel's FLAT branches are no longer instantiated
     if (src) return f16 ? launch_patch2_t<F16, true>(p, frames, cin, s, src) : launch_patch2_t<BF16, true>(p, frames, cin, s, src);
     return f16 ? launch_patch2_t<F16, false>(p, frames, cin, s, nullptr) : launch_patch2_t<BF16, false>(p, frames, cin, s, nullptr);
 }

@@ -93,6 +93,7 @@ class _Cfgs(dict):
     __slots__ = ("__weakref__",)
 
 
+TILE_PICKS = {}         # tile_cfg -> geometries the tuner has settled on it in this process (which of the 39 configurations earn their place: bench.py --tile-picks)
 _TUNING = {}            # (id(_Cfgs), geometry key) -> weakref to the _Cfgs whose configurations are still taking turns
 _CLOCK = [0]            # conv launches so far (a tuning job that has not been touched for TUNE_STALE launches no longer holds anybody up)
 TUNE_STALE = 20000
@@ -538,6 +539,7 @@ class PackedConv:
                 if med[cfg] < best_ms * 0.98:
                     best, best_ms = cfg, med[cfg]
             self._cfgs[key] = best
+            TILE_PICKS[best] = TILE_PICKS.get(best, 0) + 1
             _TUNING.pop((id(self._cfgs), key), None)
 
     def pool_t2_supported(self, x: Act) -> bool:

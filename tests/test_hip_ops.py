@@ -504,7 +504,7 @@ def test_patch_halo_training_epilogues(cin, cout):
     mask = E.Act(synth_tensor(31, "pe_m", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
     got = {}
     try:
-        for cfg in (32, 33, 38, 39, 5):
+        for cfg in (32, 33, 38, 5):
             E.FORCE_TILE_CFG = cfg
             st1 = torch.zeros((2, pc.cpad), device="cuda"); st2 = torch.zeros((2, pc.cpad), device="cuda")
             a = pc(x, pads=(0, 1, 1), residual=res, mask=mask, relu=False).buf.float().cpu()
@@ -514,7 +514,7 @@ def test_patch_halo_training_epilogues(cin, cout):
     finally:
         E.FORCE_TILE_CFG = None
     ulp = 2.0 ** -10
-    for c in (32, 33, 38, 39):
+    for c in (32, 33, 38):
         for i in range(3):      # cin = 64 walks K like the generic tile (bit-identical), cin = 128 chunk-major (one rounding step; fp32 output: 1e-5); 38 walks half chunks
             g, r = got[c][i], got[5][i]
             assert g.shape == r.shape
@@ -599,7 +599,7 @@ def test_conv_on_a_gathered_concatenation_equals_the_materialised_one(dims, chan
     cat = torch.cat(parts, dim=-1).contiguous()
     ref = conv_cl(cat.float().cpu(), wgt, scale, shift, (1, 1, 1), pf, pb, None, True)
     ran = 0
-    for cfg in (32, 33, 38, 39):
+    for cfg in (32, 33, 38):
         E.FORCE_TILE_CFG = cfg
         try:
             want = pc(E.Act(cat, cin), pads=pf, pads_back=pb).buf
