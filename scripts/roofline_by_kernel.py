@@ -5,9 +5,9 @@ import re, sys, collections
 
 def fam(name):
     name = name.strip('`')
-    m = re.match(r'(conv_bneck_tail_kernel)<[^,]+, (\w+), (\w+), (\w+)>', name)
+    m = re.match(r'(conv_bneck_tail_kernel)<[^,]+, (\w+), (\w+)>', name)          # <T, DUAL, POOLT> (round 5: the STAGED parameter is gone)
     if m:
-        return 'layer1 tail ' + {'true, true, false': '(first block: conv2 + conv3 + downsample)', 'false, true, false': '(plain block)', 'false, true, true': '(last block, maxpool2 inside)'}.get(', '.join(m.groups()[1:]), name)
+        return 'layer1 tail ' + {'true, false': '(first block: conv2 + conv3 + downsample)', 'false, false': '(plain block)', 'false, true': '(last block, maxpool2 inside)'}.get(', '.join(m.groups()[1:]), name)
     for k, v in (('conv_stem_pt_kernel', 'stem + maxpool1 (persistent, reads the fp32 clip)'), ('bneck_frame_kernel', 'layer3 whole bottleneck per frame (x5)'),
                  ('conv_tflat_kernel', 'layer1 conv1 3x1x1 (x3)'), ('conv_bneck_tail128_kernel', 'layer2 tails (x3)'), ('conv_p8_kernel', 'ping-pong 256 x 256 tile (layer2-4 pointwise / temporal / strided)'),
                  ('conv_igemm_kernel', 'generic / split-K tiles (layer4, downsample)'), ('conv_patch', 'patch / flat halo tiles (layer4 3x3)'), ('stem_pool_fix', 'maxpool1 seam fix'), ('avgpool', 'global average pool')):

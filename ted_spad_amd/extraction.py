@@ -172,7 +172,8 @@ def extract_video_features_uint8(ft_model, frames: torch.Tensor, cropping_factor
     frames) -> val_augmentations (:38-50: /255, centre crop 0.8, antialiased resize) -> I3Res50.extract_features -> (n_clips, F) fp32 rows on the GPU.
     Pre-processing writes the persistent stem's 16-bit input records directly (preprocess.crop_resize_records -> I3Res50.extract_features_records): ONE launch
     per batch in front of the encoder, no fp32 clip batch in HBM. Encoders without the record path (InceptionI3d) take the fp32 clips."""
-    from . import preprocess
+    from . import engine as E, preprocess
+    E.require_cuda(frames, "extract_video_features_uint8")
     net = ft_model.i3d if hasattr(ft_model, "i3d") else ft_model
     t, h, w, c = frames.shape
     if n_clips is None:
@@ -191,7 +192,6 @@ def extract_video_features_uint8(ft_model, frames: torch.Tensor, cropping_factor
     main = torch.cuda.current_stream(dev)
     for st in pool:
         st.wait_stream(main)
-    from . import engine as E
     rec_path = hasattr(net, "extract_features_records") and E.STEM_PT and E.STEM_POOL
     stem = net.packed()["stem_pt"] if rec_path else None
     for j, (i, k) in enumerate(sharding.batch_plan(n_clips, batch, len(pool))):

@@ -248,6 +248,14 @@ def test_no_cpu_fallback():
     for holder in (ft.i3d.conv1, ft.i3d.bn1, ft.mlp.fc1):
         with pytest.raises(RuntimeError):
             holder(torch.zeros(1))
+    # the decoded-frames entries (round 5): frames / records on the CPU are refused, not converted by some host path
+    from ted_spad_amd import extraction, preprocess
+    with pytest.raises(_lib.TedSpadHipError):
+        extraction.extract_video_features_uint8(ft, torch.zeros((32, 24, 32, 3), dtype=torch.uint8), out_hw=(16, 16))
+    with pytest.raises(_lib.TedSpadHipError):
+        preprocess.crop_resize_records(torch.zeros((32, 24, 32, 3), dtype=torch.uint8), (0, 0, 24, 32), (16, 16), None, 1)
+    with pytest.raises(_lib.TedSpadHipError):
+        ft.i3d.extract_features_records(torch.zeros((1, 4, 16, 2, 8, 24), dtype=torch.float16))
 
 
 def test_resize_aa_table_matches_torch_antialias_weights():
