@@ -129,4 +129,13 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// the same for a read-once stream (nt: the lines are not kept in L2, where the weights and halos every workgroup re-reads live)
+__device__ __forceinline__ void lds_dma16_nt(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 }  // namespace tedspad

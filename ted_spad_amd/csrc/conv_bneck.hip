@@ -33,7 +33,7 @@ constexpr int BT_BM = 256;
 constexpr int BT_WSTAGE = 64 * BK * 2;
 
 __device__ __forceinline__ void gstore16(void *dst, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: the store reads its data registers late, hipcc pads nothing after an asm statement
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");   // s_nop 1: the store reads its data registers late, hipcc pads nothing after an asm statement; nt: written once, read by the next launch from HBM anyway
 }
 
 // bn3 (+ residual) + ReLU + saturation of two neighbouring output channels -> one packed pair. `b0`, `b1` carry the shift (and the second branch's
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail_kernel(const BneckKP p
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
-            lds_dma16(src, wbuf_lds + k * 1024);
+            lds_dma16_nt(src, wbuf_lds + k * 1024);
         }
     };
     // bn2's scale / shift ([2][64] fp32) go through LDS too, past everything else: read as 4-channel vectors after stage A (64 scalar global loads per lane
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_tail128_kernel(const BneckK
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint16_t *src = k * 8 + rrow < limw ? base + (size_t)(k * 8) * p.ldres + ((c0 ^ ((k & 1) << 2)) << 3) : zero;
-            lds_dma16(src, wbuf_lds + k * 1024);
+            lds_dma16_nt(src, wbuf_lds + k * 1024);
         }
     };
     if (has_res) issue_res(0);
