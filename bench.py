@@ -700,6 +700,7 @@ def main():
         tj = json.load(open(tpath))
         # a traffic figure is only quoted for the kernels it was measured on: the profile stores the hash of the kernel sources
         if (tj.get("arch") == args.arch and tj.get("batch") == args.batch and tj.get("dtype") == args.dtype and
+                {k for _, k in plan} == {args.batch} and          # ... and for the forward size it was measured on (a rank of a strong-scaling run has smaller forwards)
                 tj.get("kernel_sources_sha") == kernel_sources_sha()):
             traffic = tj["conv_traffic_bytes_per_forward"]
             traffic_all = tj.get("all_traffic_bytes_per_forward")
