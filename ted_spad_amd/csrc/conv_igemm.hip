@@ -737,8 +737,40 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  39  retired (the same on two flat tiles of 256 consecutive pixels: never picked)
 constexpr int NUM_CFGS = 39;
 
+// 64-wide sibling of a 128-wide generic tile (same M tile and ring where there is one), 0: none
+inline int narrow_sibling(int cfg) {
+    switch (cfg) {
+        case 1: case 24: return 2;
+        case 3: return 4;
+        case 6: return 7;
+        case 11: return 12;
+        case 13: case 22: return 14;
+        case 18: case 23: case 35: case 36: return 17;
+    }
+    return 0;
+}
+
 template <typename T>
 int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr) {
+    // cout = 128 k + r with r <= 64 on a 128-wide tile (Inception's 3 x 3 x 3 convs 96 -> 208, 112 -> 224, 144 -> 288, 160 -> 320 and its fused 1 x 1 x 1 reduce
+    // GEMMs): the last tile column would multiply up to 64 + 63 channels of zero weights. The first 128 k channels run on the chosen tile, the rest on its 64-wide
+    // sibling with every per-channel pointer moved (conv_patch.hip does the same for the halo tiles); the sibling launches first: if it does not take the geometry
+    // nothing has run yet and the conv goes unsplit. Every generic tile sums K in the same order: the split changes no bit.
+    static const bool split_ok = getenv("TEDSPAD_IGEMM_NO_SPLIT") == nullptr;      // A/B knob
+    const int sib = narrow_sibling(cfg);
+    if (split_ok && sib && !src && p.Cout > 128 && p.Cout % 128 != 0 && p.Cout % 128 <= 64 && !p.fold_hw && !p.x2) {
+        const int head = p.Cout / 128 * 128;
+        ConvKP a = p, b = p;
+        a.Cout = head;
+        b.Cout = p.Cout - head;
+        b.w += (size_t)head * p.Kpad; b.scale += head; b.shift += head;
+        if (b.res) b.res += head;
+        if (b.y) b.y += head;
+        if (b.mask) b.mask += head;
+        if (b.stats) b.stats += head;
+        if (b.y32) b.y32 += head;
+        if (launch_cfg<T>(sib, b, N, cin, s, nullptr) == TEDSPAD_OK) return launch_cfg<T>(cfg, a, N, cin, s, nullptr);
+    }
     switch (cfg) {
         case 9: return launch_stem_halo<T, 1, 1>(p, N, s);
         case 20: return launch_stem_halo<T, 2, 1>(p, N, s);

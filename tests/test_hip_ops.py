@@ -412,6 +412,9 @@ AGREE = [
     ("a_patch_3x3x3_c128_t2", (3, 2, 9, 17), 128, 96, (3, 3, 3), (1, 1, 1), True),      # ... two channel chunks per temporal tap, T = 2 (every frame skips a tap), ragged N, residual
     ("a_patch_3x3x3_c64_t1", (2, 1, 16, 16), 64, 64, (3, 3, 3), (1, 1, 1), False),      # ... a single frame: only the centre temporal tap runs
     ("a_cflat_3x3x3_c64_n192", (3, 4, 9, 13), 64, 192, (3, 3, 3), (1, 1, 1), True),     # flat tile (33) with temporal taps: tiles span frames AND clips (per-pixel frame validity)
+    ("a_igemm_3x3x3_c96_n208", (1, 4, 9, 10), 96, 208, (3, 3, 3), (1, 1, 1), True),      # InceptionI3d's Mixed_4b b1b (96 -> 208): 128-wide tile + its 64-wide sibling on the last 80 -> here 128 + 80: unsplit (r > 64)
+    ("a_igemm_3x3x3_c144_n288", (1, 2, 7, 9), 144, 288, (3, 3, 3), (1, 1, 1), False),    # ... Mixed_4e b1b (144 -> 288 = 2 x 128 + 32): the split generic tiles (round 5), K table, ragged everything
+    ("a_1x1x1_c192_n176", (2, 4, 9, 10), 192, 176, (1, 1, 1), (0, 0, 0), True),          # ... a fused reduce GEMM (b1a | b2a | b0 = 96 + 16 + 64): 128 + 48 channels, residual
 ]
 
 
