@@ -72,6 +72,31 @@ def ntxent_from_embeddings(z0, z1, temperature=0.1):
     return NTXentLoss(z0.device, z0.shape[0], temperature, False)(z0, z1)
 
 
+class DeviceFlag:
+    """Truth value of a 0-d device tensor, read when somebody asks for it (`bool()`, `==`, `repr`): the `skipped` entry of a step result. The non-finite check
+    runs on the step's FINAL gradients, so reading it waits for the whole backward pass; a caller that never looks never waits (torch.amp.GradScaler does not
+    report a skipped step at all)."""
+    __slots__ = ("_t", "_v")
+
+    def __init__(self, t):
+        self._t, self._v = t, None
+
+    def __bool__(self):
+        if self._v is None:
+            self._v = bool(self._t.item() != 0)
+            self._t = None
+        return self._v
+
+    def __eq__(self, other):
+        return bool(self) == bool(other)
+
+    def __hash__(self):
+        return hash(bool(self))
+
+    def __repr__(self):
+        return "DeviceFlag(%s)" % bool(self)
+
+
 class AnonymizerTrainStep:
     def __init__(self, fa_model, ft_model, params=DEFAULT_PARAMS, fb_model=None, group=None, loss_scale: float = 256.0):
         self.fa, self.ft, self.fb, self.params, self.group = fa_model, ft_model, fb_model, params, group
@@ -80,6 +105,7 @@ class AnonymizerTrainStep:
         self.batch_clips = os.environ.get("TEDSPAD_TRAIN_BATCH_CLIPS", "1") != "0"   # the three clips of an iteration as one ft batch (0: three passes, A/B)
         self.batch_views = os.environ.get("TEDSPAD_TRAIN_BATCH_VIEWS", "1") != "0"   # the two VISPR views as one fa / fb batch with per-view statistics (0: two passes)
         self.lazy_losses = os.environ.get("TEDSPAD_TRAIN_LAZY_LOSSES", "0") == "1"
+        self._pin, self._pin_used, self._posted = None, 0, []         # loss read-back (_post / _collect)
         from .unetpp import UnetPlusPlus
         self.fa_tr, self.ft_tr = (UNetPPTrainer if isinstance(fa_model, UnetPlusPlus) else UNetTrainer)(fa_model), I3DTrainer(ft_model)
         self.fb_tr = FBTrainer(fb_model) if fb_model is not None else None
@@ -126,10 +152,37 @@ class AnonymizerTrainStep:
         loss_trip = self.trip(heads[0][1], heads[1][1], heads[2][1])  # :115
         return loss_ce + p.temporal_loss_weight * loss_trip, loss_ce, loss_trip
 
-    def _val(self, t):
-        """A loss for the returned dict: a Python float (one device sync per step, as the reference's `loss.item()` logging has), or -- `lazy_losses` --
-        the detached 0-d tensor: the caller converts when it logs, and the next step's launches are queued behind this step's without a bubble."""
-        return t.detach() if self.lazy_losses else float(t.detach())
+    def _post(self, losses: dict):
+        """Start reading this step's loss values back NOW: they exist once the forward pass and the loss kernels are queued, long before the backward pass behind
+        them has run. One stack + one non-blocking copy into pinned host memory + an event; `_collect` waits for THAT event. (The first version called
+        `float(loss)` at the end of the step: a full device sync per phase -- 37 of phase 1's 50 ms with the host idle, then a host-bound phase 2 on an empty
+        queue: `scripts/phase_prologue_probe.py`; 81 ms per cfg3 iteration against 72 with the losses left on the device.) `lazy_losses`: nothing is copied,
+        the result carries the detached 0-d tensors."""
+        live = {k: v.detach() for k, v in losses.items() if v is not None}
+        if self.lazy_losses or not live:
+            self._posted.append((live, None, 0))
+            return
+        names = list(live)
+        if self._pin is None:
+            self._pin = torch.empty(32, dtype=torch.float32, pin_memory=True)
+        off = self._pin_used
+        self._pin_used += len(names)
+        self._pin[off:off + len(names)].copy_(torch.stack([live[k].float().reshape(()) for k in names]), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._posted.append((names, ev, off))
+
+    def _collect(self) -> dict:
+        """name -> Python float (or 0-d tensor under `lazy_losses`) of everything `_post` was given in this step."""
+        out = {}
+        for names, ev, off in self._posted:
+            if ev is None:
+                out.update(names)
+            else:
+                ev.synchronize()
+                out.update(zip(names, self._pin[off:off + len(names)].tolist()))
+        self._posted, self._pin_used = [], 0
+        return out
 
     def _scaled(self, g):
         return g if (g is None or self.loss_scale == 1.0) else g * self.loss_scale
@@ -159,7 +212,7 @@ class AnonymizerTrainStep:
                     opt.step()
                 finally:
                     del opt.grad_scale, opt.found_inf
-                return found_inf != 0 if self.lazy_losses else bool(found_inf.item() != 0)
+                return found_inf != 0 if self.lazy_losses else DeviceFlag(found_inf)
             if float(found_inf) != 0.0:
                 return True
             opt.step()
@@ -189,7 +242,7 @@ class AnonymizerTrainStep:
 
     # ---- phase 1 --------------------------------------------------------------------------------------------------
     def step_fa(self, inputs_video, labels, inputs_vispr=None):
-        """Update fa (phase 1). Returns a dict of python floats."""
+        """Update fa (phase 1). Returns a dict of python floats (read back as soon as the losses exist, `_post`) + `skipped`, a `DeviceFlag`."""
         p = self.params
         views = self._views(inputs_vispr)
         self.fa.train(); self.ft.eval()
@@ -232,6 +285,7 @@ class AnonymizerTrainStep:
         loss_fa = p.ft_loss_weight * loss_ft                          # :119
         if loss_fb is not None:
             loss_fa = -p.fb_loss_weight * loss_fb + loss_fa
+        self._post(dict(loss_fa=loss_fa, loss_ft=loss_ft, loss_ce=loss_ce, loss_temporal=loss_trip, loss_fb=loss_fb))
         loss_fa.backward()
         for tape_u, tape_b, z in fb_ctx:
             self.fa_tr.backward(tape_u, self.fb_tr.backward(tape_b, self._scaled(z.grad)))
@@ -248,8 +302,8 @@ class AnonymizerTrainStep:
         skipped = self._opt_step(self.opt_fa, self._unscale(self.fa), self.fa)     # :123
         self.iteration += 1
         self._check_deterministic()
-        return dict(phase=1, loss_fa=self._val(loss_fa), loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
-                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=skipped)
+        v = self._collect()
+        return dict(phase=1, loss_fa=v["loss_fa"], loss_ft=v["loss_ft"], loss_ce=v["loss_ce"], loss_temporal=v["loss_temporal"], loss_fb=v.get("loss_fb"), skipped=skipped)
 
     def _three_clips(self, clips, labels, mode, drop_masks):
         """Forward + loss + backward of ft ('train' / 'frozen') on the three clips of an iteration (:169-175 / action :64-84). The reference
@@ -266,6 +320,7 @@ class AnonymizerTrainStep:
                 pred, feat, tape = self.ft_tr.forward(x, mode, drop_mask=dm, groups=3)
                 P3, F3 = pred.detach().requires_grad_(), feat.detach().requires_grad_()
                 losses = self._utility_losses([(P3[k * nb:(k + 1) * nb], F3[k * nb:(k + 1) * nb]) for k in range(3)], lab)
+                self._post(dict(loss_ft=losses[0], loss_ce=losses[1], loss_temporal=losses[2]))
                 losses[0].backward()
                 self.ft_tr.backward(tape, self._scaled(P3.grad), self._scaled(F3.grad), on_bucket_done=self.red_ft.bucket_ready)
                 return losses
@@ -277,6 +332,7 @@ class AnonymizerTrainStep:
             tapes.append(tape)
             leaves.append((pred.detach().requires_grad_(), feat.detach().requires_grad_()))
         losses = self._utility_losses(leaves, labels)
+        self._post(dict(loss_ft=losses[0], loss_ce=losses[1], loss_temporal=losses[2]))
         losses[0].backward()
         for j, (tape, (pl, fl)) in enumerate(zip(tapes, leaves)):     # the third clip's pass finishes every bucket -> all-reduce under it
             self.ft_tr.backward(tape, self._scaled(pl.grad), self._scaled(fl.grad),
@@ -319,6 +375,7 @@ class AnonymizerTrainStep:
                     emb, tape_b = self.fb_tr.forward(x, "train")
                     ctx.append((tape_b, emb.detach().requires_grad_()))
                 loss_fb = NTXentLoss(inputs_video.device, ctx[0][1].shape[0], 0.1, False)(ctx[0][1], ctx[1][1])
+            self._post(dict(loss_fb=loss_fb))
             loss_fb.backward()
             for j, (tape_b, z) in enumerate(ctx):
                 self.fb_tr.backward(tape_b, self._scaled(z.grad), on_bucket_done=self.red_fb.bucket_ready if j == len(ctx) - 1 else None)
@@ -332,8 +389,8 @@ class AnonymizerTrainStep:
         skipped = self._opt_step(self.opt_ft, self._unscale(self.ft), self.ft)     # :193
         self.iteration += 1
         self._check_deterministic()
-        return dict(phase=2, loss_ft=self._val(loss_ft), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
-                    loss_fb=None if loss_fb is None else self._val(loss_fb), skipped=skipped)
+        v = self._collect()
+        return dict(phase=2, loss_ft=v["loss_ft"], loss_ce=v["loss_ce"], loss_temporal=v["loss_temporal"], loss_fb=v.get("loss_fb"), skipped=skipped)
 
     def step_action(self, inputs_video, labels, drop_masks=None):
         """One iteration of action_training/train_anonymized_action.py:43-94 (`--temporal_loss trip`, cross-entropy): the
@@ -356,8 +413,8 @@ class AnonymizerTrainStep:
         skipped = self._opt_step(self.opt_ft, self._unscale(self.ft), self.ft)     # :87
         self.iteration += 1
         self._check_deterministic()
-        return dict(phase="action", loss=self._val(loss), loss_ce=self._val(loss_ce), loss_temporal=self._val(loss_trip),
-                    skipped=skipped)
+        v = self._collect()
+        return dict(phase="action", loss=v["loss_ft"], loss_ce=v["loss_ce"], loss_temporal=v["loss_temporal"], skipped=skipped)
 
     def step(self, inputs_video, labels, inputs_vispr=None):
         """Alternates like train_epoch's `step` flag (:71,135): even iterations update fa, odd ones ft (and fb)."""

@@ -70,7 +70,7 @@ def test_phase1_update_fa_vs_oracle(loss_scale):
     before = {k: v.detach().clone() for k, v in fa.named_parameters()}
     ft_before = {k: v.detach().clone() for k, v in ft.state_dict().items()}
     out = step.step_fa(video.cuda(), labels.cuda())
-    assert out["phase"] == 1 and out["loss_fb"] is None and out["skipped"] is False
+    assert out["phase"] == 1 and out["loss_fb"] is None and bool(out["skipped"]) is False
     assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 5e-3 * abs(ref_l["loss_ft"])
     assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 5e-3 * abs(ref_l["loss_fa"])
     errs = _report("phase1 fa grads", {k: p.grad for k, p in fa.named_parameters()}, ref_g)
@@ -101,7 +101,7 @@ def test_phase1_with_the_default_unetpp_anonymizer_vs_oracle():
     step = AnonymizerTrainStep(fa, ft)
     before = {k: v.detach().clone() for k, v in fa.named_parameters()}
     out = step.step_fa(video.cuda(), labels.cuda())
-    assert out["phase"] == 1 and out["skipped"] is False
+    assert out["phase"] == 1 and bool(out["skipped"]) is False
     assert abs(out["loss_ft"] - ref_l["loss_ft"]) < 1e-2 * abs(ref_l["loss_ft"])
     assert abs(out["loss_fa"] - ref_l["loss_fa"]) < 1e-2 * abs(ref_l["loss_fa"])
     errs = _report("phase1 unet++ grads", {k: p.grad for k, p in fa.named_parameters() if p.grad is not None}, ref_g)
@@ -213,11 +213,11 @@ def test_a_gradient_overflow_is_seen_and_the_step_skipped(phase):
     net = fa if phase == 1 else ft
     before = {k: v.detach().clone() for k, v in net.named_parameters()}
     out = step.step_fa(video, labels) if phase == 1 else step.step_ft(video, labels)
-    assert out["skipped"] is True
+    assert bool(out["skipped"]) is True and out["skipped"] == True     # a DeviceFlag: read on demand
     assert all(torch.equal(p.detach(), before[k]) for k, p in net.named_parameters()), "a skipped step must leave the parameters alone"
     step.loss_scale = 256.0
     out = step.step_fa(video, labels) if phase == 1 else step.step_ft(video, labels)
-    assert out["skipped"] is False
+    assert bool(out["skipped"]) is False
     assert any(not torch.equal(p.detach(), before[k]) for k, p in net.named_parameters())
 
 
