@@ -17,6 +17,7 @@ python3 scripts/summarize_train.py --trace $(find $O/trace -name '*kernel_trace.
   --write $(find $O/write -name '*counter_collection.csv' | head -1) --sq $(find $O/sq -name '*counter_collection.csv' | head -1) --iters 3 \
   --out $O/train_kernels.md --title "${ROUND:-r03}: cfg3 training iteration (UNet fa + I3Res50 ft on 8 x 48 x 112^2, privacy branch fb + NT-Xent on 2 x 12 x 224^2, f16): kernel time, HBM traffic, MFMA utilisation" > $O/summary.txt
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
+python3 scripts/train_timeline.py $(find $O/trace -name '*kernel_trace.csv' | head -1) 3 > $O/train_timeline.txt
 find $O -name '*kernel_trace.csv' -size +8M -delete; find $O -name '*counter_collection.csv' -size +8M -delete
 cat $O/summary.txt
 python3 - <<'PY'
