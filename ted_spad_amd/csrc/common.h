@@ -138,4 +138,13 @@ __device__ __forceinline__ void lds_dma16_nt(const void *gsrc, unsigned lds_dst)
                  : "memory");
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2). Remap the block id so that every
+// XCD walks a CONTIGUOUS range of logical tiles: the N tiles of one pixel tile, and pixel tiles that share halo
+// rows, then hit the same L2 instead of re-reading HBM (profiles/r01: 272 MB/clip of traffic vs 129 MB minimal).
+// Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 }  // namespace tedspad

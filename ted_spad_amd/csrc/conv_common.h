@@ -45,16 +45,6 @@ constexpr int KTAB_MAX_BYTES = 10240;   // Kpad <= 10240 (one int2 per 8 K eleme
 constexpr int KTAB_SMALL_BYTES = 1024;  // "short-K" configs: Kpad <= 1024, smaller LDS -> 2-3 workgroups per CU
 
 
-// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2). Remap the block id so that every
-// XCD walks a CONTIGUOUS range of logical tiles: the N tiles of one pixel tile, and pixel tiles that share halo
-// rows, then hit the same L2 instead of re-reading HBM (profiles/r01: 272 MB/clip of traffic vs 129 MB minimal).
-// Bijective for any grid size; affects speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-
 // conv_pw.hip: persistent pointwise kernel for 1x1x1 stride-1 convolutions with cin = 64 / 128 (tile_cfg 19).
 int32_t launch_conv_pw(int dtype, const ConvKP &p, hipStream_t s, bool pool_t = false);
 

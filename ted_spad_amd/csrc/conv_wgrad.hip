@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * NY * NX) void conv_wgrad_kernel(const WgradKP 
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_S * WG_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);      // the (k, co) tiles of one pixel split share its x / dY rows: one XCD (one L2) walks them
     const int kt2 = b % p.k_tiles; b /= p.k_tiles;
     const int cot = b % p.co_tiles;
     const int ms = b / p.co_tiles;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(384) void conv_wgrad3_kernel(const WgradKP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * W3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);      // the (k, co) tiles of one pixel split share its x / dY rows: one XCD (one L2) walks them
     const int cc = b % p.cc_tiles; b /= p.cc_tiles;
     const int cot = b % p.co_tiles;
     const int ms = b / p.co_tiles;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(384) void conv_wgrad3p_kernel(const WgradKP p, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);      // the (k, co) tiles of one pixel split share its x / dY rows: one XCD (one L2) walks them
     const int cc = b % p.cc_tiles; b /= p.cc_tiles;
     const int cot = b % p.co_tiles;
     const int ms = b / p.co_tiles;

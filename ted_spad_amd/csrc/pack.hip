@@ -85,14 +85,22 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackKP p) {
 static_assert(sizeof(tedspad_pack_job) == 120 && sizeof(tedspad_fold_job) == 96 && sizeof(tedspad_wgrad_unpack_job) == 64,
               "job structs are part of the ABI (ted_spad_amd/_lib.py mirrors them)");
 
+// workgroup -> job: the last entry with block0 <= b. Every lane probes one entry per round (64-ary search: one round up to 64 jobs, two up to 4096) -- the
+// workgroups of these launches live for a few microseconds, and a binary search was 7-8 DEPENDENT loads (~5 us) in front of the first useful one.
 template <typename J>
 __device__ __forceinline__ int find_job(const J *tab, int n, int b) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n;                                  // the answer is in [lo, hi); tab[lo].block0 <= b (tab[0].block0 == 0)
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;
+        const int idx = lo + lane * step;
+        const bool ok = idx < hi && tab[idx].block0 <= b;
+        const unsigned long long m = __ballot(ok);       // lane 0 always votes
+        const int last = 63 - __builtin_clzll(m);
+        lo += last * step;
+        hi = min(hi, lo + step);
     }
-    return lo;
+    return __builtin_amdgcn_readfirstlane(lo);
 }
 
 __device__ __forceinline__ PackKP job_params(const tedspad_pack_job &j) {
@@ -108,10 +116,117 @@ __device__ __forceinline__ PackKP job_params(const tedspad_pack_job &j) {
     return p;
 }
 
+// The weight images through LDS. pack_body gathers: a forward chunk is 8 reads kt*kh*kw floats apart, a data-gradient chunk 8 reads ci*kt*kh*kw floats apart (a transpose
+// by gather, every read its own cache line: 6 GB fetched per training iteration for 0.5 GB of images, `profiles/r05_train_cfg3_kernels.md`). Here a workgroup stages a TILE
+// of the parameter with coalesced reads, scaled as pack_body scales, and assembles the 16-byte chunks from LDS -- bit-identical to pack_body:
+//   forward:        R whole output channels = ONE run of R * ci * taps floats;
+//   data gradient:  C input channels x 64 output channels: per output channel one run of C * taps floats (C = 32 / 16 / 8 for 1 / <= 3 / more taps: runs of >= 128 B).
+// Pixel-pair (stem) forms, data gradients with more than 27 taps and forward rows that do not fit the tile stay on pack_body.
+constexpr int PK_FLOATS = 64 * (8 * 27 + 1);                     // 13 888 floats = 55.6 KB: the largest tile (data gradient of a 3 x 3 x 3 conv)
+constexpr int PK_FWD_FLOATS = 4096;                              // forward tiles: as many whole rows as fit 16 KB (one row if it is longer)
+struct PkPlan { int tiled, per_tile, tiles, floats; };           // floats: LDS the job's tiles need (the launch takes the maximum over its jobs)
+__host__ __device__ inline PkPlan pk_plan(int mode, int pair_shift, int kw, int kwk, int ci, int taps, int rows_pad, int co8) {
+    PkPlan q = {0, 0, 0, 0};
+    if (pair_shift >= 0 || kwk != kw) return q;
+    if (mode == 0) {
+        const long run = (long)ci * taps;
+        if (run > PK_FLOATS) return q;
+        int R = (int)(PK_FWD_FLOATS / run);
+        R = R < 1 ? 1 : R > 64 ? 64 : R;
+        q.tiled = 1; q.per_tile = R; q.tiles = (rows_pad + R - 1) / R; q.floats = (int)(R * run);
+    } else {
+        if (taps > 27) return q;
+        const int C = taps == 1 ? 32 : taps <= 3 ? 16 : 8;
+        q.tiled = 1; q.per_tile = C; q.tiles = ((rows_pad + C - 1) / C) * ((co8 + 63) / 64); q.floats = 64 * (C * taps + 1);
+    }
+    return q;
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_fwd_tiles(const PackKP &p, float *tile, const PkPlan q, int first_tile, int tile_stride) {
+    const int taps = p.kt * p.kh * p.kw, run = p.ci * taps, R = q.per_tile;
+    const int K = taps * p.cink, kchunks = p.kpad / 8;
+    for (int t = first_tile; t < q.tiles; t += tile_stride) {
+        const int n0 = t * R, nr = min(R, p.rows_pad - n0);
+        const int nload = max(0, min(nr, min(p.co, p.rows) - n0));     // rows that carry weights; the rest of the tile is zero rows
+        __syncthreads();                                         // the previous tile's readers are done
+        for (int i = threadIdx.x; i < nload * run; i += 256) {
+            float v = p.w[(size_t)n0 * run + i];
+            if (p.scale) v *= p.scale[n0 + i / run];
+            tile[i] = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * kchunks; i += 256) {
+            const int r = i / kchunks, k0 = (i - r * kchunks) * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (r < nload && k0 < K) {
+                const int c0 = k0 % p.cink, tap = k0 / p.cink;   // (dt, dh, dw) order on both sides (kwk == kw)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = c0 + e < p.ci ? tile[r * run + (c0 + e) * taps + tap] : 0.f;
+            }
+            *reinterpret_cast<uint4 *>(p.out + (size_t)(n0 + r) * p.kpad + k0) = pack8<T>(v);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_dgrad_tiles(const PackKP &p, float *tile, const PkPlan q, int first_tile, int tile_stride) {
+    const int taps = p.kt * p.kh * p.kw, E = p.Et * p.Eh * p.Ew, C = q.per_tile;
+    const int S = C * taps + 1;                                  // floats per output channel in the tile (+1: odd stride)
+    const int n_tiles = (p.co8 + 63) / 64;
+    const int kchunks = p.kpad / 8, used = E * p.co8 / 8;        // chunks per row / chunks that carry the matrix (co8 % 8 == 0)
+    for (int t = first_tile; t < q.tiles; t += tile_stride) {
+        const int c0 = (t / n_tiles) * C, n0 = (t % n_tiles) * 64;
+        __syncthreads();                                         // the previous tile's readers are done
+        for (int i = threadIdx.x; i < 64 * C * taps; i += 256) {
+            const int n = i / (C * taps), rem = i - n * (C * taps);
+            const int c = c0 + rem / taps;
+            float v = 0.f;
+            if (n0 + n < p.co && c < p.ci && c < p.rows) {
+                v = p.w[((size_t)(n0 + n) * p.ci + c0) * taps + rem];
+                if (p.scale) v *= p.scale[n0 + n];
+            }
+            tile[n * S + rem] = v;
+        }
+        __syncthreads();
+        const int nch = min(64, p.co8 - n0) / 8;                 // 8-channel chunks of this tile per (row, tap)
+        for (int i = threadIdx.x; i < C * E * nch; i += 256) {
+            const int jn = i % nch, e = (i / nch) % E, r = i / (nch * E);
+            if (c0 + r >= p.rows_pad) continue;
+            int ee = e;
+            const int ew = ee % p.Ew; ee /= p.Ew;
+            const int eh = ee % p.Eh; const int et = ee / p.Eh;
+            const int dt = p.ct + p.st * (p.Et - 1 - et), dh = p.ch + p.sh * (p.Eh - 1 - eh), dw = p.cw + p.sw * (p.Ew - 1 - ew);
+            const int tp = (dt * p.kh + dh) * p.kw + dw;
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tile[(jn * 8 + u) * S + r * taps + tp];
+            *reinterpret_cast<uint4 *>(p.out + (size_t)(c0 + r) * p.kpad + (size_t)e * p.co8 + n0 + jn * 8) = pack8<T>(v);
+        }
+        if (n0 == 0) {                                           // the rows' K padding [E * co8, kpad): zeros, written by the tile that holds channel 0
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (int i = threadIdx.x; i < C * (kchunks - used); i += 256) {
+                const int r = i / (kchunks - used), k = used + i % (kchunks - used);
+                if (c0 + r < p.rows_pad) *reinterpret_cast<uint4 *>(p.out + (size_t)(c0 + r) * p.kpad + (size_t)k * 8) = z;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_multi_kernel(const tedspad_pack_job *tab, int njobs) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // the launch's largest tile (tedspad_pack_multi)
     const int ji = find_job(tab, njobs, (int)blockIdx.x);
     const tedspad_pack_job &j = tab[ji];
     const PackKP p = job_params(j);
+    const PkPlan q = pk_plan(p.mode, p.pair_shift, p.kw, p.kwk, p.ci, p.kt * p.kh * p.kw, p.rows_pad, p.co8);      // job-uniform; the host planned nblocks with it
+    if (q.tiled) {
+        const int b = (int)blockIdx.x - j.block0;
+        if (p.mode == 0) { if (j.dtype == TEDSPAD_F16) pack_fwd_tiles<F16>(p, tile, q, b, j.nblocks); else pack_fwd_tiles<BF16>(p, tile, q, b, j.nblocks); }
+        else { if (j.dtype == TEDSPAD_F16) pack_dgrad_tiles<F16>(p, tile, q, b, j.nblocks); else pack_dgrad_tiles<BF16>(p, tile, q, b, j.nblocks); }
+        return;
+    }
     const long first = (long)((int)blockIdx.x - j.block0) * 256 + threadIdx.x, stride = (long)j.nblocks * 256;
     if (j.dtype == TEDSPAD_F16) pack_body<F16>(p, first, stride);
     else pack_body<BF16>(p, first, stride);
@@ -203,6 +318,7 @@ extern "C" int32_t tedspad_pack_conv_weights(const float *w, const float *scale,
 extern "C" int32_t tedspad_pack_multi(tedspad_pack_job *jobs, int32_t njobs, void *table_dev, int32_t upload, void *stream) {
     TS_REQUIRE(jobs && table_dev && njobs > 0, "tedspad_pack_multi: bad arguments");
     long blocks = 0;
+    int lds_floats = 0;
     for (int i = 0; i < njobs; ++i) {
         tedspad_pack_job &j = jobs[i];
         TS_REQUIRE(j.w && j.out && j.co > 0 && j.ci > 0 && j.kt > 0 && j.kh > 0 && j.kw > 0 && j.cink % 8 == 0 && j.kpad % 8 == 0 && j.rows_pad >= j.rows &&
@@ -211,7 +327,10 @@ extern "C" int32_t tedspad_pack_multi(tedspad_pack_job *jobs, int32_t njobs, voi
         const long K = j.mode == 1 ? (long)j.geo[0] * j.geo[1] * j.geo[2] * ((j.co + 7) / 8 * 8) : (long)j.kt * j.kh * j.kwk * j.cink;
         TS_REQUIRE(K <= j.kpad && (j.mode == 0 || (j.geo[0] > 0 && j.geo[1] > 0 && j.geo[2] > 0)), "tedspad_pack_multi: kpad too small for a job's matrix");
         const long chunks = (long)j.rows_pad * (j.kpad / 8);
-        long g = (chunks + 1023) / 1024;                       // ~4 chunks of 8 weights per thread
+        long g = (chunks + 1023) / 1024;                       // pack_body: ~4 chunks of 8 weights per thread
+        const PkPlan q = pk_plan(j.mode, j.pair_shift, j.kw, j.kwk, j.ci, j.kt * j.kh * j.kw, j.rows_pad, (j.co + 7) / 8 * 8);
+        if (q.tiled) g = q.tiles;                              // one tile per workgroup (up to the cap)
+        if (q.floats > lds_floats) lds_floats = q.floats;
         g = g < 1 ? 1 : (g > 256 ? 256 : g);
         j.block0 = (int32_t)blocks; j.nblocks = (int32_t)g;
         blocks += g;
@@ -219,7 +338,7 @@ extern "C" int32_t tedspad_pack_multi(tedspad_pack_job *jobs, int32_t njobs, voi
     TS_REQUIRE(blocks < (1L << 30), "tedspad_pack_multi: too many jobs");
     hipStream_t s = (hipStream_t)stream;
     if (!upload_and_plan(jobs, njobs, table_dev, upload, s, "tedspad_pack_multi")) return TEDSPAD_ELAUNCH;
-    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const tedspad_pack_job *)table_dev, njobs);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)blocks), dim3(256), (size_t)lds_floats * sizeof(float), s, (const tedspad_pack_job *)table_dev, njobs);
     return check_launch("tedspad_pack_multi");
 }
 
