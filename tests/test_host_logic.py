@@ -346,3 +346,15 @@ def test_kinetics_pretrained_classifiers_load_strictly_then_get_the_new_head(tmp
     monkeypatch.setattr(ML, "SAVED_MODELS_DIR", str(tmp_path / "nowhere"))
     with pytest.raises(FileNotFoundError):
         ML.build_largei3d_classifier(num_classes=102, pretrained=True)
+
+
+def test_device_flag_reads_its_tensor_once_and_on_demand():
+    """`skipped` of a training-step result (train_step.DeviceFlag): the truth value of a 0-d tensor, read when somebody looks (bool / == / repr / hash), once."""
+    from ted_spad_amd.train_step import DeviceFlag
+    for v, want in ((0.0, False), (1.0, True), (3.0, True)):
+        f = DeviceFlag(torch.tensor(v))
+        assert f._v is None                       # nothing read yet
+        assert bool(f) is want and f == want and (f != (not want)) and repr(f) == "DeviceFlag(%s)" % want and hash(f) == hash(want)
+        assert f._t is None                       # the tensor is dropped after the first read
+    d = {"skipped": DeviceFlag(torch.tensor(0.0))}
+    assert not d["skipped"] and (True if not d["skipped"] else False)
