@@ -412,6 +412,39 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolBKP p) {
     }
 }
 
+// The UNet's pools (unet_parts.py:32: MaxPool2d(2)): 1 x 2 x 2 windows, stride 2, no padding, even frames -- every input element lies in exactly ONE window, at the
+// window-local index (ih & 1) * 2 + (iw & 1). The general kernel above spends six runtime-divisor divisions on the window bounds and three on the element decode
+// before its first load (2.95 TB/s of its bytes); here the decode is two 32-bit divisions and the loads are unconditional. Same selects, same sums: bit-identical.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k2s2_kernel(const PoolBKP p) {
+    const unsigned C8 = (unsigned)p.C8, Wi = (unsigned)p.Wi, Wo = (unsigned)p.Wo;
+    for (long idx0 = (long)blockIdx.x * 256 + threadIdx.x; idx0 < p.total; idx0 += (long)gridDim.x * 256) {
+        const unsigned idx = (unsigned)idx0;
+        const unsigned pix = idx / C8, c8 = idx - pix * C8;          // pix = (n * Ti + it) * Hi * Wi + ih * Wi + iw
+        const unsigned row = pix / Wi, iw = pix - row * Wi;          // row = (n * Ti + it) * Hi + ih; Hi even: row >> 1 = (n * Ti + it) * Ho + ho
+        const size_t oi = (size_t)(row >> 1) * Wo + (iw >> 1);
+        const int li = (int)((row & 1u) * 2u + (iw & 1u));
+        const uint2 pk = *reinterpret_cast<const uint2 *>(p.idx + (oi * C8 + c8) * 8);
+        const uint4 gq = *reinterpret_cast<const uint4 *>(p.dy + oi * p.lddy + c8 * 8);
+        float xv[8], acc[8], g[8];
+        if (p.relu_mask) unpack8<T>(*reinterpret_cast<const uint4 *>(p.x + (size_t)pix * p.ldx + c8 * 8), xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        if (p.add) unpack8<T>(*reinterpret_cast<const uint4 *>(p.add + (size_t)pix * p.ldadd + c8 * 8), acc);
+        unpack8<T>(gq, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = (int)(((i < 4 ? pk.x : pk.y) >> (8 * (i & 3))) & 255u);
+            acc[i] += (a == li) ? g[i] : 0.f;
+        }
+        if (p.relu_mask) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = xv[i] > 0.f ? acc[i] : 0.f;
+        }
+        *reinterpret_cast<uint4 *>(p.dx + (size_t)pix * p.lddx + c8 * 8) = pack8_lim<T>(acc, __builtin_inff());
+    }
+}
+
 // global average pool backward: dx[n,p,c] = dfeat[n,c] / S
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float *dfeat, const uint16_t *mask, int ldmask, uint16_t *dx, int n, int spatial, int C8, int lddx) {
@@ -474,16 +507,25 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const uint16_t *dy,
             const float wl1 = w1r - w1, wl0 = 1.f - wl1;
             wwv[k] = uw <= min(ow_sz - 1, 2 * iw + 3) ? (w1 == iw ? wl0 : 0.f) + (w1 + w1p == iw ? wl1 : 0.f) : 0.f;
         }
+        // A candidate row with weight: its six column candidates are loaded TOGETHER (clamped to the frame; the ones without weight are not added) -- the first form
+        // tested each column's weight in front of its load, a chain of up to 16 dependent-in-order loads per thread (1.7 TB/s of its bytes).
+        int uwc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) uwc[k] = min(uw_lo + k, ow_sz - 1);
 #pragma unroll
         for (int kh_ = 0; kh_ < 6; ++kh_) {
             const float wh = whv[kh_];
             if (wh == 0.f) continue;
+            const uint16_t *rowp = dy + ((n * Ho + uh_lo + kh_ + py) * Wo + px) * (long)lddy + c8 * 8;
+            uint4 q[6];
+#pragma unroll
+            for (int kw_ = 0; kw_ < 6; ++kw_) q[kw_] = *reinterpret_cast<const uint4 *>(rowp + (long)uwc[kw_] * lddy);
 #pragma unroll
             for (int kw_ = 0; kw_ < 6; ++kw_) {
                 const float ww = wwv[kw_];
                 if (ww == 0.f) continue;
                 float g[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(dy + ((n * Ho + uh_lo + kh_ + py) * Wo + uw_lo + kw_ + px) * (long)lddy + c8 * 8), g);
+                unpack8<T>(q[kw_], g);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] += wh * ww * g[i];
             }
@@ -623,6 +665,11 @@ extern "C" int32_t tedspad_maxpool_bwd(const tedspad_pool_desc *d, const void *x
     p.relu_mask = relu_mask;
     p.total = (long)d->n * d->t * d->h * d->w * p.C8;
     hipStream_t s = (hipStream_t)stream;
+    if (p.total < (1L << 31) && d->kt == 1 && d->kh == 2 && d->kw == 2 && d->st == 1 && d->sh == 2 && d->sw == 2 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
+        d->h % 2 == 0 && d->w % 2 == 0 && d->to == d->t && d->ho == d->h / 2 && d->wo == d->w / 2) {
+        LAUNCH_T(d->dtype, maxpool_bwd_k2s2_kernel, dim3(grid_for(p.total)), p);
+        return check_launch("tedspad_maxpool_bwd");
+    }
     if (p.total < (1L << 31)) {
         if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL((maxpool_bwd_kernel<F16, unsigned>), dim3(grid_for(p.total)), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((maxpool_bwd_kernel<BF16, unsigned>), dim3(grid_for(p.total)), dim3(256), 0, s, p);
