@@ -630,7 +630,11 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
                "tedspad_bn_bwd_reduce: bad arguments (relu needs y, or z + gamma + beta to recompute the mask)");
     const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
     long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
-    if (pblocks > 2048 / cgroups) pblocks = 2048 / cgroups;
+    // Every workgroup ends in 2 x C float atomics on the same 2 x C addresses: past ~1000 workgroups per address the atomics, not the bytes, set the time, the sooner the
+    // more channels there are (scripts/bn_probe.py, 384 frames: 112^2 x 64 237 us at 2048 workgroups, 217 at 1024, 254 at 512; 14^2 x 512 63 / 46 / 36 us).
+    static const long wg_env = getenv("TEDSPAD_BNR_BLOCKS") ? atol(getenv("TEDSPAD_BNR_BLOCKS")) : 0;      // A/B knob
+    const long wg_cap = wg_env > 0 ? wg_env : (C <= 128 ? 1024 : 512);
+    if (pblocks > wg_cap / cgroups) pblocks = wg_cap / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;
     LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z,
