@@ -190,6 +190,88 @@ __global__ __launch_bounds__(256) void maxpool_k3s1_kernel(const uint16_t *x, ui
     }
 }
 
+// The same pool with every input element fetched ONCE: the column-walking kernel above loads each frame for the threads of three output frames and each row for two row
+// pairs -- 6 loads per output through L1 / L2 (2.7 TB/s of its bytes on the Inception module inputs). Here a workgroup owns a band of HB rows x W columns x CG
+// 8-channel groups of ONE clip and walks its frames: frame t + 1 is fetched into registers (coalesced: CG x 16 contiguous bytes per pixel) while frame t's spatial
+// 3 x 3 maxima are read from LDS (two frame buffers with a border of `padv`; one barrier per frame), and an output frame is the max of three consecutive spatial maxima
+// kept in registers. HBM sees (HB + 2) / HB reads and one write per element. Maxima are exact: bit-identical to the kernels above.
+constexpr int K3_NL = 10, K3_NO = 8;                     // per thread: input rows of a frame tile (HB + 2), output rows (HB)
+struct K3S1Geo {
+    int HB, CG, bands, cgroups;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_k3s1_lds_kernel(const uint16_t *x, uint16_t *y, int Tn, int H, int W, int C8, int ldx, int ldy, uint32_t padw,
+                                                               const K3S1Geo g) {
+    extern __shared__ __attribute__((aligned(16))) uint4 k3buf[];
+    const uint4 padv = make_uint4(padw, padw, padw, padw);
+    int b = blockIdx.x;
+    const int cgi = b % g.cgroups; b /= g.cgroups;
+    const int band = b % g.bands;
+    const int n = b / g.bands;
+    const int c80 = cgi * g.CG, ncg = min(g.CG, C8 - c80);
+    const int h0 = band * g.HB, nh = min(g.HB, H - h0);
+    const int RW = W + 2;                                  // cells per tile row (a border column each side)
+    const int cells = (g.HB + 2) * RW * g.CG;              // per frame buffer
+    for (int i = threadIdx.x; i < 2 * cells; i += 256) k3buf[i] = padv;       // borders (and the rows outside the frame) stay `padv` for good
+    // a thread owns one (column, channel group) and every rp-th row: its k-th piece is an affine function of k (no per-piece tables)
+    const int tpr = W * ncg, rp = 256 / tpr;               // threads per row, rows per pass (the launcher made W * CG <= 256)
+    const int lane_r = threadIdx.x / tpr, lc = threadIdx.x - lane_r * tpr;
+    const int c = lc / ncg, q = lc - c * ncg;
+    const bool live = lane_r < rp;
+    const int r_lo = h0 == 0 ? 1 : 0, r_hi = min(nh + 1, H - h0);             // tile rows r (frame row h0 - 1 + r) that lie inside the frame
+    const int src0 = ((h0 - 1 + lane_r) * W + c) * ldx + (c80 + q) * 8, srcs = rp * W * ldx;
+    const int cel0 = (lane_r * RW + c + 1) * g.CG + q, cels = rp * RW * g.CG;
+    const int dst0 = ((h0 + lane_r) * W + c) * ldy + (c80 + q) * 8, dsts = rp * W * ldy;
+    const size_t fsx = (size_t)H * W * ldx, fsy = (size_t)H * W * ldy;
+    const uint16_t *xn = x + (size_t)n * Tn * fsx;
+    uint16_t *yn = y + (size_t)n * Tn * fsy;
+    uint4 in[K3_NL];
+#pragma unroll
+    for (int k = 0; k < K3_NL; ++k) in[k] = padv;
+    bool rowin[K3_NL];
+#pragma unroll
+    for (int k = 0; k < K3_NL; ++k) { const int r = lane_r + k * rp; rowin[k] = live && r >= r_lo && r <= r_hi; }
+#define K3_FETCH(TT)                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < K3_NL; ++k)                                                                   \
+        if (rowin[k]) in[k] = *reinterpret_cast<const uint4 *>(xn + (size_t)(TT) * fsx + src0 + k * srcs)
+#define K3_PUT(FF)                                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < K3_NL; ++k)                                                                   \
+        if (rowin[k]) (FF)[cel0 + k * cels] = in[k]
+    K3_FETCH(0);
+    __syncthreads();                                       // the fill is done
+    K3_PUT(k3buf);
+    __syncthreads();
+    uint4 s1[K3_NO], s2[K3_NO];                            // spatial maxima of frames t - 1 and t - 2
+#pragma unroll
+    for (int k = 0; k < K3_NO; ++k) { s1[k] = padv; s2[k] = padv; }
+    const int dR = RW * g.CG, dC = g.CG;
+    for (int t = 0; t <= Tn; ++t) {
+        if (t + 1 < Tn) { K3_FETCH(t + 1); }
+        const uint4 *F = k3buf + (t & 1) * cells + cel0 + dR;          // the centre cell of output row lane_r
+#pragma unroll
+        for (int k = 0; k < K3_NO; ++k) {
+            const int r = lane_r + k * rp;
+            if (live && r < nh) {
+                uint4 s0 = padv;                           // frame Tn: padding
+                if (t < Tn) {
+                    const uint4 *cp = F + k * cels;
+                    const uint4 r0 = max8<T>(max8<T>(cp[-dR - dC], cp[-dR]), cp[-dR + dC]);
+                    const uint4 r1 = max8<T>(max8<T>(cp[-dC], cp[0]), cp[dC]);
+                    const uint4 r2 = max8<T>(max8<T>(cp[dR - dC], cp[dR]), cp[dR + dC]);
+                    s0 = max8<T>(max8<T>(r0, r1), r2);
+                }
+                if (t >= 1) *reinterpret_cast<uint4 *>(yn + (size_t)(t - 1) * fsy + dst0 + k * dsts) = max8<T>(max8<T>(s2[k], s1[k]), s0);
+                s2[k] = s1[k]; s1[k] = s0;
+            }
+        }
+        if (t + 1 < Tn) { uint4 *Fn = k3buf + ((t + 1) & 1) * cells; K3_PUT(Fn); }       // that buffer was last read in iteration t - 1: everybody passed the barrier that ended it
+        __syncthreads();
+    }
+#undef K3_FETCH
+#undef K3_PUT
+}
+
 // mean over `spatial` pixels, fp32 accumulate + output. A workgroup owns 64 8-channel chunks of one sample; its four waves take every fourth
 // pixel (four independent load streams per chunk: the one-thread-per-chunk form was latency-bound, 47 us for 90 MB at the bench size) and
 // are summed through LDS.
@@ -464,6 +546,37 @@ extern "C" int32_t tedspad_maxpool_fwd_idx(const tedspad_pool_desc *d, const voi
     hipStream_t s = (hipStream_t)stream;
     if (!idx && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 && d->ph == 1 && d->pw == 1 &&
         d->to == d->t && d->ho == d->h && d->wo == d->w) {
+        {   // every element fetched once (maxpool_k3s1_lds_kernel) where a frame band fits its per-thread budgets; TEDSPAD_POOL_NO_LDS=1: the column walk (A/B knob)
+            static const bool lds_ok = getenv("TEDSPAD_POOL_NO_LDS") == nullptr;
+            K3S1Geo g;
+            g.CG = p.C8 < 8 ? p.C8 : 8;                    // 128 contiguous bytes per pixel (4 and 16 measured: -0.5 % each on InceptionI3d)
+            while (g.CG * 2 <= p.C8 && d->w * g.CG * 2 <= 128 && (long)d->h * d->w * g.CG * 2 <= 2048) g.CG *= 2;       // small frames: more channel groups per workgroup
+            const int rp = d->w * g.CG <= 256 ? 256 / (d->w * g.CG) : 0;      // tile rows per pass of the 256 threads
+            int hb = d->h;
+            while (rp && hb > 1 && ((hb + rp - 1) / rp > K3_NO || (hb + 2 + rp - 1) / rp > K3_NL)) --hb;
+            g.HB = hb; g.bands = (d->h + hb - 1) / hb; g.cgroups = (p.C8 + g.CG - 1) / g.CG;
+            const long lds = 2L * (hb + 2) * (d->w + 2) * g.CG * 16;
+            const long wgs = (long)d->n * g.bands * g.cgroups;
+            const bool fits = rp >= 1 && (hb + rp - 1) / rp <= K3_NO && (hb + 2 + rp - 1) / rp <= K3_NL && lds <= 150 * 1024 && wgs < (1L << 30) &&
+                              (long)d->h * d->w * (d->ldx > d->ldy ? d->ldx : d->ldy) < (1L << 31) && (hb >= 4 || hb == d->h);
+            if (lds_ok && fits) {
+                const uint32_t ninf2 = d->dtype == TEDSPAD_F16 ? 0xFC00FC00u : 0xFF80FF80u;
+                const uint32_t padw2 = d->pad_zero ? 0u : ninf2;
+                static thread_local int attr_k3[2] = {0, 0};
+                const int ti = d->dtype == TEDSPAD_F16 ? 0 : 1;
+                if (!attr_k3[ti]) {
+                    const void *fn = ti == 0 ? (const void *)maxpool_k3s1_lds_kernel<F16> : (const void *)maxpool_k3s1_lds_kernel<BF16>;
+                    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                        set_error("tedspad_maxpool_fwd: cannot raise the dynamic LDS limit");
+                        return TEDSPAD_ELAUNCH;
+                    }
+                    attr_k3[ti] = 1;
+                }
+                if (ti == 0) hipLaunchKernelGGL(maxpool_k3s1_lds_kernel<F16>, dim3((unsigned)wgs), dim3(256), (size_t)lds, s, p.x, p.y, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw2, g);
+                else hipLaunchKernelGGL(maxpool_k3s1_lds_kernel<BF16>, dim3((unsigned)wgs), dim3(256), (size_t)lds, s, p.x, p.y, d->t, d->h, d->w, p.C8, p.ldx, p.ldy, padw2, g);
+                return check_launch("tedspad_maxpool_fwd");
+            }
+        }
         long rows = (long)d->n * d->t * ((d->h + 1) / 2) * p.C8;
         int segs = 1;                                             // enough threads for ~8 waves per SIMD on 256 CUs
         while (rows * segs < 256L * 2048 && (d->w + segs - 1) / segs > 4) ++segs;
