@@ -326,6 +326,9 @@ POOLS = [
     ("inc_3x3x3_s1_odd_hw", (2, 2, 7, 7), 832, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),
     ("k3s1_skip_padding", (2, 3, 5, 6), 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), False),
     ("k3s1_degenerate", (1, 1, 1, 1), 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),
+    ("k3s1_banded_28", (2, 3, 28, 28), 200, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),        # LDS frame tiles: four row bands with halo rows, a ragged last channel group (25 = 3 x 8 + 1)
+    ("k3s1_banded_odd", (1, 5, 19, 23), 72, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), False),      # ... odd frame, a short last band, -inf padding
+    ("k3s1_wide_column_walk", (1, 2, 5, 40), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True),  # W x 8 groups > 256 threads: the column-walking kernel
     ("inc_3x3x3_s2_same", (1, 8, 28, 28), 32, (3, 3, 3), (2, 2, 2), (0, 0, 0), (1, 1, 1), True),
     ("inc_2x2x2_s2_odd", (1, 4, 7, 7), 64, (2, 2, 2), (2, 2, 2), (0, 0, 0), (0, 1, 1), True),
     ("unet_2x2", (3, 1, 14, 14), 128, (1, 2, 2), (1, 2, 2), (0, 0, 0), (0, 0, 0), False),
