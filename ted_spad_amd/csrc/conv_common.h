@@ -66,4 +66,9 @@ struct PatchSrc {
 int32_t launch_conv_patch(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, int mode = 0, const PatchSrc *src = nullptr);
 int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr, int flat = 0);   // tile_cfg 38 / 39: two patches (two flat tiles) per workgroup   // mode 1: tile_cfg 33 (256 consecutive pixels), 2: tile_cfg 34 (temporal)
 
+// conv_patch3.hip: PERSISTENT two-patch kernel (tile_cfg 40): 8 waves, one workgroup per CU, halo double-buffered, weight ring of six stages (resident for cin <= 64),
+// epilogue straight from the accumulators; 1 x 3 x 3 'same' convs with 32 < cout <= 64
+int32_t launch_conv_patch3(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src = nullptr);
+void patch3_set_det(int on);
+
 }  // namespace tedspad

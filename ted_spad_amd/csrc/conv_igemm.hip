@@ -735,7 +735,10 @@ inline long ntiles(const ConvKP &p, int bm, int bn) { return (long)((p.M + bm - 
 //  38  TWO 16 x 16 patches per workgroup sharing every weight stage (conv_patch.hip, conv_patch2_kernel): 1 x 3 x 3 'same' convs, cin % 64 == 0, K in half chunks
 //      of 32 channels, a kernel row of weights per stage: a third fewer bytes through the LDS fill path than tile 32
 //  39  retired (the same on two flat tiles of 256 consecutive pixels: never picked)
-constexpr int NUM_CFGS = 39;
+//  40  PERSISTENT two-patch kernel (conv_patch3.hip, round 6): tile 38's tile on 8 waves, one workgroup per CU walking a run of tiles; halo double-buffered (the next
+//      half chunk's / next tile's halo issued a half chunk ahead), weight ring of six stages filled five ahead -- resident when cin <= 64 --, epilogue straight from the
+//      accumulators (v_permlane16_swap -> 16-byte pieces), batch statistics summed in registers over the whole run; 32 < cout <= 64; sums bit-identical to tile 38's
+constexpr int NUM_CFGS = 40;
 
 // 64-wide sibling of a 128-wide generic tile (same M tile and ring where there is one), 0: none
 inline int narrow_sibling(int cfg) {
@@ -812,6 +815,7 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, cons
         case 33: return launch_conv_patch(T::kDtype, p, N, cin, s, 1, src);
         case 34: return launch_conv_patch(T::kDtype, p, N, cin, s, 2);
         case 38: return launch_conv_patch2(T::kDtype, p, N, cin, s, src);
+        case 40: return launch_conv_patch3(T::kDtype, p, N, cin, s, src);
         case 26: return launch_conv_p8(T::kDtype, p, s, 16);
     }
     set_error("tedspad_conv_fwd: tile_cfg %d out of range 0..%d", cfg, NUM_CFGS);
@@ -973,8 +977,8 @@ static int32_t conv_fwd_impl(const tedspad_conv_desc *d, const void *x, const vo
     PatchSrc gsrc{};
     if (gathered) {       // the input is a gathered concatenation: patch / flat halo tiles only
         if (d->tile_cfg <= 0) cfg = (d->kh - 1) * d->w + d->kw - 1 + 256 <= 384 - 1 ? 33 : 32;
-        if (cfg != 32 && cfg != 33 && cfg != 38 && cfg != 39) {
-            set_error("tedspad_conv_fwd_ex: gathered sources (nchunk_src) run on tile_cfg 32 / 33 / 38 / 39 only");
+        if (cfg != 32 && cfg != 33 && cfg != 38 && cfg != 39 && cfg != 40) {
+            set_error("tedspad_conv_fwd_ex: gathered sources (nchunk_src) run on tile_cfg 32 / 33 / 38 / 40 only");
             return TEDSPAD_EUNSUPPORTED;
         }
         TS_REQUIRE(!dual && !pool_t && !p.fold_hw && d->kt == 1 && d->cin % 64 == 0 && ex->nchunk_src == d->cin / 64 && ex->nchunk_src <= 8,

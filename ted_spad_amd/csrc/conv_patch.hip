@@ -789,5 +789,8 @@ int32_t launch_conv_patch2(int dtype, const ConvKP &p, int N, int cin, hipStream
 
 }  // namespace tedspad
 namespace tedspad {
-int32_t det_ctl_patch(int op, int on) { return det_ctl(op, on); }
+int32_t det_ctl_patch(int op, int on) {
+    if (op == 0) patch3_set_det(on);      // the persistent tile (40) declines batch statistics in deterministic mode: its flush is not gated
+    return det_ctl(op, on);
+}
 }  // namespace tedspad

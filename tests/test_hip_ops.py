@@ -451,7 +451,7 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
                 continue                                   # configuration not applicable to this geometry
     finally:
         E.FORCE_TILE_CFG = None
-    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33, 34, 35, 36, 37, 38, 39)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
+    REASSOC = (15, 16, 22, 23, 24, 26, 28, 32, 33, 34, 35, 36, 37, 38, 39, 40)  # halo-direct (K walked chunk-major), split-K tiles, 16x16x32 MFMA: fp32 sums re-associated
     generic = {c: o for c, o in outs.items() if c not in REASSOC}
     assert len(generic) >= 4, sorted(outs)
     first = next(iter(generic.values()))
@@ -461,6 +461,8 @@ def test_every_tile_configuration_gives_the_same_result(case, dtype):
     for c in REASSOC:
         if c in outs:
             assert bool(((outs[c] - first).abs() <= ulp * first.abs() + 1e-4).all()), c
+    if 40 in outs:       # the persistent two-patch tile walks K exactly as the two-patch tile does: same bits
+        assert 38 in outs and torch.equal(outs[40], outs[38])
     print(name, "configurations run:", sorted(outs))
 
 
@@ -510,8 +512,10 @@ def test_patch_halo_training_epilogues(cin, cout):
     mask = E.Act(synth_tensor(31, "pe_m", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
     got = {}
     try:
-        for cfg in (32, 33, 38, 5):
+        for cfg in (32, 33, 38, 40, 5):
             E.FORCE_TILE_CFG = cfg
+            if cfg == 40 and not 32 < cout <= 64:
+                continue
             st1 = torch.zeros((2, pc.cpad), device="cuda"); st2 = torch.zeros((2, pc.cpad), device="cuda")
             a = pc(x, pads=(0, 1, 1), residual=res, mask=mask, relu=False).buf.float().cpu()
             bq = pc(x, pads=(0, 1, 1), relu=True, stats=st1).buf.float().cpu()
@@ -520,7 +524,10 @@ def test_patch_halo_training_epilogues(cin, cout):
     finally:
         E.FORCE_TILE_CFG = None
     ulp = 2.0 ** -10
-    for c in (32, 33, 38):
+    if 40 in got:               # the persistent tile: tile 38's sums bit for bit (16-bit and fp32 outputs); statistics: float atomics in another order
+        for i in range(3):
+            assert torch.equal(got[40][i], got[38][i]), i
+    for c in (32, 33, 38) + ((40,) if 40 in got else ()):
         for i in range(3):      # cin = 64 walks K like the generic tile (bit-identical), cin = 128 chunk-major (one rounding step; fp32 output: 1e-5); 38 walks half chunks
             g, r = got[c][i], got[5][i]
             assert g.shape == r.shape
@@ -530,6 +537,48 @@ def test_patch_halo_training_epilogues(cin, cout):
                 assert bool(((g - r).abs() <= (ulp if i < 2 else 2e-5) * r.abs() + 1e-4).all()), (c, i)
         for i in (3, 4):        # batch statistics: float atomics in a different order
             assert rel_l2(got[c][i], got[5][i]) < 1e-5, (c, i)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dims,cin,cout,nwg", [((2, 1, 20, 37), 64, 64, 1), ((2, 1, 20, 37), 64, 64, 4), ((3, 1, 33, 16), 128, 64, 2), ((1, 2, 18, 20), 96, 40, 3),
+                                              ((5, 1, 48, 48), 192, 64, 7), ((1, 1, 16, 16), 32, 48, 0), ((3, 1, 112, 112), 64, 64, 0), ((2, 1, 50, 70), 320, 64, 5)])
+def test_persistent_two_patch_tile_equals_the_two_patch_tile(dims, cin, cout, nwg, dtype, monkeypatch):
+    """tile_cfg 40 (conv_patch3.hip: persistent 8-wave workgroups, double-buffered halo, weight ring -- resident for cin <= 64, streamed otherwise --,
+    epilogue from the accumulators) against tile 38, whose K order it keeps: BIT-EQUAL 16-bit outputs with residual + ReLU, with the ReLU-backward mask, and
+    fp32 outputs; batch statistics (summed in registers over a workgroup's whole run of tiles) to fp32 rounding; and against the oracle's conv. `nwg` forces a
+    small persistent grid (TEDSPAD_P3_NWG) so that a workgroup walks several tiles: odd patch counts, ragged patches, the weight ring wrapping across tiles."""
+    from oracle.conv_ref import conv_cl
+    from ted_spad_amd import engine as E
+    tdt = E.DTYPES[dtype][0]
+    n, t, h, w = dims
+    name = "p3_%d_%d_%d" % (cin, cout, h)
+    if nwg:
+        monkeypatch.setenv("TEDSPAD_P3_NWG", str(nwg))
+    x = synth_tensor(41, name + "x", (n, t, h, w, cin), -1, 1).to(tdt)
+    wgt = (synth_tensor(41, name + "w", (cout, cin, 1, 3, 3), -1, 1) * (2.0 / (9 * cin)) ** 0.5).to(tdt).float()
+    scale, shift = synth_tensor(41, name + "s", (cout,), 0.5, 1.5), synth_tensor(41, name + "b", (cout,), -0.3, 0.3)
+    pc = E.PackedConv(wgt, scale, shift, dtype=dtype, device="cuda")
+    xa = E.Act(x.cuda(), cin)
+    res = E.Act(synth_tensor(41, name + "r", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
+    mask = E.Act(synth_tensor(41, name + "m", (n, t, h, w, pc.cout), -1, 1).to(tdt).cuda(), pc.cout)
+    got = {}
+    try:
+        for cfg in (38, 40):
+            E.FORCE_TILE_CFG = cfg
+            st1 = torch.zeros((2, pc.cpad), device="cuda"); st2 = torch.zeros((2, pc.cpad), device="cuda")
+            a = pc(xa, pads=(0, 1, 1), residual=res, relu=True).buf.float().cpu()
+            b = pc(xa, pads=(0, 1, 1), residual=res, mask=mask, relu=False).buf.float().cpu()
+            c = pc(xa, pads=(0, 1, 1), relu=True, stats=st1).buf.float().cpu()
+            d = pc(xa, pads=(0, 1, 1), relu=False, stats=st2, y32=True).cpu()
+            got[cfg] = (a, b, c, d, st1.cpu(), st2.cpu())
+    finally:
+        E.FORCE_TILE_CFG = None
+    for i in range(4):
+        assert torch.equal(got[40][i], got[38][i]), i
+    for i in (4, 5):
+        assert rel_l2(got[40][i], got[38][i]) < 1e-5, i
+    ref = conv_cl(x.float(), wgt, scale, shift, (1, 1, 1), (0, 1, 1), (0, 1, 1), res.buf.float().cpu()[..., :cout], relu=True)
+    assert rel_l2(got[40][0][..., :cout], ref) < (2e-3 if dtype == "f16" else 1.2e-2)
 
 
 def test_flat_halo_kernels_on_awkward_geometries():
@@ -605,7 +654,7 @@ def test_conv_on_a_gathered_concatenation_equals_the_materialised_one(dims, chan
     cat = torch.cat(parts, dim=-1).contiguous()
     ref = conv_cl(cat.float().cpu(), wgt, scale, shift, (1, 1, 1), pf, pb, None, True)
     ran = 0
-    for cfg in (32, 33, 38):
+    for cfg in (32, 33, 38, 40):
         E.FORCE_TILE_CFG = cfg
         try:
             want = pc(E.Act(cat, cin), pads=pf, pads_back=pb).buf
