@@ -32,17 +32,26 @@ namespace tedspad {
 namespace {
 
 __device__ uint4 g_zero16p3;
+#ifdef TEDSPAD_P3_STAMPS
+__device__ unsigned long long *g_dbg_p3;   // stamp build (scripts/p3_cycles.py): [wave][64] s_memtime stamps of workgroup 0's third tile
+#define P3_STAMP(k) do { if (stamp_on && lane == 0) g_dbg_p3[wave * 64 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define P3_STAMP(k) do { } while (0)
+#endif
 __device__ uint4 g_sink_p3[64];          // where the masked-off lanes of the epilogue stores go (never read): every piece issues the same number of stores
 
 constexpr int P3_S = 16;                                                            // patch side
 constexpr int P3_WH = 18, P3_NP = P3_WH * P3_WH, P3_PSLOTS = P3_NP * 4;             // 1296 16-byte slots per patch and half chunk
-constexpr int P3_HALO = (2 * P3_PSLOTS + 63) / 64 * 64 * 16;                        // 41 984: both patches' halos of a half chunk (41 wave instructions; the last one's upper half is padding)
-constexpr int P3_WST = 3 * 64 * 64;                                                 // a weight stage [3 dw][64 co][32 k]: 12 288 bytes; a tap unit is a third of it
+constexpr int P3_HG = 21 * 1024;                                                    // a group's halo of a half chunk: 21 wave instructions (the last one: 16 lanes of data)
+constexpr int P3_HALO = 2 * P3_HG;                                                  // 43 008: both patches
+constexpr int P3_WST = 3 * 64 * 64;                                                 // a weight stage [3 dw][64 co][32 k]: 12 288 bytes
 constexpr int P3_WTAP = 64 * 64;
-constexpr int P3_LDS_RES = 2 * P3_HALO + 6 * P3_WST + 512;                          // 158 208: two halo buffers, six resident stages, scale / shift
-constexpr int P3_LDS_STR = 3 * P3_HALO + 9 * P3_WTAP + 512;                         // 163 328: three halo buffers, nine tap units, scale / shift
+constexpr int P3_NWS = 6;                                                           // weight stages in LDS: all of them when cin <= 64, otherwise a ring filled five stages ahead
+constexpr int P3_WBASE = 2 * P3_HALO;
+constexpr int P3_SCB = P3_WBASE + P3_NWS * P3_WST;                                  // scale[64] | shift[64]
+constexpr int P3_LDS = P3_SCB + 512;                                                // 160 256
 constexpr int P3_NT = 512;
-static_assert(P3_LDS_RES <= 160 * 1024 && P3_LDS_STR <= 160 * 1024, "one workgroup per CU");
+static_assert(P3_LDS <= 160 * 1024, "one workgroup per CU");
 
 struct Patch3Geo {
     int tiles_h, tiles_w, npatch, ntiles, nhc, dbg;
@@ -104,56 +113,66 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     if (t_begin >= t_end) return;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16p3);
-    const int nhc = g.nhc;
-    // RES: at most six weight stages (nhc <= 2): fetched once, resident
-    constexpr int NB = RES ? 2 : 3;                        // halo buffers
-    constexpr int WBASE = NB * P3_HALO;
-    constexpr int SCB = RES ? WBASE + 6 * P3_WST : WBASE + 9 * P3_WTAP;     // scale[64] | shift[64]
+    const int nhc = g.nhc;                                 // RES: nhc <= 2 (at most six weight stages: fetched once, resident)
+    const int S = nhc * 3;                                 // stages (= phases) per tile
     const int ntl = t_end - t_begin;
-    const int HS_total = ntl * nhc;                        // half chunks of this workgroup
-    const int NP_total = HS_total * 9;                     // phases (= weight tap units) of this workgroup
+    const int total = ntl * S;                             // phases of this workgroup
     const int grp = wave >> 2, wr = wave & 3;
     const int l15 = lane & 15, kg = lane >> 4;
     const int nst = (p.y ? 1 : 0) + (p.y32 ? 2 : 0);       // stores per epilogue piece
-    const int dbg = g.dbg;                                 // timing ablations (wrong results; TEDSPAD_P3_ABLATE): 4 no epilogue pieces in the loop, 8 no halo DMA in the loop, 16 no weight DMA in the loop (folded into the existence flags: no cost when off)
+    const int dbg = g.dbg;                                 // timing ablations (wrong results; TEDSPAD_P3_ABLATE): 4 no epilogue in the loop, 8 no halo DMA in the loop, 16 no weight DMA in the loop
 
-    // ---- halo pieces: slot s of a half chunk -> patch s / 1296, position (s % 1296) >> 2, LDS piece s & 3. The geometry of a slot is recomputed per piece (~25
-    // vector instructions in a load segment) instead of living in registers: the two accumulator sets need them ------------------------------------------------
-    P3Tile ht = p3_decode(t_begin, g);                     // the tile whose halos are being issued
-    auto halo_piece = [&](int s0, int hcx, int buf) __attribute__((always_inline))  {      // one wave instruction: slots s0 .. s0 + 63; s0 is wave-uniform
-        int lz = lane;
-        asm volatile("" : "+v"(lz));                       // the slot geometry is NOT loop-invariant for the register allocator: ~25 instructions per piece instead of registers
-        const int s = s0 + lz;
-        const int q = s >= P3_PSLOTS ? 1 : 0, r = s - q * P3_PSLOTS;
-        const int pos = r >> 2, hr = (pos * 3641) >> 16, hcl = pos - hr * P3_WH;         // pos / 18 for pos < 1296
-        const int c8 = ((r & 3) ^ ((pos >> 1) & 3)) << 3;
-        const int ih = (q ? ht.ph0[1] : ht.ph0[0]) - 1 + hr, iw = (q ? ht.pw0[1] : ht.pw0[0]) - 1 + hcl;
-        const int pf = q ? ht.pf[1] : ht.pf[0];
-        const bool ok = s < 2 * P3_PSLOTS && (q ? ht.pon[1] : ht.pon[0]) && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+    // ---- halo: a group fetches ITS OWN patch's halo (what a group reads it has waited for itself: one phase between wait and read is enough). Slot s of a patch and half chunk
+    // -> position s >> 2 (halo row, column), LDS piece s & 3; piece i of a thread = slot i * 256 + (tid & 255): i = 0..4, and i = 5 for the group's first wave (16 lanes of data) ----
+    const int lt = tid & 255;
+    int hgeo[6];                                           // (c8 << 16) | (halo row << 8) | halo column, or -1: no such slot
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int sl = i * 256 + lt;
+        const int pos = sl >> 2, hr = pos / P3_WH, hcl = pos - hr * P3_WH;
+        hgeo[i] = (sl < P3_PSLOTS && (i < 5 || wr == 0)) ? ((((sl & 3) ^ ((pos >> 1) & 3)) << 3) << 16) | (hr << 8) | hcl : -1;
+    }
+    int hpos[6], hposU[SRC ? 6 : 1];                       // pixel index of the slot in the frame (in a half-resolution source), -1: zero
+    auto halo_tile = [&](int tile) {                       // the slots' sources for this group's patch of `tile`
+        int pi = 2 * tile + grp;
+        const bool pon = pi < g.npatch;
+        if (!pon) pi = 2 * tile;
+        const int tw = pi % g.tiles_w, t2 = pi / g.tiles_w;
+        const int pw0 = tw * P3_S, ph0 = (t2 % g.tiles_h) * P3_S, pf = t2 / g.tiles_h;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int ih = ph0 - 1 + ((hgeo[i] >> 8) & 0xff), iw = pw0 - 1 + (hgeo[i] & 0xff);
+            const bool ok = hgeo[i] >= 0 && pon && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            hpos[i] = ok ? (pf * p.Hi + ih) * p.Wi + iw : -1;
+            if (SRC) hposU[i] = ok ? (pf * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1) : -1;
+        }
+    };
+    auto halo_piece = [&](int i, int hcx, int buf) {
         const uint16_t *sp = p.x + hcx * 32;
         long sl = p.ldx;
-        int pix = (pf * p.Hi + ih) * p.Wi + iw;
+        int pix = hpos[i];
         if (SRC) {
             const int ck = hcx >> 1;
             sp = gs.ptr[ck] + (hcx & 1) * 32; sl = gs.ld[ck];
-            if ((gs.up >> ck) & 1) pix = (pf * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1);
+            if ((gs.up >> ck) & 1) pix = hposU[i];
         }
-        lds_dma16(ok ? sp + pix * sl + c8 : zero, lds0 + buf * P3_HALO + s0 * 16);
+        lds_dma16(hpos[i] >= 0 ? sp + pix * sl + (hgeo[i] >> 16) : zero, lds0 + buf * P3_HALO + grp * P3_HG + (i * 256 + wr * 64) * 16);
     };
-    // all eight waves: piece i = slots i * 512 + tid (i = 0..4; i = 5: wave 0 alone); waves 4-7 alone: piece i = slots i * 256 + (tid - 256) (i = 0..9; i = 10: wave 4 alone)
-    auto halo_piece8 = [&](int i, int hcx, int buf) __attribute__((always_inline))  { halo_piece(i * 512 + wave * 64, hcx, buf); };
-    auto halo_piece4 = [&](int i, int hcx, int buf) __attribute__((always_inline))  { halo_piece(i * 256 + (wave - 4) * 64, hcx, buf); };
 
-    // ---- weights: a tap unit [64 co][32 k], piece c of row co at c ^ ((co >> 1) & 3); a stage = the three taps dw of a kernel row -------------------------------
-    const int wco = (wave & 3) * 16 + (lane >> 2);                                   // tap units are moved by four waves, 16 rows each
+    // ---- weights: a stage [3 dw][64 co][32 k], piece c of row co at c ^ ((co >> 1) & 3); moved by the four waves of ONE group, a tap each instruction ---------------------
+    const int wco = wr * 16 + (lane >> 2);
     const int wof4 = wco * p.Kpad + (((lane & 3) ^ ((wco >> 1) & 3)) << 3);
-    auto issue_unit = [&](int hcx, int tap, int upos) __attribute__((always_inline))  {        // waves 0-3 (streamed weights): tap (dh * 3 + dw) of half chunk hcx -> ring position upos
-        lds_dma16(p.w + tap * p.cin + hcx * 32 + wof4, lds0 + WBASE + upos * P3_WTAP + (wave & 3) * 1024);
+    auto issue_stage = [&](int st, int slot) {             // stage st of a tile (every tile streams the same weights) -> ring slot
+        const int hcx = st / 3, dh = st - hcx * 3;
+        const uint16_t *src = p.w + dh * 3 * p.cin + hcx * 32 + wof4;
+        const unsigned dst = lds0 + P3_WBASE + slot * P3_WST + wr * 1024;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) lds_dma16(src + dw * p.cin, dst + dw * P3_WTAP);
     };
 
     // ---- MFMA roles --------------------------------------------------------------------------------------------------------------------------------------------
-    const unsigned wrd = (unsigned)(l15 * 64 + ((kg ^ ((l15 >> 1) & 3)) << 4));       // this lane's piece of weight row (16 a + l15) of a tap unit
-    const unsigned hq = (unsigned)(grp * (P3_PSLOTS * 16));
+    const unsigned wrd = (unsigned)(l15 * 64 + ((kg ^ ((l15 >> 1) & 3)) << 4));       // this lane's piece of weight row (16 a + l15) of a tap
+    const unsigned hq = (unsigned)(grp * P3_HG);
     float s1[STATS ? 4 : 1][4], s2[STATS ? 4 : 1][4];       // batch statistics of this lane's channels (16 a + 4 kg + j) over every tile of the workgroup
     if constexpr (STATS) {
 #pragma unroll
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     auto ep_piece = [&](f32x4 (&acc)[4][4], const int k) {
         const int r = k >> 1, pp = k & 1;
         int lz = lane;
-        asm volatile("" : "+v"(lz));                       // a piece's addresses are invariant over the tile's half chunks: computed here, not hoisted to the tile's top and kept (spilled) in registers
+        asm volatile("" : "+v"(lz));                       // keeps a piece's addresses out of the loops' preheaders (they would live -- spilled -- across the whole tile)
         const int l15 = lz & 15, kg = lz >> 4;
         const int ho = ep_ho0 + r, wo = ep_wo0 + l15;
         const bool valid = ep_pon && ho < p.Ho && wo < p.Wo;
@@ -219,8 +238,8 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int a = 2 * pp + h;
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(dsm + SCB + (a * 16 + kg * 4) * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4 *>(dsm + SCB + 256 + (a * 16 + kg * 4) * 4);
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + (a * 16 + kg * 4) * 4);
+                const f32x4 sf = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + 256 + (a * 16 + kg * 4) * 4);
                 float w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = acc[r][a][j] * sc[j] + sf[j];
@@ -244,8 +263,8 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int a = 2 * pp + h;
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(dsm + SCB + (a * 16 + kg * 4) * 4);
-            const f32x4 sf = *reinterpret_cast<const f32x4 *>(dsm + SCB + 256 + (a * 16 + kg * 4) * 4);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + (a * 16 + kg * 4) * 4);
+            const f32x4 sf = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + 256 + (a * 16 + kg * 4) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[h][j] = acc[r][a][j] * sc[j] + sf[j];
             if constexpr (STATS) {
@@ -300,27 +319,19 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
         }
     };
 
-    // ---- prologue: scale / shift, the first halo(s), the weights -----------------------------------------------------------------------------------------------
+    // ---- prologue: scale / shift, the first halo, the weights ------------------------------------------------------------------------------------------------------
     if (tid < 64) {
-        *reinterpret_cast<float *>(dsm + SCB + tid * 4) = p.scale[tid];
-        *reinterpret_cast<float *>(dsm + SCB + 256 + tid * 4) = p.shift[tid];
+        *reinterpret_cast<float *>(dsm + P3_SCB + tid * 4) = p.scale[tid];
+        *reinterpret_cast<float *>(dsm + P3_SCB + 256 + tid * 4) = p.shift[tid];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    halo_tile(t_begin);
     for (int i = 0; i < 6; ++i)
-        if (i < 5 || wave == 0) halo_piece8(i, 0, 0);
-    if (NB == 3 && HS_total > 1) {                          // nhc >= 3 here: half chunk 1 of the first tile
-        for (int i = 0; i < 6; ++i)
-            if (i < 5 || wave == 0) halo_piece8(i, 1, 1);
-    }
-    if (RES) {
-        for (int st = 0; st < nhc * 3; ++st)
-            for (int dw = 0; dw < 3; ++dw)
-                if (((st * 3 + dw) & 1) == grp) {           // every group moves every other tap unit
-                    const int hcx = st / 3, dh = st - hcx * 3;
-                    lds_dma16(p.w + (dh * 3 + dw) * p.cin + hcx * 32 + wof4, lds0 + WBASE + st * P3_WST + dw * P3_WTAP + (wave & 3) * 1024);
-                }
-    } else if (wave < 4) {
-        for (int u = 0; u < 8; ++u) issue_unit(u / 9, u % 9, u);      // units 0..7 (nhc >= 3: NP_total >= 27)
+        if (i < 5 || wr == 0) halo_piece(i, 0, 0);
+    {
+        const int npre = RES ? S : (total < 5 ? total : 5);      // streamed: stage n + 5 is issued in phase n
+        for (int k = 0; k < npre; ++k)
+            if ((k & 1) == grp) issue_stage(k % S, k);
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -328,137 +339,120 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- cursors (wave-uniform) --------------------------------------------------------------------------------------------------------------------------------
-    int n = 0;                                             // phase of this workgroup (= weight tap unit read in it)
+    int n = 0;                                             // phase (= weight stage) of this workgroup
     int hb = 0;                                            // halo buffer of the half chunk being multiplied
-    int hi_hs = NB - 1, hi_tile = t_begin, hi_hc = NB - 1, hi_buf = NB - 1;      // the half chunk whose halo is being issued: NB - 1 ahead
-    while (hi_hc >= nhc) { hi_hc -= nhc; ++hi_tile; }
-    int wu_hc = 0, wu_tap = 8, wu_pos = 8;                 // streamed weights: the unit issued in the current phase is n + 8
-    int rd_pos = 0;                                        // ring position of the unit read in the current phase
-
-    uint4 fw[4], fa[4];
-    const bool no_h = (dbg & 8) != 0;
-    const int NPI = (dbg & 16) ? 0 : NP_total;             // weight units that get issued in the loop
-    // hc_pieces: the epilogue pieces of this half chunk's phases (the tile before is being drained): RES with two half chunks: 0..3 in phases 5..8 of the first, 4..7 in phases
-    // 5..8 of the second (the phases that issue no halo DMA); otherwise 0..7 in phases 1..8 of the first half chunk.
-    auto half_chunk = [&](f32x4 (&accC)[4][4], f32x4 (&accD)[4][4], const int hc, const bool draining) {
-        const bool h_exists = hi_hs < HS_total && !no_h;   // is there a half chunk NB - 1 ahead whose halo this half chunk's phases issue?
-        if (h_exists && hi_hc == 0 && hi_tile != t_begin) ht = p3_decode(hi_tile, g);      // its tile's patches (scalar arithmetic; no piece is issued before it)
-        const bool split = RES && nhc == 2;
-        const bool pieces_here = draining && (split || hc == 0);
-        // ---- this half chunk's fragment addresses: Vw[dwi][e] + immediate. Position (4 wr + r + dh) * 18 + dw + l15 of the halo has its k-group kg at piece kg ^ t with
-        // t = ((position >> 1) & 3) = (dh + r + ((dw + l15) >> 1)) & 3: dw = 0 / 2 share u0 = (l15 >> 1) & 3 (dw = 2: one more), dw = 1 has u1 = ((l15 + 1) >> 1) & 3 ----
-        unsigned Vw[2][4];
-        {
-            int lz = lane;
-            asm volatile("" : "+v"(lz));
-            const unsigned l15z = lz & 15, kgz = lz >> 4;
-            const unsigned B00 = (unsigned)(hb * P3_HALO) + hq + (72u * wr + l15z) * 64u + kgz * 16u;
-            const unsigned u0 = (l15z >> 1) & 3u, u1 = ((l15z + 1u) >> 1) & 3u;
+    int wslot = 0, wislot = 5;                             // ring slot of the stage read in this phase / issued in this phase (n + 5)
+    f32x4 acc[4][4];
+    uint4 fw[3][4], fa[3][4];
+    const bool no_h = (dbg & 8) != 0, no_w = (dbg & 16) != 0, no_ep = (dbg & 4) != 0;
+    for (int tl = 0; tl < ntl; ++tl) {
+        const int tile = t_begin + tl;
+#ifdef TEDSPAD_P3_STAMPS
+        const bool stamp_on = g_dbg_p3 && blockIdx.x == 0 && tl == 2;
+#endif
+        for (int hc = 0; hc < nhc; ++hc) {
+            // the half chunk whose halo this one's first two phases fetch: the next of this tile, or the first of the next tile
+            const bool h_next_tile = hc + 1 == nhc;
+            const bool h_exists = (!h_next_tile || tl + 1 < ntl) && !no_h;
+            const int h_hc = h_next_tile ? 0 : hc + 1;
+            // ---- this half chunk's fragment addresses: Vw[dwi][e] + immediate. Position (4 wr + r + dh) * 18 + dw + l15 of the halo has its k-group kg at piece kg ^ t with
+            // t = ((position >> 1) & 3) = (dh + r + ((dw + l15) >> 1)) & 3: dw = 0 / 2 share u0 = (l15 >> 1) & 3 (dw = 2: one more), dw = 1 has u1 = ((l15 + 1) >> 1) & 3 ----
+            unsigned Vw[2][4];
+            {
+                const unsigned B00 = (unsigned)(hb * P3_HALO) + hq + (72u * wr + l15) * 64u + kg * 16u;
+                const unsigned u0 = (l15 >> 1) & 3u, u1 = ((l15 + 1u) >> 1) & 3u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { Vw[0][e] = B00 ^ (((u0 + e) & 3u) << 4); Vw[1][e] = B00 ^ (((u1 + e) & 3u) << 4); }
-        }
-        const unsigned wres = (unsigned)(WBASE + hc * 3 * P3_WST) + wrd;      // RES: this half chunk's three stages
+                for (int e = 0; e < 4; ++e) { Vw[0][e] = B00 ^ (((u0 + e) & 3u) << 4); Vw[1][e] = B00 ^ (((u1 + e) & 3u) << 4); }
+            }
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int dh = j / 3, dw = j - dh * 3;
-            // ================= LOAD segment =================
-            const unsigned wb = RES ? wres + (unsigned)(dh * P3_WST + dw * P3_WTAP) : (unsigned)(WBASE + rd_pos * P3_WTAP) + wrd;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                fa[r] = *reinterpret_cast<const uint4 *>(dsm + Vw[dw == 1 ? 1 : 0][(dh + r + (dw == 2 ? 1 : 0)) & 3] + (unsigned)(1152 * (r + dh) + 64 * dw));
-            if (RES) {                                     // halo one half chunk ahead, all waves: pieces 0..4 in phases 0..4 (wave 0: its sixth beside the first)
-                if (h_exists) {
-                    if (j == 0 && wave == 0) halo_piece8(5, hi_hc, hi_buf);
-                    if (j < 5) halo_piece8(j, hi_hc, hi_buf);
+            for (int dh = 0; dh < 3; ++dh) {
+                // ================= LOAD segment: the three taps of kernel row dh =================
+                P3_STAMP((hc * 3 + dh) * 6 + 0);
+                // DMA first (the longest way to go), then the finished tile's epilogue (the fragment registers are still free for it), then this phase's fragment reads
+                if (h_exists && dh < 2) {                  // pieces 0, 1, 2 (and the group's sixth) in the first phase, 3, 4 in the second
+                    if (dh == 0) {
+                        if (h_next_tile) halo_tile(tile + 1);
+                        halo_piece(0, h_hc, hb ^ 1); halo_piece(1, h_hc, hb ^ 1); halo_piece(2, h_hc, hb ^ 1);
+                        if (wr == 0) halo_piece(5, h_hc, hb ^ 1);
+                    } else {
+                        halo_piece(3, h_hc, hb ^ 1); halo_piece(4, h_hc, hb ^ 1);
+                    }
                 }
-            } else if (wave < 4) {                         // weights: unit n + 8
-                if (n + 8 < NPI) issue_unit(wu_hc, wu_tap, wu_pos);
-            } else if (h_exists) {                          // halo two half chunks ahead, waves 4-7: one piece per phase (two in phase 0, wave 4: two in phase 1)
-                if (j == 0) halo_piece4(9, hi_hc, hi_buf);
-                if (j == 1 && wave == 4) halo_piece4(10, hi_hc, hi_buf);
-                halo_piece4(j, hi_hc, hi_buf);
-            }
-            if (pieces_here) {
-                if (split) { if (j >= 5) { if (hc == 0) ep_piece(accD, j - 5); else ep_piece(accD, j - 1); } }      // (the piece index must be a constant: the accumulators are registers)
-                else if (j >= 1) ep_piece(accD, j - 1);
-            }
-            if (j == 0 && hc == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) accC[r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            P3_SEG_END();
-            // ================= COMPUTE segment =================
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) accC[r][a] = T::mfma16(fw[a], fa[r], accC[r][a]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- counted waits. The epilogue's stores share the queue: those issued behind the oldest DMA that may stay in flight are allowed on top (every piece issues
-            // exactly nst stores: masked lanes write to the sink); counting fewer than were issued only waits longer ----
-            if (RES) {
-                // the halo issued in phases 0..4 of this half chunk is read from phase 9 on: landed by the wait of phase 7; behind its last piece: the stores of phases 5..7 (4..7 when the
-                // eight pieces run in phases 1..8)
-                if (j == 7 && h_exists) wait_vmcnt_dyn(pieces_here ? (split ? 3 : 4) * nst : 0);
-            } else if (wave < 4) {
-                // every third phase: units up to n + 4 landed (they are read up to phase n + 4 + 2, the next wait comes in phase n + 3); n + 5 .. n + 8 may stay in flight, and the stores
-                // of the four phases that issued them
-                if (dw == 2) {
-                    const int last = n + 8 < NPI ? n + 8 : NPI - 1;
-                    int d = last - (n + 4);
-                    d = d < 0 ? 0 : d;
-                    const int ns = pieces_here ? (j < 4 ? j : 4) : 0;
-                    wait_vmcnt_dyn(d == 4 ? 4 + ns * nst : d);
+                const bool w_own = !RES && ((n + 5) & 1) == grp && n + 5 < total && !no_w;       // this group moves stage n + 5 (its slot held stage n - 1)
+                if (w_own) {
+                    int st5 = (hc * 3 + dh + 5) % S;
+                    issue_stage(st5, wislot);
                 }
-            } else if (j == 7) {
-                // the halo issued during the half chunk before this one is read from phase 9 on: behind its last piece lie this half chunk's pieces (2 + 1 + 6 in phases 0..7; wave 4 one
-                // more, which it waits for too) and the stores of phases 1..7
-                wait_vmcnt_dyn(h_exists ? 9 + (pieces_here ? 7 * nst : 0) : (pieces_here ? 7 * nst : 0));
+                P3_STAMP((hc * 3 + dh) * 6 + 1);      // DMA issued
+                if (dh == 0 && hc == 0) {
+                    if (tl > 0 && !no_ep) {                // the tile before: its epilogue, straight from the accumulators, beside the other group's MFMAs
+                        ep_set(tile - 1);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ep_piece(acc, k);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const unsigned wb = (unsigned)(P3_WBASE + (RES ? hc * 3 + dh : wslot) * P3_WST) + wrd;
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) fw[dw][a] = *reinterpret_cast<const uint4 *>(dsm + wb + dw * P3_WTAP + a * 1024);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        fa[dw][r] = *reinterpret_cast<const uint4 *>(dsm + Vw[dw == 1 ? 1 : 0][(dh + r + (dw == 2 ? 1 : 0)) & 3] + (unsigned)(1152 * (r + dh) + 64 * dw));
+                }
+                P3_STAMP((hc * 3 + dh) * 6 + 2);      // weights DMA, epilogue done
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                P3_SEG_END();
+                // ================= COMPUTE segment =================
+                P3_STAMP((hc * 3 + dh) * 6 + 3);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[r][a] = T::mfma16(fw[dw][a], fa[dw][r], acc[r][a]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                P3_STAMP((hc * 3 + dh) * 6 + 4);      // MFMAs issued
+                // ---- counted waits (this wave's queue, oldest first, per half chunk: [phase 0: halo x 3 (4), W?, the epilogue's stores] [phase 1: halo x 2, W?] [phase 2: W?];
+                // a group issues W in every other phase). What must have landed:
+                //   * phase 2: this group's halo of the next half chunk (read from the next phase on, by this group only): everything but the youngest W stage;
+                //   * phase 1: stage n + 2 if this group moved it (issued in phase n - 3; the phase-2 wait of the half chunk before let exactly it stay in flight; the other
+                //     group may read it from phase n + 2 on, two phases after this wait): behind it lie halo x 3 (4), W (n + 4), the stores, halo x 2;
+                //   * stages n + 1 (phase 1) and n + 3, n + 4 (phase 2) are covered by the phase-2 waits (every stage but the youngest has landed there).
+                if (RES) {
+                    if (dh == 2 && h_exists) wait_vmcnt<0>();
+                } else if (n + 6 >= total || no_w) {
+                    if (dh >= 1) wait_vmcnt<0>();           // the tail of the run: few stages left in flight, no counting
+                } else if (dh == 2) {
+                    wait_vmcnt<3>();                        // one of phases 1 / 2 issued a stage: the youngest three
+                } else if (dh == 1 && ((n + 2) & 1) == grp) {
+                    wait_vmcnt_dyn((h_exists ? 8 : 3) + (hc == 0 && tl > 0 && !no_ep ? 8 * nst : 0));
+                }
+                P3_STAMP((hc * 3 + dh) * 6 + 5);      // DMA waited for
+                P3_SEG_END();
+                ++n;
+                if (!RES) {
+                    if (++wslot == P3_NWS) wslot = 0;
+                    if (++wislot == P3_NWS) wislot = 0;
+                }
             }
-            P3_SEG_END();
-            // ---- cursors ----
-            ++n;
-            if (!RES) {
-                if (++rd_pos == 9) rd_pos = 0;
-                if (++wu_pos == 9) wu_pos = 0;
-                if (++wu_tap == 9) { wu_tap = 0; if (++wu_hc == nhc) wu_hc = 0; }
-            }
+            hb ^= 1;
         }
-        if (++hb == NB) hb = 0;
-        ++hi_hs;
-        if (++hi_buf == NB) hi_buf = 0;
-        if (++hi_hc == nhc) { hi_hc = 0; ++hi_tile; }
-    };
-
-    f32x4 accA[4][4], accB[4][4];
-    auto tile_body = [&](f32x4 (&accC)[4][4], f32x4 (&accD)[4][4], const int tl) {
-        const bool draining = tl > 0 && !(dbg & 4);
-        if (draining) ep_set(t_begin + tl - 1);
-        for (int hc = 0; hc < nhc; ++hc) half_chunk(accC, accD, hc, draining);
-    };
-    for (int tl = 0; tl < ntl; tl += 2) {
-        tile_body(accA, accB, tl);
-        if (tl + 1 < ntl) tile_body(accB, accA, tl + 1);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();             // pairs with the last in-loop barrier of waves 4-7
     asm volatile("" ::: "memory");
     // ---- the last tile's epilogue ------------------------------------------------------------------------------------------------------------------------------------
     ep_set(t_end - 1);
-    if (!(dbg & 4)) {
-        if (ntl & 1) {
+    if (!no_ep) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ep_piece(accA, k);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ep_piece(accB, k);
-        }
+        for (int k = 0; k < 8; ++k) ep_piece(acc, k);
     }
     flush_stats();
 }
@@ -493,7 +487,7 @@ int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, con
     }
     PatchSrc gsrc{};
     if (SRC) gsrc = *src;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(P3_NT), RES ? P3_LDS_RES : P3_LDS_STR, s, p, g, gsrc);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(P3_NT), P3_LDS, s, p, g, gsrc);
     return check_launch("tedspad_conv_fwd(persistent two-patch halo)");
 }
 
@@ -529,3 +523,8 @@ int32_t launch_conv_patch3(int dtype, const ConvKP &p, int N, int cin, hipStream
 }
 
 }  // namespace tedspad
+#ifdef TEDSPAD_P3_STAMPS
+extern "C" int32_t tedspad_debug_set_p3_ts(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(tedspad::g_dbg_p3), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
