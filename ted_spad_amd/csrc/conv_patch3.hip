@@ -223,7 +223,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
             }
         }
     };
-    auto ep_piece = [&](f32x4 (&acc)[4][4], const int k) {
+    auto ep_piece = [&](f32x4 (&acc)[4][4], const f32x4 (&scv)[4], const f32x4 (&sfv)[4], const int k) {
         const int r = k >> 1, pp = k & 1;
         int lz = lane;
         asm volatile("" : "+v"(lz));                       // keeps a piece's addresses out of the loops' preheaders (they would live -- spilled -- across the whole tile)
@@ -238,8 +238,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int a = 2 * pp + h;
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + (a * 16 + kg * 4) * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + 256 + (a * 16 + kg * 4) * 4);
+                const f32x4 sc = scv[a], sf = sfv[a];
                 float w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = acc[r][a][j] * sc[j] + sf[j];
@@ -263,8 +262,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int a = 2 * pp + h;
-            const f32x4 sc = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + (a * 16 + kg * 4) * 4);
-            const f32x4 sf = *reinterpret_cast<const f32x4 *>(dsm + P3_SCB + 256 + (a * 16 + kg * 4) * 4);
+            const f32x4 sc = scv[a], sf = sfv[a];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[h][j] = acc[r][a][j] * sc[j] + sf[j];
             if constexpr (STATS) {
@@ -317,6 +315,19 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 *dst = f32x4{v[h][0], v[h][1], v[h][2], v[h][3]};
             }
         }
+    };
+
+    auto epilogue = [&](f32x4 (&acc)[4][4]) {
+        unsigned so = (unsigned)(P3_SCB + kg * 16);
+        asm volatile("" : "+v"(so));                       // scale / shift of this lane's channels: eight reads per epilogue, here (not hoisted out of the tile loop into 32 registers)
+        f32x4 scv[4], sfv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            scv[a] = *reinterpret_cast<const f32x4 *>(dsm + so + a * 64);
+            sfv[a] = *reinterpret_cast<const f32x4 *>(dsm + so + 256 + a * 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ep_piece(acc, scv, sfv, k);
     };
 
     // ---- prologue: scale / shift, the first halo, the weights ------------------------------------------------------------------------------------------------------
@@ -387,8 +398,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 if (dh == 0 && hc == 0) {
                     if (tl > 0 && !no_ep) {                // the tile before: its epilogue, straight from the accumulators, beside the other group's MFMAs
                         ep_set(tile - 1);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) ep_piece(acc, k);
+                        epilogue(acc);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -450,10 +460,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     asm volatile("" ::: "memory");
     // ---- the last tile's epilogue ------------------------------------------------------------------------------------------------------------------------------------
     ep_set(t_end - 1);
-    if (!no_ep) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) ep_piece(acc, k);
-    }
+    if (!no_ep) epilogue(acc);
     flush_stats();
 }
 
