@@ -340,7 +340,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     for (int i = 0; i < 6; ++i)
         if (i < 5 || wr == 0) halo_piece(i, 0, 0);
     {
-        const int npre = RES ? S : (total < 5 ? total : 5);      // streamed: stage n + 5 is issued in phase n
+        const int npre = RES ? S : (total < 4 ? total : 4);      // streamed: stage n + 4 is issued in phase n
         for (int k = 0; k < npre; ++k)
             if ((k & 1) == grp) issue_stage(k % S, k);
     }
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 
     int n = 0;                                             // phase (= weight stage) of this workgroup
     int hb = 0;                                            // halo buffer of the half chunk being multiplied
-    int wslot = 0, wislot = 5;                             // ring slot of the stage read in this phase / issued in this phase (n + 5)
+    int wslot = 0, wislot = 4;                             // ring slot of the stage read in this phase / issued in this phase (n + 4: its slot held stage n - 2, whose last reads -- the other group's third tap -- ended one segment ago)
     f32x4 acc[4][4];
-    uint4 fw[3][4], fa[3][4];
+    uint4 fw[2][4], fa[2][4];                              // two taps' fragments; the third tap's are read into the first set behind the first tap's MFMAs
     const bool no_h = (dbg & 8) != 0, no_w = (dbg & 16) != 0, no_ep = (dbg & 4) != 0;
     for (int tl = 0; tl < ntl; ++tl) {
         const int tile = t_begin + tl;
@@ -389,11 +389,8 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                         halo_piece(3, h_hc, hb ^ 1); halo_piece(4, h_hc, hb ^ 1);
                     }
                 }
-                const bool w_own = !RES && ((n + 5) & 1) == grp && n + 5 < total && !no_w;       // this group moves stage n + 5 (its slot held stage n - 1)
-                if (w_own) {
-                    int st5 = (hc * 3 + dh + 5) % S;
-                    issue_stage(st5, wislot);
-                }
+                const bool w_own = !RES && ((n + 4) & 1) == grp && n + 4 < total && !no_w;       // this group moves stage n + 4
+                if (w_own) issue_stage((hc * 3 + dh + 4) % S, wislot);
                 P3_STAMP((hc * 3 + dh) * 6 + 1);      // DMA issued
                 if (dh == 0 && hc == 0) {
                     if (tl > 0 && !no_ep) {                // the tile before: its epilogue, straight from the accumulators, beside the other group's MFMAs
@@ -408,12 +405,12 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 }
                 const unsigned wb = (unsigned)(P3_WBASE + (RES ? hc * 3 + dh : wslot) * P3_WST) + wrd;
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
+                for (int dw = 0; dw < 2; ++dw) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) fw[dw][a] = *reinterpret_cast<const uint4 *>(dsm + wb + dw * P3_WTAP + a * 1024);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        fa[dw][r] = *reinterpret_cast<const uint4 *>(dsm + Vw[dw == 1 ? 1 : 0][(dh + r + (dw == 2 ? 1 : 0)) & 3] + (unsigned)(1152 * (r + dh) + 64 * dw));
+                        fa[dw][r] = *reinterpret_cast<const uint4 *>(dsm + Vw[dw == 1 ? 1 : 0][(dh + r) & 3] + (unsigned)(1152 * (r + dh) + 64 * dw));
                 }
                 P3_STAMP((hc * 3 + dh) * 6 + 2);      // weights DMA, epilogue done
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -422,28 +419,48 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 P3_STAMP((hc * 3 + dh) * 6 + 3);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int a = 0; a < 4; ++a) acc[r][a] = T::mfma16(fw[0][a], fa[0][r], acc[r][a]);
+                __builtin_amdgcn_sched_barrier(0);
+                // the third tap's fragments, into the first tap's registers: they land under the second tap's MFMAs (a third fewer fragment registers, a third fewer reads in the
+                // load segment, which is the longer one)
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) acc[r][a] = T::mfma16(fw[dw][a], fa[dw][r], acc[r][a]);
+                for (int a = 0; a < 4; ++a) fw[0][a] = *reinterpret_cast<const uint4 *>(dsm + wb + 2 * P3_WTAP + a * 1024);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    fa[0][r] = *reinterpret_cast<const uint4 *>(dsm + Vw[0][(dh + r + 1) & 3] + (unsigned)(1152 * (r + dh) + 64 * 2));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[r][a] = T::mfma16(fw[1][a], fa[1][r], acc[r][a]);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[r][a] = T::mfma16(fw[0][a], fa[0][r], acc[r][a]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 P3_STAMP((hc * 3 + dh) * 6 + 4);      // MFMAs issued
-                // ---- counted waits (this wave's queue, oldest first, per half chunk: [phase 0: halo x 3 (4), W?, the epilogue's stores] [phase 1: halo x 2, W?] [phase 2: W?];
-                // a group issues W in every other phase). What must have landed:
-                //   * phase 2: this group's halo of the next half chunk (read from the next phase on, by this group only): everything but the youngest W stage;
-                //   * phase 1: stage n + 2 if this group moved it (issued in phase n - 3; the phase-2 wait of the half chunk before let exactly it stay in flight; the other
-                //     group may read it from phase n + 2 on, two phases after this wait): behind it lie halo x 3 (4), W (n + 4), the stores, halo x 2;
-                //   * stages n + 1 (phase 1) and n + 3, n + 4 (phase 2) are covered by the phase-2 waits (every stage but the youngest has landed there).
+                // ---- counted waits. This wave's queue, oldest first, per half chunk: [phase 0: halo x 3 (4), W?, the epilogue's stores] [phase 1: halo x 2, W?] [phase 2: W?]; a group
+                // issues a stage (three instructions) in every other phase: stage n + 4 in phase n when (n + 4) & 1 is its number. What must have landed:
+                //   * phase 2: this group's halo of the next half chunk (read from the next phase on, by this group only): everything but the youngest stage (issued in this phase or the one
+                //     before); with it every stage of this group up to n + 2 has landed;
+                //   * phases 0 and 1, when stage n + 2 is this group's (issued in phase n - 2; the other group reads it from phase n + 2 on, two phases after this wait): in phase 0 it was the
+                //     youngest of the phase-2 wait before: behind it lie halo x 3 (4), W (n + 4) and the stores; in phase 1 it was issued in the phase-2 load before that wait: behind it lie
+                //     [phase 0] halo x 3 (4), the stores, [phase 1] halo x 2, W (n + 4). (Counting a piece too few only waits longer.)
                 if (RES) {
                     if (dh == 2 && h_exists) wait_vmcnt<0>();
-                } else if (n + 6 >= total || no_w) {
-                    if (dh >= 1) wait_vmcnt<0>();           // the tail of the run: few stages left in flight, no counting
+                } else if (n + 5 >= total || no_w) {
+                    wait_vmcnt<0>();                        // the tail of the run: few stages left in flight, no counting
                 } else if (dh == 2) {
-                    wait_vmcnt<3>();                        // one of phases 1 / 2 issued a stage: the youngest three
-                } else if (dh == 1 && ((n + 2) & 1) == grp) {
-                    wait_vmcnt_dyn((h_exists ? 8 : 3) + (hc == 0 && tl > 0 && !no_ep ? 8 * nst : 0));
+                    wait_vmcnt<3>();
+                } else if (((n + 2) & 1) == grp) {
+                    const int st = hc == 0 && tl > 0 && !no_ep ? 8 * nst : 0;
+                    wait_vmcnt_dyn((dh == 0 ? (h_exists ? 6 : 3) : (h_exists ? 8 : 3)) + st);
                 }
                 P3_STAMP((hc * 3 + dh) * 6 + 5);      // DMA waited for
                 P3_SEG_END();
