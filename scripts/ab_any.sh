@@ -2,6 +2,7 @@
 # Same-box A/B of two builds of libtedspad_hip.so (ab/old.so, ab/new.so take turns) on any bench.py command line.
 # Usage (inside one gpurun call): bash scripts/ab_any.sh ROUNDS KEY[,KEY..] -- bench.py args ...     KEY = JSON paths to print, e.g. value or train_cfg3.iteration_ms
 set -e
+trap 'cp ab/new.so ted_spad_amd/libtedspad_hip.so' EXIT      # a failed / timed-out run must not leave the OLD library in the package
 R=$1; KEYS=$2; shift 3
 mkdir -p gpurun_out
 for r in $(seq 1 $R); do

@@ -1,4 +1,5 @@
 #!/bin/bash
+trap 'cp ab/new.so ted_spad_amd/libtedspad_hip.so' EXIT
 # Same-box A/B of two builds of libtedspad_hip.so: ab/old.so and ab/new.so take turns as the library; bench.py (cfg2) with 2 streams and with 1.
 # Usage (inside one gpurun call): bash scripts/ab_lib.sh [rounds]
 set -e

@@ -1,4 +1,5 @@
 #!/bin/bash
+trap 'cp ab/new.so ted_spad_amd/libtedspad_hip.so' EXIT
 # same-box A/B of two library builds (ab/old.so, ab/new.so) on isolated conv probes: bash scripts/ab_probe.sh
 for r in 1 2; do
 for v in old new; do

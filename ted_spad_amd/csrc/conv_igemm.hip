@@ -758,7 +758,10 @@ int32_t launch_cfg(int cfg, const ConvKP &p, int N, int cin, hipStream_t s, cons
     // cout = 128 k + r with r <= 64 on a 128-wide tile (Inception's 3 x 3 x 3 convs 96 -> 208, 112 -> 224, 144 -> 288, 160 -> 320 and its fused 1 x 1 x 1 reduce
     // GEMMs): the last tile column would multiply up to 64 + 63 channels of zero weights. The first 128 k channels run on the chosen tile, the rest on its 64-wide
     // sibling with every per-channel pointer moved (conv_patch.hip does the same for the halo tiles); the sibling launches first: if it does not take the geometry
-    // nothing has run yet and the conv goes unsplit. Every generic tile sums K in the same order: the split changes no bit.
+    // nothing has run yet and the conv goes unsplit (if the HEAD launch fails after it, the error is returned and y holds only the last channels). The KS = 1 tiles sum K in
+    // one order: for them the split changes no bit. The split-K tiles (22 / 23 / 24 / 35 / 36, KS = 2) have KS = 1 siblings: their last r channels are summed in the plain K order,
+    // the head in the split order -- the same one-rounding-step difference those tiles have against every other tile (test_every_tile_configuration_gives_the_same_result),
+    // so TEDSPAD_IGEMM_NO_SPLIT=1 is bit-identical to the split only for KS = 1 tiles.
     static const bool split_ok = getenv("TEDSPAD_IGEMM_NO_SPLIT") == nullptr;      // A/B knob
     const int sib = narrow_sibling(cfg);
     if (split_ok && sib && !src && p.Cout > 128 && p.Cout % 128 != 0 && p.Cout % 128 <= 64 && !p.fold_hw && !p.x2) {

@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import engine as E
+from . import _lib, engine as E
 from .params import BNParams, ConvParams, LinearParams, params_signature
 
 # (planes, blocks, spatial stride, temp_conv) -- large_i3d.py:142-145
@@ -117,11 +117,14 @@ class I3Res50(nn.Module):
         P = self.packed()
         if records is not None:
             E.require_cuda(records, "I3Res50")
+            if not (E.STEM_PT and E.STEM_POOL) or "stem_pt" not in P:
+                raise _lib.TedSpadHipError("I3Res50: the stem-record input needs the persistent stem with the fused pool (TEDSPAD_STEM_PT / TEDSPAD_STEM_POOL are off, "
+                                           "or this weight shape has no persistent stem): feed the (B,3,T,H,W) clip instead")
             st = P["stem_pt"]
             if records.dim() != 6 or tuple(records.shape[3:]) != (2, records.shape[4], 24) or records.dtype != st.torch_dtype or not records.is_contiguous():
                 raise ValueError("expected contiguous stem records (n, frame pairs, h, 2, w/2, 24) of %s, got %s %s" % (st.torch_dtype, tuple(records.shape), records.dtype))
-            if (records.shape[2] + 1) // 2 < 3 or records.shape[4] < 3:
-                raise ValueError("frames too small for conv1 + maxpool1")
+            if records.shape[1] < 1 or (records.shape[2] + 1) // 2 < 3 or records.shape[4] < 3:
+                raise ValueError("stem records need at least one frame pair and frames of 5 x 6 pixels for conv1 + maxpool1, got %s" % (tuple(records.shape),))
             a = st.conv_pool(records)                                    # conv1 + bn1 + ReLU + maxpool1 from the records (the LDS-DMA loader of csrc/conv_stem_pt.hip)
             x = None
         else:

@@ -72,6 +72,11 @@ def ntxent_from_embeddings(z0, z1, temperature=0.1):
     return NTXentLoss(z0.device, z0.shape[0], temperature, False)(z0, z1)
 
 
+def _flag(v):
+    """`skipped` always has one type: constants are wrapped too (bool(), ==, repr work the same; json: use bool(flag))."""
+    return v if isinstance(v, DeviceFlag) else DeviceFlag.const(bool(v))
+
+
 class DeviceFlag:
     """Truth value of a 0-d device tensor, read when somebody asks for it (`bool()`, `==`, `repr`): the `skipped` entry of a step result. The non-finite check
     runs on the step's FINAL gradients, so reading it waits for the whole backward pass; a caller that never looks never waits (torch.amp.GradScaler does not
@@ -80,6 +85,12 @@ class DeviceFlag:
 
     def __init__(self, t):
         self._t, self._v = t, None
+
+    @classmethod
+    def const(cls, v: bool):
+        f = cls(None)
+        f._v = bool(v)
+        return f
 
     def __bool__(self):
         if self._v is None:
@@ -205,7 +216,7 @@ class AnonymizerTrainStep:
         try:
             if found_inf is None:
                 opt.step()
-                return False
+                return _flag(False)
             if fused:
                 opt.grad_scale, opt.found_inf = None, found_inf
                 try:
@@ -214,9 +225,9 @@ class AnonymizerTrainStep:
                     del opt.grad_scale, opt.found_inf
                 return found_inf != 0 if self.lazy_losses else DeviceFlag(found_inf)
             if float(found_inf) != 0.0:
-                return True
+                return _flag(True)
             opt.step()
-            return False
+            return _flag(False)
         finally:
             if fused:       # a fused step leaves the parameters' version counters alone: say that they changed (TE.mark_updated)
                 TE.mark_updated(module.parameters())
@@ -243,6 +254,7 @@ class AnonymizerTrainStep:
     # ---- phase 1 --------------------------------------------------------------------------------------------------
     def step_fa(self, inputs_video, labels, inputs_vispr=None):
         """Update fa (phase 1). Returns a dict of python floats (read back as soon as the losses exist, `_post`) + `skipped`, a `DeviceFlag`."""
+        self._posted, self._pin_used = [], 0           # (a step that raised between _post and _collect leaves nothing behind)
         p = self.params
         views = self._views(inputs_vispr)
         self.fa.train(); self.ft.eval()
@@ -342,6 +354,7 @@ class AnonymizerTrainStep:
     # ---- phase 2 --------------------------------------------------------------------------------------------------
     def step_ft(self, inputs_video, labels, drop_masks=None, inputs_vispr=None):
         """Update ft and fb (phase 2)."""
+        self._posted, self._pin_used = [], 0           # (a step that raised between _post and _collect leaves nothing behind)
         p = self.params
         views = self._views(inputs_vispr)
         self.fa.eval(); self.ft.train()
@@ -398,6 +411,7 @@ class AnonymizerTrainStep:
         BatchNorm3d layers frozen (`freeze_bn`, :39-40: running statistics, gamma / beta are buffers and get no gradient;
         dropout and the mlp head follow the train flag), loss = CE(pred of clip 1) + w * triplet(feat1, feat2, feat3)
         (:64-84), then the optimizer step on ft (:86-88; the GradScaler is the static `loss_scale` here)."""
+        self._posted, self._pin_used = [], 0           # (a step that raised between _post and _collect leaves nothing behind)
         p = self.params
         self.fa.eval(); self.ft.train()
         self.opt_ft.zero_grad(set_to_none=True)                       # :46
