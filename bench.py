@@ -415,6 +415,12 @@ def bench_train_main(args, dev, world, rank, dry):
         dist.destroy_process_group()
 
 
+def _table_hash(table) -> str:
+    """Short digest of a tile table (engine.export_tile_table): equal on every rank after the broadcast."""
+    import hashlib
+    return hashlib.sha1(repr(sorted((k, sorted(v.items(), key=repr)) for k, v in table.items())).encode()).hexdigest()[:12]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -564,7 +570,7 @@ def main():
                 return host_feats
             return full
 
-        tiles_ok = None
+        tiles_ok, table_hash = None, None
         with torch.no_grad():
             # batch sizes (= conv geometries) any rank will run
             sizes = sorted({k for r in range(world) for _, k in sharding.batch_plan(
@@ -588,6 +594,8 @@ def main():
                     sync()
                     from ted_spad_amd.extraction import share_tile_choices
                     share_tile_choices(ft)
+                    net = ft.i3d if hasattr(ft, "i3d") else ft
+                    table_hash = _table_hash(_E.export_tile_table(net.packed()))
             elif dry and world > 1:
                 # rehearsal of the tile-table hand-off with stand-in objects (no kernels): rank 0 "decides", every rank must end with the same table
                 from ted_spad_amd import engine as _E
@@ -605,6 +613,7 @@ def main():
                 if rank != 0:
                     _E.import_tile_table(fake, box[0])
                 mine = _E.export_tile_table(fake)
+                table_hash = _table_hash(mine)
                 flags = [None] * world
                 dist.all_gather_object(flags, mine == box[0] and all(len(v) == len(sizes) for v in mine.values()))
                 tiles_ok = all(flags)
@@ -625,8 +634,14 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # what every rank ran, in rank 0's line: a ragged or mistuned rank is visible in the driver's SCALE record
+        ranks = None
+        if world > 1:
+            ranks = [None] * world
+            dist.all_gather_object(ranks, {"rank": rank, "clip_times": [lo, hi], "n_local": n_local, "plan": [k for _, k in plan], "tile_table": table_hash,
+                                           "ms_per_step": round(dt / max(1, timed_steps) * 1e3, 3)})
         return {"dt": float(tmax.item()), "out": out, "ev": ev, "T_total": T_total, "n_local": n_local, "clips": clips, "plan": plan, "sizes": sizes,
-                "tiles_ok": tiles_ok}
+                "tiles_ok": tiles_ok, "ranks": ranks}
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))] if not dry else []
     # rank 0's device->host copy of a step runs on its own stream, under the next step's forwards (it still completes inside the timed
@@ -636,7 +651,7 @@ def main():
 
     W = run_workload(args.scaling, args.steps, tune=True)
     dt, out, ev, T_total, n_local, clips = W["dt"], W["out"], W["ev"], W["T_total"], W["n_local"], W["clips"]
-    tiles_ok, plan, sizes = W["tiles_ok"], W["plan"], W["sizes"]
+    tiles_ok, plan, sizes, rank_info = W["tiles_ok"], W["plan"], W["sizes"], W["ranks"]
     total_clips = T_total * args.crops * args.steps
     value = total_clips / dt
     # N > 1: the other reading of "clips/s at N GPUs" in the same line -- `value` is cfg4 as BASELINE.json words it (ONE video's clips split over the ranks,
@@ -675,6 +690,8 @@ def main():
                       "parallelism": "clip-sharded x%d + RCCL all-gather of (T,10,F) features" % world}}
     if weak is not None:
         res["weak_scaling"] = weak
+    if rank_info:
+        res["ranks"] = rank_info
 
     if dry:
         # the stub's rows are a known function of the global clip index: the gathered (T, crops, F) block must be complete and ordered

@@ -61,6 +61,27 @@ def test_two_rank_strong_scaling_dry_run_splits_one_video():
     assert j["gather_ok"] is True and j["tile_table_ok"] is True
 
 
+def test_eight_rank_strong_scaling_dry_run_has_the_cfg4_shards():
+    """cfg4's shape at N = 8: ONE video of 225 clip times over 8 ranks = 29 / 29 / 29 / 29 / 29 / 29 / 29 / 22 clip times (x crops clips), every rank's shard, forward
+    plan and tile-table digest in rank 0's line (`ranks`), the gathered block complete and ordered, the tile table identical everywhere."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-cpu", "--steps", "1", "--warmup", "0",
+           "--clip-times", "225", "--crops", "2", "--scaling", "strong", "--no-weak"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_lines(r.stdout)
+    assert len(j) == 1, r.stdout
+    j = j[0]
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["clips_per_step"] == 225 * 2
+    assert j["gather_ok"] is True and j["tile_table_ok"] is True
+    rk = j["ranks"]
+    assert [x["rank"] for x in rk] == list(range(8))
+    assert [x["clip_times"][1] - x["clip_times"][0] for x in rk] == [29] * 7 + [22] and rk[0]["clip_times"][0] == 0 and rk[7]["clip_times"][1] == 225
+    assert all(x["n_local"] == (x["clip_times"][1] - x["clip_times"][0]) * 2 and sum(x["plan"]) == x["n_local"] for x in rk)
+    assert len({x["tile_table"] for x in rk}) == 1 and rk[0]["tile_table"]
+
+
 def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
     """`python bench.py --gpus 2 ...` exactly as `--gpus 1` is started (no torch.distributed.run, WORLD_SIZE unset): the parent starts the two ranks as a child
     process, relays ONE JSON line and exits 0. N > 1 defaults to strong scaling (cfg4: one video split over the ranks) with the weak figure in the same line."""
