@@ -539,7 +539,10 @@ int32_t launch_conv_patch3(int dtype, const ConvKP &p, int N, int cin, hipStream
         return f16 ? launch_patch3_t<F16, false, false, true>(p, frames, cin, s, nullptr) : launch_patch3_t<BF16, false, false, true>(p, frames, cin, s, nullptr);
     }
     if (st) {
-        if (src) return f16 ? launch_patch3_t<F16, true, true, false>(p, frames, cin, s, src) : launch_patch3_t<BF16, true, true, false>(p, frames, cin, s, src);
+        if (src) {      // (no caller: the gathered concatenation is the eval path of unet++; its 12 more registers would spill beside the statistics)
+            set_error("tedspad_conv_fwd: tile_cfg 40 has no batch statistics on gathered sources");
+            return TEDSPAD_EINVAL;
+        }
         return f16 ? launch_patch3_t<F16, false, true, false>(p, frames, cin, s, nullptr) : launch_patch3_t<BF16, false, true, false>(p, frames, cin, s, nullptr);
     }
     if (src) return f16 ? launch_patch3_t<F16, true, false, false>(p, frames, cin, s, src) : launch_patch3_t<BF16, true, false, false>(p, frames, cin, s, src);
