@@ -102,7 +102,8 @@ __device__ __forceinline__ P3Tile p3_decode(int tile, const Patch3Geo &g) {
     asm volatile("" ::: "memory");            \
     __builtin_amdgcn_sched_barrier(0)
 
-template <typename T, bool SRC, bool STATS, bool RES>
+// GEN: the general epilogue (residual / ReLU-backward mask / fp32 output / bf16); otherwise the inference epilogue (F16: scale / shift, ReLU, saturation, 16-bit store)
+template <typename T, bool SRC, bool STATS, bool RES, bool GEN>
 __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, const Patch3Geo g, const PatchSrc gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -206,7 +207,6 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     // ---- the epilogue of a finished tile, in eight pieces (accumulator row r = k >> 1, channel groups 2 pp, 2 pp + 1 with pp = k & 1) ----------------------------------
     int ep_pf = 0, ep_ho0 = 0, ep_wo0 = 0;                 // this wave's patch of the tile being drained: frame, first row of the wave, first column
     bool ep_pon = false;
-    const bool ep_fast = !p.res && !p.mask && !p.y32 && p.y;
     const float ep_lo = p.relu ? 0.f : -p.sat;
     auto ep_set = [&](int tile) __attribute__((always_inline))  {
         int pi = 2 * tile + grp;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
         const size_t m = ((size_t)ep_pf * p.Ho + ho) * p.Wo + wo;
         const int poff = (2 * pp + (kg & 1)) * 16 + (kg >> 1) * 8;       // this lane's 16-byte piece (8 channels) of the pixel's row, after the swap
         const bool on = valid && poff < p.Cout;                          // 8-channel pieces beyond cout are neither read nor stored
-        if (T::kDtype == TEDSPAD_F16 && ep_fast) {      // the inference epilogue (scale / shift, ReLU, saturation, 16-bit store): ~30 vector instructions per piece
+        if constexpr (!GEN) {      // the inference epilogue (scale / shift, ReLU, saturation, 16-bit store): ~30 vector instructions per piece
             uint32_t pk[2][2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -258,63 +258,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
             *dst = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
             return;
         }
-        float v[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int a = 2 * pp + h;
-            const f32x4 sc = scv[a], sf = sfv[a];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[h][j] = acc[r][a][j] * sc[j] + sf[j];
-            if constexpr (STATS) {
-                if (valid) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { s1[a][j] += v[h][j]; s2[a][j] += v[h][j] * v[h][j]; }
-                }
-            }
-        }
-        if (p.res) {
-            uint4 rv = make_uint4(0u, 0u, 0u, 0u);
-            if (on) rv = *reinterpret_cast<const uint4 *>(p.res + m * p.ldres + poff);
-            swap16(rv.x, rv.z); swap16(rv.y, rv.w);                      // -> (x, y): this lane's 4 channels of group 2 pp, (z, w): of group 2 pp + 1
-            const uint32_t rw[2][2] = {{rv.x, rv.y}, {rv.z, rv.w}};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v[h][0] += T::to_f32((uint16_t)(rw[h][0] & 0xffffu)); v[h][1] += T::to_f32((uint16_t)(rw[h][0] >> 16));
-                v[h][2] += T::to_f32((uint16_t)(rw[h][1] & 0xffffu)); v[h][3] += T::to_f32((uint16_t)(rw[h][1] >> 16));
-            }
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[h][j] = __builtin_fmaxf(v[h][j], 0.f);
-        }
-        if (p.mask) {           // ReLU backward fused into the data gradient that produces d(input)
-            uint4 mv = make_uint4(0u, 0u, 0u, 0u);
-            if (on) mv = *reinterpret_cast<const uint4 *>(p.mask + m * p.ldmask + poff);
-            swap16(mv.x, mv.z); swap16(mv.y, mv.w);
-            const uint32_t mw[2][2] = {{mv.x, mv.y}, {mv.z, mv.w}};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v[h][0] = T::to_f32((uint16_t)(mw[h][0] & 0xffffu)) > 0.f ? v[h][0] : 0.f; v[h][1] = T::to_f32((uint16_t)(mw[h][0] >> 16)) > 0.f ? v[h][1] : 0.f;
-                v[h][2] = T::to_f32((uint16_t)(mw[h][1] & 0xffffu)) > 0.f ? v[h][2] : 0.f; v[h][3] = T::to_f32((uint16_t)(mw[h][1] >> 16)) > 0.f ? v[h][3] : 0.f;
-            }
-        }
-        if (p.y) {
-            uint32_t x0 = pack2_lim<T>(v[0][0], v[0][1], p.sat), x1 = pack2_lim<T>(v[0][2], v[0][3], p.sat);
-            uint32_t y0 = pack2_lim<T>(v[1][0], v[1][1], p.sat), y1 = pack2_lim<T>(v[1][2], v[1][3], p.sat);
-            swap16(x0, y0); swap16(x1, y1);
-            uint4 *dst = on ? reinterpret_cast<uint4 *>(p.y + m * p.ldy + poff) : g_sink_p3 + lane;
-            *dst = make_uint4(x0, x1, y0, y1);
-        }
-        if (p.y32) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int nch = (2 * pp + h) * 16 + kg * 4;
-                f32x4 *dst = (valid && nch < p.Cout) ? reinterpret_cast<f32x4 *>(p.y32 + m * p.ldy32 + nch) : reinterpret_cast<f32x4 *>(g_sink_p3 + lane);
-                *dst = f32x4{v[h][0], v[h][1], v[h][2], v[h][3]};
-            }
-        }
+        // (the general epilogue -- residual, ReLU-backward mask, fp32 output, bf16 -- runs as whole-tile passes: epilogue_general below)
     };
 
     auto epilogue = [&](f32x4 (&acc)[4][4]) {
@@ -326,8 +270,108 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
             scv[a] = *reinterpret_cast<const f32x4 *>(dsm + so + a * 64);
             sfv[a] = *reinterpret_cast<const f32x4 *>(dsm + so + 256 + a * 64);
         }
+        if constexpr (!GEN) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ep_piece(acc, scv, sfv, k);
+            for (int k = 0; k < 8; ++k) ep_piece(acc, scv, sfv, k);
+            return;
+        } else {
+        // ---- the general epilogue as passes over the whole tile, in the accumulators: scale / shift (+ statistics); the residual's eight 16-byte pieces requested TOGETHER (one
+        // wait instead of eight: a load's wait also drains the DMA queue), added; ReLU; the mask's pieces likewise; rounding / stores. Per element the operations and their order are
+        // those of tiles 32 / 38: same bits ----
+        int lz = lane;
+        asm volatile("" : "+v"(lz));
+        const int l15z = lz & 15, kgz = lz >> 4;
+        const int wo = ep_wo0 + l15z;
+        size_t mrow[4];
+        bool vrow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vrow[r] = ep_pon && ep_ho0 + r < p.Ho && wo < p.Wo;
+            mrow[r] = ((size_t)ep_pf * p.Ho + ep_ho0 + r) * p.Wo + wo;
+        }
+        const int poff0 = (kgz & 1) * 16 + (kgz >> 1) * 8;                 // + 32 pp: this lane's 16-byte piece of the pixel's row, after the swap
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][a][j] = acc[r][a][j] * scv[a][j] + sfv[a][j];
+                if constexpr (STATS) {
+                    if (vrow[r]) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s1[a][j] += acc[r][a][j]; s2[a][j] += acc[r][a][j] * acc[r][a][j]; }
+                    }
+                }
+            }
+        auto load8 = [&](const uint16_t *base, int ld, uint4 (&q)[8]) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = k >> 1, poff = poff0 + 32 * (k & 1);
+                q[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (vrow[r] && poff < p.Cout) q[k] = *reinterpret_cast<const uint4 *>(base + mrow[r] * ld + poff);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { swap16(q[k].x, q[k].z); swap16(q[k].y, q[k].w); }      // -> (x, y): this lane's 4 channels of group 2 pp, (z, w): of group 2 pp + 1
+        };
+        if (p.res) {
+            uint4 q[8];
+            load8(p.res, p.ldres, q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = k >> 1, pp = k & 1;
+                const uint32_t rw[2][2] = {{q[k].x, q[k].y}, {q[k].z, q[k].w}};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 &v = acc[r][2 * pp + h];
+                    v[0] += T::to_f32((uint16_t)(rw[h][0] & 0xffffu)); v[1] += T::to_f32((uint16_t)(rw[h][0] >> 16));
+                    v[2] += T::to_f32((uint16_t)(rw[h][1] & 0xffffu)); v[3] += T::to_f32((uint16_t)(rw[h][1] >> 16));
+                }
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[r][a][j] = __builtin_fmaxf(acc[r][a][j], 0.f);
+        }
+        if (p.mask) {           // ReLU backward fused into the data gradient that produces d(input)
+            uint4 q[8];
+            load8(p.mask, p.ldmask, q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = k >> 1, pp = k & 1;
+                const uint32_t mw[2][2] = {{q[k].x, q[k].y}, {q[k].z, q[k].w}};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 &v = acc[r][2 * pp + h];
+                    v[0] = T::to_f32((uint16_t)(mw[h][0] & 0xffffu)) > 0.f ? v[0] : 0.f; v[1] = T::to_f32((uint16_t)(mw[h][0] >> 16)) > 0.f ? v[1] : 0.f;
+                    v[2] = T::to_f32((uint16_t)(mw[h][1] & 0xffffu)) > 0.f ? v[2] : 0.f; v[3] = T::to_f32((uint16_t)(mw[h][1] >> 16)) > 0.f ? v[3] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = k >> 1, pp = k & 1, poff = poff0 + 32 * pp;
+            const f32x4 &v0 = acc[r][2 * pp], &v1 = acc[r][2 * pp + 1];
+            if (p.y) {
+                uint32_t x0 = pack2_lim<T>(v0[0], v0[1], p.sat), x1 = pack2_lim<T>(v0[2], v0[3], p.sat);
+                uint32_t y0 = pack2_lim<T>(v1[0], v1[1], p.sat), y1 = pack2_lim<T>(v1[2], v1[3], p.sat);
+                swap16(x0, y0); swap16(x1, y1);
+                uint4 *dst = (vrow[r] && poff < p.Cout) ? reinterpret_cast<uint4 *>(p.y + mrow[r] * p.ldy + poff) : g_sink_p3 + lane;
+                *dst = make_uint4(x0, x1, y0, y1);
+            }
+            if (p.y32) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nch = (2 * pp + h) * 16 + kgz * 4;
+                    f32x4 *dst = (vrow[r] && nch < p.Cout) ? reinterpret_cast<f32x4 *>(p.y32 + mrow[r] * p.ldy32 + nch) : reinterpret_cast<f32x4 *>(g_sink_p3 + lane);
+                    *dst = h ? v1 : v0;
+                }
+            }
+        }
+        }
     };
 
     // ---- prologue: scale / shift, the first halo, the weights ------------------------------------------------------------------------------------------------------
@@ -484,7 +528,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 int g_p3_cus = 0;
 bool g_p3_det = false;       // deterministic mode: the persistent kernel's statistics flush is not gated (det_gate.h): it declines statistics then
 
-template <typename T, bool SRC, bool STATS, bool RES>
+template <typename T, bool SRC, bool STATS, bool RES, bool GEN>
 int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, const PatchSrc *src) {
     Patch3Geo g;
     g.tiles_h = (p.Ho + P3_S - 1) / P3_S; g.tiles_w = (p.Wo + P3_S - 1) / P3_S;
@@ -501,7 +545,7 @@ int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, con
     int grid = nwg_env > 0 ? nwg_env : g_p3_cus;
     if (grid > g.ntiles) grid = g.ntiles;
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_patch3_kernel<T, SRC, STATS, RES>;
+    auto kfn = conv_patch3_kernel<T, SRC, STATS, RES, GEN>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -530,23 +574,25 @@ int32_t launch_conv_patch3(int dtype, const ConvKP &p, int N, int cin, hipStream
     }
     const int frames = N * p.Ti;
     const bool f16 = dtype == TEDSPAD_F16, st = p.stats != nullptr;
-    if (cin <= 64) {      // weights resident (a gathered concatenation of one source is just a tensor: not instantiated)
-        if (src) {
-            set_error("tedspad_conv_fwd: tile_cfg 40 takes gathered sources with cin >= 128 only");
-            return TEDSPAD_EINVAL;
-        }
-        if (st) return f16 ? launch_patch3_t<F16, false, true, true>(p, frames, cin, s, nullptr) : launch_patch3_t<BF16, false, true, true>(p, frames, cin, s, nullptr);
-        return f16 ? launch_patch3_t<F16, false, false, true>(p, frames, cin, s, nullptr) : launch_patch3_t<BF16, false, false, true>(p, frames, cin, s, nullptr);
+    const bool gen = !f16 || p.res || p.mask || p.y32 || !p.y;       // the general epilogue
+    const bool res = cin <= 64;                                       // weights resident
+    if (src && (res || st)) {      // (no caller: a gathered concatenation of one source is just a tensor; the gathered concatenation is the eval path of unet++)
+        set_error("tedspad_conv_fwd: tile_cfg 40 takes gathered sources with cin >= 128 and without batch statistics only");
+        return TEDSPAD_EINVAL;
     }
-    if (st) {
-        if (src) {      // (no caller: the gathered concatenation is the eval path of unet++; its 12 more registers would spill beside the statistics)
-            set_error("tedspad_conv_fwd: tile_cfg 40 has no batch statistics on gathered sources");
-            return TEDSPAD_EINVAL;
-        }
-        return f16 ? launch_patch3_t<F16, false, true, false>(p, frames, cin, s, nullptr) : launch_patch3_t<BF16, false, true, false>(p, frames, cin, s, nullptr);
+#define P3_GO(TT, SRC_, ST_, RES_, GEN_) return launch_patch3_t<TT, SRC_, ST_, RES_, GEN_>(p, frames, cin, s, src)
+    if (f16) {
+        if (res) { if (st) { if (gen) P3_GO(F16, false, true, true, true); P3_GO(F16, false, true, true, false); } if (gen) P3_GO(F16, false, false, true, true); P3_GO(F16, false, false, true, false); }
+        if (src) { if (gen) P3_GO(F16, true, false, false, true); P3_GO(F16, true, false, false, false); }
+        if (st) { if (gen) P3_GO(F16, false, true, false, true); P3_GO(F16, false, true, false, false); }
+        if (gen) P3_GO(F16, false, false, false, true);
+        P3_GO(F16, false, false, false, false);
     }
-    if (src) return f16 ? launch_patch3_t<F16, true, false, false>(p, frames, cin, s, src) : launch_patch3_t<BF16, true, false, false>(p, frames, cin, s, src);
-    return f16 ? launch_patch3_t<F16, false, false, false>(p, frames, cin, s, nullptr) : launch_patch3_t<BF16, false, false, false>(p, frames, cin, s, nullptr);
+    if (res) { if (st) P3_GO(BF16, false, true, true, true); P3_GO(BF16, false, false, true, true); }
+    if (src) P3_GO(BF16, true, false, false, true);
+    if (st) P3_GO(BF16, false, true, false, true);
+    P3_GO(BF16, false, false, false, true);
+#undef P3_GO
 }
 
 }  // namespace tedspad
