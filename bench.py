@@ -776,6 +776,13 @@ def main():
         with torch.no_grad():
             ft.i3d._trunk(clips[:10], taps=taps)
         res["act_absmax"] = {k: round(float(v.buf.float().abs().max()), 3) for k, v in taps.items()}   # f16 saturates at 65504
+        # ... and the device-side counter of clamped stores (tedspad_count_saturated over the stage outputs of the production forward)
+        ft.i3d.check_saturation = True
+        with torch.no_grad():
+            ft.i3d.extract_features(clips[:10])
+        sat, bad = ft.i3d.saturation_counts()
+        ft.i3d.check_saturation = False
+        res["act_saturated"] = {"at_f16_max": sat, "non_finite": bad, "clips": 10}
     if world == 1 and not args.no_train:
         del clips, W
         torch.cuda.empty_cache()

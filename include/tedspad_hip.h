@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TEDSPAD_ABI_VERSION 4   /* 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4); 4: tedspad_bneck_l1_* removed, tedspad_frames_crop_resize_tp added (round 5) */
+#define TEDSPAD_ABI_VERSION 5   /* 5: tedspad_count_saturated added (round 6); 2: the BatchNorm entries take `zdtype` / `groups` / `dbias`, multi-job refresh entries (round 2); 3: tedspad_conv_extras.nosat / .nchunk_src, the fp32-clip stem entry (round 4); 4: tedspad_bneck_l1_* removed, tedspad_frames_crop_resize_tp added (round 5) */
 
 enum { TEDSPAD_F16 = 0, TEDSPAD_BF16 = 1, TEDSPAD_F32 = 2 /* only where an argument says so (the BatchNorm `zdtype`) */ };
 enum { TEDSPAD_OK = 0, TEDSPAD_EINVAL = -1, TEDSPAD_ELAUNCH = -2, TEDSPAD_EUNSUPPORTED = -3 };
@@ -532,6 +532,11 @@ int32_t tedspad_frames_crop_resize_pil(const void *frames, int32_t T, int32_t H,
  * length == 0 (test_mode): out (T, ncrops, F+1) = the rows + magnitude channel. */
 int32_t tedspad_segment_pool_mag(const float *feat, int32_t T, int32_t ncrops, int32_t F, int32_t length, float *out,
                                  void *stream);
+
+/* f16 head-room made observable (large_i3d.py:78-79 runs in fp32 / autocast fp16, where an overflow is an inf; the inference stores here SATURATE at
+ * +-65504 instead, silently): counts, in a channels-last 16-bit tensor of `rows` pixels x `c` channels (pixel stride ldx), the elements AT the largest finite
+ * value of the type (f16: what a clamped store writes; bf16: never) into out2[0] and the non-finite ones into out2[1] (both ADDED to). */
+int32_t tedspad_count_saturated(const void *x, int64_t rows, int32_t c, int32_t ldx, int32_t dtype, uint32_t *out2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtedspad_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
-ABI_VERSION = 4          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
+ABI_VERSION = 5          # TEDSPAD_ABI_VERSION of include/tedspad_hip.h this binding was written against
 
 
 class ConvDesc(C.Structure):
@@ -121,6 +121,7 @@ SYMBOLS = {
     "tedspad_frames_crop_resize_tp": (_I32, [_P] + [_I32] * 16 + [_P, _P, C.c_float, _I32, _P] + [_I32] * 4 + [_P]),
     "tedspad_frames_crop_resize_pil": (_I32, [_P] + [_I32] * 10 + [_P, _I32, _P, _I32, _P] + [_I64] * 4 + [_P]),
     "tedspad_segment_pool_mag": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    "tedspad_count_saturated": (_I32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
 }
 
 _lib = None

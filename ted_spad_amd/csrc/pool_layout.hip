@@ -511,10 +511,49 @@ __global__ __launch_bounds__(256) void add_channels_kernel(const uint4 *x, uint4
     }
 }
 
+// f16 head-room made observable (the inference stores saturate silently at +-65504, common.h): elements of a channels-last tensor that sit AT the largest finite
+// value of their type (f16: 0x7bff -- what a clamped store writes; bf16 stores are never clamped: none) and elements that are not finite. One pass, 16 bytes per
+// lane, a wave reduction and one atomic pair per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void count_saturated_kernel(const uint4 *x, long rows, int c8, int ldx8, unsigned *out) {
+    const long total = rows * c8;
+    unsigned sat = 0, bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const uint4 v = x[r * ldx8 + (i - r * c8)];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned e = (w[k] >> (16 * h)) & 0x7fffu;
+                if (T::kDtype == TEDSPAD_F16) { sat += e == 0x7bffu; bad += e >= 0x7c00u; }
+                else bad += e >= 0x7f80u;
+            }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sat += __shfl_xor(sat, d, 64); bad += __shfl_xor(bad, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (sat | bad)) {
+        if (sat) atomicAdd(out, sat);
+        if (bad) atomicAdd(out + 1, bad);
+    }
+}
+
 }  // namespace
 }  // namespace tedspad
 
 using namespace tedspad;
+
+extern "C" int32_t tedspad_count_saturated(const void *x, int64_t rows, int32_t c, int32_t ldx, int32_t dtype, uint32_t *out2, void *stream) {
+    TS_REQUIRE(x && out2 && rows >= 0 && c > 0 && c % 8 == 0 && ldx >= c && ldx % 8 == 0 && (uintptr_t)x % 16 == 0, "tedspad_count_saturated: x 16-byte aligned, c and ldx multiples of 8, ldx >= c");
+    TS_REQUIRE(dtype == TEDSPAD_F16 || dtype == TEDSPAD_BF16, "tedspad_count_saturated: dtype");
+    if (rows == 0) return TEDSPAD_OK;
+    const long total = rows * (c / 8);
+    const int grid = (int)(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+    if (dtype == TEDSPAD_F16) hipLaunchKernelGGL((count_saturated_kernel<F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (long)rows, c / 8, ldx / 8, out2);
+    else hipLaunchKernelGGL((count_saturated_kernel<BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)x, (long)rows, c / 8, ldx / 8, out2);
+    return check_launch("tedspad_count_saturated");
+}
 
 extern "C" int32_t tedspad_abi_version(void) { return TEDSPAD_ABI_VERSION; }
 extern "C" const char *tedspad_last_error(void) { return g_err; }

@@ -923,6 +923,17 @@ def global_avgpool(x: Act) -> torch.Tensor:
     return y
 
 
+def count_saturated(x: Act, counter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Adds to `counter` (uint32-as-int32 x 2 on the device; made if None): elements of `x` at the largest finite f16 value -- what a clamped (saturated) inference
+    store writes -- and non-finite elements (tedspad_count_saturated). No host sync: read it when convenient."""
+    if counter is None:
+        counter = torch.zeros(2, dtype=torch.int32, device=x.buf.device)
+    n, t, h, w = x.dims
+    code = _lib.F16 if x.buf.dtype == torch.float16 else _lib.BF16
+    check(_lib.lib().tedspad_count_saturated(x.ptr, n * t * h * w, x.c, x.ld, code, counter.data_ptr(), _stream_ptr()), "tedspad_count_saturated")
+    return counter
+
+
 def avgpool3d_stride1(x: Act, k) -> torch.Tensor:
     """nn.AvgPool3d(k, stride 1): (n,t,h,w,c) -> fp32 (n, c, t-kt+1, h-kh+1, w-kw+1)."""
     n, t, h, w = x.dims

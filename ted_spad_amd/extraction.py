@@ -140,8 +140,23 @@ def extract_features(full_vid, vid_features, save_path, fa_model, ft_model, anon
         x = feed(clips, fa_model if anonymized else None, layout, fa_batch=fa_batch)
         f = _extract_fn(ft_model)(x).flatten(1)
         vid_features[i:i + f.shape[0]] = f.cpu().numpy()
+    warn_if_saturated(ft_model)
     np.save(save_path, vid_features)
     return vid_features
+
+
+def warn_if_saturated(ft_model) -> int:
+    """With `I3Res50.check_saturation` on (TEDSPAD_CHECK_SATURATION=1): reads the encoder's saturation counter and warns when an f16 activation store was clamped at
+    +-65504 (the reference's fp32 / autocast run would carry an inf there): features of that video are not trustworthy. Returns the count (0 when the check is off)."""
+    import warnings
+    net = ft_model.i3d if hasattr(ft_model, "i3d") else ft_model
+    if not getattr(net, "check_saturation", False) or not hasattr(net, "saturation_counts"):
+        return 0
+    sat, bad = net.saturation_counts(reset=True)
+    if sat or bad:
+        warnings.warn("I3Res50: %d activation(s) saturated at the f16 limit (65504) and %d were not finite in this video's forwards: the features are unreliable "
+                      "(bf16 keeps the range: load_ft_model(...).i3d.compute_dtype = 'bf16' at 3e-3 rel-L2)" % (sat, bad), RuntimeWarning)
+    return sat + bad
 
 
 @torch.no_grad()

@@ -8,6 +8,8 @@ network is just the launch sequence below.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -154,6 +156,8 @@ class I3Res50(nn.Module):
             a = E.maxpool(a, (2, 3, 3), (2, 2, 2))                       # large_i3d.py:138
         if taps is not None:
             taps["maxpool1"] = a
+        if self.check_saturation:
+            self._sat = E.count_saturated(a, self._sat)
         pooled = False
         for li in range(1, 5):
             if li == 2 and not pooled:
@@ -204,7 +208,24 @@ class I3Res50(nn.Module):
                     a = P[p + "conv3"](h, residual=res, relu=True)       # bn3 + (+= residual) + ReLU fused
             if taps is not None:
                 taps["layer%d" % li] = a
+            if self.check_saturation:
+                self._sat = E.count_saturated(a, self._sat)
         return a
+
+    # ---- f16 head-room, observable -----------------------------------------------------------------------------------
+    check_saturation = os.environ.get("TEDSPAD_CHECK_SATURATION", "0") == "1"
+    _sat = None
+
+    def saturation_counts(self, reset: bool = True):
+        """(elements at +-65504, non-finite elements) seen in the stage outputs (maxpool1, layer1..4) of every forward since the last reset, with
+        `check_saturation = True` (or TEDSPAD_CHECK_SATURATION=1): the inference stores saturate instead of overflowing (csrc/common.h), silently -- a released
+        checkpoint whose activations outgrow f16 shows up here (one read pass per stage output: off by default). Reads the device counter (a sync)."""
+        if self._sat is None:
+            return 0, 0
+        v = self._sat.cpu().numpy().astype("uint32")
+        if reset:
+            self._sat.zero_()
+        return int(v[0]), int(v[1])
 
     def extract_features(self, x: torch.Tensor) -> torch.Tensor:
         """large_i3d.py:249-263 -> (B, 2048, 1, 1, 1) fp32."""

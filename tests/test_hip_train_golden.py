@@ -519,3 +519,47 @@ def test_f16_head_room_of_the_activations(scale):
     print("max |activation| per stage, unscaled:", {k: round(v, 2) for k, v in base_max.items()}, " x%g:" % scale, {k: round(v, 3) for k, v in smax.items()})
     assert max(smax.values()) < 65504 * 0.5
     assert rel_l2(f2 / scale, f1) < 1e-3
+
+
+def test_saturated_f16_stores_are_counted_on_the_device():
+    """The inference stores clamp at +-65504 (csrc/common.h) where the reference's run would carry an inf: `I3Res50.check_saturation` makes that observable
+    (tedspad_count_saturated over the stage outputs of the PRODUCTION forward: fused kernels, no taps). 0 on the synthetic weights; with the stem's BatchNorm
+    scaled x 4096 (every later activation scales along, test above) the deep stages hit the limit and the counter fires; extraction warns."""
+    import warnings
+    from ted_spad_amd import engine as E, extraction
+    from ted_spad_amd.model_loaders import load_ft_model
+    ft = load_ft_model("largei3d", num_classes=102)
+    sd = synth_state_dict(ft.state_dict(), 0)
+    x = synth_clips(0, 2, (3, 16, 224, 224)).cuda()
+    ft.load_state_dict(sd)
+    ft = ft.cuda().eval()
+    ft.i3d.check_saturation = True
+    with torch.no_grad():
+        ft.i3d.extract_features(x)
+    assert ft.i3d.saturation_counts() == (0, 0)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k in sd2:
+        bn = k.rsplit(".", 1)[0]
+        if not k.startswith("i3d.") or bn + ".running_var" not in sd2:
+            continue
+        if bn == "i3d.bn1" and k.endswith((".weight", ".bias")):
+            sd2[k] = sd2[k] * 4096.0
+        elif bn != "i3d.bn1" and k.endswith((".bias", ".running_mean")):
+            sd2[k] = sd2[k] * 4096.0
+    ft.load_state_dict(sd2)
+    with torch.no_grad():
+        ft.i3d.extract_features(x)
+        sat, bad = ft.i3d.saturation_counts(reset=False)
+        assert sat > 0 and bad == 0, (sat, bad)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert extraction.warn_if_saturated(ft) == sat
+        assert any("saturated" in str(i.message) for i in w)
+    assert ft.i3d.saturation_counts() == (0, 0)                 # read and reset
+    # the kernel itself on a known tensor: 3 elements at the limit, 2 not finite, a pixel stride wider than the channels
+    t = torch.zeros(5, 1, 3, 7, 24, dtype=torch.float16, device="cuda")
+    t[0, 0, 0, 0, 1] = 65504.0; t[4, 0, 2, 6, 15] = -65504.0; t[2, 0, 1, 3, 8] = 65504.0
+    t[1, 0, 0, 0, 0] = float("inf"); t[3, 0, 2, 2, 9] = float("nan")
+    t[0, 0, 0, 0, 20] = 65504.0                                  # outside the 16 channels counted
+    c = E.count_saturated(E.Act(t, 16))
+    assert c.cpu().tolist() == [3, 2]

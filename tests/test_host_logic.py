@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libtedspad_hip.so lacks %s" % name
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().tedspad_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().tedspad_abi_version() == _lib.ABI_VERSION == 5
 
 
 # kernels that are allowed to keep private memory, with the reason; everything else in the library must have NO VGPR spill and NO scratch
