@@ -19,6 +19,8 @@
 //     v_permlane16_swap turns the 16 x 16 x 32 accumulator quads (4 channels = 8 bytes per lane) into 16-byte pieces, 64 contiguous bytes per pixel and store;
 //   * the training extras from registers as well: batch statistics are summed per lane over ALL tiles of the workgroup and flushed once (2 atomic
 //     instructions per wave instead of 128 atomics per patch), fp32 output, ReLU-backward mask, residual.
+//   * LOADER WAVES for the streamed-weight inference variants (template flag LDR): waves 8..11 issue every LDS-DMA instruction and do the counted waits, on the same phase
+//     schedule; the compute waves' load segments are fragment reads only (400 x 112^2, 128 / 192 / 320 -> 64 channels: 945 / 1 313 / 2 020 -> 850 / 1 200 / 1 847 us).
 // K is walked (half chunk, dh, dw) exactly as tile 38 does: the sums are bit-identical to tile 38's.
 //
 // Ordering argument (segments are the barrier-delimited intervals; group 0 runs LOAD of phase n in segment 2n and COMPUTE in 2n + 1, group 1 one segment later; every
@@ -50,7 +52,7 @@ constexpr int P3_NWS = 6;                                                       
 constexpr int P3_WBASE = 2 * P3_HALO;
 constexpr int P3_SCB = P3_WBASE + P3_NWS * P3_WST;                                  // scale[64] | shift[64]
 constexpr int P3_LDS = P3_SCB + 512;                                                // 160 256
-constexpr int P3_NT = 512;
+constexpr int P3_NT = 512, P3_NTL = 768;                                            // threads: 8 compute waves (two groups of four); LDR: + 4 loader waves
 static_assert(P3_LDS <= 160 * 1024, "one workgroup per CU");
 
 struct Patch3Geo {
@@ -103,8 +105,11 @@ __device__ __forceinline__ P3Tile p3_decode(int tile, const Patch3Geo &g) {
     __builtin_amdgcn_sched_barrier(0)
 
 // GEN: the general epilogue (residual / ReLU-backward mask / fp32 output / bf16); otherwise the inference epilogue (F16: scale / shift, ReLU, saturation, 16-bit store)
-template <typename T, bool SRC, bool STATS, bool RES, bool GEN>
-__global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, const Patch3Geo g, const PatchSrc gs) {
+// LDR (the streamed-weight inference variants): four more waves (8..11, one per SIMD beside its two compute waves) issue every DMA and do the counted waits; the
+// compute waves issue no vector-memory instruction but the epilogue's stores. A vector-memory instruction holds its wave for its queueing time (200-400 cycles behind the CU's
+// other requests: profiles/r06_p3_stamps.md); in a compute wave's load segment that is time its SIMD partner's MFMAs wait for at the next barrier. 168 registers per wave.
+template <typename T, bool SRC, bool STATS, bool RES, bool GEN, bool LDR>
+__global__ __launch_bounds__(LDR ? P3_NTL : P3_NT) void conv_patch3_kernel(const ConvKP p, const Patch3Geo g, const PatchSrc gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,50 +128,61 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     const int nst = (p.y ? 1 : 0) + (p.y32 ? 2 : 0);       // stores per epilogue piece
     const int dbg = g.dbg;                                 // timing ablations (wrong results; TEDSPAD_P3_ABLATE): 4 no epilogue in the loop, 8 no halo DMA in the loop, 16 no weight DMA in the loop
 
-    // ---- halo: a group fetches ITS OWN patch's halo (what a group reads it has waited for itself: one phase between wait and read is enough). Slot s of a patch and half chunk
-    // -> position s >> 2 (halo row, column), LDS piece s & 3; piece i of a thread = slot i * 256 + (tid & 255): i = 0..4, and i = 5 for the group's first wave (16 lanes of data) ----
+    // ---- halo: slot s of a patch and half chunk -> position s >> 2 (halo row, column), LDS piece s & 3; four waves move a patch's 1296 slots: piece i = slot i * 256 + (tid & 255),
+    // i = 0..4, and i = 5 for the first of the four (16 lanes of data). Without loader waves a group fetches ITS OWN patch's halo (what a group reads it has waited for itself:
+    // one phase between wait and read is enough); the loader waves fetch both patches' (entries 0..5: patch 0, 6..11: patch 1) ----
+    constexpr int NHP = LDR ? 12 : 6;
+    const bool loader = LDR && wave >= 8;
+    const int w4 = wave & 3;                               // this wave among the four that move a unit (= wr for a compute wave)
     const int lt = tid & 255;
-    int hgeo[6];                                           // (c8 << 16) | (halo row << 8) | halo column, or -1: no such slot
+    int hgeo[NHP];                                         // (c8 << 16) | (halo row << 8) | halo column, or -1: no such slot
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int ii = 0; ii < NHP; ++ii) {
+        const int i = ii % 6;
         const int sl = i * 256 + lt;
         const int pos = sl >> 2, hr = pos / P3_WH, hcl = pos - hr * P3_WH;
-        hgeo[i] = (sl < P3_PSLOTS && (i < 5 || wr == 0)) ? ((((sl & 3) ^ ((pos >> 1) & 3)) << 3) << 16) | (hr << 8) | hcl : -1;
+        hgeo[ii] = (sl < P3_PSLOTS && (i < 5 || w4 == 0)) ? ((((sl & 3) ^ ((pos >> 1) & 3)) << 3) << 16) | (hr << 8) | hcl : -1;
     }
-    int hpos[6], hposU[SRC ? 6 : 1];                       // pixel index of the slot in the frame (in a half-resolution source), -1: zero
-    auto halo_tile = [&](int tile) {                       // the slots' sources for this group's patch of `tile`
-        int pi = 2 * tile + grp;
-        const bool pon = pi < g.npatch;
-        if (!pon) pi = 2 * tile;
-        const int tw = pi % g.tiles_w, t2 = pi / g.tiles_w;
-        const int pw0 = tw * P3_S, ph0 = (t2 % g.tiles_h) * P3_S, pf = t2 / g.tiles_h;
+    int hpos[NHP], hposU[SRC ? NHP : 1];                   // pixel index of the slot in the frame (in a half-resolution source), -1: zero
+    auto halo_tile = [&](int tile) {                       // the slots' sources: this group's patch of `tile` (loader waves: both patches)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int ih = ph0 - 1 + ((hgeo[i] >> 8) & 0xff), iw = pw0 - 1 + (hgeo[i] & 0xff);
-            const bool ok = hgeo[i] >= 0 && pon && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            hpos[i] = ok ? (pf * p.Hi + ih) * p.Wi + iw : -1;
-            if (SRC) hposU[i] = ok ? (pf * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1) : -1;
+        for (int q0 = 0; q0 < (LDR ? 2 : 1); ++q0) {
+            const int q = LDR ? q0 : grp;
+            int pi = 2 * tile + q;
+            const bool pon = pi < g.npatch;
+            if (!pon) pi = 2 * tile;
+            const int tw = pi % g.tiles_w, t2 = pi / g.tiles_w;
+            const int pw0 = tw * P3_S, ph0 = (t2 % g.tiles_h) * P3_S, pf = t2 / g.tiles_h;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int ii = q0 * 6 + i;
+                const int ih = ph0 - 1 + ((hgeo[ii] >> 8) & 0xff), iw = pw0 - 1 + (hgeo[ii] & 0xff);
+                const bool ok = hgeo[ii] >= 0 && pon && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                hpos[ii] = ok ? (pf * p.Hi + ih) * p.Wi + iw : -1;
+                if (SRC) hposU[ii] = ok ? (pf * (p.Hi >> 1) + (ih >> 1)) * (p.Wi >> 1) + (iw >> 1) : -1;
+            }
         }
     };
-    auto halo_piece = [&](int i, int hcx, int buf) {
+    auto halo_piece = [&](int ii, int hcx, int buf) {
         const uint16_t *sp = p.x + hcx * 32;
         long sl = p.ldx;
-        int pix = hpos[i];
+        int pix = hpos[ii];
         if (SRC) {
             const int ck = hcx >> 1;
             sp = gs.ptr[ck] + (hcx & 1) * 32; sl = gs.ld[ck];
-            if ((gs.up >> ck) & 1) pix = hposU[i];
+            if ((gs.up >> ck) & 1) pix = hposU[ii];
         }
-        lds_dma16(hpos[i] >= 0 ? sp + pix * sl + (hgeo[i] >> 16) : zero, lds0 + buf * P3_HALO + grp * P3_HG + (i * 256 + wr * 64) * 16);
+        const int q = LDR ? ii / 6 : grp, i = ii % 6;
+        lds_dma16(hpos[ii] >= 0 ? sp + pix * sl + (hgeo[ii] >> 16) : zero, lds0 + buf * P3_HALO + q * P3_HG + (i * 256 + w4 * 64) * 16);
     };
 
     // ---- weights: a stage [3 dw][64 co][32 k], piece c of row co at c ^ ((co >> 1) & 3); moved by the four waves of ONE group, a tap each instruction ---------------------
-    const int wco = wr * 16 + (lane >> 2);
+    const int wco = w4 * 16 + (lane >> 2);
     const int wof4 = wco * p.Kpad + (((lane & 3) ^ ((wco >> 1) & 3)) << 3);
     auto issue_stage = [&](int st, int slot) {             // stage st of a tile (every tile streams the same weights) -> ring slot
         const int hcx = st / 3, dh = st - hcx * 3;
         const uint16_t *src = p.w + dh * 3 * p.cin + hcx * 32 + wof4;
-        const unsigned dst = lds0 + P3_WBASE + slot * P3_WST + wr * 1024;
+        const unsigned dst = lds0 + P3_WBASE + slot * P3_WST + w4 * 1024;
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) lds_dma16(src + dw * p.cin, dst + dw * P3_WTAP);
     };
@@ -380,16 +396,67 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
         *reinterpret_cast<float *>(dsm + P3_SCB + 256 + tid * 4) = p.shift[tid];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    halo_tile(t_begin);
-    for (int i = 0; i < 6; ++i)
-        if (i < 5 || wr == 0) halo_piece(i, 0, 0);
-    {
-        const int npre = RES ? S : (total < 4 ? total : 4);      // streamed: stage n + 4 is issued in phase n
-        for (int k = 0; k < npre; ++k)
-            if ((k & 1) == grp) issue_stage(k % S, k);
+    const bool no_h = (dbg & 8) != 0, no_w = (dbg & 16) != 0, no_ep = (dbg & 4) != 0;
+    if constexpr (LDR) {
+        if (loader) {
+            // ================= the loader waves' whole program: the phase schedule and its barriers, a phase's weight stage in its first segment, the halo pieces in its second
+            // (the buffer's last reads -- group 1's third tap of the phase before -- end with the first), then the counted wait =================
+            halo_tile(t_begin);
+            for (int ii = 0; ii < 12; ++ii)
+                if (ii % 6 < 5 || w4 == 0) halo_piece(ii, 0, 0);
+            {
+                const int npre = total < 4 ? total : 4;              // stage n + 4 is issued in phase n
+                for (int k = 0; k < npre; ++k) issue_stage(k % S, k);
+            }
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int n = 0, hb = 0, wislot = 4;
+            for (int tl = 0; tl < ntl; ++tl) {
+                for (int hc = 0; hc < nhc; ++hc) {
+                    const bool h_next_tile = hc + 1 == nhc;
+                    const bool h_exists = (!h_next_tile || tl + 1 < ntl) && !no_h;
+                    const int h_hc = h_next_tile ? 0 : hc + 1;
+#pragma unroll
+                    for (int dh = 0; dh < 3; ++dh) {
+                        if (n + 4 < total && !no_w) issue_stage((hc * 3 + dh + 4) % S, wislot);      // into the slot of stage n - 2
+                        P3_SEG_END();
+                        if (h_exists && dh < 2) {               // patch 0's pieces in the first phase, patch 1's in the second
+                            if (dh == 0 && h_next_tile) halo_tile(t_begin + tl + 1);
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) halo_piece(dh * 6 + i, h_hc, hb ^ 1);
+                            if (w4 == 0) halo_piece(dh * 6 + 5, h_hc, hb ^ 1);
+                        }
+                        // What must have landed when this phase ends (both groups read it from the next phase on): weight stage n + 1 and, after a half chunk's third phase, the next
+                        // half chunk's halo. This wave's queue per half chunk: [phase 0: W x 3, halo x 5 (6)] [phase 1: W x 3, halo x 5 (6)] [phase 2: W x 3]. Stage n + 1 was issued at the
+                        // top of phase n - 3; behind it lie (phase 0) halo 5 | W 3, halo 5 | W 3 | W 3, halo 5 and (phase 1) halo 5 | W 3 | W 3, halo 5 | W 3, halo 5 -- this half chunk's
+                        // halo only if there is one. Behind the halo's last piece lies the stage of phase 2. Counting fewer than were issued only waits longer.
+                        if (n + 5 >= total || n < 3 || no_w || no_h) wait_vmcnt<0>();
+                        else if (dh == 2) wait_vmcnt<3>();
+                        else if (dh == 0) { if (h_exists) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
+                        else { if (h_exists) wait_vmcnt<24>(); else wait_vmcnt<14>(); }
+                        P3_SEG_END();
+                        ++n;
+                        if (++wislot == P3_NWS) wislot = 0;
+                    }
+                    hb ^= 1;
+                }
+            }
+            __builtin_amdgcn_s_barrier();                   // pairs with the last in-loop barrier of waves 4-7
+            return;
+        }
+    } else {
+        halo_tile(t_begin);
+        for (int i = 0; i < 6; ++i)
+            if (i < 5 || wr == 0) halo_piece(i, 0, 0);
+        {
+            const int npre = RES ? S : (total < 4 ? total : 4);      // streamed: stage n + 4 is issued in phase n
+            for (int k = 0; k < npre; ++k)
+                if ((k & 1) == grp) issue_stage(k % S, k);
+        }
+        wait_vmcnt<0>();
     }
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                           // the prologue's DMA has landed (every wave's, or the loaders')
     asm volatile("" ::: "memory");
     if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
@@ -399,7 +466,6 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
     int wslot = 0, wislot = 4;                             // ring slot of the stage read in this phase / issued in this phase (n + 4: its slot held stage n - 2, whose last reads -- the other group's third tap -- ended one segment ago)
     f32x4 acc[4][4];
     uint4 fw[2][4], fa[2][4];                              // two taps' fragments; the third tap's are read into the first set behind the first tap's MFMAs
-    const bool no_h = (dbg & 8) != 0, no_w = (dbg & 16) != 0, no_ep = (dbg & 4) != 0;
     for (int tl = 0; tl < ntl; ++tl) {
         const int tile = t_begin + tl;
 #ifdef TEDSPAD_P3_STAMPS
@@ -424,6 +490,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 // ================= LOAD segment: the three taps of kernel row dh =================
                 P3_STAMP((hc * 3 + dh) * 6 + 0);
                 // DMA first (the longest way to go), then the finished tile's epilogue (the fragment registers are still free for it), then this phase's fragment reads
+                if constexpr (!LDR) {
                 if (h_exists && dh < 2) {                  // pieces 0, 1, 2 (and the group's sixth) in the first phase, 3, 4 in the second
                     if (dh == 0) {
                         if (h_next_tile) halo_tile(tile + 1);
@@ -435,6 +502,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 }
                 const bool w_own = !RES && ((n + 4) & 1) == grp && n + 4 < total && !no_w;       // this group moves stage n + 4
                 if (w_own) issue_stage((hc * 3 + dh + 4) % S, wislot);
+                }
                 P3_STAMP((hc * 3 + dh) * 6 + 1);      // DMA issued
                 if (dh == 0 && hc == 0) {
                     if (tl > 0 && !no_ep) {                // the tile before: its epilogue, straight from the accumulators, beside the other group's MFMAs
@@ -496,7 +564,8 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
                 //   * phases 0 and 1, when stage n + 2 is this group's (issued in phase n - 2; the other group reads it from phase n + 2 on, two phases after this wait): in phase 0 it was the
                 //     youngest of the phase-2 wait before: behind it lie halo x 3 (4), W (n + 4) and the stores; in phase 1 it was issued in the phase-2 load before that wait: behind it lie
                 //     [phase 0] halo x 3 (4), the stores, [phase 1] halo x 2, W (n + 4). (Counting a piece too few only waits longer.)
-                if (RES) {
+                if constexpr (LDR) {
+                } else if (RES) {
                     if (dh == 2 && h_exists) wait_vmcnt<0>();
                 } else if (n + 5 >= total || no_w) {
                     wait_vmcnt<0>();                        // the tail of the run: few stages left in flight, no counting
@@ -528,7 +597,7 @@ __global__ __launch_bounds__(P3_NT) void conv_patch3_kernel(const ConvKP p, cons
 int g_p3_cus = 0;
 bool g_p3_det = false;       // deterministic mode: the persistent kernel's statistics flush is not gated (det_gate.h): it declines statistics then
 
-template <typename T, bool SRC, bool STATS, bool RES, bool GEN>
+template <typename T, bool SRC, bool STATS, bool RES, bool GEN, bool LDR = false>
 int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, const PatchSrc *src) {
     Patch3Geo g;
     g.tiles_h = (p.Ho + P3_S - 1) / P3_S; g.tiles_w = (p.Wo + P3_S - 1) / P3_S;
@@ -545,7 +614,7 @@ int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, con
     int grid = nwg_env > 0 ? nwg_env : g_p3_cus;
     if (grid > g.ntiles) grid = g.ntiles;
     static thread_local int attr_set[2] = {0, 0};
-    auto kfn = conv_patch3_kernel<T, SRC, STATS, RES, GEN>;
+    auto kfn = conv_patch3_kernel<T, SRC, STATS, RES, GEN, LDR>;
     if (!attr_set[T::kDtype]) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("tedspad_conv_fwd: cannot raise the dynamic LDS limit");
@@ -555,7 +624,7 @@ int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, con
     }
     PatchSrc gsrc{};
     if (SRC) gsrc = *src;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(P3_NT), P3_LDS, s, p, g, gsrc);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(LDR ? P3_NTL : P3_NT), P3_LDS, s, p, g, gsrc);
     return check_launch("tedspad_conv_fwd(persistent two-patch halo)");
 }
 
@@ -580,7 +649,12 @@ int32_t launch_conv_patch3(int dtype, const ConvKP &p, int N, int cin, hipStream
         set_error("tedspad_conv_fwd: tile_cfg 40 takes gathered sources with cin >= 128 and without batch statistics only");
         return TEDSPAD_EINVAL;
     }
-#define P3_GO(TT, SRC_, ST_, RES_, GEN_) return launch_patch3_t<TT, SRC_, ST_, RES_, GEN_>(p, frames, cin, s, src)
+    static const bool ldr_ok = getenv("TEDSPAD_P3_LOADERS") == nullptr || atoi(getenv("TEDSPAD_P3_LOADERS")) != 0;      // A/B knob: 0 = the streamed variants without loader waves
+#define P3_GO(TT, SRC_, ST_, RES_, GEN_)                                                                     \
+    do {                                                                                                     \
+        if (!(RES_) && !(ST_) && ldr_ok) return launch_patch3_t<TT, SRC_, false, false, GEN_, true>(p, frames, cin, s, src);   \
+        return launch_patch3_t<TT, SRC_, ST_, RES_, GEN_>(p, frames, cin, s, src);                           \
+    } while (0)
     if (f16) {
         if (res) { if (st) { if (gen) P3_GO(F16, false, true, true, true); P3_GO(F16, false, true, true, false); } if (gen) P3_GO(F16, false, false, true, true); P3_GO(F16, false, false, true, false); }
         if (src) { if (gen) P3_GO(F16, true, false, false, true); P3_GO(F16, true, false, false, false); }
