@@ -451,17 +451,14 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver starts `--gpus 1`: this process has not touched the GPU (importing torch does not) and starts the N ranks as a
         # CHILD `python -m torch.distributed.run` (never an exec), relays rank 0's JSON line (inherited stdout) and exits with the child's code
-        import socket
         import subprocess
-        so = socket.socket()
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-        so.close()
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if args.dry_run_cpu:
             env.setdefault("OMP_NUM_THREADS", "1")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher's own c10d rendezvous on a port IT binds (no probe-close-reuse race with other jobs on the box); 127.0.0.1 because the container's
+        # hostname may not resolve
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd, env=env).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
