@@ -375,19 +375,25 @@ __global__ __launch_bounds__(384) void conv_wgrad3_kernel(const WgradKP p) {
 // conv_wgrad3_kernel walks flat pixels and takes three 66-row activation tiles per 64 outputs (33 KB with dY, each input pixel once per kernel row) plus per-lane
 // row tracking and edge masks. Here a step is a PATCH of 4 rows x 16 columns of one image: its dY tile (64 rows, 8 KB) and ONE halo of 6 x 18 input positions
 // (108 rows, 13.5 KB) that serves all nine taps -- tap (dh, dw) of patch row r is the 16 halo rows from (r + dh) * 18 + dw -- 21.5 KB per 64 outputs. Positions
-// outside the image are zero rows, decided per DMA slot from the patch origin: no edge masks, no row tracking. The 24 KB stage leaves room for a THREE-slot ring
+// outside the image are zero rows, decided per DMA slot from the patch origin: no edge masks, no row tracking. The 22 KB stage leaves room for a THREE-slot ring
 // at two workgroups per CU (the three-tile kernel: two slots, 70 KB), so a step's tiles are requested two steps ahead. MFMA roles, fragment layout and the flush
 // are conv_wgrad3_kernel's. Frames whose width is not a multiple of 16 pay for the zero columns (W = 56: 12.5 %): the host picks per layer (launcher below).
-constexpr int W3P_XR = 128;                        // halo rows per stage (108 used)
-constexpr int W3P_STAGE = WG_SUB + W3P_XR * 128;   // 24 KB
-constexpr int W3P_S = 3;
+constexpr int W3P_STAGE = WG_SUB + 112 * 128;      // 22 KB: 64 dY rows + 112 halo rows (108 used: 14 DMA groups of 8)
+constexpr int W3P_STAGE0 = WG_SUB + 128 * 128;     // without loader waves: 16 halo groups (4 DMA instructions on each of the 6 waves)
 
 struct Wgrad3pGeo {
     int tiles_h, tiles_w, npatch, patches_per_split;
 };
 
-template <typename T>
-__global__ __launch_bounds__(384) void conv_wgrad3p_kernel(const WgradKP p, const Wgrad3pGeo g) {
+// NLD > 0: NLD LOADER waves (6 ..) issue every LDS-DMA instruction of the step (22 groups: the halo's rows 112 .. 127 are never read) and do the counted waits; the six
+// compute waves touch no global memory between the first barrier and the flush, so the ~300 cycles a wave sits behind each DMA instruction it issues (4 per step
+// against 24 MFMAs) leave the MFMA pipes (tile 40's loader waves, conv_patch3.hip): 64 -> 64 at 384 x 112^2 545 -> 420 us, the other UNet shapes -13 ... -19 %.
+// Where a step goes then (scripts/w3p_ablate.sh, 64 -> 64: 419 us whole): MFMAs + barriers alone 265 us (six compute waves on four SIMDs: two of them carry twice
+// the MFMAs), DMA + barriers alone 247 us (1.23 GB: 5 TB/s, the HBM rate), fragment reads + MFMAs without DMA 333 us -- the layer sits AT the ridge (288 FLOP per byte),
+// and the three streams overlap to 0.63 of their sum. Both forms: a halo row's B fragment is read ONCE and serves the up to three (patch row, kernel row) pairs on it
+// -- 6 fragment pairs per step instead of 12 (on its own: no change). S: slots of the ring.
+template <typename T, int NLD, int S>
+__global__ __launch_bounds__(384 + 64 * NLD) void conv_wgrad3p_kernel(const WgradKP p, const Wgrad3pGeo g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,41 +408,78 @@ __global__ __launch_bounds__(384) void conv_wgrad3p_kernel(const WgradKP p, cons
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16w);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
 
-    // ---- DMA roles: 24 groups of 8 rows per step (8 of dY, 16 of halo), group j * 6 + wave for j = 0 .. 3; a lane moves chunk (lane & 7) ^ swz(row) of its row -------
-    int rr[4], rc[4], kcs[4];                         // per group: the row's patch-relative (row, column) -- halo groups: relative to the halo origin -- and its source chunk
-    bool isy[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int gi = j * 6 + wave;                  // wave-uniform
-        isy[j] = gi < 8;
-        const int row = (isy[j] ? gi : gi - 8) * 8 + (lane >> 3);
-        kcs[j] = ((lane & 7) ^ wg_swz(row)) * 8;
-        if (isy[j]) { rr[j] = row >> 4; rc[j] = row & 15; }
-        else { rr[j] = row < 108 ? row / 18 : 64; rc[j] = row < 108 ? row - (row / 18) * 18 : 0; }      // rows 108.. : never inside an image
-    }
-
+    // ---- DMA roles: groups of 8 rows (8 of dY, then the halo's), a lane moves chunk (lane & 7) ^ swz(row) of its row. Without loaders: 24 groups, j * 6 + wave for
+    // j = 0 .. 3; with: the 22 groups that hold rows a fragment reads, j * 2 + (wave - 6) for j = 0 .. 10 (dY for j < 4 on both) -------------------------------------
+    constexpr bool LDR = NLD > 0;
+    constexpr int STG = LDR ? W3P_STAGE : W3P_STAGE0;
+    constexpr int NG = LDR ? 22 : 24, JW = LDR ? NLD : 6, NJ = (NG + JW - 1) / JW;
+    const int w0 = LDR ? wave - 6 : wave;
+    const int n_mine = (NG - w0 + JW - 1) / JW;          // groups of this wave (wave-uniform)
+    auto role = [&](int j, int &r_r, int &r_c, int &kcs, bool &isy) {
+        const int gi = j * JW + w0;                   // wave-uniform
+        isy = gi < 8;
+        const int row = (isy ? gi : gi - 8) * 8 + (lane >> 3);
+        kcs = ((lane & 7) ^ wg_swz(row)) * 8;
+        if (isy) { r_r = row >> 4; r_c = row & 15; }
+        else { r_r = row < 108 ? row / 18 : 64; r_c = row < 108 ? row - (row / 18) * 18 : 0; }      // rows 108.. : never inside an image
+    };
     auto issue = [&](int step, int slot) {
+#ifdef TEDSPAD_W3P_ABLATE
+        if (TEDSPAD_W3P_ABLATE & 4) return;
+#endif
         const int pi = p_begin + step;
         const int tx = pi % g.tiles_w, t2 = pi / g.tiles_w;
         const int ox = tx * 16, oy = (t2 % g.tiles_h) * 4, f = t2 / g.tiles_h;
-        const unsigned stage = lds0 + slot * W3P_STAGE;
+        const unsigned stage = lds0 + slot * STG;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gi = j * 6 + wave;
+        for (int j = 0; j < NJ; ++j) {
+            const int gi = j * JW + w0;
+            if (gi >= NG) break;                          // wave-uniform (the last round of an uneven split)
+            int r_r, r_c, kcs; bool isy;
+            role(j, r_r, r_c, kcs, isy);
             const uint16_t *src;
-            if (isy[j]) {
-                const int y = oy + rr[j], x = ox + rc[j];
-                const bool ok = y < H && x < W && cot * 64 + (kcs[j]) < p.Cout;
-                src = ok ? p.dy + ((size_t)(f * H + y) * W + x) * p.ldy + cot * 64 + kcs[j] : zero;
+            if (isy) {
+                const int y = oy + r_r, x = ox + r_c;
+                const bool ok = y < H && x < W && cot * 64 + kcs < p.Cout;
+                src = ok ? p.dy + ((size_t)(f * H + y) * W + x) * p.ldy + cot * 64 + kcs : zero;
             } else {
-                const int y = oy - 1 + rr[j], x = ox - 1 + rc[j];
+                const int y = oy - 1 + r_r, x = ox - 1 + r_c;
                 const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                src = ok ? p.x + ((size_t)(f * H + y) * W + x) * p.ldx + cc * 64 + kcs[j] : zero;
+                src = ok ? p.x + ((size_t)(f * H + y) * W + x) * p.ldx + cc * 64 + kcs : zero;
             }
-            lds_dma16(src, stage + (isy[j] ? gi * 1024 : WG_SUB + (gi - 8) * 1024));
+            lds_dma16(src, stage + (isy ? gi * 1024 : WG_SUB + (gi - 8) * 1024));
         }
     };
 
+#define W3_SEG() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    if (LDR && wave >= 6) {                            // ---- the loader waves: the ring's producer ----
+        for (int i = 0; i < S - 1 && i < nsteps; ++i) issue(i, i);
+        for (int step = 0; step < nsteps; ++step) {
+            // step's pieces landed; those of the up to S - 2 steps after it may stay in flight (a count the switch does not know waits for everything: stricter, never wrong)
+            const int ahead = min(S - 2, nsteps - 1 - step);
+            switch (ahead * n_mine) {
+                case 3: wait_vmcnt<3>(); break;
+                case 4: wait_vmcnt<4>(); break;
+                case 5: wait_vmcnt<5>(); break;
+                case 6: wait_vmcnt<6>(); break;
+                case 8: wait_vmcnt<8>(); break;
+                case 10: wait_vmcnt<10>(); break;
+                case 11: wait_vmcnt<11>(); break;
+                case 12: wait_vmcnt<12>(); break;
+                case 15: wait_vmcnt<15>(); break;
+                case 16: wait_vmcnt<16>(); break;
+                case 18: wait_vmcnt<18>(); break;
+                case 20: wait_vmcnt<20>(); break;
+                case 22: wait_vmcnt<22>(); break;
+                case 24: wait_vmcnt<24>(); break;
+                case 33: wait_vmcnt<33>(); break;
+                default: wait_vmcnt<0>(); break;
+            }
+            W3_SEG();
+            if (step + S - 1 < nsteps) issue(step + S - 1, (step + S - 1) % S);            // its slot held step - 1: every wave is past it
+        }
+        return;
+    }
 
     // ---- MFMA roles (conv_wgrad3_kernel's) ------------------------------------------------------------------------------------------------------------------------
     const int dw = wave % 3, cih = wave / 3;
@@ -465,37 +508,79 @@ __global__ __launch_bounds__(384) void conv_wgrad3p_kernel(const WgradKP p, cons
         return __builtin_bit_cast(uint2, v);
     };
 
-    if (nsteps > 0) issue(0, 0);
-    if (nsteps > 1) issue(1, 1);
-    for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) wait_vmcnt<4>(); else wait_vmcnt<0>();      // this step's four pieces landed; the next step's may stay in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) issue(step + 2, (step + 2) % W3P_S);        // its slot held step - 1: every wave is past it
-        const unsigned char *Y = smem + (step % W3P_S) * W3P_STAGE;
+    uint4 fa[4][2], fb[6];                                                 // dY fragments of patch row ks (k-step), x fragments of halo row hr = ks + d
+#ifdef TEDSPAD_W3P_ABLATE                                                  // timing experiments only (scripts/w3p_ablate.sh): 1 = no MFMAs, 2 = no fragment reads, 4 = no DMA
+    if (TEDSPAD_W3P_ABLATE & 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fa[i >> 1][i & 1] = make_uint4(lane, i, 0, 0); asm volatile("" : "+v"(fa[i >> 1][i & 1].x), "+v"(fa[i >> 1][i & 1].y), "+v"(fa[i >> 1][i & 1].z), "+v"(fa[i >> 1][i & 1].w)); }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { fb[i] = make_uint4(lane, i, 1, 0); asm volatile("" : "+v"(fb[i].x), "+v"(fb[i].y), "+v"(fb[i].z), "+v"(fb[i].w)); }
+    }
+#endif
+    auto read_frags = [&](int step) {
+#ifdef TEDSPAD_W3P_ABLATE
+        if (TEDSPAD_W3P_ABLATE & 2) return;
+#endif
+        const unsigned char *Y = smem + (step % S) * STG;
         const unsigned char *X = Y + WG_SUB;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                                   // k-step = patch row ks
-            uint4 fa[2];
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const uint2 lo = tr(Y + ks * 16 * 128 + offa[a][0]), hi = tr(Y + ks * 16 * 128 + offa[a][1]);
-                fa[a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                fa[ks][a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
+#pragma unroll
+        for (int hr = 0; hr < 6; ++hr) {
+            uint2 v[2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int rb = hr * 18 + rowb[rd];
+                v[rd] = tr(X + rb * 128 + ((((cb >> 3) ^ wg_swz(rb))) << 4) + (cb & 7) * 2);
+            }
+            fb[hr] = make_uint4(v[0].x, v[0].y, v[1].x, v[1].y);
+        }
+    };
+    auto compute = [&]() {
+#ifdef TEDSPAD_W3P_ABLATE
+        if (TEDSPAD_W3P_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(fa[i >> 1][i & 1].x), "v"(fa[i >> 1][i & 1].y), "v"(fa[i >> 1][i & 1].z), "v"(fa[i >> 1][i & 1].w));
+#pragma unroll
+            for (int i = 0; i < 6; ++i) asm volatile("" :: "v"(fb[i].x), "v"(fb[i].y), "v"(fb[i].z), "v"(fb[i].w));
+            return;
+        }
+#endif
+#pragma unroll
+        for (int hr = 0; hr < 6; ++hr)
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                uint2 v[2];
+                const int ks = hr - d;
+                if (ks < 0 || ks > 3) continue;
 #pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    const int rb = (ks + d) * 18 + rowb[rd];
-                    v[rd] = tr(X + rb * 128 + ((((cb >> 3) ^ wg_swz(rb))) << 4) + (cb & 7) * 2);
-                }
-                const uint4 fb = make_uint4(v[0].x, v[0].y, v[1].x, v[1].y);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) acc[d][a] = T::mfma(fa[a], fb, acc[d][a]);
+                for (int a = 0; a < 2; ++a) acc[d][a] = T::mfma(fa[ks][a], fb[hr], acc[d][a]);
             }
+    };
+    if (LDR) {
+        for (int step = 0; step < nsteps; ++step) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frags(step);
+            compute();
+        }
+    } else {
+        if (nsteps > 0) issue(0, 0);
+        if (nsteps > 1) issue(1, 1);
+        for (int step = 0; step < nsteps; ++step) {
+            if (step + 1 < nsteps) wait_vmcnt<4>(); else wait_vmcnt<0>();      // this step's four pieces landed; the next step's may stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (step + 2 < nsteps) issue(step + 2, (step + 2) % 3);            // its slot held step - 1: every wave is past it
+            read_frags(step);
+            compute();
         }
     }
+#undef W3_SEG
 
     const bool det = det_enter();
     const int l31 = lane & 31, lh = lane >> 5;
@@ -580,10 +665,18 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
             if (sp < 1) sp = 1;
             g3.patches_per_split = (int)((g3.npatch + sp - 1) / sp);
             sp = (g3.npatch + g3.patches_per_split - 1) / g3.patches_per_split;
-            static thread_local int attr3p[2] = {0, 0};
-            const int ti = d->dtype == TEDSPAD_F16 ? 0 : 1;
+            // TEDSPAD_WGRAD3P_LOADERS = 0: without the loader waves (A/B knob). Measured and not kept (profiles/r06_ab_experiments.md): 2 loaders (half the gain), 6 (= 4),
+            // rings of 4 / 5 slots (= 3), the two compute groups a barrier segment apart (slower), an LDS-counter hand-over instead of the barrier (slower)
+            static const bool ld3p = getenv("TEDSPAD_WGRAD3P_LOADERS") == nullptr || atoi(getenv("TEDSPAD_WGRAD3P_LOADERS")) != 0;
+            const int form = ld3p ? 1 : 0;
+            static thread_local int attr3p[4] = {0, 0, 0, 0};
+            const bool h16 = d->dtype == TEDSPAD_F16;
+            const int ti = form * 2 + (h16 ? 0 : 1);
+#define W3P_FN(N) (h16 ? (const void *)conv_wgrad3p_kernel<F16, N, 3> : (const void *)conv_wgrad3p_kernel<BF16, N, 3>)
+            const void *fn = form == 0 ? W3P_FN(0) : W3P_FN(4);
+#undef W3P_FN
+            const int ring = 3;
             if (!attr3p[ti]) {
-                const void *fn = ti == 0 ? (const void *)conv_wgrad3p_kernel<F16> : (const void *)conv_wgrad3p_kernel<BF16>;
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     set_error("tedspad_conv_wgrad: cannot raise the dynamic LDS limit");
                     return TEDSPAD_ELAUNCH;
@@ -591,8 +684,12 @@ extern "C" int32_t tedspad_conv_wgrad(const tedspad_conv_desc *d, const void *x,
                 attr3p[ti] = 1;
             }
             const dim3 gridp((unsigned)(tiles3 * sp));
-            if (ti == 0) hipLaunchKernelGGL((conv_wgrad3p_kernel<F16>), gridp, dim3(384), W3P_S * W3P_STAGE, s, p, g3);
-            else hipLaunchKernelGGL((conv_wgrad3p_kernel<BF16>), gridp, dim3(384), W3P_S * W3P_STAGE, s, p, g3);
+            const int nthr = form == 0 ? 384 : 640;
+            void *kargs[2] = {(void *)&p, (void *)&g3};
+            if (hipLaunchKernel(fn, gridp, dim3(nthr), kargs, ring * (form == 0 ? W3P_STAGE0 : W3P_STAGE), s) != hipSuccess) {
+                set_error("tedspad_conv_wgrad: launch failed");
+                return TEDSPAD_ELAUNCH;
+            }
             return check_launch("tedspad_conv_wgrad");
         }
         if (d->dtype == TEDSPAD_F16) hipLaunchKernelGGL((conv_wgrad3_kernel<F16>), grid3, dim3(384), 0, s, p);
