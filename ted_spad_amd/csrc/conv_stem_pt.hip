@@ -184,17 +184,29 @@ __device__ __forceinline__ void stem_pt_phase16(const unsigned char *dsm, const 
 // converted and written as 4 x 16 bytes (one k8-half of 4 positions). 440 / 400 tasks per row-parity region: one per thread. The loads are ordinary vector
 // loads into registers, so they need no LDS slot while in flight: the rows of patch i + 2 are requested a WHOLE patch before they are written (right after the
 // rows of patch i + 1 left the same registers), which no LDS-DMA ring could afford here (160 KB are full).
-template <typename T, int NW, bool POOL, int MF = 32, bool DIRECT = false>
-__global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
+//
+// LW > 0 (DIRECT): LW LOADER waves beside the NW compute waves. The loaders own everything that touches global memory in the loop -- the fp32 loads of the halo rows,
+// their conversion and LDS writes, the row pooling and its stores -- on the same two barriers per patch, with the same schedule (a region's rows are requested a whole
+// patch before they are written); the compute waves run the MFMA phases and the epilogue into LDS and nothing else, and carry none of the 64 staging registers:
+// 16 waves at 128 registers instead of 8 at 256 (LW = 8: one task per loader thread and region, as in the 8-wave form). On the record path (LW = 4) the loaders issue
+// the halo LDS-DMA and wait for it, and pool the rows. Measured (375 clips, isolated): fp32 clip 4 045 -> 3 880 us, records 3 450 -> 3 160 us; cfg2 bench +1.2 %.
+// What bounds the fp32 form either way is the VALU port the conversion (3 instructions per value pair) and the address arithmetic share with the MFMA issue.
+template <typename T, int NW, bool POOL, int MF = 32, bool DIRECT = false, int LW = 0>
+__global__ __launch_bounds__(64 * (NW + LW)) void conv_stem_pt_kernel(const StemPT p) {
     static_assert(MF == 32 || (MF == 16 && NW == 8 && POOL), "the 16x16x32 form is built for 8 waves with the pool fused");
     static_assert(!DIRECT || (MF == 16 && NW == 8 && POOL), "the fp32-clip loader is built for the production form");
+    static_assert(LW == 0 || (MF == 16 && NW == 8 && POOL), "loader waves are built for the production forms");
     constexpr int NA = NW == 8 ? 1 : 2;
     constexpr int XB_OFF = pt_xb_off(MF);
-    constexpr int PIT = (PT_POOL_PIECES + 64 * NW - 1) / (64 * NW);
-    constexpr int ROUNDS = (pt_jobs(0) + NW - 1) / NW;
+    constexpr int NPT = 64 * (LW ? LW : NW);                 // threads that pool rows / (LW) own loader tasks
+    constexpr int PIT = (PT_POOL_PIECES + NPT - 1) / NPT;
+    constexpr int NTK = LW ? (4 * pt_rows(0) * 10 + NPT - 1) / NPT : 1;      // loader tasks per thread and region
+    constexpr int NLW = LW ? LW : NW;                        // waves that issue the record path's halo DMA
+    constexpr int ROUNDS = (pt_jobs(0) + NLW - 1) / NLW;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptid = LW ? tid - 64 * NW : tid;             // index among the pooling / loader threads (LW: negative on the compute waves, which do neither)
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)dsm;
     const unsigned char *zero = reinterpret_cast<const unsigned char *>(&g_zero16s);
 
@@ -207,15 +219,18 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     if (k >= lim) return;                                   // workgroup-uniform, before any barrier
 
     // ---- resident weights: a linear 98 KB copy --------------------------------------------------------------------------------
-    for (int j = wave; j < pt_wbytes(MF) / 1024; j += NW) lds_dma16(p.wimg + j * 1024 + lane * 16, lds0 + PT_W_OFF + j * 1024);
+    if (wave < NW)
+        for (int j = wave; j < pt_wbytes(MF) / 1024; j += NW) lds_dma16(p.wimg + j * 1024 + lane * 16, lds0 + PT_W_OFF + j * 1024);
 
     // ---- halo DMA slots of this lane (patch-invariant): LDS slot s of a region = (frame, row, plane, position, half) --------------
     int off[2][ROUNDS], rc[2][ROUNDS];
+    const int dw0 = LW ? wave - NW : wave;                   // index among the DMA-issuing waves
+    auto setup_dma = [&]() {
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
-            const int s = (i * NW + wave) * 64 + lane;
+            const int s = (i * NLW + dw0) * 64 + lane;
             const int hs = s & 1;
             int q = s >> 1;
             const int pos = q % PT_PP; q /= PT_PP;
@@ -227,6 +242,8 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
             off[par][i] = ok ? f * 12 + hf * 16 + hr * p.sH + b * p.sP + (pos - 2) * PT_REC : 0;
             rc[par][i] = ok ? (hr << 8) | pos : (1 << 28);              // a row far outside any clip: the slot reads the zero page
         }
+    };
+    if (!DIRECT && !LW) setup_dma();                         // (LW: inside the loader branch)
 
     // patch coordinates advance by a constant step (nx patches): mixed-radix addition with carries instead of three integer
     // divisions per patch
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     auto issue = [&](int par, const Patch &q) {              // par is a literal at every call site
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
-            const int j = i * NW + wave;
+            const int j = i * NLW + dw0;
             if (j >= pt_jobs(par)) break;                    // wave-uniform
             const bool ok = (unsigned)(q.ih0 + (rc[par][i] >> 8)) < (unsigned)p.H && (unsigned)(q.wqm2 + (rc[par][i] & 255)) < (unsigned)p.Wq;
             lds_dma16(ok ? q.pb + off[par][i] : zero, lds0 + pt_off(par) + j * 1024);
@@ -273,38 +290,57 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     // ---- DIRECT: this thread's task of either region: (frame f, half hs) = tid / (rows * 10), halo row, column quad q4c ------------------------------
     // so[par][e]: element offset of plane e's 4 columns from the patch base; fsch[par]: 3 bits frame slot + 2 bits channel per e; ldst[par]: LDS byte
     // address of the first of the 4 positions' halves (j -> + (j >> 1) * 32 + (j & 1) * plane); dcol / drow: halo column / row of the task
-    int so[2][8], fsch[2][2], ldst[2], dcol[2], drow[2];
-    f32x4 stage[2][8];
-    if (DIRECT) {
+    int so[2][NTK][LW ? 1 : 8], fsch[2][NTK][2], ldst[2][NTK], dcol[2][NTK], drow[2][NTK];      // LW: so[.][.][0] = the task's (row, column) offset, the plane offsets are formed per load
+    f32x4 stage[2][NTK][8];
+    auto setup_tasks = [&]() {
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int per = pt_rows(par) * 10;
-            const int fh = tid / per, rem = tid - fh * per;
-            const int row = rem / 10, q4c = rem - row * 10;
-            const int f = fh >> 1, hs = fh & 1, hr = 2 * row + par;
-            const bool task = fh < 4;
-            drow[par] = task ? hr : (1 << 20);                 // no task: a row outside every clip -> zero page, and nothing is written (ldst < 0)
-            dcol[par] = 4 * q4c;
-            ldst[par] = task ? pt_off(par) + f * pt_frame(par) + row * PT_ROWB + 2 * q4c * 32 + 16 * hs : -1;
-            fsch[par][0] = fsch[par][1] = 0;
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int t = 0; t < NTK; ++t) {
+                const int tk = ptid + t * NPT;
+                const int per = pt_rows(par) * 10;
+                const int fh = tk / per, rem = tk - fh * per;
+                const int row = rem / 10, q4c = rem - row * 10;
+                const int f = fh >> 1, hs = fh & 1, hr = 2 * row + par;
+                const bool task = fh < 4;
+                drow[par][t] = task ? hr : (1 << 20);          // no task: a row outside every clip -> zero page, and nothing is written (ldst < 0)
+                dcol[par][t] = 4 * q4c;
+                ldst[par][t] = task ? pt_off(par) + f * pt_frame(par) + row * PT_ROWB + 2 * q4c * 32 + 16 * hs : -1;
+                if (LW) { drow[par][t] = (task ? hr : 4095) | (4 * q4c) << 12 | (fh & 3) << 20; dcol[par][t] = 0; so[par][t][0] = hr * p.sHf + 4 * q4c; }      // LW: row / column / (f, hs) in one word, one offset (the loader waves run at 128 registers)
+                fsch[par][t][0] = fsch[par][t][1] = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int v = 6 * f + 8 * hs + e, fs = v / 3, ch = v - 3 * fs;
+                    if (!LW) so[par][t][e] = ch * p.sC + fs * p.sT + hr * p.sHf + 4 * q4c;
+                    fsch[par][t][e >> 2] |= (fs | (ch << 3)) << (8 * (e & 3));
+                }
+            }
+    };
+    if (DIRECT && !LW) setup_tasks();                       // (LW: inside the loader branch -- nothing of it may be live on the compute waves' path)
+    auto ldst_of = [&](int par, int t) -> int {              // LDS byte address of the task's first half (-1: no task)
+        return ldst[par][t];
+    };
+    auto issue_d = [&](int par, const Patch &q) {           // par is a literal at every call site
+        const int tt0 = 4 * q.tp - p.pad_t;
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) {
+            int fc0 = fsch[par][t][0], fc1 = fsch[par][t][1], meta = drow[par][t], sb = so[par][t][0];
+            if (LW) asm volatile("" : "+v"(meta), "+v"(sb), "+v"(fc0), "+v"(fc1));      // or hipcc hoists the 32 plane offsets out of the patch loop and spills them
+            const int t_row = LW ? meta & 4095 : drow[par][t], t_col = LW ? (meta >> 12) & 255 : dcol[par][t];
+            const bool rowok = (unsigned)(q.ih0 + t_row) < (unsigned)p.H && (unsigned)(2 * q.wo0 - 4 + t_col) < (unsigned)p.W;
+            const bool hs1 = LW ? (t_row != 4095 && ((meta >> 20) & 1)) : (ldst[par][t] >= 0 && ((ldst[par][t] >> 4) & 1));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int v = 6 * f + 8 * hs + e, fs = v / 3, ch = v - 3 * fs;
-                so[par][e] = ch * p.sC + fs * p.sT + hr * p.sHf + 4 * q4c;
-                fsch[par][e >> 2] |= (fs | (ch << 3)) << (8 * (e & 3));
+                const int code = ((e < 4 ? fc0 : fc1) >> (8 * (e & 3))) & 255;
+                const bool ok = rowok && (unsigned)(tt0 + (code & 7)) < (unsigned)p.T && (code >> 3) < p.C && !(e == 7 && hs1);   // value 15 of a position meets a zero weight
+                const int o = LW ? sb + (code >> 3) * p.sC + (code & 7) * p.sT : so[par][t][e];
+                const float *src = ok ? q.pf + o : reinterpret_cast<const float *>(zero);
+                // one load from a per-lane address: left to itself hipcc turns the select into two masked loads of the same registers (clip / zero page) with an
+                // s_waitcnt vmcnt(0) between them, which serialises a thread's eight loads into four round trips
+                unsigned long sa = reinterpret_cast<unsigned long>(src);
+                asm volatile("" : "+v"(sa));
+                stage[par][t][e] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(sa);      // (address space 1: a global_load, not a flat one)
             }
-        }
-    }
-    auto issue_d = [&](int par, const Patch &q) {           // par is a literal at every call site
-        const bool rowok = (unsigned)(q.ih0 + drow[par]) < (unsigned)p.H && (unsigned)(2 * q.wo0 - 4 + dcol[par]) < (unsigned)p.W;
-        const int tt0 = 4 * q.tp - p.pad_t;
-        const bool hs1 = ldst[par] >= 0 && ((ldst[par] >> 4) & 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int code = (fsch[par][e >> 2] >> (8 * (e & 3))) & 255;
-            const bool ok = rowok && (unsigned)(tt0 + (code & 7)) < (unsigned)p.T && (code >> 3) < p.C && !(e == 7 && hs1);   // value 15 of a position meets a zero weight
-            const float *src = ok ? q.pf + so[par][e] : reinterpret_cast<const float *>(zero);
-            stage[par][e] = *reinterpret_cast<const f32x4 *>(src);
         }
         asm volatile("" ::: "memory");                       // the loads stay here (the registers are meant to be live across the next MFMA phase)
     };
@@ -318,28 +354,165 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
             return (unsigned)T::from_f32(a) | ((unsigned)T::from_f32(b) << 16);
         }
     };
-    auto commit_d = [&](int par) {                           // registers -> 4 x 16 bytes of the region's LDS image
-        if (ldst[par] < 0) return;
-        const bool last = dcol[par] == 36;                   // columns 38, 39 are outside the halo (19 positions per plane)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 v = make_uint4(cvt2(stage[par][0][j], stage[par][1][j]), cvt2(stage[par][2][j], stage[par][3][j]),
-                                       cvt2(stage[par][4][j], stage[par][5][j]), cvt2(stage[par][6][j], stage[par][7][j]));
-            if (j < 2 || !last) *reinterpret_cast<uint4 *>(dsm + ldst[par] + (j >> 1) * 32 + (j & 1) * (PT_PP * 32)) = v;
-        }
+    auto pack_d = [&](int buf, int t, int j) -> uint4 {
+        return make_uint4(cvt2(stage[buf][t][0][j], stage[buf][t][1][j]), cvt2(stage[buf][t][2][j], stage[buf][t][3][j]),
+                          cvt2(stage[buf][t][4][j], stage[buf][t][5][j]), cvt2(stage[buf][t][6][j], stage[buf][t][7][j]));
     };
-
+    auto write_d = [&](int par, int t, int j, uint4 v) {    // one k8-half of position j of the task's four
+        const bool last = (LW ? (drow[par][t] >> 12) & 255 : dcol[par][t]) == 36;      // columns 38, 39 are outside the halo (19 positions per plane)
+        const int la = ldst_of(par, t);
+        if (la >= 0 && (j < 2 || !last)) *reinterpret_cast<uint4 *>(dsm + la + (j >> 1) * 32 + (j & 1) * (PT_PP * 32)) = v;
+    };
+    auto commit_d = [&](int par) {                           // registers -> 4 x 16 bytes of the region's LDS image
+#pragma unroll
+        for (int t = 0; t < NTK; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) write_d(par, t, j, pack_d(par, t, j));
+    };
     Patch cur;
     split(base + k, cur.n, cur.tp, cur.th, cur.tw);
     locate(cur);
-    if (DIRECT) {
+    if (DIRECT && !LW) {
         issue_d(0, cur);
         issue_d(1, cur);
         commit_d(0);
         commit_d(1);
-    } else {
+    } else if (!DIRECT && !LW) {
         issue(0, cur);
         issue(1, cur);
+    }
+
+    // the successor of patch (c, kc) in this workgroup's walk (and whether there is one)
+    auto successor = [&](const Patch &c, int kc, Patch &out, int &kout) -> bool {
+        const bool wrap = !POOL || c.th + 1 == p.tiles_h;
+        kout = wrap ? kc + nx : kc;
+        out = c;
+        if (kout >= lim) return false;                      // workgroup-uniform
+        out = advance(c);
+        return true;
+    };
+    const bool dma = !(p.dbg & 1);
+    // ---- POOL: this thread's pieces of the row pooling: u -> (pooled row i of the patch, slot, 8-channel group) --------------------
+    int pxo[PIT], pi[PIT], psl[PIT];
+    uint4 carry[PIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        const int u = ptid + it * NPT;
+        psl[it] = (u >> 3) % 9;
+        pi[it] = (u >= 0 && u < PT_POOL_PIECES) ? (u >> 3) / 9 : -1;
+        pxo[it] = XB_OFF + psl[it] * 128 + (u & 7) * 16;
+        carry[it] = make_uint4(0, 0, 0, 0);
+    }
+    auto pool_rows = [&](const Patch &q) {
+        const size_t fr = (size_t)q.n * p.Tp + q.tp;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            if (LW) {                                       // the loader waves re-derive their piece per patch (three registers; they run at 128)
+                int u = ptid + it * NPT;
+                asm volatile("" : "+v"(u));
+                psl[it] = (u >> 3) % 9;
+                pi[it] = u < PT_POOL_PIECES ? (u >> 3) / 9 : -1;
+                pxo[it] = XB_OFF + psl[it] * 128 + (u & 7) * 16;
+            }
+            if (pi[it] < 0) continue;
+            const unsigned char *xb = dsm + pxo[it];
+            uint4 m;
+            int pr;
+            if (pi[it] < 3) {
+                const unsigned char *r = xb + 2 * pi[it] * PT_XB_ROW;
+                m = pk_max8<T>(pk_max8<T>(*reinterpret_cast<const uint4 *>(r), *reinterpret_cast<const uint4 *>(r + PT_XB_ROW)),
+                               *reinterpret_cast<const uint4 *>(r + 2 * PT_XB_ROW));
+                pr = 4 * q.th + pi[it];
+            } else {                                        // rows 6, 7 of the patch above + row 0 of this one
+                m = pk_max8<T>(carry[it], *reinterpret_cast<const uint4 *>(xb));
+                carry[it] = pk_max8<T>(*reinterpret_cast<const uint4 *>(xb + 6 * PT_XB_ROW), *reinterpret_cast<const uint4 *>(xb + 7 * PT_XB_ROW));
+                pr = q.th > 0 ? 4 * q.th - 1 : p.Hp;
+            }
+            const int pc = 8 * q.tw + psl[it];
+            uint16_t *dst = psl[it] < 8 ? p.y + ((fr * p.Hp + pr) * p.Wp + pc) * p.ldy : p.side + ((fr * p.Hp + pr) * p.tiles_w + q.tw) * 64;
+            if (pr < p.Hp && (psl[it] == 8 || pc < p.Wp) && !(p.dbg & 2)) gstore16(dst + (pxo[it] & 127) / 2, __builtin_bit_cast(u32x4, m));
+        }
+    };
+
+
+    // ---- LW: the loader waves ---------------------------------------------------------------------------------------------------------------------------------------
+    // barriers: #0 (weights + both regions of the first patch), then per patch MID (even rows read, odd rows visible) and END (odd rows read, even rows of the next patch
+    // visible; not after the last patch), then the final one before the last patch's row pooling -- the compute waves' sequence below.
+    if (LW && !DIRECT && wave >= NW) {                       // ---- record path: the loaders issue the halo DMA (the schedule of the 8-wave form: a region is requested when the barrier frees it)
+        setup_dma();
+        Patch c = cur, n1 = cur;
+        int kc = k, k1 = 0;
+        issue(0, c);
+        issue(1, c);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                         // #0
+        asm volatile("" ::: "memory");
+        while (true) {
+            const bool more1 = successor(c, kc, n1, k1);
+            wait_vmcnt<0>();                                  // the odd rows of patch c (and the row-pooling stores of the patch before) landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // MID of patch c
+            asm volatile("" ::: "memory");
+            if (more1 && dma) issue(0, n1);
+            if (!more1) break;
+            wait_vmcnt<0>();                                  // the even rows of the next patch landed
+            __builtin_amdgcn_s_barrier();                     // END of patch c
+            asm volatile("" ::: "memory");
+            if (dma) issue(1, n1);
+            pool_rows(c);
+            c = n1; kc = k1;
+        }
+        asm volatile("; record loaders: last barrier" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        pool_rows(c);
+        return;
+    }
+    if (LW && DIRECT && wave >= NW) {
+        setup_tasks();
+        Patch c = cur, n1 = cur, n2 = cur;
+        int kc = k, k1 = 0, k2 = 0;
+        bool more1 = successor(c, kc, n1, k1);
+        bool more2 = more1 && successor(n1, k1, n2, k2);
+        issue_d(0, c);
+        issue_d(1, c);
+        wait_vmcnt<0>();
+        commit_d(0);
+        commit_d(1);
+        bool l1 = more1 && dma;                               // the next patch's rows are to be loaded (dbg 1: none after the first patch)
+        if (l1) { issue_d(0, n1); issue_d(1, n1); }           // the second patch's rows are in flight before the first one starts
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // #0
+        asm volatile("" ::: "memory");
+        while (true) {
+            const bool l2 = more2 && dma;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // MID of patch c: its even rows are free
+            asm volatile("" ::: "memory");
+            if (l1) {
+                wait_vmcnt<8 * NTK>();                        // the even rows of the next patch, requested a patch ago (behind them: its odd rows, at most one pooling store)
+                commit_d(0);
+                if (l2) issue_d(0, n2);                       // even rows two patches ahead take over the registers
+            }
+            if (!more1) break;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // END of patch c: its odd rows are free, its column-pooled rows are in LDS
+            asm volatile("" ::: "memory");
+            if (l1) {
+                if (l2) wait_vmcnt<8 * NTK>(); else wait_vmcnt<0>();
+                commit_d(1);                                  // odd rows of the next patch
+                if (l2) issue_d(1, n2);
+            }
+            pool_rows(c);
+            c = n1; kc = k1;
+            more1 = more2; n1 = n2; k1 = k2; l1 = l2;
+            more2 = more1 && successor(n1, k1, n2, k2);
+        }
+        asm volatile("; loader waves: last barrier" ::: "memory");   // (a distinct statement: hipcc otherwise merges this tail with the compute waves' and keeps the loaders' state live across THEIR loop: two spills)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        pool_rows(c);
+        return;
     }
 
     // ---- fragment bases ---------------------------------------------------------------------------------------------------------
@@ -389,17 +562,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(sc[a][r]), "+v"(sf[a][r]));   // hipcc's wait for these loads happens here, not in the loop
 
-    // the successor of patch (c, kc) in this workgroup's walk (and whether there is one)
-    auto successor = [&](const Patch &c, int kc, Patch &out, int &kout) -> bool {
-        const bool wrap = !POOL || c.th + 1 == p.tiles_h;
-        kout = wrap ? kc + nx : kc;
-        out = c;
-        if (kout >= lim) return false;                      // workgroup-uniform
-        out = advance(c);
-        return true;
-    };
-    const bool dma = !(p.dbg & 1);
-    if (DIRECT && dma) {                                    // the second patch's rows are in flight before the first one starts
+    if (DIRECT && !LW && dma) {                             // the second patch's rows are in flight before the first one starts
         Patch n1; int k1;
         if (successor(cur, k, n1, k1)) { issue_d(0, n1); issue_d(1, n1); }
     }
@@ -407,41 +570,6 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // weights + both halo regions of the first patch visible
     asm volatile("" ::: "memory");
-
-    // ---- POOL: this thread's pieces of the row pooling: u -> (pooled row i of the patch, slot, 8-channel group) --------------------
-    int pxo[PIT], pi[PIT], psl[PIT];
-    uint4 carry[PIT];
-#pragma unroll
-    for (int it = 0; it < PIT; ++it) {
-        const int u = tid + it * 64 * NW;
-        psl[it] = (u >> 3) % 9;
-        pi[it] = u < PT_POOL_PIECES ? (u >> 3) / 9 : -1;
-        pxo[it] = XB_OFF + psl[it] * 128 + (u & 7) * 16;
-        carry[it] = make_uint4(0, 0, 0, 0);
-    }
-    auto pool_rows = [&](const Patch &q) {
-        const size_t fr = (size_t)q.n * p.Tp + q.tp;
-#pragma unroll
-        for (int it = 0; it < PIT; ++it) {
-            if (pi[it] < 0) continue;
-            const unsigned char *xb = dsm + pxo[it];
-            uint4 m;
-            int pr;
-            if (pi[it] < 3) {
-                const unsigned char *r = xb + 2 * pi[it] * PT_XB_ROW;
-                m = pk_max8<T>(pk_max8<T>(*reinterpret_cast<const uint4 *>(r), *reinterpret_cast<const uint4 *>(r + PT_XB_ROW)),
-                               *reinterpret_cast<const uint4 *>(r + 2 * PT_XB_ROW));
-                pr = 4 * q.th + pi[it];
-            } else {                                        // rows 6, 7 of the patch above + row 0 of this one
-                m = pk_max8<T>(carry[it], *reinterpret_cast<const uint4 *>(xb));
-                carry[it] = pk_max8<T>(*reinterpret_cast<const uint4 *>(xb + 6 * PT_XB_ROW), *reinterpret_cast<const uint4 *>(xb + 7 * PT_XB_ROW));
-                pr = q.th > 0 ? 4 * q.th - 1 : p.Hp;
-            }
-            const int pc = 8 * q.tw + psl[it];
-            uint16_t *dst = psl[it] < 8 ? p.y + ((fr * p.Hp + pr) * p.Wp + pc) * p.ldy : p.side + ((fr * p.Hp + pr) * p.tiles_w + q.tw) * 64;
-            if (pr < p.Hp && (psl[it] == 8 || pc < p.Wp) && !(p.dbg & 2)) gstore16(dst + (pxo[it] & 127) / 2, __builtin_bit_cast(u32x4, m));
-        }
-    };
 
     bool pending = false;                                   // POOL: the column-pooled rows of `prev` wait in LDS
     Patch prev = cur;
@@ -451,8 +579,8 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         const bool more = successor(cur, k, nxt, kn);       // workgroup-uniform
         bool more2 = false;
         nn = nxt;
-        if (DIRECT && more) more2 = successor(nxt, kn, nn, kn2);
-        if (POOL && pending) pool_rows(prev);               // before this patch's mid barrier; the epilogue after it rewrites the rows
+        if (DIRECT && !LW && more) more2 = successor(nxt, kn, nn, kn2);
+        if (POOL && !LW && pending) pool_rows(prev);        // before this patch's mid barrier; the epilogue after it rewrites the rows
 
         f32x16 acc[NA][2];
         f32x4 acc16[2][2][2];              // MF = 16: [16-channel block][row r / r + 4][frame]
@@ -471,16 +599,16 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
 
         if (MF == 16) { if (!(p.dbg & 4)) stem_pt_phase16<T, 0>(dsm, pb16, wa16, acc16); }
         else if (!(p.dbg & 4)) stem_pt_phase<T, 0, NA>(dsm, pa, wa, acc);             // taps dh = 0, 2, 4, 6 on the even halo rows
-        if (!DIRECT) wait_vmcnt<0>();                       // odd rows of this patch (the youngest operation of this wave) landed
+        if (!DIRECT && !LW) wait_vmcnt<0>();                // odd rows of this patch (the youngest operation of this wave) landed
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // DIRECT: this wave's writes of the odd rows (after the previous barrier) are in LDS
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the even rows
         asm volatile("" ::: "memory");
         if (DIRECT) {
-            if (more && dma) {
+            if (!LW && more && dma) {
                 commit_d(0);                                // even rows of the NEXT patch: requested a patch ago, written under the odd taps
                 if (more2) issue_d(0, nn);                  // ... and the ones after them take over the registers
             }
-        } else if (more && dma) issue(0, nxt);              // even rows of the NEXT patch land under the odd taps + epilogue
+        } else if (!LW && more && dma) issue(0, nxt);       // even rows of the NEXT patch land under the odd taps + epilogue
         if (MF == 16) { if (!(p.dbg & 4)) stem_pt_phase16<T, 1>(dsm, pb16, wa16, acc16); }
         else if (!(p.dbg & 4)) stem_pt_phase<T, 1, NA>(dsm, pa, wa, acc);             // taps dh = 1, 3, 5 on the odd halo rows
 
@@ -601,15 +729,16 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
         // even rows of the next patch landed; this patch's stores (issued after them; vector-memory operations retire in issue
         // order on gfx9) stay in flight
         if (DIRECT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the even rows this wave wrote after the mid barrier are in LDS
+        else if (LW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else if (stored) wait_vmcnt<2 * NA>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // ... for every wave; every wave is done reading the odd rows
         asm volatile("" ::: "memory");
         if (DIRECT) {
-            if (dma) {
+            if (!LW && dma) {
                 commit_d(1);
                 if (more2) issue_d(1, nn);
             }
-        } else if (dma) issue(1, nxt);                      // odd rows of the next patch land under its even taps
+        } else if (!LW && dma) issue(1, nxt);               // odd rows of the next patch land under its even taps
         prev = cur;
         pending = POOL;
         cur = nxt;
@@ -618,7 +747,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stem_pt_kernel(const StemPT p) {
     if (POOL) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        pool_rows(cur);
+        if (!LW) pool_rows(cur);
     }
 }
 
@@ -784,9 +913,11 @@ static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_i
     const int w8 = (variant >> 1) & 1;
     p.dbg = (variant >> 8) & 15;
     if (direct) {                          // the same form reading the fp32 clip itself
-        static thread_local int attrd[2] = {0, 0};
-        const int ti = dtype == TEDSPAD_F16 ? 0 : 1;
-        const void *fnd = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16, true> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16, true>;
+        static const bool lw = getenv("TEDSPAD_STEM_LOADERS") == nullptr || atoi(getenv("TEDSPAD_STEM_LOADERS")) != 0;       // A/B knob: 0 = the 8-wave form
+        static thread_local int attrd[4] = {0, 0, 0, 0};
+        const int ti = (dtype == TEDSPAD_F16 ? 0 : 1) + (lw ? 2 : 0);
+        const void *fnd = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16, true> : ti == 1 ? (const void *)conv_stem_pt_kernel<BF16, 8, true, 16, true>
+                        : ti == 2 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16, true, 8> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16, true, 8>;
         if (!attrd[ti]) {
             if (hipFuncSetAttribute(fnd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 set_error("%s: cannot raise the dynamic LDS limit", who);
@@ -795,11 +926,15 @@ static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_i
             attrd[ti] = 1;
         }
         if (ti == 0) hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true, 16, true>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
-        else hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16, true>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
-    } else if (pool && (variant & 4)) {           // 16x16x32 MFMA form (8 waves; w_img in the tap-pair layout)
-        static thread_local int attr16[2] = {0, 0};
-        const int ti = dtype == TEDSPAD_F16 ? 0 : 1;
-        const void *fn16 = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16>;
+        else if (ti == 1) hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16, true>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+        else if (ti == 2) hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true, 16, true, 8>), dim3(grid), dim3(1024), pt_lds_pool(16), s, p);
+        else hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16, true, 8>), dim3(grid), dim3(1024), pt_lds_pool(16), s, p);
+    } else if (pool && (variant & 4)) {           // 16x16x32 MFMA form (8 waves; w_img in the tap-pair layout), by default with 4 loader waves issuing its halo DMA
+        static const bool lw = getenv("TEDSPAD_STEM_LOADERS") == nullptr || atoi(getenv("TEDSPAD_STEM_LOADERS")) != 0;       // A/B knob: 0 = the 8-wave form (8 loader waves measured the same as 4)
+        static thread_local int attr16[4] = {0, 0, 0, 0};
+        const int ti = (dtype == TEDSPAD_F16 ? 0 : 1) + (lw ? 2 : 0);
+        const void *fn16 = ti == 0 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16> : ti == 1 ? (const void *)conv_stem_pt_kernel<BF16, 8, true, 16>
+                         : ti == 2 ? (const void *)conv_stem_pt_kernel<F16, 8, true, 16, false, 4> : (const void *)conv_stem_pt_kernel<BF16, 8, true, 16, false, 4>;
         if (!attr16[ti]) {
             if (hipFuncSetAttribute(fn16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 set_error("%s: cannot raise the dynamic LDS limit", who);
@@ -808,7 +943,9 @@ static int32_t stem_pt_launch(const char *who, const void *x_tp, const void *w_i
             attr16[ti] = 1;
         }
         if (ti == 0) hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true, 16>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
-        else hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+        else if (ti == 1) hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16>), dim3(grid), dim3(512), pt_lds_pool(16), s, p);
+        else if (ti == 2) hipLaunchKernelGGL((conv_stem_pt_kernel<F16, 8, true, 16, false, 4>), dim3(grid), dim3(768), pt_lds_pool(16), s, p);
+        else hipLaunchKernelGGL((conv_stem_pt_kernel<BF16, 8, true, 16, false, 4>), dim3(grid), dim3(768), pt_lds_pool(16), s, p);
     } else {
     const int di = ((dtype == TEDSPAD_F16 ? 0 : 1) * 2 + w8) * 2 + (pool ? 1 : 0);
     const void *fns[8] = {(const void *)conv_stem_pt_kernel<F16, 4, false>, (const void *)conv_stem_pt_kernel<F16, 4, true>,
@@ -888,6 +1025,7 @@ extern "C" int32_t tedspad_stem_pt_pool_clip_fwd(const float *x, int32_t n, int3
     TS_REQUIRE(x && w_img16 && scale && shift && y && side && n > 0 && c > 0 && c <= 3 && t > 0 && h > 0 && w > 0 && t_pairs > 0 && pad_t >= 0,
                "tedspad_stem_pt_pool_clip_fwd: bad arguments");
     TS_REQUIRE(stride_t == 2, "tedspad_stem_pt_pool_clip_fwd: temporal stride 2");
+    TS_REQUIRE(h < 4000 && w < 8000, "tedspad_stem_pt_pool_clip_fwd: frames up to 4000 x 8000 (the loader's packed task word)");
     TS_REQUIRE(sw == 1 && w % 4 == 0 && ((uintptr_t)x | (uintptr_t)(sn * 4) | (uintptr_t)(sc * 4) | (uintptr_t)(st * 4) | (uintptr_t)(sh * 4)) % 16 == 0,
                "tedspad_stem_pt_pool_clip_fwd: rows must be contiguous and 16-byte aligned (w %% 4 == 0, strides multiples of 4 elements)");
     TS_REQUIRE(sc >= 0 && st >= 0 && sh >= 0 && sn >= 0 && (c - 1) * sc + (long)(t + 8) * st + (long)(h + 32) * sh + w + 64 < (1L << 31),
