@@ -632,12 +632,36 @@ int32_t launch_patch3_t(const ConvKP &p, int frames, int cin, hipStream_t s, con
 
 void patch3_set_det(int on) { g_p3_det = on != 0; }
 
+static int32_t launch_conv_patch3_64(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src);
+
+// cout = 128: two launches, one per 64 output channels (weight rows, BatchNorm vectors, output / residual / mask / statistics columns shifted by 64): every output
+// channel is summed in the order of the 64-channel launch, the input is read twice (the layers are MFMA-bound by intensity: cin >= 64 at 112^2 and larger)
 int32_t launch_conv_patch3(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src) {
+    static const bool split128 = getenv("TEDSPAD_P3_NO_128") == nullptr;          // A/B knob
+    if (p.Cout != 128 || !split128) return launch_conv_patch3_64(dtype, p, N, cin, s, src);
+    for (int half = 0; half < 2; ++half) {
+        ConvKP q = p;
+        const int o = 64 * half;
+        q.Cout = 64;
+        q.w = p.w + (size_t)o * p.Kpad;
+        q.scale = p.scale + o; q.shift = p.shift + o;
+        if (p.y) q.y = p.y + o;
+        if (p.y32) q.y32 = p.y32 + o;
+        if (p.res) q.res = p.res + o;
+        if (p.mask) q.mask = p.mask + o;
+        if (p.stats) q.stats = p.stats + o;
+        const int32_t rc = launch_conv_patch3_64(dtype, q, N, cin, s, src);
+        if (rc != TEDSPAD_OK) return rc;          // (the first launch declines before anything is written: the conditions do not depend on the half)
+    }
+    return TEDSPAD_OK;
+}
+
+static int32_t launch_conv_patch3_64(int dtype, const ConvKP &p, int N, int cin, hipStream_t s, const PatchSrc *src) {
     const bool same = p.To == p.Ti && p.Ho == p.Hi && p.Wo == p.Wi;
     if (cin % 32 != 0 || (src && cin % 64 != 0) || p.kt != 1 || p.kh != 3 || p.kw != 3 || p.pt != 0 || p.ph != 1 || p.pw != 1 || p.st != 1 || p.sh != 1 || p.sw != 1 || !same ||
         p.Kpad < 9 * cin || p.ostrided || p.sigmoid || (!p.y && !p.y32) || (src && src->n != cin / 64) || (long)N * p.Ti * p.Hi * p.Wi >= (1L << 31) ||
         p.Cout > 64 || p.Cout <= 32 || (p.stats && g_p3_det)) {
-        set_error("tedspad_conv_fwd: persistent two-patch config (tile_cfg 40) needs a stride-1 'same' 1 x 3 x 3 conv with cin %% 32 == 0 (gathered sources: %% 64) and 32 < cout <= 64 "
+        set_error("tedspad_conv_fwd: persistent two-patch config (tile_cfg 40) needs a stride-1 'same' 1 x 3 x 3 conv with cin %% 32 == 0 (gathered sources: %% 64) and 32 < cout <= 64 or cout = 128 "
                   "(mask / stats / fp32 output allowed, no strided output map; no statistics in deterministic mode)");
         return TEDSPAD_EINVAL;
     }

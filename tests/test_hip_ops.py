@@ -541,7 +541,8 @@ def test_patch_halo_training_epilogues(cin, cout):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("dims,cin,cout,nwg", [((2, 1, 20, 37), 64, 64, 1), ((2, 1, 20, 37), 64, 64, 4), ((3, 1, 33, 16), 128, 64, 2), ((1, 2, 18, 20), 96, 40, 3),
-                                              ((5, 1, 48, 48), 192, 64, 7), ((1, 1, 16, 16), 32, 48, 0), ((3, 1, 112, 112), 64, 64, 0), ((2, 1, 50, 70), 320, 64, 5)])
+                                              ((5, 1, 48, 48), 192, 64, 7), ((1, 1, 16, 16), 32, 48, 0), ((3, 1, 112, 112), 64, 64, 0), ((2, 1, 50, 70), 320, 64, 5),
+                                              ((2, 1, 20, 37), 64, 128, 3), ((2, 1, 33, 48), 192, 128, 0)])       # cout = 128: two 64-channel launches
 def test_persistent_two_patch_tile_equals_the_two_patch_tile(dims, cin, cout, nwg, dtype, monkeypatch):
     """tile_cfg 40 (conv_patch3.hip: persistent 8-wave workgroups, double-buffered halo, weight ring -- resident for cin <= 64, streamed otherwise --,
     epilogue from the accumulators) against tile 38, whose K order it keeps: BIT-EQUAL 16-bit outputs with residual + ReLU, with the ReLU-backward mask, and
