@@ -1,4 +1,4 @@
-"""Achieved HBM rate of the train-mode BatchNorm passes on the cfg3 shapes (UNet levels at 384 frames, fb ResNet-50 at 24 images). Usage: python scripts/bn_probe.py"""
+"""Achieved HBM rate of the train-mode BatchNorm passes (backward reduction, forward apply, backward apply) on the cfg3 shapes (UNet levels at 384 frames, fb ResNet-50 at 24 images). Usage: python scripts/bn_probe.py"""
 import os, sys, ctypes as C, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ted_spad_amd import _lib
@@ -22,3 +22,13 @@ for name, n, hw, c in (("unet 112^2 x64", 384, 112, 64), ("unet 56^2 x128", 384,
                                                             sums.data_ptr(), c, px, c, c, c, c, 1, 1, 0, S), 'r'))
         by = px * c * 2 * (3 if relu_y else 2)
         print("%-20s bn_bwd_reduce (%s): %7.1f us  %5.2f TB/s" % (name, "dy,y,z" if relu_y else "dy,z; mask from z", us, by / us / 1e6))
+    stats = torch.stack([z.float().sum(0), (z.float() ** 2).sum(0)]).contiguous()
+    rm = torch.zeros(c, device='cuda'); rv = torch.ones(c, device='cuda'); mo = torch.zeros(c, device='cuda'); io = torch.zeros(c, device='cuda')
+    yo = torch.empty_like(z)
+    us = timed(lambda: _lib.check(L.tedspad_bn_train_apply(z.data_ptr(), 0, stats.data_ptr(), c, px, gam.data_ptr(), bet.data_ptr(), C.c_float(1e-5), C.c_float(0.1), rm.data_ptr(), rv.data_ptr(),
+                                                         mo.data_ptr(), io.data_ptr(), c, None, yo.data_ptr(), px, c, c, 0, c, 1, 1, 0, S), 'a'))
+    print("%-20s bn_train_apply (z -> y): %7.1f us  %5.2f TB/s" % (name, us, px * c * 4 / us / 1e6))
+    dz = torch.empty_like(z)
+    us = timed(lambda: _lib.check(L.tedspad_bn_bwd_apply(dy.data_ptr(), None, z.data_ptr(), 0, mean.data_ptr(), inv.data_ptr(), gam.data_ptr(), bet.data_ptr(), sums.data_ptr(), c, dz.data_ptr(), None,
+                                                       None, 1, px, c, c, c, c, c, 0, 1, 1, 0, S), 'b'))
+    print("%-20s bn_bwd_apply (dy, z -> dz; mask from z): %7.1f us  %5.2f TB/s" % (name, us, px * c * 6 / us / 1e6))

@@ -7,6 +7,8 @@
 // register partials -> LDS tree -> one float atomic per channel per workgroup.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "det_gate.h"
 
@@ -100,7 +102,7 @@ __device__ __forceinline__ void load_z8(const void *z, bool z16, size_t off, flo
     }
 }
 
-template <typename T>
+template <typename T, int UF>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int z16, const float *stats, int stats_ld, float count, const float *gamma,
                                                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                                                               float *mean_out, float *invstd_out, int C, const uint16_t *res, uint16_t *y, long pixels,
@@ -134,46 +136,87 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const void *z, int 
     const bool fixed = stride % C8 == 0;                  // a thread then owns the same 8 channels in every iteration
     float sc[8], sf[8];
     int have = -1;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
-        const int c8 = (int)(idx % C8);
-        const long px = idx / C8;
-        float v[8], r[8];                                 // the streaming loads first: the per-channel terms below are fetched while they are in flight
-        load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, v);
-        if (res) unpack8<T>(*reinterpret_cast<const uint4 *>(res + px * ldres + c8 * 8), r);
-        if (!fixed || have != c8) {
+    // the per-channel terms of chunk c8: 16-byte loads where the chunk is whole and the vectors are aligned (element-wise guarded loads compile to a waited-for round each)
+    const bool vec_ok = ((((uintptr_t)stats | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) && (stats_ld & 3) == 0;
+    auto terms = [&](int c8) {
+        if (vec_ok && c8 * 8 + 8 <= C) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(stats + c8 * 8), a1 = *reinterpret_cast<const f32x4 *>(stats + c8 * 8 + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4 *>(stats + stats_ld + c8 * 8), q1 = *reinterpret_cast<const f32x4 *>(stats + stats_ld + c8 * 8 + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gamma + c8 * 8), g1 = *reinterpret_cast<const f32x4 *>(gamma + c8 * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(beta + c8 * 8), b1 = *reinterpret_cast<const f32x4 *>(beta + c8 * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float mean = (i < 4 ? a0[i & 3] : a1[i & 3]) / count;
+                float var = (i < 4 ? q0[i & 3] : q1[i & 3]) / count - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const float s_ = (i < 4 ? g0[i & 3] : g1[i & 3]) * rsqrtf(var + eps);
+                sc[i] = s_; sf[i] = (i < 4 ? b0[i & 3] : b1[i & 3]) - mean * s_;
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = c8 * 8 + i;
-                float s = 0.f, b = 0.f;
+                float s_ = 0.f, b_ = 0.f;
                 if (c < C) {
                     const float mean = stats[c] / count;
                     float var = stats[stats_ld + c] / count - mean * mean;
                     var = var < 0.f ? 0.f : var;
-                    s = gamma[c] * rsqrtf(var + eps);
-                    b = beta[c] - mean * s;
+                    s_ = gamma[c] * rsqrtf(var + eps);
+                    b_ = beta[c] - mean * s_;
                 }
-                sc[i] = s; sf[i] = b;
+                sc[i] = s_; sf[i] = b_;
             }
-            have = c8;
+        }
+        have = c8;
+    };
+    // UF items per round, their streaming loads requested before the first is used (a thread walks ~8 items: 8 dependent round trips in the rolled loop; the host
+    // keeps UF = 1 on the full-resolution layers, where the unrolled form's registers cost occupancy)
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += UF * stride) {
+        int c8s[UF]; long pxs[UF]; bool ok[UF];
+        uint4 zq[UF], rq[UF]; f32x4 za[UF], zb[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const long id = idx + u * stride;
+            ok[u] = id < total;
+            if (u == 0 || !fixed) { c8s[u] = (int)(id % C8); pxs[u] = id / C8; }
+            else { c8s[u] = c8s[0]; pxs[u] = pxs[0] + u * (stride / C8); }
+            if (ok[u]) {
+                const size_t zo = zbase + pxs[u] * ldz + c8s[u] * 8;
+                if (z16) zq[u] = *reinterpret_cast<const uint4 *>((const uint16_t *)z + zo);
+                else { za[u] = *reinterpret_cast<const f32x4 *>((const float *)z + zo); zb[u] = *reinterpret_cast<const f32x4 *>((const float *)z + zo + 4); }
+                if (res) rq[u] = *reinterpret_cast<const uint4 *>(res + pxs[u] * ldres + c8s[u] * 8);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sf[i];
-        if (res) {
+        for (int u = 0; u < UF; ++u) {
+            if (!ok[u]) continue;
+            float v[8], r[8];
+            if (z16) unpack8<T>(zq[u], v);
+            else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += r[i];
-        }
-        if (relu) {
+                for (int i = 0; i < 4; ++i) { v[i] = za[u][i]; v[i + 4] = zb[u][i]; }
+            }
+            if (have != c8s[u]) terms(c8s[u]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+            for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sf[i];
+            if (res) {
+                unpack8<T>(rq[u], r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += r[i];
+            }
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaxf(v[i], 0.f);
+            }
+            *reinterpret_cast<uint4 *>(y + pxs[u] * ldy + c8s[u] * 8) = pack8_lim<T>(v, __builtin_inff());
         }
-        *reinterpret_cast<uint4 *>(y + px * ldy + c8 * 8) = pack8_lim<T>(v, __builtin_inff());
     }
 }
 
 // per-channel sums over pixels:  out[0][c] += sum g,  out[1][c] += sum g * xhat
 //   g = dy * (y > 0 if relu),  xhat = (z - mean) * invstd  (xhat term skipped when z == nullptr)
 // block = 256 threads = (256 / C8L) pixel lanes x C8L channel chunks, C8L = min(C8, 32)
-template <typename T>
+template <typename T, int UF>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, const uint16_t *y, const void *z, int z16, const float *mean,
                                                              const float *invstd, const float *gamma, const float *beta, float *out, int out_ld, long pixels,
                                                              int C8, int lddy, int ldy, int ldz, int relu) {
@@ -200,33 +243,85 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint16_t *dy, 
         // y == NULL with relu (units without a residual input): the ReLU mask is recomputed from z with the forward pass's own scale / shift
         // (tedspad_bn_train_apply: s = gamma * invstd, b = beta - mean * s, y = relu(z * s + b)) instead of re-reading the 16-bit output
         const bool remask = relu && !y;
+        // the per-channel vectors as 16-byte loads, requested together (element-wise `z ? mean[c] : 0` compiled to 32 masked loads in eight waited-for rounds:
+        // 6 us of a 30 us launch on the deep layers)
         float mu[8], is[8], ms[8], mb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            mu[i] = z ? mean[c8 * 8 + i] : 0.f; is[i] = z ? invstd[c8 * 8 + i] : 0.f;
-            ms[i] = remask ? gamma[c8 * 8 + i] * is[i] : 0.f;
-            mb[i] = remask ? beta[c8 * 8 + i] - mu[i] * ms[i] : 0.f;
-        }
-        for (long px = (long)pb * PL + pl; px < pixels; px += (long)pblocks * PL) {
-            float g[8], zz[8];
-            unpack8<T>(*reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8), g);
-            if (z) load_z8<T>(z, z16, zbase + px * ldz + c8 * 8, zz);
+        for (int i = 0; i < 8; ++i) mu[i] = is[i] = ms[i] = mb[i] = 0.f;
+        if (z) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4 *>(mean + c8 * 8), m1 = *reinterpret_cast<const f32x4 *>(mean + c8 * 8 + 4);
+            const f32x4 i0 = *reinterpret_cast<const f32x4 *>(invstd + c8 * 8), i1 = *reinterpret_cast<const f32x4 *>(invstd + c8 * 8 + 4);
+            f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
             if (remask) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g[i] = zz[i] * ms[i] + mb[i] > 0.f ? g[i] : 0.f;
-            } else if (relu) {
-                float yy[8];
-                unpack8<T>(*reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8), yy);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
+                g0 = *reinterpret_cast<const f32x4 *>(gamma + c8 * 8); g1 = *reinterpret_cast<const f32x4 *>(gamma + c8 * 8 + 4);
+                b0 = *reinterpret_cast<const f32x4 *>(beta + c8 * 8); b1 = *reinterpret_cast<const f32x4 *>(beta + c8 * 8 + 4);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s0[i] += g[i];
-            if (z) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s1[i] += g[i] * (zz[i] - mu[i]) * is[i];
+            for (int i = 0; i < 4; ++i) {
+                mu[i] = m0[i]; mu[i + 4] = m1[i]; is[i] = i0[i]; is[i + 4] = i1[i];
+                ms[i] = g0[i] * i0[i]; ms[i + 4] = g1[i] * i1[i];
+                mb[i] = b0[i] - m0[i] * ms[i]; mb[i + 4] = b1[i] - m1[i] * ms[i + 4];
             }
         }
+        // UF pixels per round, every load of the round requested before the first is used: a thread of a deep layer walks ~20 pixels, one dependent round trip
+        // each in the rolled loop (UF = 4: -15 ... -30 % on the layers of 28^2 and below; on the full-resolution layers its 184 registers cost occupancy: +5 ... +35 %,
+        // the host keeps UF = 1 where a thread walks 48 pixels or more). ZM: 0 no z, 1 z in 16 bits, 2 z in fp32; MM: 0 no mask, 1 mask recomputed from z, 2 mask from y
+        const long p0 = (long)pb * PL + pl, pstep = (long)pblocks * PL;
+        auto run = [&](auto zm_c, auto mm_c) {
+            constexpr int ZM = decltype(zm_c)::value, MM = decltype(mm_c)::value;
+            auto body = [&](const uint4 &gq, const uint4 &zq, const f32x4 &za, const f32x4 &zb, const uint4 &yq) {
+                float g[8], zz[8], yy[8];
+                unpack8<T>(gq, g);
+                if (ZM == 1) unpack8<T>(zq, zz);
+                if (ZM == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { zz[i] = za[i]; zz[i + 4] = zb[i]; }
+                }
+                if (MM == 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = zz[i] * ms[i] + mb[i] > 0.f ? g[i] : 0.f;
+                } else if (MM == 2) {
+                    unpack8<T>(yq, yy);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[i] = yy[i] > 0.f ? g[i] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s0[i] += g[i];
+                if (ZM) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s1[i] += g[i] * (zz[i] - mu[i]) * is[i];
+                }
+            };
+            long px = p0;
+            for (; px + (UF - 1) * pstep < pixels; px += UF * pstep) {
+                uint4 gq[UF], zq[UF], yq[UF];
+                f32x4 za[UF], zb[UF];
+#pragma unroll
+                for (int u = 0; u < UF; ++u) {
+                    const long q = px + u * pstep;
+                    gq[u] = *reinterpret_cast<const uint4 *>(dy + q * lddy + c8 * 8);
+                    if (ZM == 1) zq[u] = *reinterpret_cast<const uint4 *>((const uint16_t *)z + zbase + q * ldz + c8 * 8);
+                    if (ZM == 2) { za[u] = *reinterpret_cast<const f32x4 *>((const float *)z + zbase + q * ldz + c8 * 8); zb[u] = *reinterpret_cast<const f32x4 *>((const float *)z + zbase + q * ldz + c8 * 8 + 4); }
+                    if (MM == 2) yq[u] = *reinterpret_cast<const uint4 *>(y + q * ldy + c8 * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < UF; ++u) body(gq[u], zq[u], za[u], zb[u], yq[u]);     // pixels in the rolled loop's order: the sums keep their bits
+            }
+            for (; px < pixels; px += pstep) {
+                uint4 gq, zq = gq, yq = gq;
+                f32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za;
+                gq = *reinterpret_cast<const uint4 *>(dy + px * lddy + c8 * 8);
+                if (ZM == 1) zq = *reinterpret_cast<const uint4 *>((const uint16_t *)z + zbase + px * ldz + c8 * 8);
+                if (ZM == 2) { za = *reinterpret_cast<const f32x4 *>((const float *)z + zbase + px * ldz + c8 * 8); zb = *reinterpret_cast<const f32x4 *>((const float *)z + zbase + px * ldz + c8 * 8 + 4); }
+                if (MM == 2) yq = *reinterpret_cast<const uint4 *>(y + px * ldy + c8 * 8);
+                body(gq, zq, za, zb, yq);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        const int zm = !z ? 0 : z16 ? 1 : 2, mm = remask ? 1 : relu ? 2 : 0;      // (remask needs z: the host passes y otherwise)
+        if (zm == 0) { if (mm == 2) run(I0{}, I2{}); else run(I0{}, I0{}); }
+        else if (zm == 1) { if (mm == 1) run(I1{}, I1{}); else if (mm == 2) run(I1{}, I2{}); else run(I1{}, I0{}); }
+        else { if (mm == 1) run(I2{}, I1{}); else if (mm == 2) run(I2{}, I2{}); else run(I2{}, I0{}); }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s0[i]; red[1][threadIdx.x][i] = s1[i]; }
@@ -628,6 +723,7 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
                                          int32_t groups, int32_t dtype, void *stream) {
     TS_REQUIRE(dy && sums && pixels > 0 && C > 0 && C % 8 == 0 && TS_DT(dtype) && (!relu || y || (z && gamma && beta)) && (!z || (mean && invstd && TS_ZDT(zdtype, dtype, ldz))) && sums_ld >= C && groups >= 1 && groups < 65536,
                "tedspad_bn_bwd_reduce: bad arguments (relu needs y, or z + gamma + beta to recompute the mask)");
+    TS_REQUIRE((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "tedspad_bn_bwd_reduce: mean / invstd / gamma / beta must be 16-byte aligned (read as 16-byte vectors)");
     const int C8 = C / 8, C8L = C8 < 32 ? C8 : 32, cgroups = (C8 + C8L - 1) / C8L, PL = 256 / C8L;
     long pblocks = (pixels + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 pixels per lane, but enough workgroups to cover the chip
     // Every workgroup ends in 2 x C float atomics on the same 2 x C addresses: past ~1000 workgroups per address the atomics, not the bytes, set the time, the sooner the
@@ -637,8 +733,13 @@ extern "C" int32_t tedspad_bn_bwd_reduce(const void *dy, const void *y, const vo
     if (pblocks > wg_cap / cgroups) pblocks = wg_cap / cgroups;
     if (pblocks < 1) pblocks = 1;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_bwd_reduce_kernel, dim3((unsigned)(pblocks * cgroups), groups), (const uint16_t *)dy, (const uint16_t *)y, z,
-             (int)(zdtype != TEDSPAD_F32), mean, invstd, gamma, beta, sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu);
+    static const int uf_env = getenv("TEDSPAD_BNR_UNROLL") ? atoi(getenv("TEDSPAD_BNR_UNROLL")) : 0;      // A/B knob: 1 / 4 everywhere
+    const bool unroll = uf_env ? uf_env > 1 : pixels / (pblocks * PL) < 48;
+#define BNR_ARGS dim3((unsigned)(pblocks * cgroups), groups), dim3(256), 0, s, (const uint16_t *)dy, (const uint16_t *)y, z, (int)(zdtype != TEDSPAD_F32), mean, invstd, gamma, beta, \
+                 sums, sums_ld, (long)pixels, C8, lddy, ldy, ldz, relu
+    if (dtype == TEDSPAD_F16) { if (unroll) hipLaunchKernelGGL((bn_bwd_reduce_kernel<F16, 4>), BNR_ARGS); else hipLaunchKernelGGL((bn_bwd_reduce_kernel<F16, 1>), BNR_ARGS); }
+    else { if (unroll) hipLaunchKernelGGL((bn_bwd_reduce_kernel<BF16, 4>), BNR_ARGS); else hipLaunchKernelGGL((bn_bwd_reduce_kernel<BF16, 1>), BNR_ARGS); }
+#undef BNR_ARGS
     return check_launch("tedspad_bn_bwd_reduce");
 }
 
@@ -731,8 +832,16 @@ extern "C" int32_t tedspad_bn_train_apply(const void *z, int32_t zdtype, const f
                    ldy % 8 == 0 && TS_DT(dtype) && (uintptr_t)z % 16 == 0 && groups >= 1 && groups < 65536 && TS_ZDT(zdtype, dtype, ldz),
                "tedspad_bn_train_apply: bad arguments (z is fp32, or 16-bit of y's dtype with ldz % 8 == 0)");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_T(dtype, bn_train_apply_kernel, dim3(grid_for_iters(pixels * (Cz / 8), 8), groups), z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean,
-             running_var, mean, invstd, C, (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu);
+    const int gx = grid_for_iters(pixels * (Cz / 8), 8);
+    static const int uf_env = getenv("TEDSPAD_BNA_UNROLL") ? atoi(getenv("TEDSPAD_BNA_UNROLL")) : 0;      // A/B knob: 1 / 4 everywhere
+    // UF = 4 where a thread walks few items of a wide layer (measured: 28^2 x 256 and deeper gain 8 ... 45 %; 224^2 x 64 at the same item count loses 15 %;
+    // the same unrolling of tedspad_bn_bwd_apply, whose terms live in LDS, lost 5 ... 20 % everywhere and was not kept)
+    const bool unroll = uf_env ? uf_env > 1 : (Cz >= 256 && pixels * (Cz / 8) / ((long)gx * 256) <= 16);
+#define BNA_ARGS dim3(gx, groups), dim3(256), 0, s, z, (int)(zdtype != TEDSPAD_F32), stats, stats_ld, (float)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, C, \
+                 (const uint16_t *)res, (uint16_t *)y, (long)pixels, Cz / 8, ldz, ldres, ldy, relu
+    if (dtype == TEDSPAD_F16) { if (unroll) hipLaunchKernelGGL((bn_train_apply_kernel<F16, 4>), BNA_ARGS); else hipLaunchKernelGGL((bn_train_apply_kernel<F16, 1>), BNA_ARGS); }
+    else { if (unroll) hipLaunchKernelGGL((bn_train_apply_kernel<BF16, 4>), BNA_ARGS); else hipLaunchKernelGGL((bn_train_apply_kernel<BF16, 1>), BNA_ARGS); }
+#undef BNA_ARGS
     return check_launch("tedspad_bn_train_apply");
 }
 
