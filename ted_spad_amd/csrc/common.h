@@ -77,6 +77,17 @@ struct BF16 {
     }
 };
 
+// One 16-byte global load from a per-lane address the compiler cannot see through. A load from `valid ? tensor + offset : zero_page`, or `q = 0; if (valid) q = *ptr`, is otherwise
+// emitted as masked loads under their own exec masks with an s_waitcnt vmcnt(0) behind each (two writers of one register): a thread's N loads become N round trips. With the address
+// made opaque, N of these in a row are N back-to-back global_load_dwordx4 (round 6: the stem's clip loader, the residual / mask pieces of the conv epilogues).
+__device__ __forceinline__ uint4 load16_opaque(const void *ptr) {
+    typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+    unsigned long a = reinterpret_cast<unsigned long>(ptr);
+    asm volatile("" : "+v"(a));
+    const u32x4g v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4g *>(a);       // address space 1: a global_load, not a flat one
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};

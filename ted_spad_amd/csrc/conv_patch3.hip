@@ -323,8 +323,10 @@ __global__ __launch_bounds__(LDR ? P3_NTL : P3_NT) void conv_patch3_kernel(const
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int r = k >> 1, poff = poff0 + 32 * (k & 1);
-                q[k] = make_uint4(0u, 0u, 0u, 0u);
-                if (vrow[r] && poff < p.Cout) q[k] = *reinterpret_cast<const uint4 *>(base + mrow[r] * ld + poff);
+                // ONE load per piece from a per-lane address (the zero page where there is nothing to read): as `q = 0; if (valid) q = load` hipcc emitted every load under
+                // its own exec mask with an s_waitcnt vmcnt(0) behind it -- eight round trips per pass where the comment above promises one wait
+                const uint16_t *src = (vrow[r] && poff < p.Cout) ? base + mrow[r] * ld + poff : reinterpret_cast<const uint16_t *>(&g_zero16p3);
+                q[k] = load16_opaque(src);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { swap16(q[k].x, q[k].z); swap16(q[k].y, q[k].w); }      // -> (x, y): this lane's 4 channels of group 2 pp, (z, w): of group 2 pp + 1
