@@ -263,10 +263,15 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
     // Named variables, not an array: hipcc puts a conditionally filled array of this size into scratch.
     constexpr int NR = BM / RPP;          // output rows per thread
     static_assert(BM % RPP == 0 && NR <= 8, "epilogue row passes");
+    // Without a residual the same registers prefetch the ReLU-backward MASK rows (data gradients of the training step: the deep layers' launches are 10-20 us and the
+    // mask load inside the store loop was one dependent round trip per row, eight per tile).
     const bool res_pre = p.res && !p.ostrided && active;
+    const bool mask_pre = !p.res && p.mask && !p.ostrided && active;
+    const uint16_t *pre_ptr = res_pre ? p.res : p.mask;
+    const int pre_ld = res_pre ? p.ldres : p.ldmask;
     auto res_row = [&](int it) -> uint4 {
         const int m = m0 + r0 + it * RPP;
-        return (res_pre && it < NR && m < p.M) ? *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.ldres + n) : make_uint4(0, 0, 0, 0);
+        return ((res_pre || mask_pre) && it < NR && m < p.M) ? *reinterpret_cast<const uint4 *>(pre_ptr + (size_t)m * pre_ld + n) : make_uint4(0, 0, 0, 0);
     };
     const uint4 rres0 = res_row(0), rres1 = res_row(1), rres2 = res_row(2), rres3 = res_row(3);
     const uint4 rres4 = res_row(4), rres5 = res_row(5), rres6 = res_row(6), rres7 = res_row(7);
@@ -354,7 +359,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void conv_igemm_kernel(const Conv
         }
         if (p.mask) {
             float mk[8];
-            unpack8<T>(*reinterpret_cast<const uint4 *>(p.mask + op * p.ldmask + n), mk);
+            uint4 mv = rpre;
+            if (!mask_pre) mv = *reinterpret_cast<const uint4 *>(p.mask + op * p.ldmask + n);
+            unpack8<T>(mv, mk);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = mk[i] > 0.f ? v[i] : 0.f;
         }
