@@ -13,6 +13,8 @@
 // The nearest x2 upsample is the fragment address: M1 position (r, c), tap (dh, dw) reads X position ((r + dh + 1) >> 1, (c + dw + 1) >> 1).
 // Work split: 16-pixel groups of the stage's output (25 / 21 / 16 of them) dealt round-robin to the 8 waves, every wave computing all of a group's channels.
 // Three barriers per patch; no weight stream, no per-tap barrier. conv1 re-computes a 20 x 20 halo per 16 x 16 patch (1.56 x), conv2 18 x 18 (1.27 x).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace tedspad {
@@ -25,7 +27,8 @@ constexpr int UT_WIMG = UT_W1 + UT_W2 + UT_W3;                                  
 constexpr int UT_M1P = 20 * 20, UT_M2P = 18 * 18, UT_XP = 12 * 12;
 constexpr int UT_OFF_M1 = UT_WIMG, UT_OFF_M2 = UT_OFF_M1 + UT_M1P * 64, UT_OFF_X = UT_OFF_M2 + UT_M2P * 64;
 constexpr int UT_XBYTES = 2 * UT_XP * 64;                                            // 18432 per buffer
-constexpr int UT_LDS = UT_OFF_X + 2 * UT_XBYTES;                                     // 147712
+constexpr int UT_OFF_V = UT_OFF_X + 2 * UT_XBYTES;                                   // sc1, sh1, sc2, sh2 (32 floats each), b3 (4): read per stage epilogue (36 registers less in the loops)
+constexpr int UT_LDS = UT_OFF_V + 4 * 128 + 16;                                      // 148240
 static_assert(UT_LDS <= 160 * 1024 && UT_WIMG % 1024 == 0, "LDS budget");
 
 struct UppTailKP {
@@ -88,17 +91,20 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
 
     // ---- per-lane constants -----------------------------------------------------------------------------------------------------------------------------
     const unsigned wrd = (unsigned)(l15 * 64 + ((kg ^ ((l15 >> 1) & 3)) << 4));      // this lane's piece of weight row (16 a + l15)
-    float sc1[2][4], sh1[2][4], sc2[2][4], sh2[2][4], b3[4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = 16 * a + 4 * kg + e;
-            sc1[a][e] = p.sc1[co]; sh1[a][e] = p.sh1[co]; sc2[a][e] = p.sc2[co]; sh2[a][e] = p.sh2[co];
-        }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b3[e] = (4 * kg + e) < 3 ? p.b3[4 * kg + e] : 0.f;
+    if (tid < 32) {
+        float *vv = reinterpret_cast<float *>(dsm + UT_OFF_V);
+        vv[tid] = p.sc1[tid]; vv[32 + tid] = p.sh1[tid]; vv[64 + tid] = p.sc2[tid]; vv[96 + tid] = p.sh2[tid];
+        if (tid < 4) vv[128 + tid] = tid < 3 ? p.b3[tid] : 0.f;
+    }
+    auto vec4 = [&](int which, int a) -> f32x4 {            // this lane's channels 16 a + 4 kg .. + 3 of vector `which`
+        return *reinterpret_cast<const f32x4 *>(dsm + UT_OFF_V + which * 128 + (16 * a + 4 * kg) * 4);
+    };
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
 
+    // The patch loop exists three times, one per (conv1 groups, conv2 groups) of a wave -- (4, 3) wave 0, (3, 3) waves 1-4, (3, 2) waves 5-7 --, chosen OUTSIDE it: the
+    // group counts are compile-time constants inside (no `if (j < ng)` cutting a tap into basic blocks), and each copy hoists only its own fragment addresses out of its
+    // loop (chosen inside the loop, both bodies' addresses were hoisted: 74 spilled registers; re-derived per patch they cost more VALU than the pipelining gained).
+    auto run = [&](auto ng1_c, auto ng2_c) {
     int pi = blockIdx.x;
     if (pi < p.npatch) issue_x(pi, 0);
     int buf = 0;
@@ -110,64 +116,74 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
         if (pi + (int)gridDim.x < p.npatch) issue_x(pi + gridDim.x, buf ^ 1);
 
         // ---- conv1: 64 (upsampled) -> 32 on the 20 x 20 halo: groups g = wave, wave + 8, ... of 16 consecutive M1 positions ---------------------------
-        {
-            f32x4 acc[4][2];
-            int rr[4], cq[4];
+        // The group count is a COMPILE-TIME constant of the body (wave 0: 4, the others 3; `if (j < ng)` inside the tap loop cut it into basic blocks: a tap's reads, a wait,
+        // its MFMAs -- 39 % MFMA busy), and the fragments of tap t + 1 are requested before the MFMAs of tap t (two register sets, pinned with sched_group_barrier as in the stem).
+        auto conv1 = [&](auto ng_c) {
+            constexpr int NG = decltype(ng_c)::value;
+            f32x4 acc[NG][2];
+            int rr[NG], cq[NG];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NG; ++j) {
                 const int i = (wave + 8 * j) * 16 + l15;
                 rr[j] = i / 20; cq[j] = i - rr[j] * 20;
 #pragma unroll
                 for (int a = 0; a < 2; ++a) acc[j][a] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            const int ng = wave == 0 ? 4 : 3;              // 25 groups
             const unsigned xb = (unsigned)(UT_OFF_X + buf * UT_XBYTES);
+            uint4 fw[2][2], fa[2][NG];
 #pragma unroll 1
-            for (int hc = 0; hc < 2; ++hc)
+            for (int hc = 0; hc < 2; ++hc) {
+                auto load = [&](int t, uint4 (&w)[2], uint4 (&x)[NG]) {
+                    const int dh = t / 3, dw = t - 3 * dh;
+                    const unsigned wb = (unsigned)((hc * 9 + t) * 32 * 64) + wrd;
 #pragma unroll
-                for (int dh = 0; dh < 3; ++dh)
+                    for (int a = 0; a < 2; ++a) w[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
 #pragma unroll
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const unsigned wb = (unsigned)((hc * 9 + dh * 3 + dw) * 32 * 64) + wrd;
-                        uint4 fw[2], fa[4];
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < ng) {
-                                const int xp = ((rr[j] + dh + 1) >> 1) * 12 + ((cq[j] + dw + 1) >> 1);
-                                fa[j] = *reinterpret_cast<const uint4 *>(dsm + xb + hc * (UT_XP * 64) + xp * 64 + ((kg ^ ((xp >> 1) & 3)) << 4));
-                            }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < ng) {
-#pragma unroll
-                                for (int a = 0; a < 2; ++a) acc[j][a] = T::mfma16(fw[a], fa[j], acc[j][a]);
-                            }
+                    for (int j = 0; j < NG; ++j) {
+                        const int xp = ((rr[j] + dh + 1) >> 1) * 12 + ((cq[j] + dw + 1) >> 1);
+                        x[j] = *reinterpret_cast<const uint4 *>(dsm + xb + hc * (UT_XP * 64) + xp * 64 + ((kg ^ ((xp >> 1) & 3)) << 4));
                     }
+                };
+                load(0, fw[0], fa[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + NG, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < ng) {
-                    const int i = (wave + 8 * j) * 16 + l15;
-                    const bool in = (unsigned)(oy - 2 + rr[j]) < (unsigned)p.H && (unsigned)(ox - 2 + cq[j]) < (unsigned)p.W;
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 1 < 9) load(t + 1, fw[(t + 1) & 1], fa[(t + 1) & 1]);
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        float v[4];
+                    for (int j = 0; j < NG; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = in ? __builtin_fmaxf(acc[j][a][e] * sc1[a][e] + sh1[a][e], 0.f) : 0.f;
-                        uint2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-                        *reinterpret_cast<uint2 *>(dsm + UT_OFF_M1 + i * 64 + (((2 * a + (kg >> 1)) ^ ((i >> 1) & 3)) << 4) + (kg & 1) * 8) = pk;
-                    }
+                        for (int a = 0; a < 2; ++a) acc[j][a] = T::mfma16(fw[t & 1][a], fa[t & 1][j], acc[j][a]);
+                    if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NG, 0);      // the LDS reads of tap t + 1
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NG, 0);                      // the MFMAs of tap t
                 }
-        }
+            }
+            f32x4 sc[2], sh[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { sc[a] = vec4(0, a); sh[a] = vec4(1, a); }
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int i = (wave + 8 * j) * 16 + l15;
+                const bool in = (unsigned)(oy - 2 + rr[j]) < (unsigned)p.H && (unsigned)(ox - 2 + cq[j]) < (unsigned)p.W;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = in ? __builtin_fmaxf(acc[j][a][e] * sc[a][e] + sh[a][e], 0.f) : 0.f;
+                    uint2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                    *reinterpret_cast<uint2 *>(dsm + UT_OFF_M1 + i * 64 + (((2 * a + (kg >> 1)) ^ ((i >> 1) & 3)) << 4) + (kg & 1) * 8) = pk;
+                }
+            }
+        };
+        conv1(ng1_c);                                       // 25 groups: 4 on wave 0, 3 on the others
         __syncthreads();
 
         // ---- conv2: 32 -> 32 on 18 x 18: 21 groups of 16 consecutive M2 positions (the last one has 4) ------------------------------------------------
-        {
-            f32x4 acc[3][2];
-            int rr[3], cq[3], idx[3];
+        auto conv2 = [&](auto ng_c) {
+            constexpr int NG = decltype(ng_c)::value;
+            f32x4 acc[NG][2];
+            int rr[NG], cq[NG], idx[NG];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NG; ++j) {
                 const int i = (wave + 8 * j) * 16 + l15;
                 idx[j] = i;
                 const int ic = i < UT_M2P ? i : UT_M2P - 1;
@@ -175,60 +191,75 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) acc[j][a] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            const int ng = wave < 5 ? 3 : 2;               // 21 groups
+            uint4 fw[2][2], fa[2][NG];
+            auto load = [&](int t, uint4 (&w)[2], uint4 (&x)[NG]) {
+                const int dh = t / 3, dw = t - 3 * dh;
+                const unsigned wb = (unsigned)(UT_W1 + t * 32 * 64) + wrd;
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
+                for (int a = 0; a < 2; ++a) w[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const unsigned wb = (unsigned)(UT_W1 + (dh * 3 + dw) * 32 * 64) + wrd;
-                    uint4 fw[2], fa[3];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) fw[a] = *reinterpret_cast<const uint4 *>(dsm + wb + a * 1024);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (j < ng) {
-                            const int mp = (rr[j] + dh) * 20 + cq[j] + dw;
-                            fa[j] = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M1 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
-                        }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (j < ng) {
-#pragma unroll
-                            for (int a = 0; a < 2; ++a) acc[j][a] = T::mfma16(fw[a], fa[j], acc[j][a]);
-                        }
+                for (int j = 0; j < NG; ++j) {
+                    const int mp = (rr[j] + dh) * 20 + cq[j] + dw;
+                    x[j] = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M1 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
                 }
+            };
+            load(0, fw[0], fa[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + NG, 0);
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (j < ng && idx[j] < UT_M2P) {
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) load(t + 1, fw[(t + 1) & 1], fa[(t + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < NG; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) acc[j][a] = T::mfma16(fw[t & 1][a], fa[t & 1][j], acc[j][a]);
+                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NG, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NG, 0);
+            }
+            f32x4 sc[2], sh[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { sc[a] = vec4(2, a); sh[a] = vec4(3, a); }
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                if (idx[j] < UT_M2P) {
                     const int i = idx[j];
                     const bool in = (unsigned)(oy - 1 + rr[j]) < (unsigned)p.H && (unsigned)(ox - 1 + cq[j]) < (unsigned)p.W;
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = in ? __builtin_fmaxf(acc[j][a][e] * sc2[a][e] + sh2[a][e], 0.f) : 0.f;
+                        for (int e = 0; e < 4; ++e) v[e] = in ? __builtin_fmaxf(acc[j][a][e] * sc[a][e] + sh[a][e], 0.f) : 0.f;
                         uint2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                         *reinterpret_cast<uint2 *>(dsm + UT_OFF_M2 + i * 64 + (((2 * a + (kg >> 1)) ^ ((i >> 1) & 3)) << 4) + (kg & 1) * 8) = pk;
                     }
                 }
-        }
+        };
+        conv2(ng2_c);                                       // 21 groups: 3 on waves 0-4, 2 on waves 5-7
         __syncthreads();
 
         // ---- head: 32 -> 3 (+ bias) on 16 x 16: output rows wave, wave + 8; fp32 NCHW straight from the accumulators ----------------------------------
         {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            uint4 fw[2], fa[2][2];
+            auto load = [&](int t, uint4 &w, uint4 (&x)[2]) {
+                const int dh = t / 3, dw = t - 3 * dh;
+                w = *reinterpret_cast<const uint4 *>(dsm + (unsigned)(UT_W1 + UT_W2 + t * 16 * 64) + wrd);
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const uint4 fw = *reinterpret_cast<const uint4 *>(dsm + (unsigned)(UT_W1 + UT_W2 + (dh * 3 + dw) * 16 * 64) + wrd);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int mp = (wave + 8 * j + dh) * 18 + l15 + dw;
-                        const uint4 fa = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M2 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
-                        acc[j] = T::mfma16(fw, fa, acc[j]);
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    const int mp = (wave + 8 * j + dh) * 18 + l15 + dw;
+                    x[j] = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M2 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
                 }
+            };
+            load(0, fw[0], fa[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) load(t + 1, fw[(t + 1) & 1], fa[(t + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = T::mfma16(fw[t & 1], fa[t & 1][j], acc[j]);
+                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            const f32x4 b3 = *reinterpret_cast<const f32x4 *>(dsm + UT_OFF_V + 4 * 128);
             if (kg == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -241,6 +272,10 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
             }
         }
     }
+    };
+    if (wave == 0) run(I4{}, I3{});
+    else if (wave < 5) run(I3{}, I3{});
+    else run(I3{}, I2{});
 }
 
 }  // namespace
