@@ -99,20 +99,63 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
     auto vec4 = [&](int which, int a) -> f32x4 {            // this lane's channels 16 a + 4 kg .. + 3 of vector `which`
         return *reinterpret_cast<const f32x4 *>(dsm + UT_OFF_V + which * 128 + (16 * a + 4 * kg) * 4);
     };
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
 
-    // The patch loop exists three times, one per (conv1 groups, conv2 groups) of a wave -- (4, 3) wave 0, (3, 3) waves 1-4, (3, 2) waves 5-7 --, chosen OUTSIDE it: the
-    // group counts are compile-time constants inside (no `if (j < ng)` cutting a tap into basic blocks), and each copy hoists only its own fragment addresses out of its
-    // loop (chosen inside the loop, both bodies' addresses were hoisted: 74 spilled registers; re-derived per patch they cost more VALU than the pipelining gained).
-    auto run = [&](auto ng1_c, auto ng2_c) {
+    // The patch loop exists four times, one per (conv1, conv2, head) group counts of a wave -- (4, 3, 0) wave 0, (3, 3, 3) waves 1-2, (3, 3, 2) waves 3-4, (3, 2, 2) waves 5-7 --,
+    // chosen OUTSIDE it: the group counts are compile-time constants inside (no `if (j < ng)` cutting a tap into basic blocks), and each copy hoists only its own fragment
+    // addresses out of its loop (chosen inside the loop, both bodies' addresses were hoisted: 74 spilled registers; re-derived per patch they cost more VALU than the pipelining gained).
+    // TWO stages per patch: [conv1 of this patch + the HEAD of the patch before] | [conv2]. The head reads M2, conv1 reads X and writes M1: independent, so the head's
+    // 16 row groups go to the waves conv1 leaves lighter (wave 0 carries conv1's 25th group and no head group): one barrier and the head's 18 MFMAs less on the critical wave.
+    auto run = [&](auto ng1_c, auto ng2_c, auto ng3_c) {
     int pi = blockIdx.x;
     if (pi < p.npatch) issue_x(pi, 0);
     int buf = 0;
+    int pf = -1, poy = 0, pox = 0;                         // the patch before (its head is still to do)
+    // ---- head: 32 -> 3 (+ bias) on 16 x 16: output rows (wave - 1) + 7 j of waves 1-7; fp32 NCHW straight from the accumulators ----------------------------------
+    auto head = [&](int f, int oy, int ox) {
+        constexpr int NG = decltype(ng3_c)::value;
+        if constexpr (NG > 0) {
+            f32x4 acc[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint4 fw[2], fa[2][NG];
+            auto load = [&](int t, uint4 &w, uint4 (&x)[NG]) {
+                const int dh = t / 3, dw = t - 3 * dh;
+                w = *reinterpret_cast<const uint4 *>(dsm + (unsigned)(UT_W1 + UT_W2 + t * 16 * 64) + wrd);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int mp = (wave - 1 + 7 * j + dh) * 18 + l15 + dw;
+                    x[j] = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M2 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
+                }
+            };
+            load(0, fw[0], fa[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + NG, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) load(t + 1, fw[(t + 1) & 1], fa[(t + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) acc[j] = T::mfma16(fw[t & 1], fa[t & 1][j], acc[j]);
+                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NG, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NG, 0);
+            }
+            const f32x4 b3 = *reinterpret_cast<const f32x4 *>(dsm + UT_OFF_V + 4 * 128);
+            if (kg == 0) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int yy = oy + wave - 1 + 7 * j, xx = ox + l15;
+                    if (yy < p.H && xx < p.W) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) p.y[(((size_t)f * 3 + e) * p.H + yy) * p.W + xx] = acc[j][e] + b3[e];
+                    }
+                }
+            }
+        }
+    };
     for (; pi < p.npatch; pi += gridDim.x, buf ^= 1) {
         int f, oy, ox;
         patch_org(pi, f, oy, ox);
-        wait_vmcnt<0>();                                   // this patch's X (and, the first time, the weights) landed; the previous patch's stores are out
-        __syncthreads();                                   // ... in every wave; and every wave is done with the previous patch's M2 and the other X buffer
+        wait_vmcnt<0>();                                   // this patch's X (and, the first time, the weights) landed; the stores of the head before last are out
+        __syncthreads();                                   // ... in every wave; and every wave is done with conv2 of the patch before (M2 complete, M1 free) and the other X buffer
         if (pi + (int)gridDim.x < p.npatch) issue_x(pi + gridDim.x, buf ^ 1);
 
         // ---- conv1: 64 (upsampled) -> 32 on the 20 x 20 halo: groups g = wave, wave + 8, ... of 16 consecutive M1 positions ---------------------------
@@ -175,6 +218,7 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
             }
         };
         conv1(ng1_c);                                       // 25 groups: 4 on wave 0, 3 on the others
+        if (pf >= 0) head(pf, poy, pox);                    // the patch before: its M2 is complete since the barrier above
         __syncthreads();
 
         // ---- conv2: 32 -> 32 on 18 x 18: 21 groups of 16 consecutive M2 positions (the last one has 4) ------------------------------------------------
@@ -234,48 +278,15 @@ __global__ __launch_bounds__(512) void unetpp_tail_kernel(const UppTailKP p) {
                 }
         };
         conv2(ng2_c);                                       // 21 groups: 3 on waves 0-4, 2 on waves 5-7
-        __syncthreads();
-
-        // ---- head: 32 -> 3 (+ bias) on 16 x 16: output rows wave, wave + 8; fp32 NCHW straight from the accumulators ----------------------------------
-        {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            uint4 fw[2], fa[2][2];
-            auto load = [&](int t, uint4 &w, uint4 (&x)[2]) {
-                const int dh = t / 3, dw = t - 3 * dh;
-                w = *reinterpret_cast<const uint4 *>(dsm + (unsigned)(UT_W1 + UT_W2 + t * 16 * 64) + wrd);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int mp = (wave + 8 * j + dh) * 18 + l15 + dw;
-                    x[j] = *reinterpret_cast<const uint4 *>(dsm + UT_OFF_M2 + mp * 64 + ((kg ^ ((mp >> 1) & 3)) << 4));
-                }
-            };
-            load(0, fw[0], fa[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t + 1 < 9) load(t + 1, fw[(t + 1) & 1], fa[(t + 1) & 1]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = T::mfma16(fw[t & 1], fa[t & 1][j], acc[j]);
-                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-            const f32x4 b3 = *reinterpret_cast<const f32x4 *>(dsm + UT_OFF_V + 4 * 128);
-            if (kg == 0) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int yy = oy + wave + 8 * j, xx = ox + l15;
-                    if (yy < p.H && xx < p.W) {
-#pragma unroll
-                        for (int e = 0; e < 3; ++e) p.y[(((size_t)f * 3 + e) * p.H + yy) * p.W + xx] = acc[j][e] + b3[e];
-                    }
-                }
-            }
-        }
+        pf = f; poy = oy; pox = ox;
     }
+    __syncthreads();                                       // the last patch's M2
+    if (pf >= 0) head(pf, poy, pox);
     };
-    if (wave == 0) run(I4{}, I3{});
-    else if (wave < 5) run(I3{}, I3{});
-    else run(I3{}, I2{});
+    if (wave == 0) run(I4{}, I3{}, I0{});
+    else if (wave < 3) run(I3{}, I3{}, I3{});               // head rows (wave - 1) + 7 j < 16: three on waves 1 and 2
+    else if (wave < 5) run(I3{}, I3{}, I2{});
+    else run(I3{}, I2{}, I2{});
 }
 
 }  // namespace
